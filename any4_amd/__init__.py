@@ -1,0 +1,12 @@
+"""any4_amd -- MI355X-native tinygemm: the any4 / int4 / nf4 / mx4 W4A16 small-batch GEMM hot path of
+facebookresearch/any4 as hand-written gfx950 HIP kernels behind a C ABI, with the reference's
+`torch.ops.tinygemm.*`, `tinygemm_lib.functional` and `modules` API on top.
+
+Importing this package loads the HIP library and registers the ops; it raises ImportError if the
+library has not been built (`python -m any4_amd.build`).  There is no CPU fallback.
+"""
+from . import ops as _ops  # noqa: F401
+from . import functional, modules, utils  # noqa: F401
+from .modules import Any4Linear, Int4Linear, Int8Linear  # noqa: F401
+
+__all__ = ["functional", "modules", "utils", "Any4Linear", "Int4Linear", "Int8Linear"]

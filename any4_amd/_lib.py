@@ -1,0 +1,71 @@
+"""ctypes binding of include/tinygemm_hip.h.  No fallbacks: if the HIP library is missing the
+import fails loudly (build it with `python -m any4_amd.build`)."""
+from __future__ import annotations
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libtinygemm_hip.so")
+
+TG_BF16, TG_F16 = 0, 1
+TG_Q_INT4, TG_Q_ANY4_GLOBAL, TG_Q_ANY4_ROWWISE, TG_Q_MX4 = 0, 1, 2, 3
+
+_i32, _i64, _vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p
+
+
+class W4Gemm(ctypes.Structure):
+    """struct tg_w4_gemm (include/tinygemm_hip.h)"""
+
+    _fields_ = [
+        ("x", _vp), ("w", _vp), ("qinfo", _vp), ("lut", _vp), ("y", _vp),
+        ("m", _i64), ("wrows", _i64), ("k", _i64),
+        ("group", _i32), ("qtype", _i32), ("dtype", _i32), ("w_on_right", _i32), ("inner_k_tiles", _i32),
+        ("batch", _i32),
+        ("stride_x", _i64), ("stride_w", _i64), ("stride_qinfo", _i64), ("stride_lut", _i64), ("stride_y", _i64),
+    ]
+
+
+# name -> argtypes, exactly the prototypes of include/tinygemm_hip.h
+SYMBOLS = {
+    "tg_abi_version": [],
+    "tg_error_string": [ctypes.c_int],
+    "tg_convert_to_Bint4": [_vp, _i64, _i64, ctypes.c_int, _vp, ctypes.c_int, _vp],
+    "tg_convert_to_Aint4": [_vp, _i64, _i64, ctypes.c_int, _vp, ctypes.c_int, _vp],
+    "tg_convert_to_A16": [_vp, _i64, _i64, _vp, ctypes.c_int, _vp],
+    "tg_convert_from_A16": [_vp, _i64, _i64, _vp, ctypes.c_int, _vp],
+    "tg_convert_to_B16": [_vp, _i64, _i64, ctypes.c_int, _vp, ctypes.c_int, _vp],
+    "tg_convert_from_B16": [_vp, _i64, _i64, ctypes.c_int, _vp, ctypes.c_int, _vp],
+    "tg_dequant_int4": [_vp, _i64, _vp, ctypes.c_int, _vp],
+    "tg_gemm_w4": [ctypes.POINTER(W4Gemm), ctypes.c_int, _vp],
+    "tg_gemm_f16": [_vp, _vp, _vp, _i64, _i64, _i64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp],
+}
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"tinygemm HIP library not built: {LIB_PATH} is missing. "
+            "Run `python -m any4_amd.build` (needs hipcc; cross-compiles gfx950 without a GPU). "
+            "There is no CPU/PyTorch fallback for the tinygemm ops."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+        fn.argtypes = argtypes
+        fn.restype = ctypes.c_char_p if name == "tg_error_string" else ctypes.c_int
+    if lib.tg_abi_version() != 1:
+        raise ImportError(f"{LIB_PATH}: ABI version {lib.tg_abi_version()} != 1; rebuild")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().tg_error_string(rc).decode()
+        raise RuntimeError(f"tinygemm::{what}: {msg} (code {rc})")

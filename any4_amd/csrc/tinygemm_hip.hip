@@ -1,0 +1,812 @@
+// tinygemm_hip.hip -- hand-written gfx950 (MI355X / CDNA4) kernels + the C ABI of
+// include/tinygemm_hip.h.  Written for wave64 + v_mfma_f32_16x16x32_{bf16,f16}; there is no
+// CUDA path, no hipify output and no multi-backend dispatch in this file.
+//
+// Reference behaviour being replaced (facebookresearch/any4 @ 2025-07-18, file:line):
+//   tinygemm_lib/TinyGemmImpl.cuh:23-345      the split-K tile kernel
+//   tinygemm_lib/MatrixLayoutA.cuh:375-816    weights-as-A int4 load + dequant
+//   tinygemm_lib/MatrixLayoutB.cuh:686-1101   weights-as-B int4 load + dequant
+//   tinygemm_lib/Dequantization.cuh:17-178, 331-351
+//   tinygemm_lib/TinyGemm_int4.cu:294-548     host validation / dispatch
+//   tinygemm_lib/TinyGemm_bf16.cu:163-327     16-bit weights
+//   tinygemm_lib/TinyGemmConvert{A,B}.cu      layout / packing kernels
+//   tinygemm_lib/TinyGemmDequantize.cu:19-58  debug dequant op
+//
+// Design notes live in DESIGN.md; the short version of the GEMM kernel:
+//   * one workgroup = one 16-row weight tile, split-K over its waves (step = one 16-byte
+//     packed-weight load per lane = 1 KiB per wave, streamed with non-temporal loads);
+//   * W is the MFMA A operand (16 weight rows x 32 k), X the B operand (32 k x 16 activation
+//     rows).  The reference's packed words are consumed AS STORED: a 2x2 / 4x4 word transpose
+//     between the four 16-lane rows of the wave (v_permlane16_swap / v_permlane32_swap) gives
+//     every lane a contiguous k-chunk, so the X fragment is one contiguous 16-byte load;
+//   * the 16-entry LUT lives in LDS as f32, one private bank column per lane
+//     ([16 entries][64 lanes]) so the 8 data-dependent lookups per word never conflict;
+//     the lookup address is built with one v_perm_b32 per nibble;
+//   * dequant = v_fma_f32(lut, scale, zero) then v_cvt_pk_bf16_f32 (RNE): the f32 product of
+//     two 16-bit floats is exact, so this equals the reference's single-rounding bf16 fma;
+//   * fp32 partial tiles meet in LDS, a fixed-order sum gives a deterministic result.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/tinygemm_hip.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+
+__device__ __forceinline__ float u2f(uint32_t u) { return __builtin_bit_cast(float, u); }
+__device__ __forceinline__ uint32_t f2u(float f) { return __builtin_bit_cast(uint32_t, f); }
+
+// ---- 16-bit float traits ---------------------------------------------------------------------
+struct BF16 {
+  static __device__ __forceinline__ float to_f32(uint16_t h) { return u2f(((uint32_t)h) << 16); }
+  static __device__ __forceinline__ float lo_f32(uint32_t pair) { return u2f(pair << 16); }
+  static __device__ __forceinline__ float hi_f32(uint32_t pair) { return u2f(pair & 0xffff0000u); }
+  // round-to-nearest-even pack; lowers to v_cvt_pk_bf16_f32 on gfx950
+  static __device__ __forceinline__ uint32_t pack2(float a, float b) {
+    f32x2 v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+  }
+  static __device__ __forceinline__ uint16_t from_f32(float a) { return (uint16_t)(pack2(a, 0.f) & 0xffffu); }
+  static __device__ __forceinline__ f32x4 mfma(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  }
+};
+struct F16 {
+  static __device__ __forceinline__ float to_f32(uint16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
+  static __device__ __forceinline__ float lo_f32(uint32_t pair) { return to_f32((uint16_t)(pair & 0xffffu)); }
+  static __device__ __forceinline__ float hi_f32(uint32_t pair) { return to_f32((uint16_t)(pair >> 16)); }
+  static __device__ __forceinline__ uint32_t pack2(float a, float b) {
+    f32x2 v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2));
+  }
+  static __device__ __forceinline__ uint16_t from_f32(float a) { return (uint16_t)(pack2(a, 0.f) & 0xffffu); }
+  static __device__ __forceinline__ f32x4 mfma(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  }
+};
+
+// fp4-e2m1 values in code order (reference FloatDefs.cuh:18-34)
+__device__ const float kMX4Values[16] = {0.0f,  0.5f,  1.0f,  1.5f,  2.0f,  3.0f,  4.0f,  6.0f,
+                                         -0.0f, -0.5f, -1.0f, -1.5f, -2.0f, -3.0f, -4.0f, -6.0f};
+
+// ---- kernel parameters ----------------------------------------------------------------------
+struct GemmParams {
+  const char* x;
+  const char* w;
+  const char* qinfo;
+  const char* lut;
+  char* y;
+  int32_t m, wrows, k;
+  int32_t ntiles;   // packed.size(0): 8-row (Bint4) or 16-row (Aint4) tiles
+  int32_t ksuper;   // packed.size(1)
+  int32_t gshift;   // log2(group)
+  int32_t ngroups;  // k / group
+  int32_t qtype;
+  int64_t stride_x, stride_w, stride_qinfo, stride_lut, stride_y;
+};
+
+enum { CANON_NONE = 0, CANON_PAIR = 1, CANON_QUAD = 2 };
+
+// Word transpose between the four 16-lane rows of a wave so that every lane ends up with the
+// four words (q = 0..3) of ONE k-chunk.  See DESIGN.md "canonical chunk".
+template <int CANON>
+__device__ __forceinline__ void canonicalize(u32x4& w) {
+  if constexpr (CANON == CANON_PAIR) {
+    // lane holds (q=2p, j0) (q=2p, j1) (q=2p+1, j0) (q=2p+1, j1); partner row holds the other p.
+    auto r0 = __builtin_amdgcn_permlane16_swap(w[0], w[1], false, false);
+    auto r1 = __builtin_amdgcn_permlane16_swap(w[2], w[3], false, false);
+    // now (q0, q2, q1, q3) of one chunk
+    w = u32x4{r0[0], r1[0], r0[1], r1[1]};
+  } else if constexpr (CANON == CANON_QUAD) {
+    // lane row Q holds words j = 0..3 of q = Q: 4x4 transpose across the rows
+    auto r0 = __builtin_amdgcn_permlane16_swap(w[0], w[1], false, false);
+    auto r1 = __builtin_amdgcn_permlane16_swap(w[2], w[3], false, false);
+    auto s0 = __builtin_amdgcn_permlane32_swap(r0[0], r1[0], false, false);
+    auto s1 = __builtin_amdgcn_permlane32_swap(r0[1], r1[1], false, false);
+    w = u32x4{s0[0], s1[0], s0[1], s1[1]};
+  }
+}
+
+// One prefetch slot = everything a lane needs for one step.
+template <int NMMA>
+struct Slot {
+  u32x4 w;         // 4 packed words
+  uint32_t q;      // scale|zero pair (or mx4 exponent byte)
+  u32x4 x[NMMA];   // X fragments
+};
+
+template <typename DT, bool LAYOUT_A, int CANON, bool QMX, int WAVES, int DEPTH>
+__global__ void __launch_bounds__(WAVES * 64) w4_gemm_kernel(const GemmParams p) {
+  constexpr int CHUNK = LAYOUT_A ? 16 : 32;  // k covered by one lane per step
+  constexpr int KSTEP = 4 * CHUNK;           // k covered by one wave per step
+  constexpr int NMMA = LAYOUT_A ? 2 : 4;     // MFMAs per step
+  constexpr int WPL = (CANON == CANON_NONE) ? 1 : (CANON == CANON_PAIR ? 2 : 4);  // words per (t) in the packed layout
+
+  __shared__ float s_tab[16 * 64];        // [entry][lane] f32 LUT, one bank column per lane
+  __shared__ f32x4 s_red[WAVES * 64];     // split-K partial tiles
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 15;  // weight row within the tile (A operand) / activation row (B operand)
+  const int Q = lane >> 4;  // k-chunk selector
+  const int r = i & 7;
+
+  const int rt = blockIdx.x, ct = blockIdx.y;
+  const int64_t b = blockIdx.z;
+  const char* xb = p.x + b * p.stride_x;
+  const char* wb = p.w + b * p.stride_w;
+  const char* qb = p.qinfo + b * p.stride_qinfo;
+  const char* lb = p.lut ? p.lut + b * p.stride_lut : nullptr;
+  char* yb = p.y + b * p.stride_y;
+
+  const int row0 = rt * 16;
+  const int row = row0 + i;
+  const bool row_ok = row < p.wrows;
+
+  // ---- per-lane addressing of the packed weights ----
+  const int tile = LAYOUT_A ? rt : 2 * rt + (i >> 3);
+  const bool tile_ok = tile < p.ntiles;
+  int toff;
+  if constexpr (CANON == CANON_NONE) toff = 4 * r;
+  else if constexpr (CANON == CANON_PAIR) toff = 4 * r + 2 * (Q & 1);
+  else toff = 4 * r + Q;
+  const uint32_t* wlane = reinterpret_cast<const uint32_t*>(wb) + ((int64_t)tile * p.ksuper * 32 + toff) * WPL;
+
+  const int xrow = min(ct * 16 + i, p.m - 1);
+  const char* xlane = xb + ((int64_t)xrow * p.k + Q * CHUNK) * 2;
+
+  const int nsteps_total = (p.k + KSTEP - 1) / KSTEP;
+  // wave w owns steps w, w + WAVES, ...
+  const int nsteps = (nsteps_total - wave + WAVES - 1) / WAVES;
+
+  auto load_slot = [&](int j, Slot<NMMA>& sl) {
+    const int s = wave + j * WAVES;
+    const bool step_ok = j < nsteps;
+    int ks;
+    if constexpr (CANON == CANON_NONE) ks = 4 * s + Q;
+    else if constexpr (CANON == CANON_PAIR) ks = 2 * s + (Q >> 1);
+    else ks = s;
+    sl.w = u32x4{0, 0, 0, 0};
+    if (step_ok && tile_ok && ks < p.ksuper) {
+      sl.w = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wlane + (int64_t)ks * 32 * WPL));
+    }
+    const int kk = s * KSTEP + Q * CHUNK;  // first k of this lane's canonical chunk
+    const bool k_ok = step_ok && kk < p.k;
+    sl.q = QMX ? 127u : 0u;
+    if (k_ok && row_ok) {
+      const int g = kk >> p.gshift;
+      if constexpr (QMX) {
+        sl.q = reinterpret_cast<const uint8_t*>(qb)[(int64_t)row * p.ngroups + g];
+      } else {
+        sl.q = reinterpret_cast<const uint32_t*>(qb)[(int64_t)g * p.wrows + row];
+      }
+    }
+#pragma unroll
+    for (int h = 0; h < NMMA; ++h) {
+      sl.x[h] = u32x4{0, 0, 0, 0};
+      if (k_ok) sl.x[h] = *reinterpret_cast<const u32x4*>(xlane + ((int64_t)s * KSTEP + 8 * h) * 2);
+    }
+  };
+
+  Slot<NMMA> slots[DEPTH];
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d) load_slot(d, slots[d]);
+
+  // ---- build the f32 LUT in LDS while the first loads are in flight ----
+  for (int e = wave; e < 16; e += WAVES) {
+    float v;
+    if (p.qtype == TG_Q_INT4) {
+      v = (float)(e - 8);
+    } else if (p.qtype == TG_Q_MX4) {
+      v = kMX4Values[e];
+    } else if (p.qtype == TG_Q_ANY4_GLOBAL) {
+      v = DT::to_f32(reinterpret_cast<const uint16_t*>(lb)[e]);
+    } else {
+      v = row_ok ? DT::to_f32(reinterpret_cast<const uint16_t*>(lb)[(int64_t)row * 16 + e]) : 0.f;
+    }
+    s_tab[e * 64 + lane] = v;
+  }
+  __syncthreads();
+
+  const char* tabp = reinterpret_cast<const char*>(s_tab);
+  const uint32_t lane4 = (uint32_t)lane * 4u;
+  const uint32_t sh = LAYOUT_A ? (uint32_t)(i >> 3) * 4u : 0u;
+
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+
+  auto lookup = [&](uint32_t src, uint32_t sel) -> float {
+    // byte 0 <- lane*4, byte 1 <- the selected nibble-byte of src, bytes 2,3 <- 0
+    const uint32_t off = __builtin_amdgcn_perm(src, lane4, sel);
+    return *reinterpret_cast<const float*>(tabp + off);
+  };
+
+  auto process = [&](Slot<NMMA>& sl) {
+    u32x4 w = sl.w;
+    canonicalize<CANON>(w);
+    float s, z;
+    if constexpr (QMX) {
+      // e8m0: 2^(e-127), 255 -> NaN (reference Dequantization.cuh:331-339)
+      const uint32_t e = sl.q;
+      s = u2f(e == 255u ? 0x7fc00000u : (e == 0u ? 0x00400000u : (e << 23)));
+      z = 0.f;
+    } else {
+      s = DT::lo_f32(sl.q);
+      z = DT::hi_f32(sl.q);
+    }
+    if constexpr (!LAYOUT_A) {
+      // Bint4 word: nibble p holds v[e], p = {0,4,1,5,2,6,3,7}[e]; v[e] is k = 2q + 8(e>>1) + (e&1)
+      uint32_t wa[4], wb4[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        wa[q] = w[q] & 0x0f0f0f0fu;          // bytes: v0 v4 v1 v5
+        wb4[q] = (w[q] >> 4) & 0x0f0f0f0fu;  // bytes: v2 v6 v3 v7
+      }
+#pragma unroll
+      for (int h = 0; h < 4; ++h) {
+        u32x4 a;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const uint32_t src = (h & 1) ? wb4[q] : wa[q];
+          const float f0 = lookup(src, 0x0c0c0400u + ((uint32_t)(h >> 1) << 8));      // v[2h]   -> k = 8h + 2q
+          const float f1 = lookup(src, 0x0c0c0400u + ((uint32_t)((h >> 1) + 2) << 8));  // v[2h+1] -> k = 8h + 2q + 1
+          a[q] = DT::pack2(__builtin_fmaf(f0, s, z), __builtin_fmaf(f1, s, z));
+        }
+        acc = DT::mfma(a, sl.x[h], acc);
+      }
+    } else {
+      // Aint4 word: low nibbles = row r (k0 k2 k1 k3 in bytes 0..3), high nibbles = row r + 8
+      uint32_t ws[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) ws[q] = (w[q] >> sh) & 0x0f0f0f0fu;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        u32x4 a;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float f0 = lookup(ws[q], 0x0c0c0400u + ((uint32_t)h << 8));        // k = 8h + 2q
+          const float f1 = lookup(ws[q], 0x0c0c0400u + ((uint32_t)(h + 2) << 8));  // k = 8h + 2q + 1
+          a[q] = DT::pack2(__builtin_fmaf(f0, s, z), __builtin_fmaf(f1, s, z));
+        }
+        acc = DT::mfma(a, sl.x[h], acc);
+      }
+    }
+  };
+
+  for (int jb = 0; jb < nsteps; jb += DEPTH) {
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+      if (jb + d < nsteps) {
+        Slot<NMMA> cur = slots[d];
+        load_slot(jb + d + DEPTH, slots[d]);
+        process(cur);
+      }
+    }
+  }
+
+  // ---- split-K tail: partial tiles meet in LDS, fixed-order sum, 16-bit store ----
+  s_red[wave * 64 + lane] = acc;
+  __syncthreads();
+  if (tid < 256) {
+    const int c = tid >> 4, rr = tid & 15;  // 16 consecutive threads -> 16 consecutive weight rows
+    const float* red = reinterpret_cast<const float*>(s_red);
+    const int src = (((rr >> 2) * 16 + c) << 2) + (rr & 3);  // MFMA C/D: col = lane&15, row = 4*(lane>>4)+reg
+    float sum = 0.f;
+#pragma unroll
+    for (int wv = 0; wv < WAVES; ++wv) sum += red[wv * 256 + src];
+    const int col = ct * 16 + c;
+    const int rowg = row0 + rr;
+    if (col < p.m && rowg < p.wrows) {
+      reinterpret_cast<uint16_t*>(yb)[(int64_t)col * p.wrows + rowg] = DT::from_f32(sum);
+    }
+  }
+}
+
+// ---- 16-bit weights (reference TinyGemm_bf16.cu) ---------------------------------------------
+// Same tile/split-K structure; the A operand is gathered dword-wise from the fragment-order
+// tensor (each dword = two adjacent k of one row), no dequantisation.
+struct F16GemmParams {
+  const char* x;
+  const char* w;
+  char* y;
+  int32_t m, wrows, k;
+  int32_t ktiles_padded;  // k-tiles present in the TC tensor (size(1) * I)
+  int32_t inner;          // I
+};
+
+template <typename DT, bool LAYOUT_A, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64) f16_gemm_kernel(const F16GemmParams p) {
+  __shared__ f32x4 s_red[WAVES * 64];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 15, Q = lane >> 4, r = i & 7;
+  const int rt = blockIdx.x, ct = blockIdx.y;
+  const int row0 = rt * 16, row = row0 + i;
+  const bool row_ok = row < p.wrows;
+  const uint32_t* wd = reinterpret_cast<const uint32_t*>(p.w);
+  const int xrow = min(ct * 16 + i, p.m - 1);
+  const int nsteps_total = (p.k + 31) / 32;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int s = wave; s < nsteps_total; s += WAVES) {
+    // lane (i, Q): k = 32 s + 8 Q + 0..7  = k-tile kt, half hh
+    const int kt = 2 * s + (Q >> 1), hh = Q & 1;
+    const bool k_ok = (32 * s + 8 * Q) < p.k && kt < p.ktiles_padded;
+    u32x4 a = {0, 0, 0, 0}, xv = {0, 0, 0, 0};
+    if (k_ok && row_ok) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        int64_t idx;
+        if constexpr (LAYOUT_A) {
+          // [mT][kT][32][8 halfs] = 4 dwords: d0=(m0;k0,k1) d1=(m1;k0,k1) d2=(m0;k2,k3) d3=(m1;k2,k3)
+          idx = (((int64_t)rt * p.ktiles_padded + kt) * 32 + 4 * r + q) * 4 + 2 * hh + (i >> 3);
+        } else {
+          // [nT][kT/I][32][4 I halfs]: per k-tile 2 dwords d0=(k0,k1) d1=(k2,k3)
+          const int tile = 2 * rt + (i >> 3);
+          idx = ((((int64_t)tile * (p.ktiles_padded / p.inner) + kt / p.inner) * 32 + 4 * r + q) * p.inner + (kt % p.inner)) * 2 + hh;
+        }
+        a[q] = wd[idx];
+      }
+    }
+    if (k_ok) xv = *reinterpret_cast<const u32x4*>(p.x + ((int64_t)xrow * p.k + 32 * s + 8 * Q) * 2);
+    acc = DT::mfma(a, xv, acc);
+  }
+  s_red[wave * 64 + lane] = acc;
+  __syncthreads();
+  if (tid < 256) {
+    const int c = tid >> 4, rr = tid & 15;
+    const float* red = reinterpret_cast<const float*>(s_red);
+    const int src = (((rr >> 2) * 16 + c) << 2) + (rr & 3);
+    float sum = 0.f;
+#pragma unroll
+    for (int wv = 0; wv < WAVES; ++wv) sum += red[wv * 256 + src];
+    const int col = ct * 16 + c, rowg = row0 + rr;
+    if (col < p.m && rowg < p.wrows) reinterpret_cast<uint16_t*>(p.y)[(int64_t)col * p.wrows + rowg] = DT::from_f32(sum);
+  }
+}
+
+// ---- packing kernels (integer only, bit-exact) -----------------------------------------------
+// One workgroup stages a [ROWS x KB] tile of codes as bytes in LDS with fully coalesced 16-byte
+// reads of the int32 input, then every thread assembles output words from four 2-byte LDS reads
+// and writes them contiguously (the packed tile is contiguous in the output tensor).
+
+// Bint4: tile = 8 rows (one n-tile) x KB k.   ref TinyGemmConvertB.cu:252-308
+template <int I>
+__global__ void __launch_bounds__(256) pack_Bint4_kernel(const int32_t* __restrict__ in, int32_t* __restrict__ out,
+                                                        int64_t n, int64_t k, int64_t ksuper) {
+  constexpr int KB = 512;  // k per workgroup; multiple of 16*I for I <= 8
+  __shared__ uint8_t s_codes[8][KB + 16];
+  const int tid = threadIdx.x;
+  const int64_t nT = blockIdx.y;
+  const int64_t kb0 = (int64_t)blockIdx.x * KB;
+  // load: 8 rows x 512 ints = 1024 x int4
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int idx = it * 256 + tid;
+    const int rr = idx >> 7, c4 = idx & 127;
+    const int64_t row = nT * 8 + rr, kk = kb0 + c4 * 4;
+    uint32_t pk = 0;
+    if (row < n && kk < k) {  // k % 32 == 0 -> whole int4 in range
+      const int4 v = *reinterpret_cast<const int4*>(in + row * k + kk);
+      pk = ((uint32_t)v.x & 0xffu) | (((uint32_t)v.y & 0xffu) << 8) | (((uint32_t)v.z & 0xffu) << 16) | ((uint32_t)v.w << 24);
+    }
+    *reinterpret_cast<uint32_t*>(&s_codes[rr][c4 * 4]) = pk;
+  }
+  __syncthreads();
+  // words of this tile: [kS_local][t][j], KB/(16 I) super-tiles x 32 x I/2 = KB words
+  constexpr int WORDS = KB;  // 8 rows * KB / 8
+#pragma unroll
+  for (int it = 0; it < WORDS / 256; ++it) {
+    const int wi = it * 256 + tid;
+    const int j = wi % (I / 2);
+    const int t = (wi / (I / 2)) & 31;
+    const int ksl = wi / (16 * I);
+    const int64_t ks = kb0 / (16 * I) + ksl;
+    if (ks >= ksuper) continue;
+    const int rr = t >> 2, q = t & 3;
+    const int kl = (ksl * I + 2 * j) * 16 + 2 * q;
+    const uint8_t* src = &s_codes[rr][kl];
+    uint32_t v[8];
+#pragma unroll
+    for (int pr = 0; pr < 4; ++pr) {
+      const uint32_t two = *reinterpret_cast<const uint16_t*>(src + 8 * pr);
+      v[2 * pr] = two & 0xffu;
+      v[2 * pr + 1] = two >> 8;
+    }
+    const uint32_t pack = (v[7] << 28) | (v[5] << 24) | (v[3] << 20) | (v[1] << 16) | (v[6] << 12) | (v[4] << 8) | (v[2] << 4) | v[0];
+    out[((nT * ksuper + ks) * 32 + t) * (I / 2) + j] = (int32_t)pack;
+  }
+}
+
+// Aint4: tile = 16 rows (one m-tile) x KB k.   ref TinyGemmConvertA.cu:226-285
+template <int I>
+__global__ void __launch_bounds__(256) pack_Aint4_kernel(const int32_t* __restrict__ in, int32_t* __restrict__ out,
+                                                        int64_t m, int64_t k, int64_t ksuper) {
+  constexpr int KB = 256;
+  __shared__ uint8_t s_codes[16][KB + 16];
+  const int tid = threadIdx.x;
+  const int64_t mT = blockIdx.y;
+  const int64_t kb0 = (int64_t)blockIdx.x * KB;
+  const bool vec_ok = (k & 3) == 0;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int idx = it * 256 + tid;
+    const int rr = idx >> 6, c4 = idx & 63;
+    const int64_t row = mT * 16 + rr, kk = kb0 + c4 * 4;
+    uint32_t pk = 0;
+    if (row < m) {
+      if (vec_ok && kk + 3 < k) {
+        const int4 v = *reinterpret_cast<const int4*>(in + row * k + kk);
+        pk = ((uint32_t)v.x & 0xffu) | (((uint32_t)v.y & 0xffu) << 8) | (((uint32_t)v.z & 0xffu) << 16) | ((uint32_t)v.w << 24);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (kk + e < k) pk |= ((uint32_t)in[row * k + kk + e] & 0xffu) << (8 * e);
+      }
+    }
+    *reinterpret_cast<uint32_t*>(&s_codes[rr][c4 * 4]) = pk;
+  }
+  __syncthreads();
+  // words of this tile: [kS_local][t][inner]: KB/16 k-tiles x 32 = 512 words
+  constexpr int WORDS = KB * 2;
+#pragma unroll
+  for (int it = 0; it < WORDS / 256; ++it) {
+    const int wi = it * 256 + tid;
+    const int inner = wi % I;
+    const int t = (wi / I) & 31;
+    const int ksl = wi / (32 * I);
+    const int64_t ks = kb0 / (16 * I) + ksl;
+    if (ks >= ksuper) continue;
+    const int m0 = t >> 2, q = t & 3;
+    const int kl = (ksl * I + inner) * 16 + 2 * q;
+    const uint32_t a0 = *reinterpret_cast<const uint16_t*>(&s_codes[m0][kl]);          // (m0,k0) (m0,k1)
+    const uint32_t b0 = *reinterpret_cast<const uint16_t*>(&s_codes[m0 + 8][kl]);      // (m1,k0) (m1,k1)
+    const uint32_t a1 = *reinterpret_cast<const uint16_t*>(&s_codes[m0][kl + 8]);      // (m0,k2) (m0,k3)
+    const uint32_t b1 = *reinterpret_cast<const uint16_t*>(&s_codes[m0 + 8][kl + 8]);  // (m1,k2) (m1,k3)
+    const uint32_t v0 = a0 & 0xffu, v1 = a0 >> 8, v2 = b0 & 0xffu, v3 = b0 >> 8;
+    const uint32_t v4 = a1 & 0xffu, v5 = a1 >> 8, v6 = b1 & 0xffu, v7 = b1 >> 8;
+    const uint32_t pack = (v7 << 28) | (v5 << 24) | (v3 << 20) | (v1 << 16) | (v6 << 12) | (v4 << 8) | (v2 << 4) | v0;
+    out[((mT * ksuper + ks) * 32 + t) * I + inner] = (int32_t)pack;
+  }
+}
+
+// ---- 16-bit fragment-order conversions (pure data movement) ------------------------------------
+// ref TinyGemmConvertA.cu:19-141 / 442-546 and TinyGemmConvertB.cu:20-66 / 136-176
+__global__ void __launch_bounds__(256) to_A16_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out,
+                                                    int64_t m, int64_t k, int64_t mTiles, int64_t kTiles) {
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= mTiles * kTiles * 32) return;
+  const int t = gid & 31;
+  const int64_t kT = (gid >> 5) % kTiles, mT = (gid >> 5) / kTiles;
+  const int64_t m0 = mT * 16 + (t >> 2), m1 = m0 + 8;
+  const int64_t k0 = kT * 16 + (t & 3) * 2;
+  uint16_t v[8];
+  auto at = [&](int64_t rr, int64_t cc) -> uint16_t { return (rr < m && cc < k) ? in[rr * k + cc] : (uint16_t)0; };
+  v[0] = at(m0, k0); v[1] = at(m0, k0 + 1); v[2] = at(m1, k0); v[3] = at(m1, k0 + 1);
+  v[4] = at(m0, k0 + 8); v[5] = at(m0, k0 + 9); v[6] = at(m1, k0 + 8); v[7] = at(m1, k0 + 9);
+  u32x4 o = {v[0] | ((uint32_t)v[1] << 16), v[2] | ((uint32_t)v[3] << 16), v[4] | ((uint32_t)v[5] << 16), v[6] | ((uint32_t)v[7] << 16)};
+  *reinterpret_cast<u32x4*>(out + gid * 8) = o;
+}
+
+__global__ void __launch_bounds__(256) from_A16_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out,
+                                                      int64_t m, int64_t k, int64_t mTiles, int64_t kTiles) {
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= mTiles * kTiles * 32) return;
+  const int t = gid & 31;
+  const int64_t kT = (gid >> 5) % kTiles, mT = (gid >> 5) / kTiles;
+  const u32x4 o = *reinterpret_cast<const u32x4*>(in + gid * 8);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int64_t rr = mT * 16 + (t >> 2) + 8 * ((e >> 1) & 1);
+    const int64_t cc = kT * 16 + (t & 3) * 2 + 8 * (e >> 2) + (e & 1);
+    const uint16_t val = (uint16_t)(o[e >> 1] >> (16 * (e & 1)));
+    if (rr < m && cc < k) out[rr * k + cc] = val;
+  }
+}
+
+__global__ void __launch_bounds__(256) to_B16_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out,
+                                                    int64_t n, int64_t k, int64_t nTiles, int64_t totalK, int inner) {
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= nTiles * totalK * 32) return;
+  const int t = gid & 31;
+  const int64_t kT = (gid >> 5) % totalK, nT = (gid >> 5) / totalK;
+  const int64_t n0 = nT * 8 + (t >> 2);
+  const int64_t k0 = kT * 16 + (t & 3) * 2;
+  auto at = [&](int64_t cc) -> uint32_t { return (n0 < n && cc < k) ? in[n0 * k + cc] : 0u; };
+  u32x2 o = {at(k0) | (at(k0 + 1) << 16), at(k0 + 8) | (at(k0 + 9) << 16)};
+  uint16_t* dst = out + ((nT * (totalK / inner) + kT / inner) * 32 + t) * (4 * inner) + (kT % inner) * 4;
+  *reinterpret_cast<u32x2*>(dst) = o;
+}
+
+__global__ void __launch_bounds__(256) from_B16_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out,
+                                                      int64_t n, int64_t k, int64_t nTiles, int64_t kTiles,
+                                                      int64_t outerK, int inner) {
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= nTiles * kTiles * 32) return;
+  const int t = gid & 31;
+  const int64_t kT = (gid >> 5) % kTiles, nT = (gid >> 5) / kTiles;
+  const int64_t n0 = nT * 8 + (t >> 2);
+  if (n0 >= n) return;
+  const uint16_t* src = in + ((nT * outerK + kT / inner) * 32 + t) * (4 * inner) + (kT % inner) * 4;
+  const u32x2 o = *reinterpret_cast<const u32x2*>(src);
+  const int64_t k0 = kT * 16 + (t & 3) * 2;
+  const int64_t ks[4] = {k0, k0 + 1, k0 + 8, k0 + 9};
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    if (ks[e] < k) out[n0 * k + ks[e]] = (uint16_t)(o[e >> 1] >> (16 * (e & 1)));
+}
+
+// debug op, ref TinyGemmDequantize.cu:19-34 (grid-stride, one word -> 8 bf16 = 16 bytes)
+__global__ void __launch_bounds__(256) dequant_int4_kernel(const int32_t* __restrict__ in, u32x4* __restrict__ out, int64_t count) {
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < count; idx += (int64_t)gridDim.x * 256) {
+    const uint32_t w = (uint32_t)in[idx];
+    u32x4 o;
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii) {
+      const float lo = (float)((int)((w >> (4 * ii)) & 0xfu) - 8);
+      const float hi = (float)((int)((w >> (4 * ii + 16)) & 0xfu) - 8);
+      o[ii] = BF16::pack2(lo, hi);
+    }
+    out[idx] = o;
+  }
+}
+
+// ---- host side ---------------------------------------------------------------------------------
+
+struct DeviceScope {
+  int prev = -1;
+  bool ok = true;
+  explicit DeviceScope(int device) {
+    if (device < 0) return;
+    if (hipGetDevice(&prev) != hipSuccess) { ok = false; return; }
+    if (prev != device && hipSetDevice(device) != hipSuccess) ok = false;
+    if (prev == device) prev = -1;
+  }
+  ~DeviceScope() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+
+inline int launch_status() {
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : (int)e;
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+template <typename DT, bool LAYOUT_A, int CANON, bool QMX>
+int launch_w4(const GemmParams& p, dim3 grid, hipStream_t st) {
+  // 16 waves x depth 2 keeps 32 KiB of packed weights in flight per CU at one tile per CU
+  constexpr int WAVES = 16, DEPTH = 2;
+  hipLaunchKernelGGL((w4_gemm_kernel<DT, LAYOUT_A, CANON, QMX, WAVES, DEPTH>), grid, dim3(WAVES * 64), 0, st, p);
+  return launch_status();
+}
+
+template <typename DT, bool LAYOUT_A, int CANON>
+int launch_w4_q(const GemmParams& p, dim3 grid, hipStream_t st) {
+  return p.qtype == TG_Q_MX4 ? launch_w4<DT, LAYOUT_A, CANON, true>(p, grid, st)
+                             : launch_w4<DT, LAYOUT_A, CANON, false>(p, grid, st);
+}
+
+template <typename DT, bool LAYOUT_A>
+int launch_w4_c(const GemmParams& p, int canon, dim3 grid, hipStream_t st) {
+  switch (canon) {
+    case CANON_NONE: return launch_w4_q<DT, LAYOUT_A, CANON_NONE>(p, grid, st);
+    case CANON_PAIR: return launch_w4_q<DT, LAYOUT_A, CANON_PAIR>(p, grid, st);
+    default: return launch_w4_q<DT, LAYOUT_A, CANON_QUAD>(p, grid, st);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int tg_abi_version(void) { return TG_ABI_VERSION; }
+
+const char* tg_error_string(int code) {
+  switch (code) {
+    case 0: return "ok";
+    case TG_E_NULL: return "a required tensor is missing (null data pointer)";
+    case TG_E_INNER_K: return "innerKTiles is not valid for this layout (Aint4/A: 1,2,4; Bint4: 2,4,8; B16: 1,2; A16: 1)";
+    case TG_E_K_DIV: return "k must be a multiple of 32 and of innerKTiles * 16 (isEvenDivisor(k, 32), isEvenDivisor(kTiles, innerKTiles))";
+    case TG_E_GROUP: return "qGroupSize must be 32, 64, 128 or 256 and divide k";
+    case TG_E_DTYPE: return "activation dtype must be bfloat16 or float16 (mx4: bfloat16 only)";
+    case TG_E_QTYPE: return "unknown 4-bit quantization type";
+    case TG_E_SHAPE: return "inconsistent or non-positive sizes";
+    case TG_E_ALIGN: return "device buffers must be 16-byte aligned";
+    case TG_E_DEVICE: return "could not select the requested device";
+    default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown tinygemm error";
+  }
+}
+
+int tg_convert_to_Bint4(const int32_t* in, int64_t n, int64_t k, int I, int32_t* out, int device, tg_stream_t stream) {
+  if (!in || !out) return TG_E_NULL;
+  if (!(I == 2 || I == 4 || I == 8)) return TG_E_INNER_K;  // ConvertB.cu:327
+  if (n <= 0 || k <= 0) return TG_E_SHAPE;
+  if (k % (I * 16) != 0) return TG_E_K_DIV;               // ConvertB.cu:337
+  if (!aligned16(in)) return TG_E_ALIGN;
+  DeviceScope ds(device);
+  if (!ds.ok) return TG_E_DEVICE;
+  const int64_t nTiles = cdiv(n, 8), ksuper = k / (I * 16);
+  dim3 grid((unsigned)cdiv(k, 512), (unsigned)nTiles);
+  hipStream_t st = (hipStream_t)stream;
+  if (I == 2) hipLaunchKernelGGL(pack_Bint4_kernel<2>, grid, dim3(256), 0, st, in, out, n, k, ksuper);
+  else if (I == 4) hipLaunchKernelGGL(pack_Bint4_kernel<4>, grid, dim3(256), 0, st, in, out, n, k, ksuper);
+  else hipLaunchKernelGGL(pack_Bint4_kernel<8>, grid, dim3(256), 0, st, in, out, n, k, ksuper);
+  return launch_status();
+}
+
+int tg_convert_to_Aint4(const int32_t* in, int64_t m, int64_t k, int I, int32_t* out, int device, tg_stream_t stream) {
+  if (!in || !out) return TG_E_NULL;
+  if (!(I == 1 || I == 2 || I == 4)) return TG_E_INNER_K;  // ConvertA.cu:299
+  if (m <= 0 || k <= 0) return TG_E_SHAPE;
+  if (!aligned16(in)) return TG_E_ALIGN;
+  DeviceScope ds(device);
+  if (!ds.ok) return TG_E_DEVICE;
+  const int64_t mTiles = cdiv(m, 16), ksuper = cdiv(k, I * 16);
+  dim3 grid((unsigned)cdiv(ksuper * I * 16, 256), (unsigned)mTiles);
+  hipStream_t st = (hipStream_t)stream;
+  if (I == 1) hipLaunchKernelGGL(pack_Aint4_kernel<1>, grid, dim3(256), 0, st, in, out, m, k, ksuper);
+  else if (I == 2) hipLaunchKernelGGL(pack_Aint4_kernel<2>, grid, dim3(256), 0, st, in, out, m, k, ksuper);
+  else hipLaunchKernelGGL(pack_Aint4_kernel<4>, grid, dim3(256), 0, st, in, out, m, k, ksuper);
+  return launch_status();
+}
+
+int tg_convert_to_A16(const void* rm, int64_t m, int64_t k, void* tc, int device, tg_stream_t stream) {
+  if (!rm || !tc) return TG_E_NULL;
+  if (m <= 0 || k <= 0) return TG_E_SHAPE;
+  if (!aligned16(tc)) return TG_E_ALIGN;
+  DeviceScope ds(device);
+  if (!ds.ok) return TG_E_DEVICE;
+  const int64_t mT = cdiv(m, 16), kT = cdiv(k, 16);
+  hipLaunchKernelGGL(to_A16_kernel, dim3((unsigned)cdiv(mT * kT * 32, 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const uint16_t*)rm, (uint16_t*)tc, m, k, mT, kT);
+  return launch_status();
+}
+
+int tg_convert_from_A16(const void* tc, int64_t m, int64_t k, void* rm, int device, tg_stream_t stream) {
+  if (!rm || !tc) return TG_E_NULL;
+  if (m <= 0 || k <= 0) return TG_E_SHAPE;
+  if (!aligned16(tc)) return TG_E_ALIGN;
+  DeviceScope ds(device);
+  if (!ds.ok) return TG_E_DEVICE;
+  const int64_t mT = cdiv(m, 16), kT = cdiv(k, 16);
+  hipLaunchKernelGGL(from_A16_kernel, dim3((unsigned)cdiv(mT * kT * 32, 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const uint16_t*)tc, (uint16_t*)rm, m, k, mT, kT);
+  return launch_status();
+}
+
+int tg_convert_to_B16(const void* rm, int64_t n, int64_t k, int I, void* tc, int device, tg_stream_t stream) {
+  if (!rm || !tc) return TG_E_NULL;
+  if (!(I == 1 || I == 2)) return TG_E_INNER_K;  // ConvertB.cu:84
+  if (n <= 0 || k <= 0) return TG_E_SHAPE;
+  if (!aligned16(tc)) return TG_E_ALIGN;
+  DeviceScope ds(device);
+  if (!ds.ok) return TG_E_DEVICE;
+  const int64_t nT = cdiv(n, 8), totalK = cdiv(k, 16 * I) * I;
+  hipLaunchKernelGGL(to_B16_kernel, dim3((unsigned)cdiv(nT * totalK * 32, 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const uint16_t*)rm, (uint16_t*)tc, n, k, nT, totalK, I);
+  return launch_status();
+}
+
+int tg_convert_from_B16(const void* tc, int64_t n, int64_t k, int I, void* rm, int device, tg_stream_t stream) {
+  if (!rm || !tc) return TG_E_NULL;
+  if (!(I == 1 || I == 2)) return TG_E_INNER_K;
+  if (n <= 0 || k <= 0) return TG_E_SHAPE;
+  if (!aligned16(tc)) return TG_E_ALIGN;
+  DeviceScope ds(device);
+  if (!ds.ok) return TG_E_DEVICE;
+  const int64_t nT = cdiv(n, 8), kT = cdiv(k, 16), outerK = cdiv(k, 16 * I);
+  hipLaunchKernelGGL(from_B16_kernel, dim3((unsigned)cdiv(nT * kT * 32, 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const uint16_t*)tc, (uint16_t*)rm, n, k, nT, kT, outerK, I);
+  return launch_status();
+}
+
+int tg_dequant_int4(const int32_t* in, int64_t count, void* out_bf16, int device, tg_stream_t stream) {
+  if (!in || !out_bf16) return TG_E_NULL;
+  if (count <= 0) return TG_E_SHAPE;
+  if (!aligned16(out_bf16)) return TG_E_ALIGN;
+  DeviceScope ds(device);
+  if (!ds.ok) return TG_E_DEVICE;
+  const int64_t blocks = cdiv(count, 256);
+  hipLaunchKernelGGL(dequant_int4_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0,
+                     (hipStream_t)stream, in, (u32x4*)out_bf16, count);
+  return launch_status();
+}
+
+int tg_gemm_w4(const tg_w4_gemm* a, int device, tg_stream_t stream) {
+  if (!a || !a->x || !a->w || !a->qinfo || !a->y) return TG_E_NULL;
+  if (a->qtype < TG_Q_INT4 || a->qtype > TG_Q_MX4) return TG_E_QTYPE;
+  if ((a->qtype == TG_Q_ANY4_GLOBAL || a->qtype == TG_Q_ANY4_ROWWISE) && !a->lut) return TG_E_NULL;
+  if (!(a->dtype == TG_BF16 || a->dtype == TG_F16)) return TG_E_DTYPE;
+  if (a->qtype == TG_Q_MX4 && a->dtype != TG_BF16) return TG_E_DTYPE;  // TinyGemm_int4.cu:758,782
+  if (a->m <= 0 || a->wrows <= 0 || a->k <= 0 || a->m > INT32_MAX || a->wrows > INT32_MAX || a->k > INT32_MAX) return TG_E_SHAPE;
+  const int I = a->inner_k_tiles;
+  const bool on_right = a->w_on_right != 0;
+  if (on_right ? !(I == 2 || I == 4 || I == 8) : !(I == 1 || I == 2 || I == 4)) return TG_E_INNER_K;
+  // TinyGemmImpl.cuh:370-376: kTiles % innerKTiles == 0, k % 32 == 0
+  if (a->k % 32 != 0 || a->k % (16 * I) != 0) return TG_E_K_DIV;
+  const int g = a->group;
+  if (!(g == 32 || g == 64 || g == 128 || g == 256) || a->k % g != 0) return TG_E_GROUP;  // TinyGemm_int4.cu:379-387
+  const int rows_per_tile = on_right ? 8 : 16;
+  if (a->wrows % rows_per_tile != 0) return TG_E_SHAPE;
+  if (!aligned16(a->x) || !aligned16(a->w) || (reinterpret_cast<uintptr_t>(a->qinfo) & 3u)) return TG_E_ALIGN;
+  const int batch = a->batch > 1 ? a->batch : 1;
+  if (batch > 1 && ((a->stride_x | a->stride_w) & 15)) return TG_E_ALIGN;
+
+  GemmParams p;
+  p.x = (const char*)a->x;
+  p.w = (const char*)a->w;
+  p.qinfo = (const char*)a->qinfo;
+  p.lut = (const char*)a->lut;
+  p.y = (char*)a->y;
+  p.m = (int32_t)a->m;
+  p.wrows = (int32_t)a->wrows;
+  p.k = (int32_t)a->k;
+  p.ntiles = (int32_t)(a->wrows / rows_per_tile);
+  p.ksuper = (int32_t)(a->k / (16 * I));
+  p.gshift = g == 32 ? 5 : g == 64 ? 6 : g == 128 ? 7 : 8;
+  p.ngroups = (int32_t)(a->k / g);
+  p.qtype = a->qtype;
+  p.stride_x = batch > 1 ? a->stride_x : 0;
+  p.stride_w = batch > 1 ? a->stride_w : 0;
+  p.stride_qinfo = batch > 1 ? a->stride_qinfo : 0;
+  p.stride_lut = batch > 1 ? a->stride_lut : 0;
+  p.stride_y = batch > 1 ? a->stride_y : 0;
+
+  DeviceScope ds(device);
+  if (!ds.ok) return TG_E_DEVICE;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((unsigned)cdiv(a->wrows, 16), (unsigned)cdiv(a->m, 16), (unsigned)batch);
+  // packed words per lane-quad in the layout decide the in-register transpose
+  const int canon = on_right ? (I == 2 ? CANON_NONE : I == 4 ? CANON_PAIR : CANON_QUAD)
+                             : (I == 1 ? CANON_NONE : I == 2 ? CANON_PAIR : CANON_QUAD);
+  if (a->dtype == TG_BF16) {
+    return on_right ? launch_w4_c<BF16, false>(p, canon, grid, st) : launch_w4_c<BF16, true>(p, canon, grid, st);
+  }
+  return on_right ? launch_w4_c<F16, false>(p, canon, grid, st) : launch_w4_c<F16, true>(p, canon, grid, st);
+}
+
+int tg_gemm_f16(const void* x, const void* w, void* y, int64_t m, int64_t wrows, int64_t k, int dtype,
+                int w_on_right, int I, int device, tg_stream_t stream) {
+  if (!x || !w || !y) return TG_E_NULL;
+  if (!(dtype == TG_BF16 || dtype == TG_F16)) return TG_E_DTYPE;
+  if (m <= 0 || wrows <= 0 || k <= 0 || m > INT32_MAX || wrows > INT32_MAX || k > INT32_MAX) return TG_E_SHAPE;
+  if (w_on_right ? !(I == 1 || I == 2) : I != 1) return TG_E_INNER_K;
+  if (k % 32 != 0) return TG_E_K_DIV;  // TinyGemmImpl.cuh:376
+  if (wrows % (w_on_right ? 8 : 16) != 0) return TG_E_SHAPE;
+  if (!aligned16(x) || !aligned16(w)) return TG_E_ALIGN;
+  F16GemmParams p;
+  p.x = (const char*)x;
+  p.w = (const char*)w;
+  p.y = (char*)y;
+  p.m = (int32_t)m;
+  p.wrows = (int32_t)wrows;
+  p.k = (int32_t)k;
+  p.inner = I;
+  p.ktiles_padded = (int32_t)(cdiv(k, 16 * I) * I);
+  DeviceScope ds(device);
+  if (!ds.ok) return TG_E_DEVICE;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((unsigned)cdiv(wrows, 16), (unsigned)cdiv(m, 16));
+  constexpr int WAVES = 8;
+  if (dtype == TG_BF16) {
+    if (w_on_right) hipLaunchKernelGGL((f16_gemm_kernel<BF16, false, WAVES>), grid, dim3(WAVES * 64), 0, st, p);
+    else hipLaunchKernelGGL((f16_gemm_kernel<BF16, true, WAVES>), grid, dim3(WAVES * 64), 0, st, p);
+  } else {
+    if (w_on_right) hipLaunchKernelGGL((f16_gemm_kernel<F16, false, WAVES>), grid, dim3(WAVES * 64), 0, st, p);
+    else hipLaunchKernelGGL((f16_gemm_kernel<F16, true, WAVES>), grid, dim3(WAVES * 64), 0, st, p);
+  }
+  return launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,139 @@
+"""Quantized Linear modules with the reference's class names, constructor kwargs, parameter /
+attribute names and `reshape_weight()` protocol (modules.py:12-230 in facebookresearch/any4), so that
+`quantize.{intq,anyq}_layer`, `eval.py` and `benchmark.py` can use them unchanged.
+
+Parameters:
+  weight            int32 [out][in] codes 0..15; after reshape_weight(): the packed 4-D int32 tensor
+  scales_and_zeros  [in / group_size][out][2]
+  lut               Any4Linear only: [out][16] (per_row) or [16]
+  bias              optional [out]
+The string attribute `kernel` names the functional (any4_amd/functional.py) used by forward().
+"""
+from __future__ import annotations
+
+import torch
+
+from . import functional as F
+
+_T = torch.ops.tinygemm
+
+
+class _PackedLinear(torch.nn.Module):
+    """Shared machinery: parameter creation, one-off packing and the forward epilogue."""
+
+    # kernel name -> which packer produces the layout that kernel consumes
+    _PACKERS: dict = {}
+    _DEFAULT_INNER_K = 4
+
+    def _make_common(self, in_features, out_features, bias, device, dtype, group_size, kernel, w_inner_k, zero_init):
+        self.in_features = in_features
+        self.out_features = out_features
+        self.group_size = group_size
+        alloc = torch.zeros if zero_init else torch.empty
+        self.weight = torch.nn.Parameter(alloc((out_features, in_features), device=device, dtype=torch.int32), requires_grad=False)
+        self.scales_and_zeros = torch.nn.Parameter(alloc((in_features // group_size, out_features, 2), device=device, dtype=dtype))
+        if bias:
+            self.bias = torch.nn.Parameter(torch.empty(out_features, device=device, dtype=dtype))
+        else:
+            self.register_parameter("bias", None)
+        self.kernel = kernel
+        self.w_inner_k = w_inner_k
+        self.weight_reshaped = False
+
+    def reshape_weight(self, w_inner_k: int | None = None):
+        """Pack `weight` once into the layout `self.kernel` consumes."""
+        if w_inner_k is None:
+            w_inner_k = self._DEFAULT_INNER_K
+        packer = self._PACKERS.get(self.kernel)
+        if packer is None:
+            raise ValueError(f"Unsupported kernel type {self.kernel}")
+        self.weight.data = getattr(_T, packer)(self.weight, w_inner_k)
+        self.weight_reshaped = True
+        self.w_inner_k = w_inner_k
+
+    def _gemm(self, x2d: torch.Tensor) -> torch.Tensor:
+        raise NotImplementedError
+
+    def forward(self, input: torch.Tensor) -> torch.Tensor:
+        lead = input.shape[:-1]
+        y = self._gemm(input.view(-1, input.shape[-1]))
+        if self.bias is not None:
+            y = y + self.bias
+        return y.view(*lead, y.shape[-1])
+
+    def extra_repr(self) -> str:
+        return (f"in_features={self.in_features}, out_features={self.out_features}, bias={self.bias is not None}, "
+                f"group_size={self.group_size}")
+
+
+class Int4Linear(_PackedLinear):
+    _PACKERS = {
+        "linear_y_f16RM_x_f16RM_W_int4TC": "convert_matrix_to_m16n8k16_Bint4_layout",
+        "linear_y_f16RM_W_int4TC_x_f16RM": "convert_matrix_to_m16n8k16_Aint4_layout",
+        "linear_y_f16TC_x_f16TC_W_int4TC": "convert_matrix_to_m16n8k16_Bint4_layout",
+    }
+    _KERNELS = ("linear_y_f16RM_x_f16RM_W_int4TC", "linear_y_f16RM_W_int4TC_x_f16RM",
+                "linear_y_f16TC_W_int4TC_x_f16TC", "linear_y_f16TC_x_f16TC_W_int4TC")
+
+    def __init__(self, in_features: int, out_features: int, bias: bool = True, device=None, dtype=None,
+                 group_size: int = 128, kernel: str = "linear_y_f16RM_W_int4TC_x_f16RM", w_inner_k: int = 4) -> None:
+        super().__init__()
+        self._make_common(in_features, out_features, bias, device, dtype, group_size, kernel, w_inner_k, zero_init=True)
+
+    def _gemm(self, x):
+        if self.kernel not in self._KERNELS:
+            raise ValueError(f"Unsupported kernel type {self.kernel}")
+        return getattr(F, self.kernel)(x, self.weight, self.scales_and_zeros, self.group_size,
+                                       w_inner_k=self.w_inner_k, reshape_weight=not self.weight_reshaped)
+
+
+class Int8Linear(_PackedLinear):
+    """API parity only: the int8 kernels are not part of this build, the ops raise."""
+    _PACKERS = {
+        "linear_y_f16RM_x_f16RM_W_int8TC": "convert_matrix_to_m16n8k16_Bint8_layout",
+        "linear_y_f16RM_W_int8TC_x_f16RM": "convert_matrix_to_m16n8k16_Aint8_layout",
+    }
+    _KERNELS = ("linear_y_f16RM_x_f16RM_W_int8TC", "linear_y_f16RM_W_int8TC_x_f16RM", "linear_y_f16TC_W_int8TC_x_f16TC")
+    _DEFAULT_INNER_K = 2
+
+    def __init__(self, in_features: int, out_features: int, bias: bool = True, device=None, dtype=None,
+                 group_size: int = 128, kernel: str = "linear_y_f16RM_W_int8TC_x_f16RM", w_inner_k: int = 2) -> None:
+        super().__init__()
+        self._make_common(in_features, out_features, bias, device, dtype, group_size, kernel, w_inner_k, zero_init=True)
+
+    def _gemm(self, x):
+        if self.kernel not in self._KERNELS:
+            raise ValueError(f"Unsupported kernel type {self.kernel}")
+        return getattr(F, self.kernel)(x, self.weight, self.scales_and_zeros, self.group_size,
+                                       w_inner_k=self.w_inner_k, reshape_weight=not self.weight_reshaped)
+
+
+class Any4Linear(_PackedLinear):
+    _N_BIT = 4
+    _PACKERS = {
+        "linear_y_f16RM_x_f16RM_W_any4TC": "convert_matrix_to_m16n8k16_Bint4_layout",
+        "linear_y_f16RM_W_any4TC_x_f16RM": "convert_matrix_to_m16n8k16_Aint4_layout",
+    }
+
+    @property
+    def N_BIT(self):
+        return self._N_BIT
+
+    def __init__(self, in_features: int, out_features: int, bias: bool = True, device=None, dtype=None,
+                 group_size: int = 128, kernel: str = "linear_y_f16RM_x_f16RM_W_any4TC", w_inner_k: int = 4,
+                 per_row: bool = True) -> None:
+        super().__init__()
+        self.n_bit = 4
+        self._make_common(in_features, out_features, bias, device, dtype, group_size, kernel, w_inner_k, zero_init=False)
+        self.per_row = per_row
+        lut_shape = (out_features, 2 ** self.N_BIT) if per_row else (2 ** self.N_BIT,)
+        self.lut = torch.nn.Parameter(torch.empty(*lut_shape, device=device, dtype=dtype))
+
+    def _gemm(self, x):
+        if self.kernel not in self._PACKERS:
+            raise ValueError(f"Unsupported kernel type {self.kernel}")
+        return getattr(F, self.kernel)(x, self.weight, self.lut, self.scales_and_zeros, self.group_size,
+                                       w_inner_k=self.w_inner_k, reshape_weight=not self.weight_reshaped)
+
+    def extra_repr(self) -> str:
+        return super().extra_repr() + f", per_row={self.per_row}"

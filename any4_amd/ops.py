@@ -1,0 +1,364 @@
+"""`torch.ops.tinygemm.*` -- the reference's op surface (tinygemm_lib/TinyGemm.cpp:17-122), registered
+from Python with torch.library and implemented by calls into the C-ABI HIP library
+(include/tinygemm_hip.h).  ROCm tensors dispatch on the "CUDA" key; there is deliberately no CPU
+implementation, so a CPU tensor (or a missing .so) fails loudly instead of falling back.
+
+Host-side validation mirrors the TORCH_CHECKs of the reference host functions
+(TinyGemm_int4.cu:28-548, TinyGemm_bf16.cu, TinyGemmConvert{A,B}.cu) and raises RuntimeError like
+c10::Error does.  Outputs are allocated here with torch.empty (caching allocator, current stream)
+and handed to the library, which never allocates.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import TG_BF16, TG_F16, TG_Q_ANY4_GLOBAL, TG_Q_ANY4_ROWWISE, TG_Q_INT4, TG_Q_MX4, W4Gemm
+
+_L = _lib.load()  # ImportError if the HIP library has not been built
+
+NAMESPACE = "tinygemm"
+
+# schema strings: verbatim argument lists of TinyGemm.cpp:17-122
+SCHEMAS = {
+    "convert_matrix_to_m16n8k16_A_layout": "(Tensor t, int innerKTiles) -> Tensor",
+    "convert_matrix_to_m16n8k16_Aint4_layout": "(Tensor t, int innerKTiles) -> Tensor",
+    "convert_matrix_to_m16n8k16_Aint8_layout": "(Tensor t, int innerKTiles) -> Tensor",
+    "convert_matrix_from_m16n8k16_A_layout": "(Tensor t, int m, int k) -> Tensor",
+    "convert_matrix_to_m16n8k16_B_layout": "(Tensor t, int innerKTiles) -> Tensor",
+    "convert_matrix_to_m16n8k16_Bint4_layout": "(Tensor t, int innerKTiles) -> Tensor",
+    "convert_matrix_to_m16n8k16_Bint8_layout": "(Tensor t, int innerKTiles) -> Tensor",
+    "convert_matrix_from_m16n8k16_B_layout": "(Tensor t, int n, int k) -> Tensor",
+    "tinygemm_y_f16TC_x_f16TC_w_int4TC": "(Tensor A, Tensor B, int qGroupSize, Tensor qScaleAndZeros, bool weightOnRight) -> Tensor",
+    "tinygemm_y_f16RM_x_f16RM_w_int4TC": "(Tensor A, Tensor B, int qGroupSize, Tensor qScaleAndZeros, bool weightOnRight) -> Tensor",
+    "tinygemm_y_f16TC_x_f16TC_w_any4TC": "(Tensor A, Tensor B, int qGroupSize, Tensor qScaleAndZeros, Tensor int4DequantValues, bool weightOnRight) -> Tensor",
+    "tinygemm_y_f16RM_x_f16RM_w_any4TC": "(Tensor A, Tensor B, int qGroupSize, Tensor qScaleAndZeros, Tensor int4DequantValues, bool weightOnRight) -> Tensor",
+    "tinygemm_y_f16TC_x_f16TC_w_mx4TC": "(Tensor A, Tensor B, int qGroupSize, Tensor mx4Exponents, bool weightOnRight) -> Tensor",
+    "tinygemm_y_f16RM_x_f16RM_w_mx4TC": "(Tensor A, Tensor B, int qGroupSize, Tensor mx4Exponents, bool weightOnRight) -> Tensor",
+    "tinygemm_y_f16TC_x_f16TC_w_int8TC": "(Tensor A, Tensor B, int qGroupSize, Tensor qScaleAndZeros, bool weightOnRight) -> Tensor",
+    "tinygemm_y_f16RM_x_f16RM_w_int8TC": "(Tensor A, Tensor B, int qGroupSize, Tensor qScaleAndZeros, bool weightOnRight) -> Tensor",
+    "tinygemm_y_f16TC_x_f16TC_w_f16TC": "(Tensor A, Tensor B, bool weightOnRight) -> Tensor",
+    "tinygemm_y_f16RM_x_f16RM_w_f16TC": "(Tensor A, Tensor B, bool weightOnRight) -> Tensor",
+    "tinygemm_dequant_int4": "(Tensor t) -> Tensor",
+}
+
+_F16_TYPES = (torch.bfloat16, torch.float16)
+
+
+def _check(cond: bool, msg: str) -> None:
+    if not cond:
+        raise RuntimeError(f"tinygemm: {msg}")
+
+
+def _cdiv(a: int, b: int) -> int:
+    return (a + b - 1) // b
+
+
+def _dt(t: torch.Tensor) -> int:
+    return TG_BF16 if t.dtype == torch.bfloat16 else TG_F16
+
+
+def _stream(t: torch.Tensor) -> int:
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _dev(t: torch.Tensor) -> int:
+    return t.device.index if t.device.index is not None else torch.cuda.current_device()
+
+
+# ---------------------------------------------------------------------------------------------
+# layout conversion
+# ---------------------------------------------------------------------------------------------
+
+def convert_matrix_to_m16n8k16_Bint4_layout(t: torch.Tensor, innerKTiles: int) -> torch.Tensor:
+    _check(t.dim() == 2, "Bint4 layout: input must be 2-D [n][k]")
+    _check(t.dtype == torch.int32, "Bint4 layout: input must be int32")
+    _check(t.is_contiguous(), "Bint4 layout: input must be contiguous")
+    _check(innerKTiles in (2, 4, 8), "Bint4 layout: innerKTiles must be 2, 4 or 8")
+    n, k = t.shape
+    _check(k % (innerKTiles * 16) == 0, "Bint4 layout: k must be a multiple of innerKTiles * 16")
+    out = torch.empty((_cdiv(n, 8), k // (innerKTiles * 16), 32, innerKTiles // 2), dtype=torch.int32, device=t.device)
+    _lib.check(_L.tg_convert_to_Bint4(t.data_ptr(), n, k, innerKTiles, out.data_ptr(), _dev(t), _stream(t)),
+               "convert_matrix_to_m16n8k16_Bint4_layout")
+    return out
+
+
+def convert_matrix_to_m16n8k16_Aint4_layout(t: torch.Tensor, innerKTiles: int) -> torch.Tensor:
+    _check(t.dim() == 2, "Aint4 layout: input must be 2-D [m][k]")
+    _check(t.dtype == torch.int32, "Aint4 layout: input must be int32")
+    _check(t.is_contiguous(), "Aint4 layout: input must be contiguous")
+    _check(innerKTiles in (1, 2, 4), "Aint4 layout: innerKTiles must be 1, 2 or 4")
+    m, k = t.shape
+    out = torch.empty((_cdiv(m, 16), _cdiv(k, innerKTiles * 16), 32, innerKTiles), dtype=torch.int32, device=t.device)
+    _lib.check(_L.tg_convert_to_Aint4(t.data_ptr(), m, k, innerKTiles, out.data_ptr(), _dev(t), _stream(t)),
+               "convert_matrix_to_m16n8k16_Aint4_layout")
+    return out
+
+
+def convert_matrix_to_m16n8k16_A_layout(t: torch.Tensor, innerKTiles: int) -> torch.Tensor:
+    _check(innerKTiles == 1, "A layout: innerKTiles must be 1")
+    _check(t.dtype in _F16_TYPES, "A layout: input must be bfloat16 or float16")
+    _check(t.dim() == 2 and t.is_contiguous(), "A layout: input must be a contiguous 2-D matrix")
+    m, k = t.shape
+    out = torch.empty((_cdiv(m, 16), _cdiv(k, 16), 32, 8), dtype=t.dtype, device=t.device)
+    _lib.check(_L.tg_convert_to_A16(t.data_ptr(), m, k, out.data_ptr(), _dev(t), _stream(t)),
+               "convert_matrix_to_m16n8k16_A_layout")
+    return out
+
+
+def convert_matrix_from_m16n8k16_A_layout(t: torch.Tensor, m: int, k: int) -> torch.Tensor:
+    _check(t.dtype in _F16_TYPES, "A layout: input must be bfloat16 or float16")
+    _check(t.dim() == 4 and t.is_contiguous(), "A layout: input must be a contiguous 4-D tensor")
+    _check(_cdiv(m, 16) == t.size(0) and _cdiv(k, 16) == t.size(1), "A layout: tile counts do not match (m, k)")
+    _check(t.size(2) == 32 and t.size(3) == 8, "A layout: expected [.., .., 32, 8]")
+    out = torch.empty((m, k), dtype=t.dtype, device=t.device)
+    _lib.check(_L.tg_convert_from_A16(t.data_ptr(), m, k, out.data_ptr(), _dev(t), _stream(t)),
+               "convert_matrix_from_m16n8k16_A_layout")
+    return out
+
+
+def convert_matrix_to_m16n8k16_B_layout(t: torch.Tensor, innerKTiles: int) -> torch.Tensor:
+    _check(t.dtype in _F16_TYPES, "B layout: input must be bfloat16 or float16")
+    _check(t.dim() == 2 and t.is_contiguous(), "B layout: input must be a contiguous 2-D matrix")
+    _check(innerKTiles in (1, 2), "B layout: innerKTiles must be 1 or 2")
+    n, k = t.shape
+    out = torch.empty((_cdiv(n, 8), _cdiv(k, 16 * innerKTiles), 32, innerKTiles * 4), dtype=t.dtype, device=t.device)
+    _lib.check(_L.tg_convert_to_B16(t.data_ptr(), n, k, innerKTiles, out.data_ptr(), _dev(t), _stream(t)),
+               "convert_matrix_to_m16n8k16_B_layout")
+    return out
+
+
+def convert_matrix_from_m16n8k16_B_layout(t: torch.Tensor, n: int, k: int) -> torch.Tensor:
+    _check(t.dtype in _F16_TYPES, "B layout: input must be bfloat16 or float16")
+    _check(t.dim() == 4 and t.is_contiguous(), "B layout: input must be a contiguous 4-D tensor")
+    _check(t.size(3) % 4 == 0 and t.size(3) // 4 in (1, 2), "B layout: innermost dim must be 4 or 8")
+    inner = t.size(3) // 4
+    _check(_cdiv(n, 8) == t.size(0) and _cdiv(k, 16 * inner) == t.size(1) and t.size(2) == 32,
+           "B layout: tile counts do not match (n, k)")
+    out = torch.empty((n, k), dtype=t.dtype, device=t.device)
+    _lib.check(_L.tg_convert_from_B16(t.data_ptr(), n, k, inner, out.data_ptr(), _dev(t), _stream(t)),
+               "convert_matrix_from_m16n8k16_B_layout")
+    return out
+
+
+def tinygemm_dequant_int4(t: torch.Tensor) -> torch.Tensor:
+    _check(t.dtype == torch.int32 and t.dim() == 1, "dequant_int4: expected a 1-D int32 tensor")
+    t = t.contiguous()
+    out = torch.empty((t.numel() * 8,), dtype=torch.bfloat16, device=t.device)
+    if t.numel():
+        _lib.check(_L.tg_dequant_int4(t.data_ptr(), t.numel(), out.data_ptr(), _dev(t), _stream(t)), "tinygemm_dequant_int4")
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# 4-bit weight GEMMs
+# ---------------------------------------------------------------------------------------------
+
+def _w4_rm(A, B, q_group, qinfo, lut, qtype, weight_on_right, opname):
+    """Row-major activations / output.  Mirrors tinygemm_y_FT16RM_x_FT16RM_w_int4TC
+    (TinyGemm_int4.cu:294-548)."""
+    _check(A.device == B.device, "A and B must be on the same device")
+    if weight_on_right:
+        x, w = A, B
+        _check(x.dim() == 2 and x.is_contiguous(), "activations must be a contiguous 2-D matrix")
+        _check(w.dim() == 4 and w.dtype == torch.int32 and w.is_contiguous(), "weights must be a contiguous 4-D int32 tensor")
+        inner = w.size(3) * 2
+        _check(inner in (2, 4, 8), "Bint4 weights: innermost dim must be 1, 2 or 4")
+        wrows = w.size(0) * 8
+    else:
+        w, x = A, B
+        _check(w.dim() == 4 and w.dtype == torch.int32 and w.is_contiguous(), "weights must be a contiguous 4-D int32 tensor")
+        _check(x.dim() == 2 and x.is_contiguous(), "activations must be a contiguous 2-D matrix")
+        inner = w.size(3)
+        _check(inner in (1, 2, 4), "Aint4 weights: innermost dim must be 1, 2 or 4")
+        wrows = w.size(0) * 16
+    m, k = x.shape
+    k_tiles = _cdiv(k, 16)
+    _check(w.size(1) == _cdiv(k_tiles, inner), "weights: k super-tiles do not match the activations' k")
+    _check(w.size(2) == 32, "weights: dim 2 must be 32")
+    _check(x.dtype in _F16_TYPES, "activation dtype must be bfloat16 or float16")
+    _check(q_group in (32, 64, 128, 256), "qGroupSize must be 32, 64, 128 or 256")
+    _check(qinfo.device == x.device, "quantization info must be on the activations' device")
+    if qtype == TG_Q_MX4:
+        _check(x.dtype == torch.bfloat16, "mx4 supports bfloat16 activations only")
+        _check(k % q_group == 0, "qGroupSize must divide k")
+        _check(qinfo.dtype == torch.uint8 and qinfo.dim() == 2, "mx4Exponents must be a 2-D uint8 tensor")
+        _check(qinfo.size(0) == wrows and qinfo.size(1) == k // q_group, "mx4Exponents must be [weight rows (tile padded)][k / qGroupSize]")
+    else:
+        _check(qinfo.dim() == 3, "qScaleAndZeros must be 3-D [k / qGroupSize][weight rows][2]")
+        n_groups = qinfo.size(0)
+        _check(n_groups > 0 and k % n_groups == 0, "number of q-groups must divide k")
+        _check(k // n_groups == q_group, "qScaleAndZeros.size(0) must equal k / qGroupSize")
+        _check(qinfo.size(1) == wrows, "qScaleAndZeros.size(1) must equal the tile-padded weight rows")
+        _check(qinfo.size(2) == 2, "qScaleAndZeros.size(2) must be 2")
+        _check(qinfo.dtype == x.dtype, "qScaleAndZeros dtype must match the activations")
+    if lut is not None:
+        _check(lut.device == x.device, "int4DequantValues must be on the activations' device")
+        _check(lut.dtype == x.dtype, "int4DequantValues dtype must match the activations")
+        if lut.dim() == 1:
+            _check(lut.size(0) == 16, "int4DequantValues must have 16 entries")
+            qtype = TG_Q_ANY4_GLOBAL
+        else:
+            _check(lut.dim() == 2 and lut.size(0) == wrows and lut.size(1) == 16,
+                   "row-wise int4DequantValues must be [weight rows (tile padded)][16]")
+            qtype = TG_Q_ANY4_ROWWISE
+        lut = lut.contiguous()
+    qinfo = qinfo.contiguous()
+    _check(k % 32 == 0 and k_tiles % inner == 0, "k must be a multiple of 32 and of innerKTiles * 16")
+    if x.data_ptr() % 16:
+        x = x.clone()
+    y = torch.empty((m, wrows), dtype=x.dtype, device=x.device)
+    if m == 0:
+        return y
+    args = W4Gemm(
+        x=x.data_ptr(), w=w.data_ptr(), qinfo=qinfo.data_ptr(), lut=(lut.data_ptr() if lut is not None else None),
+        y=y.data_ptr(), m=m, wrows=wrows, k=k, group=q_group, qtype=qtype, dtype=_dt(x),
+        w_on_right=1 if weight_on_right else 0, inner_k_tiles=inner, batch=1,
+    )
+    _lib.check(_L.tg_gemm_w4(ctypes.byref(args), _dev(x), _stream(x)), opname)
+    return y
+
+
+def _w4_tc(A, B, q_group, qinfo, lut, qtype, weight_on_right, opname):
+    """Fragment-order activations / output (TinyGemm_int4.cu:28-292).  Implemented as
+    un-layout -> row-major GEMM -> re-layout, all on the device."""
+    _check(A.dim() == 4 and A.is_contiguous() and A.size(2) == 32, "A must be a contiguous 4-D tensor-core layout tensor")
+    _check(B.dim() == 4 and B.is_contiguous() and B.size(2) == 32, "B must be a contiguous 4-D tensor-core layout tensor")
+    if weight_on_right:
+        _check(A.size(3) == 8, "activations (A layout) must have innermost dim 8")
+        _check(B.size(3) in (1, 2, 4) and B.dtype == torch.int32, "weights (Bint4 layout) must be int32 with innermost dim 1, 2 or 4")
+        k_tiles_a, k_tiles_b = A.size(1), B.size(1) * B.size(3) * 2
+        _check(k_tiles_a == k_tiles_b, "A and B disagree on k")
+        m_pad, k = A.size(0) * 16, k_tiles_a * 16
+        x = convert_matrix_from_m16n8k16_A_layout(A, m_pad, k)
+        y = _w4_rm(x, B, q_group, qinfo, lut, qtype, True, opname)       # [m_pad][n_pad]
+        return convert_matrix_to_m16n8k16_A_layout(y, 1)                 # [mTiles][ceil(nTiles/2)][32][8]
+    _check(A.size(3) in (1, 2, 4) and A.dtype == torch.int32, "weights (Aint4 layout) must be int32 with innermost dim 1, 2 or 4")
+    _check(B.size(3) in (4, 8), "activations (B layout) must have innermost dim 4 or 8")
+    b_inner = B.size(3) // 4
+    k_tiles_a, k_tiles_b = A.size(1) * A.size(3), B.size(1) * b_inner
+    _check(k_tiles_a == k_tiles_b, "A and B disagree on k")
+    n_pad, k = B.size(0) * 8, k_tiles_b * 16
+    x = convert_matrix_from_m16n8k16_B_layout(B, n_pad, k)
+    y = _w4_rm(A, x, q_group, qinfo, lut, qtype, False, opname)          # [n_pad][m_pad]
+    return convert_matrix_to_m16n8k16_B_layout(y, b_inner)               # [nTiles][ceil(mTiles/I)][32][4 I]
+
+
+def tinygemm_y_f16RM_x_f16RM_w_int4TC(A, B, qGroupSize, qScaleAndZeros, weightOnRight):
+    return _w4_rm(A, B, qGroupSize, qScaleAndZeros, None, TG_Q_INT4, weightOnRight, "tinygemm_y_f16RM_x_f16RM_w_int4TC")
+
+
+def tinygemm_y_f16TC_x_f16TC_w_int4TC(A, B, qGroupSize, qScaleAndZeros, weightOnRight):
+    return _w4_tc(A, B, qGroupSize, qScaleAndZeros, None, TG_Q_INT4, weightOnRight, "tinygemm_y_f16TC_x_f16TC_w_int4TC")
+
+
+def tinygemm_y_f16RM_x_f16RM_w_any4TC(A, B, qGroupSize, qScaleAndZeros, int4DequantValues, weightOnRight):
+    return _w4_rm(A, B, qGroupSize, qScaleAndZeros, int4DequantValues, TG_Q_ANY4_ROWWISE, weightOnRight,
+                  "tinygemm_y_f16RM_x_f16RM_w_any4TC")
+
+
+def tinygemm_y_f16TC_x_f16TC_w_any4TC(A, B, qGroupSize, qScaleAndZeros, int4DequantValues, weightOnRight):
+    return _w4_tc(A, B, qGroupSize, qScaleAndZeros, int4DequantValues, TG_Q_ANY4_ROWWISE, weightOnRight,
+                  "tinygemm_y_f16TC_x_f16TC_w_any4TC")
+
+
+def tinygemm_y_f16RM_x_f16RM_w_mx4TC(A, B, qGroupSize, mx4Exponents, weightOnRight):
+    return _w4_rm(A, B, qGroupSize, mx4Exponents, None, TG_Q_MX4, weightOnRight, "tinygemm_y_f16RM_x_f16RM_w_mx4TC")
+
+
+def tinygemm_y_f16TC_x_f16TC_w_mx4TC(A, B, qGroupSize, mx4Exponents, weightOnRight):
+    return _w4_tc(A, B, qGroupSize, mx4Exponents, None, TG_Q_MX4, weightOnRight, "tinygemm_y_f16TC_x_f16TC_w_mx4TC")
+
+
+# ---------------------------------------------------------------------------------------------
+# 16-bit weights (TinyGemm_bf16.cu)
+# ---------------------------------------------------------------------------------------------
+
+def tinygemm_y_f16RM_x_f16RM_w_f16TC(A, B, weightOnRight):
+    _check(A.device == B.device, "A and B must be on the same device")
+    if weightOnRight:
+        x, w = A, B
+        _check(w.dim() == 4 and w.is_contiguous() and w.size(2) == 32 and w.size(3) in (4, 8), "weights must be in B layout")
+        inner, wrows = w.size(3) // 4, w.size(0) * 8
+    else:
+        w, x = A, B
+        _check(w.dim() == 4 and w.is_contiguous() and w.size(2) == 32 and w.size(3) == 8, "weights must be in A layout")
+        inner, wrows = 1, w.size(0) * 16
+    _check(x.dim() == 2 and x.is_contiguous(), "activations must be a contiguous 2-D matrix")
+    _check(x.dtype in _F16_TYPES and w.dtype == x.dtype, "activations and weights must share a 16-bit float dtype")
+    m, k = x.shape
+    _check(w.size(1) == _cdiv(_cdiv(k, 16), inner), "weights: k tiles do not match the activations' k")
+    _check(k % 32 == 0, "k must be a multiple of 32")
+    if x.data_ptr() % 16:
+        x = x.clone()
+    y = torch.empty((m, wrows), dtype=x.dtype, device=x.device)
+    if m:
+        _lib.check(_L.tg_gemm_f16(x.data_ptr(), w.data_ptr(), y.data_ptr(), m, wrows, k, _dt(x), 1 if weightOnRight else 0,
+                                  inner, _dev(x), _stream(x)), "tinygemm_y_f16RM_x_f16RM_w_f16TC")
+    return y
+
+
+def tinygemm_y_f16TC_x_f16TC_w_f16TC(A, B, weightOnRight):
+    _check(A.dim() == 4 and B.dim() == 4, "A and B must be 4-D tensor-core layout tensors")
+    if weightOnRight:
+        _check(A.size(3) == 8, "activations (A layout) must have innermost dim 8")
+        m_pad, k = A.size(0) * 16, A.size(1) * 16
+        x = convert_matrix_from_m16n8k16_A_layout(A, m_pad, k)
+        y = tinygemm_y_f16RM_x_f16RM_w_f16TC(x, B, True)
+        return convert_matrix_to_m16n8k16_A_layout(y, 1)
+    b_inner = B.size(3) // 4
+    n_pad, k = B.size(0) * 8, B.size(1) * b_inner * 16
+    x = convert_matrix_from_m16n8k16_B_layout(B, n_pad, k)
+    y = tinygemm_y_f16RM_x_f16RM_w_f16TC(A, x, False)
+    return convert_matrix_to_m16n8k16_B_layout(y, b_inner)
+
+
+# ---------------------------------------------------------------------------------------------
+# int8 weights: out of this build's scope.  The schemas exist so
+# that callers see a clear error instead of an AttributeError.
+# ---------------------------------------------------------------------------------------------
+
+def _int8_unbuilt(*_args, **_kw):
+    raise RuntimeError("tinygemm: the int8-weight path is not built in this MI355X library (int4/any4/mx4/f16 only)")
+
+
+_IMPLS = {
+    "convert_matrix_to_m16n8k16_A_layout": convert_matrix_to_m16n8k16_A_layout,
+    "convert_matrix_to_m16n8k16_Aint4_layout": convert_matrix_to_m16n8k16_Aint4_layout,
+    "convert_matrix_to_m16n8k16_Aint8_layout": _int8_unbuilt,
+    "convert_matrix_from_m16n8k16_A_layout": convert_matrix_from_m16n8k16_A_layout,
+    "convert_matrix_to_m16n8k16_B_layout": convert_matrix_to_m16n8k16_B_layout,
+    "convert_matrix_to_m16n8k16_Bint4_layout": convert_matrix_to_m16n8k16_Bint4_layout,
+    "convert_matrix_to_m16n8k16_Bint8_layout": _int8_unbuilt,
+    "convert_matrix_from_m16n8k16_B_layout": convert_matrix_from_m16n8k16_B_layout,
+    "tinygemm_y_f16TC_x_f16TC_w_int4TC": tinygemm_y_f16TC_x_f16TC_w_int4TC,
+    "tinygemm_y_f16RM_x_f16RM_w_int4TC": tinygemm_y_f16RM_x_f16RM_w_int4TC,
+    "tinygemm_y_f16TC_x_f16TC_w_any4TC": tinygemm_y_f16TC_x_f16TC_w_any4TC,
+    "tinygemm_y_f16RM_x_f16RM_w_any4TC": tinygemm_y_f16RM_x_f16RM_w_any4TC,
+    "tinygemm_y_f16TC_x_f16TC_w_mx4TC": tinygemm_y_f16TC_x_f16TC_w_mx4TC,
+    "tinygemm_y_f16RM_x_f16RM_w_mx4TC": tinygemm_y_f16RM_x_f16RM_w_mx4TC,
+    "tinygemm_y_f16TC_x_f16TC_w_int8TC": _int8_unbuilt,
+    "tinygemm_y_f16RM_x_f16RM_w_int8TC": _int8_unbuilt,
+    "tinygemm_y_f16TC_x_f16TC_w_f16TC": tinygemm_y_f16TC_x_f16TC_w_f16TC,
+    "tinygemm_y_f16RM_x_f16RM_w_f16TC": tinygemm_y_f16RM_x_f16RM_w_f16TC,
+    "tinygemm_dequant_int4": tinygemm_dequant_int4,
+}
+
+_library = None
+
+
+def register() -> None:
+    """Define the schemas and bind the CUDA(=ROCm)-key implementations.  Idempotent."""
+    global _library
+    if _library is not None:
+        return
+    lib = torch.library.Library(NAMESPACE, "DEF")
+    for name, schema in SCHEMAS.items():
+        lib.define(name + schema)
+        lib.impl(name, _IMPLS[name], "CUDA")
+    _library = lib
+
+
+register()

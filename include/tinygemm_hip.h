@@ -1,0 +1,149 @@
+/*
+ * tinygemm_hip.h -- C ABI of the MI355X (gfx950) tinygemm W4A16 small-batch GEMM library.
+ *
+ * This is the drop-in boundary for the reference's native extension
+ * (facebookresearch/any4, tinygemm_lib/ *.cu sources): every entry point below replaces one host
+ * function the reference registers with torch (tinygemm_lib/TinyGemm.cpp:17-200,
+ * prototypes tinygemm_lib/TinyGemm.h:23-216).  The signatures carry plain device
+ * pointers and sizes only: no torch types, no allocation inside the library (the caller
+ * owns every buffer, outputs included), no global state, no host synchronisation.
+ * All functions launch asynchronously on `stream` and are safe to call from several host
+ * threads on distinct streams, and under hipGraph stream capture.
+ *
+ * Return value: 0 on success; a negative TG_E_* code when a precondition the reference
+ * checks with TORCH_CHECK fails (nothing is launched); a positive value is the hipError_t
+ * reported by the launch.  Never throws.
+ *
+ * Layout vocabulary (identical to the reference, TinyGemm.h:19-103):
+ *   RM       row-major 16-bit matrix [rows][k]
+ *   A16      m16n8k16 "A" fragment order  [ceil(m/16)][ceil(k/16)][32][8]        16-bit
+ *   B16      m16n8k16 "B" fragment order  [ceil(n/8)][ceil(k/(16 I))][32][4 I]   16-bit, I in {1,2}
+ *   Aint4    packed 4-bit, weights on the left   [ceil(m/16)][ceil(k/(16 I))][32][I]   int32, I in {1,2,4}
+ *   Bint4    packed 4-bit, weights on the right  [ceil(n/8)][k/(16 I)][32][I/2]       int32, I in {2,4,8}
+ * The packed int4 words are bit-identical to the reference's
+ * (TinyGemmConvertA.cu:226-285, TinyGemmConvertB.cu:252-308), so a state_dict packed by
+ * either implementation loads in the other.
+ */
+#ifndef TINYGEMM_HIP_H_
+#define TINYGEMM_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TG_ABI_VERSION 1
+
+#if defined(__GNUC__)
+#define TG_API __attribute__((visibility("default")))
+#else
+#define TG_API
+#endif
+
+typedef void* tg_stream_t; /* a hipStream_t; NULL = the null stream */
+
+/* 16-bit float type of activations / scales / LUT / outputs */
+enum { TG_BF16 = 0, TG_F16 = 1 };
+
+/* 4-bit quantisation variant; mirrors Int4_QType (tinygemm_lib/TinyGemmUtils.cuh:21-32) */
+enum {
+  TG_Q_INT4 = 0,         /* uniform int4: value = code - 8                                  */
+  TG_Q_ANY4_GLOBAL = 1,  /* one 16-entry LUT for the whole matrix (the reference's NF4 path) */
+  TG_Q_ANY4_ROWWISE = 2, /* one 16-entry LUT per weight row (any4)                         */
+  TG_Q_MX4 = 3           /* fp4-e2m1 codes with an e8m0 exponent per group                 */
+};
+
+/* precondition failures (wording of the matching TORCH_CHECK is in tg_error_string) */
+enum {
+  TG_E_NULL = -1,      /* a required pointer is NULL                                       */
+  TG_E_INNER_K = -2,   /* innerKTiles not valid for this layout                            */
+  TG_E_K_DIV = -3,     /* k not divisible as the layout / kernel requires                  */
+  TG_E_GROUP = -4,     /* qGroupSize not in {32,64,128,256} or does not divide k           */
+  TG_E_DTYPE = -5,     /* dtype not bf16/fp16, or mx4 with fp16                            */
+  TG_E_QTYPE = -6,     /* unknown quantisation variant                                     */
+  TG_E_SHAPE = -7,     /* negative / zero / inconsistent sizes                             */
+  TG_E_ALIGN = -8,     /* a buffer is not 16-byte aligned                                  */
+  TG_E_DEVICE = -9     /* hipSetDevice failed / no such device                             */
+};
+
+TG_API int tg_abi_version(void);
+TG_API const char* tg_error_string(int code);
+
+/* ---- layout conversion ------------------------------------------------------------------ */
+
+/* replaces convert_matrix_to_m16n8k16_Bint4_layout (TinyGemmConvertB.cu:312-364).
+ * in  : int32 [n][k], codes 0..15            out : int32 [ceil(n/8)][k/(16 I)][32][I/2]
+ * requires I in {2,4,8}, k % (16 I) == 0 */
+TG_API int tg_convert_to_Bint4(const int32_t* in, int64_t n, int64_t k, int inner_k_tiles, int32_t* out,
+                        int device, tg_stream_t stream);
+
+/* replaces convert_matrix_to_m16n8k16_Aint4_layout (TinyGemmConvertA.cu:289-333).
+ * in  : int32 [m][k]                         out : int32 [ceil(m/16)][ceil(k/(16 I))][32][I]
+ * requires I in {1,2,4}; ragged m, k are zero-padded */
+TG_API int tg_convert_to_Aint4(const int32_t* in, int64_t m, int64_t k, int inner_k_tiles, int32_t* out,
+                        int device, tg_stream_t stream);
+
+/* replace convert_matrix_{to,from}_m16n8k16_A_layout (TinyGemmConvertA.cu:150-223, 554-626).
+ * 16-bit payload (bf16 or fp16: pure data movement).  rm: [m][k]; tc: [ceil(m/16)][ceil(k/16)][32][8] */
+TG_API int tg_convert_to_A16(const void* rm, int64_t m, int64_t k, void* tc, int device, tg_stream_t stream);
+TG_API int tg_convert_from_A16(const void* tc, int64_t m, int64_t k, void* rm, int device, tg_stream_t stream);
+
+/* replace convert_matrix_{to,from}_m16n8k16_B_layout (TinyGemmConvertB.cu:76-133, 186-249).
+ * rm: [n][k]; tc: [ceil(n/8)][ceil(k/(16 I))][32][4 I], I in {1,2} */
+TG_API int tg_convert_to_B16(const void* rm, int64_t n, int64_t k, int inner_k_tiles, void* tc, int device,
+                      tg_stream_t stream);
+TG_API int tg_convert_from_B16(const void* tc, int64_t n, int64_t k, int inner_k_tiles, void* rm, int device,
+                        tg_stream_t stream);
+
+/* replaces the debug op tinygemm_dequant_int4 (TinyGemmDequantize.cu:36-58):
+ * each int32 -> 8 bf16 (nibble - 8) in the order [n0,n4,n1,n5,n2,n6,n3,n7]. */
+TG_API int tg_dequant_int4(const int32_t* in, int64_t count, void* out_bf16, int device, tg_stream_t stream);
+
+/* ---- the hot path: Y[act][wrow] = X[act][k] . dequant(W)[wrow][k]^T ----------------------- */
+
+/*
+ * replaces tinygemm_y_f16RM_x_f16RM_w_{int4,any4,mx4}TC
+ * (TinyGemm_int4.cu:294-548 -> launch_tinygemm_kernel, TinyGemmImpl.cuh:347-431 ->
+ *  tinygemm_m16n8k16_chunk_kernel :23-345 with {A,B}Layout_TC_int4 + {A,B}Layout_RM).
+ *
+ * Both sides of the reference API produce the same row-major result indexed
+ * [activation row][weight row] (weightOnRight: [m][n]; otherwise [n_act][m_w],
+ * TinyGemm_int4.cu:450-456), so one entry point serves both; `w_on_right` only says
+ * which packed layout `w` is in.
+ */
+typedef struct tg_w4_gemm {
+  const void* x;     /* activations, RM 16-bit [m][k]                                          */
+  const void* w;     /* packed weights: Bint4 if w_on_right else Aint4                         */
+  const void* qinfo; /* int4/any4: 16-bit scales_and_zeros [k/group][wrows][2] (scale, zero)   */
+                     /* mx4: uint8 e8m0 exponents [wrows][k/group]                              */
+  const void* lut;   /* any4: 16-bit LUT [16] (global) or [wrows][16] (row-wise); else NULL    */
+  void* y;           /* out, RM 16-bit [m][wrows]                                              */
+  int64_t m;         /* activation rows (any m >= 1; tuned for m <= 16)                        */
+  int64_t wrows;     /* weight rows INCLUDING tile padding: 8*size(0) (Bint4) / 16*size(0) (Aint4) */
+  int64_t k;         /* reduction length; k % 32 == 0 and k % (16 I) == 0                      */
+  int32_t group;     /* quantisation group size along k: 32, 64, 128 or 256                    */
+  int32_t qtype;     /* TG_Q_*                                                                 */
+  int32_t dtype;     /* TG_BF16 / TG_F16 (mx4: bf16 only)                                      */
+  int32_t w_on_right;    /* 1: w is Bint4, 0: w is Aint4                                      */
+  int32_t inner_k_tiles; /* I of the packed layout                                            */
+  /* optional stacked launch over `batch` independent problems of identical shape:
+   * operand b lives at base + b*stride (bytes).  batch <= 1 ignores the strides.             */
+  int32_t batch;
+  int64_t stride_x, stride_w, stride_qinfo, stride_lut, stride_y;
+} tg_w4_gemm;
+
+TG_API int tg_gemm_w4(const tg_w4_gemm* args, int device, tg_stream_t stream);
+
+/*
+ * replaces tinygemm_y_f16RM_x_f16RM_w_f16TC (TinyGemm_bf16.cu:163-327): un-quantised 16-bit
+ * weights in A16 (w_on_right = 0) or B16 (w_on_right = 1, I in {1,2}) fragment order.
+ * x RM [m][k]; y RM [m][wrows]; wrows includes tile padding.
+ */
+TG_API int tg_gemm_f16(const void* x, const void* w, void* y, int64_t m, int64_t wrows, int64_t k, int dtype,
+                int w_on_right, int inner_k_tiles, int device, tg_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TINYGEMM_HIP_H_ */
