@@ -25,11 +25,12 @@ def hipcc() -> str:
     raise RuntimeError("hipcc not found (set HIPCC=...)")
 
 
-def needs_build() -> bool:
+def needs_build() -> bool:  # noqa
     if not os.path.exists(OUT):
         return True
     t = os.path.getmtime(OUT)
-    return any(os.path.getmtime(p) > t for p in (SRC, HDR))
+    srcs = [HDR] + [os.path.join(HERE, "csrc", f) for f in os.listdir(os.path.join(HERE, "csrc"))]
+    return any(os.path.getmtime(p) > t for p in srcs)
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
@@ -37,7 +38,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         return OUT
     os.makedirs(OUT_DIR, exist_ok=True)
     cmd = [hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden",
-           "-Wno-comment", SRC, "-o", OUT + ".tmp"]
+           "-Wno-comment", "-Wno-int-to-pointer-cast", SRC, "-o", OUT + ".tmp"]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
         print(" ".join(cmd), file=sys.stderr)

@@ -28,6 +28,8 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+#include <type_traits>
 
 #include "../../include/tinygemm_hip.h"
 
@@ -78,238 +80,8 @@ struct F16 {
 __device__ const float kMX4Values[16] = {0.0f,  0.5f,  1.0f,  1.5f,  2.0f,  3.0f,  4.0f,  6.0f,
                                          -0.0f, -0.5f, -1.0f, -1.5f, -2.0f, -3.0f, -4.0f, -6.0f};
 
-// ---- kernel parameters ----------------------------------------------------------------------
-struct GemmParams {
-  const char* x;
-  const char* w;
-  const char* qinfo;
-  const char* lut;
-  char* y;
-  int32_t m, wrows, k;
-  int32_t ntiles;   // packed.size(0): 8-row (Bint4) or 16-row (Aint4) tiles
-  int32_t ksuper;   // packed.size(1)
-  int32_t gshift;   // log2(group)
-  int32_t ngroups;  // k / group
-  int32_t qtype;
-  int64_t stride_x, stride_w, stride_qinfo, stride_lut, stride_y;
-};
-
-enum { CANON_NONE = 0, CANON_PAIR = 1, CANON_QUAD = 2 };
-
-// Word transpose between the four 16-lane rows of a wave so that every lane ends up with the
-// four words (q = 0..3) of ONE k-chunk.  See DESIGN.md "canonical chunk".
-template <int CANON>
-__device__ __forceinline__ void canonicalize(u32x4& w) {
-  if constexpr (CANON == CANON_PAIR) {
-    // lane holds (q=2p, j0) (q=2p, j1) (q=2p+1, j0) (q=2p+1, j1); partner row holds the other p.
-    auto r0 = __builtin_amdgcn_permlane16_swap(w[0], w[1], false, false);
-    auto r1 = __builtin_amdgcn_permlane16_swap(w[2], w[3], false, false);
-    // now (q0, q2, q1, q3) of one chunk
-    w = u32x4{r0[0], r1[0], r0[1], r1[1]};
-  } else if constexpr (CANON == CANON_QUAD) {
-    // lane row Q holds words j = 0..3 of q = Q: 4x4 transpose across the rows
-    auto r0 = __builtin_amdgcn_permlane16_swap(w[0], w[1], false, false);
-    auto r1 = __builtin_amdgcn_permlane16_swap(w[2], w[3], false, false);
-    auto s0 = __builtin_amdgcn_permlane32_swap(r0[0], r1[0], false, false);
-    auto s1 = __builtin_amdgcn_permlane32_swap(r0[1], r1[1], false, false);
-    w = u32x4{s0[0], s1[0], s0[1], s1[1]};
-  }
-}
-
-// One prefetch slot = everything a lane needs for one step.
-template <int NMMA>
-struct Slot {
-  u32x4 w;         // 4 packed words
-  uint32_t q;      // scale|zero pair (or mx4 exponent byte)
-  u32x4 x[NMMA];   // X fragments
-};
-
-template <typename DT, bool LAYOUT_A, int CANON, bool QMX, int WAVES, int DEPTH>
-__global__ void __launch_bounds__(WAVES * 64) w4_gemm_kernel(const GemmParams p) {
-  constexpr int CHUNK = LAYOUT_A ? 16 : 32;  // k covered by one lane per step
-  constexpr int KSTEP = 4 * CHUNK;           // k covered by one wave per step
-  constexpr int NMMA = LAYOUT_A ? 2 : 4;     // MFMAs per step
-  constexpr int WPL = (CANON == CANON_NONE) ? 1 : (CANON == CANON_PAIR ? 2 : 4);  // words per (t) in the packed layout
-
-  __shared__ float s_tab[16 * 64];        // [entry][lane] f32 LUT, one bank column per lane
-  __shared__ f32x4 s_red[WAVES * 64];     // split-K partial tiles
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int i = lane & 15;  // weight row within the tile (A operand) / activation row (B operand)
-  const int Q = lane >> 4;  // k-chunk selector
-  const int r = i & 7;
-
-  const int rt = blockIdx.x, ct = blockIdx.y;
-  const int64_t b = blockIdx.z;
-  const char* xb = p.x + b * p.stride_x;
-  const char* wb = p.w + b * p.stride_w;
-  const char* qb = p.qinfo + b * p.stride_qinfo;
-  const char* lb = p.lut ? p.lut + b * p.stride_lut : nullptr;
-  char* yb = p.y + b * p.stride_y;
-
-  const int row0 = rt * 16;
-  const int row = row0 + i;
-  const bool row_ok = row < p.wrows;
-
-  // ---- per-lane addressing of the packed weights ----
-  const int tile = LAYOUT_A ? rt : 2 * rt + (i >> 3);
-  const bool tile_ok = tile < p.ntiles;
-  int toff;
-  if constexpr (CANON == CANON_NONE) toff = 4 * r;
-  else if constexpr (CANON == CANON_PAIR) toff = 4 * r + 2 * (Q & 1);
-  else toff = 4 * r + Q;
-  const uint32_t* wlane = reinterpret_cast<const uint32_t*>(wb) + ((int64_t)tile * p.ksuper * 32 + toff) * WPL;
-
-  const int xrow = min(ct * 16 + i, p.m - 1);
-  const char* xlane = xb + ((int64_t)xrow * p.k + Q * CHUNK) * 2;
-
-  const int nsteps_total = (p.k + KSTEP - 1) / KSTEP;
-  // wave w owns steps w, w + WAVES, ...
-  const int nsteps = (nsteps_total - wave + WAVES - 1) / WAVES;
-
-  auto load_slot = [&](int j, Slot<NMMA>& sl) {
-    const int s = wave + j * WAVES;
-    const bool step_ok = j < nsteps;
-    int ks;
-    if constexpr (CANON == CANON_NONE) ks = 4 * s + Q;
-    else if constexpr (CANON == CANON_PAIR) ks = 2 * s + (Q >> 1);
-    else ks = s;
-    sl.w = u32x4{0, 0, 0, 0};
-    if (step_ok && tile_ok && ks < p.ksuper) {
-      sl.w = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wlane + (int64_t)ks * 32 * WPL));
-    }
-    const int kk = s * KSTEP + Q * CHUNK;  // first k of this lane's canonical chunk
-    const bool k_ok = step_ok && kk < p.k;
-    sl.q = QMX ? 127u : 0u;
-    if (k_ok && row_ok) {
-      const int g = kk >> p.gshift;
-      if constexpr (QMX) {
-        sl.q = reinterpret_cast<const uint8_t*>(qb)[(int64_t)row * p.ngroups + g];
-      } else {
-        sl.q = reinterpret_cast<const uint32_t*>(qb)[(int64_t)g * p.wrows + row];
-      }
-    }
-#pragma unroll
-    for (int h = 0; h < NMMA; ++h) {
-      sl.x[h] = u32x4{0, 0, 0, 0};
-      if (k_ok) sl.x[h] = *reinterpret_cast<const u32x4*>(xlane + ((int64_t)s * KSTEP + 8 * h) * 2);
-    }
-  };
-
-  Slot<NMMA> slots[DEPTH];
-#pragma unroll
-  for (int d = 0; d < DEPTH; ++d) load_slot(d, slots[d]);
-
-  // ---- build the f32 LUT in LDS while the first loads are in flight ----
-  for (int e = wave; e < 16; e += WAVES) {
-    float v;
-    if (p.qtype == TG_Q_INT4) {
-      v = (float)(e - 8);
-    } else if (p.qtype == TG_Q_MX4) {
-      v = kMX4Values[e];
-    } else if (p.qtype == TG_Q_ANY4_GLOBAL) {
-      v = DT::to_f32(reinterpret_cast<const uint16_t*>(lb)[e]);
-    } else {
-      v = row_ok ? DT::to_f32(reinterpret_cast<const uint16_t*>(lb)[(int64_t)row * 16 + e]) : 0.f;
-    }
-    s_tab[e * 64 + lane] = v;
-  }
-  __syncthreads();
-
-  const char* tabp = reinterpret_cast<const char*>(s_tab);
-  const uint32_t lane4 = (uint32_t)lane * 4u;
-  const uint32_t sh = LAYOUT_A ? (uint32_t)(i >> 3) * 4u : 0u;
-
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-
-  auto lookup = [&](uint32_t src, uint32_t sel) -> float {
-    // byte 0 <- lane*4, byte 1 <- the selected nibble-byte of src, bytes 2,3 <- 0
-    const uint32_t off = __builtin_amdgcn_perm(src, lane4, sel);
-    return *reinterpret_cast<const float*>(tabp + off);
-  };
-
-  auto process = [&](Slot<NMMA>& sl) {
-    u32x4 w = sl.w;
-    canonicalize<CANON>(w);
-    float s, z;
-    if constexpr (QMX) {
-      // e8m0: 2^(e-127), 255 -> NaN (reference Dequantization.cuh:331-339)
-      const uint32_t e = sl.q;
-      s = u2f(e == 255u ? 0x7fc00000u : (e == 0u ? 0x00400000u : (e << 23)));
-      z = 0.f;
-    } else {
-      s = DT::lo_f32(sl.q);
-      z = DT::hi_f32(sl.q);
-    }
-    if constexpr (!LAYOUT_A) {
-      // Bint4 word: nibble p holds v[e], p = {0,4,1,5,2,6,3,7}[e]; v[e] is k = 2q + 8(e>>1) + (e&1)
-      uint32_t wa[4], wb4[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        wa[q] = w[q] & 0x0f0f0f0fu;          // bytes: v0 v4 v1 v5
-        wb4[q] = (w[q] >> 4) & 0x0f0f0f0fu;  // bytes: v2 v6 v3 v7
-      }
-#pragma unroll
-      for (int h = 0; h < 4; ++h) {
-        u32x4 a;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const uint32_t src = (h & 1) ? wb4[q] : wa[q];
-          const float f0 = lookup(src, 0x0c0c0400u + ((uint32_t)(h >> 1) << 8));      // v[2h]   -> k = 8h + 2q
-          const float f1 = lookup(src, 0x0c0c0400u + ((uint32_t)((h >> 1) + 2) << 8));  // v[2h+1] -> k = 8h + 2q + 1
-          a[q] = DT::pack2(__builtin_fmaf(f0, s, z), __builtin_fmaf(f1, s, z));
-        }
-        acc = DT::mfma(a, sl.x[h], acc);
-      }
-    } else {
-      // Aint4 word: low nibbles = row r (k0 k2 k1 k3 in bytes 0..3), high nibbles = row r + 8
-      uint32_t ws[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) ws[q] = (w[q] >> sh) & 0x0f0f0f0fu;
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        u32x4 a;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float f0 = lookup(ws[q], 0x0c0c0400u + ((uint32_t)h << 8));        // k = 8h + 2q
-          const float f1 = lookup(ws[q], 0x0c0c0400u + ((uint32_t)(h + 2) << 8));  // k = 8h + 2q + 1
-          a[q] = DT::pack2(__builtin_fmaf(f0, s, z), __builtin_fmaf(f1, s, z));
-        }
-        acc = DT::mfma(a, sl.x[h], acc);
-      }
-    }
-  };
-
-  for (int jb = 0; jb < nsteps; jb += DEPTH) {
-#pragma unroll
-    for (int d = 0; d < DEPTH; ++d) {
-      if (jb + d < nsteps) {
-        Slot<NMMA> cur = slots[d];
-        load_slot(jb + d + DEPTH, slots[d]);
-        process(cur);
-      }
-    }
-  }
-
-  // ---- split-K tail: partial tiles meet in LDS, fixed-order sum, 16-bit store ----
-  s_red[wave * 64 + lane] = acc;
-  __syncthreads();
-  if (tid < 256) {
-    const int c = tid >> 4, rr = tid & 15;  // 16 consecutive threads -> 16 consecutive weight rows
-    const float* red = reinterpret_cast<const float*>(s_red);
-    const int src = (((rr >> 2) * 16 + c) << 2) + (rr & 3);  // MFMA C/D: col = lane&15, row = 4*(lane>>4)+reg
-    float sum = 0.f;
-#pragma unroll
-    for (int wv = 0; wv < WAVES; ++wv) sum += red[wv * 256 + src];
-    const int col = ct * 16 + c;
-    const int rowg = row0 + rr;
-    if (col < p.m && rowg < p.wrows) {
-      reinterpret_cast<uint16_t*>(yb)[(int64_t)col * p.wrows + rowg] = DT::from_f32(sum);
-    }
-  }
-}
+#include "w4_gemm.cuh"
+#include "w4_gemm_stream.cuh"
 
 // ---- 16-bit weights (reference TinyGemm_bf16.cu) ---------------------------------------------
 // Same tile/split-K structure; the A operand is gathered dword-wise from the fragment-order
@@ -583,26 +355,101 @@ inline int launch_status() {
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+int g_dbg_variant = 0;
+
+// Launch geometry.  Streaming shapes (many tiles) use 8-wave workgroups, two per CU, and the
+// smallest split-K that still puts >= ~16 waves on every CU; a single small matrix (one tile per
+// CU) uses one 16-wave workgroup per tile with split-K 16.
+struct Geometry {
+  int waves, splitk, sk_shift;
+};
+
+inline Geometry pick_geometry(int64_t rowtiles, int64_t coltiles, int64_t batch, int64_t nsteps) {
+  const int64_t tiles = rowtiles * coltiles * batch;
+  const int64_t want_waves = 256 * 16;  // 256 CUs x 16 waves
+  Geometry g;
+  if (g_dbg_variant > 0) {  // developer override: variant = 100 * waves + splitk
+    g.waves = g_dbg_variant / 100;
+    g.splitk = g_dbg_variant % 100;
+  } else if (tiles * 8 <= want_waves) {
+    g.waves = 16;
+    g.splitk = 16;
+  } else {
+    g.waves = 8;
+    int sk = 1;
+    while (sk < 8 && tiles * sk * 2 <= want_waves) sk *= 2;
+    g.splitk = sk;
+  }
+  while (g.splitk > 1 && g.splitk > nsteps) g.splitk >>= 1;
+  g.sk_shift = 0;
+  while ((1 << g.sk_shift) < g.splitk) ++g.sk_shift;
+  return g;
+}
+
 template <typename DT, bool LAYOUT_A, int CANON, bool QMX>
-int launch_w4(const GemmParams& p, dim3 grid, hipStream_t st) {
-  // 16 waves x depth 2 keeps 32 KiB of packed weights in flight per CU at one tile per CU
-  constexpr int WAVES = 16, DEPTH = 2;
-  hipLaunchKernelGGL((w4_gemm_kernel<DT, LAYOUT_A, CANON, QMX, WAVES, DEPTH>), grid, dim3(WAVES * 64), 0, st, p);
+int launch_w4(GemmParams& p, int64_t coltiles, int64_t batch, hipStream_t st) {
+  constexpr int KSTEP = LAYOUT_A ? 64 : 128;
+  const Geometry g = pick_geometry(p.rowtiles, coltiles, batch, (p.k + KSTEP - 1) / KSTEP);
+  p.splitk = g.splitk;
+  p.sk_shift = g.sk_shift;
+  const int tpb = g.waves / g.splitk;
+  dim3 grid((unsigned)((p.rowtiles + tpb - 1) / tpb), (unsigned)coltiles, (unsigned)batch);
+  static const int use_stream = getenv("TG_STREAM") ? atoi(getenv("TG_STREAM")) : 0;
+  if (use_stream && g.waves == 8) {
+    constexpr int WPL = CANON == CANON_NONE ? 1 : (CANON == CANON_PAIR ? 2 : 4);
+    constexpr int UNIT = LAYOUT_A ? 64 : 128;
+    StreamParams sp;
+    sp.x = p.x; sp.w = p.w; sp.qinfo = p.qinfo; sp.lut = p.lut; sp.y = p.y;
+    sp.m = p.m; sp.wrows = p.wrows; sp.k = p.k; sp.ntiles = p.ntiles; sp.ksuper = p.ksuper;
+    sp.gshift = p.gshift; sp.ngroups = p.ngroups; sp.qtype = p.qtype; sp.rowtiles = p.rowtiles;
+    sp.stride_x = p.stride_x; sp.stride_w = p.stride_w; sp.stride_qinfo = p.stride_qinfo;
+    sp.stride_lut = p.stride_lut; sp.stride_y = p.stride_y;
+    const int nunits = (p.k + UNIT - 1) / UNIT;
+    const int upg = (1 << p.gshift) > UNIT ? (1 << p.gshift) / UNIT : 1;  // units per quantisation group
+    int sk = g.splitk;
+    while (sk > 1 && nunits < 4 * sk * upg) sk >>= 1;
+    int nu = (nunits + 4 * sk - 1) / (4 * sk);
+    nu = (nu + upg - 1) / upg * upg;
+    sp.splitk = sk;
+    sp.sk_shift = 0;
+    while ((1 << sp.sk_shift) < sk) ++sp.sk_shift;
+    sp.units_per_lane = nu;
+    const int tpbs = 8 / sk;
+    dim3 sgrid((unsigned)((p.rowtiles + tpbs - 1) / tpbs), (unsigned)coltiles, (unsigned)batch);
+    if constexpr (std::is_same<DT, BF16>::value && !LAYOUT_A && CANON == CANON_PAIR && !QMX) {
+      static const int abl = getenv("TG_ABL") ? atoi(getenv("TG_ABL")) : 0;
+      if (abl) {
+        if (abl == 1) hipLaunchKernelGGL((w4_gemm_stream_kernel<DT, LAYOUT_A, WPL, QMX, 8, 4, 1>), sgrid, dim3(512), 0, st, sp);
+        if (abl == 2) hipLaunchKernelGGL((w4_gemm_stream_kernel<DT, LAYOUT_A, WPL, QMX, 8, 4, 2>), sgrid, dim3(512), 0, st, sp);
+        if (abl == 3) hipLaunchKernelGGL((w4_gemm_stream_kernel<DT, LAYOUT_A, WPL, QMX, 8, 4, 3>), sgrid, dim3(512), 0, st, sp);
+        if (abl == 4) hipLaunchKernelGGL((w4_gemm_stream_kernel<DT, LAYOUT_A, WPL, QMX, 8, 4, 4>), sgrid, dim3(512), 0, st, sp);
+        if (abl == 5) hipLaunchKernelGGL((w4_gemm_stream_kernel<DT, LAYOUT_A, WPL, QMX, 8, 4, 5>), sgrid, dim3(512), 0, st, sp);
+        return launch_status();
+      }
+    }
+    hipLaunchKernelGGL((w4_gemm_stream_kernel<DT, LAYOUT_A, WPL, QMX, 8, 4>), sgrid, dim3(512), 0, st, sp);
+    return launch_status();
+  }
+  if (g.waves == 16) {
+    hipLaunchKernelGGL((w4_gemm_kernel<DT, LAYOUT_A, CANON, QMX, 16, 2, 4>), grid, dim3(16 * 64), 0, st, p);
+  } else {
+    hipLaunchKernelGGL((w4_gemm_kernel<DT, LAYOUT_A, CANON, QMX, 8, 2, 4>), grid, dim3(8 * 64), 0, st, p);
+  }
   return launch_status();
 }
 
 template <typename DT, bool LAYOUT_A, int CANON>
-int launch_w4_q(const GemmParams& p, dim3 grid, hipStream_t st) {
-  return p.qtype == TG_Q_MX4 ? launch_w4<DT, LAYOUT_A, CANON, true>(p, grid, st)
-                             : launch_w4<DT, LAYOUT_A, CANON, false>(p, grid, st);
+int launch_w4_q(GemmParams& p, int64_t coltiles, int64_t batch, hipStream_t st) {
+  return p.qtype == TG_Q_MX4 ? launch_w4<DT, LAYOUT_A, CANON, true>(p, coltiles, batch, st)
+                             : launch_w4<DT, LAYOUT_A, CANON, false>(p, coltiles, batch, st);
 }
 
 template <typename DT, bool LAYOUT_A>
-int launch_w4_c(const GemmParams& p, int canon, dim3 grid, hipStream_t st) {
+int launch_w4_c(GemmParams& p, int canon, int64_t coltiles, int64_t batch, hipStream_t st) {
   switch (canon) {
-    case CANON_NONE: return launch_w4_q<DT, LAYOUT_A, CANON_NONE>(p, grid, st);
-    case CANON_PAIR: return launch_w4_q<DT, LAYOUT_A, CANON_PAIR>(p, grid, st);
-    default: return launch_w4_q<DT, LAYOUT_A, CANON_QUAD>(p, grid, st);
+    case CANON_NONE: return launch_w4_q<DT, LAYOUT_A, CANON_NONE>(p, coltiles, batch, st);
+    case CANON_PAIR: return launch_w4_q<DT, LAYOUT_A, CANON_PAIR>(p, coltiles, batch, st);
+    default: return launch_w4_q<DT, LAYOUT_A, CANON_QUAD>(p, coltiles, batch, st);
   }
 }
 
@@ -757,6 +604,12 @@ int tg_gemm_w4(const tg_w4_gemm* a, int device, tg_stream_t stream) {
   p.gshift = g == 32 ? 5 : g == 64 ? 6 : g == 128 ? 7 : 8;
   p.ngroups = (int32_t)(a->k / g);
   p.qtype = a->qtype;
+  {
+    static const int env_dbg = getenv("TG_DBG") ? atoi(getenv("TG_DBG")) : 0;
+    static const int env_var = getenv("TG_VARIANT") ? atoi(getenv("TG_VARIANT")) : 0;
+    p.dbg = env_dbg;
+    g_dbg_variant = env_var;
+  }
   p.stride_x = batch > 1 ? a->stride_x : 0;
   p.stride_w = batch > 1 ? a->stride_w : 0;
   p.stride_qinfo = batch > 1 ? a->stride_qinfo : 0;
@@ -766,14 +619,15 @@ int tg_gemm_w4(const tg_w4_gemm* a, int device, tg_stream_t stream) {
   DeviceScope ds(device);
   if (!ds.ok) return TG_E_DEVICE;
   hipStream_t st = (hipStream_t)stream;
-  dim3 grid((unsigned)cdiv(a->wrows, 16), (unsigned)cdiv(a->m, 16), (unsigned)batch);
+  p.rowtiles = (int32_t)cdiv(a->wrows, 16);
+  const int64_t coltiles = cdiv(a->m, 16);
   // packed words per lane-quad in the layout decide the in-register transpose
   const int canon = on_right ? (I == 2 ? CANON_NONE : I == 4 ? CANON_PAIR : CANON_QUAD)
                              : (I == 1 ? CANON_NONE : I == 2 ? CANON_PAIR : CANON_QUAD);
   if (a->dtype == TG_BF16) {
-    return on_right ? launch_w4_c<BF16, false>(p, canon, grid, st) : launch_w4_c<BF16, true>(p, canon, grid, st);
+    return on_right ? launch_w4_c<BF16, false>(p, canon, coltiles, batch, st) : launch_w4_c<BF16, true>(p, canon, coltiles, batch, st);
   }
-  return on_right ? launch_w4_c<F16, false>(p, canon, grid, st) : launch_w4_c<F16, true>(p, canon, grid, st);
+  return on_right ? launch_w4_c<F16, false>(p, canon, coltiles, batch, st) : launch_w4_c<F16, true>(p, canon, coltiles, batch, st);
 }
 
 int tg_gemm_f16(const void* x, const void* w, void* y, int64_t m, int64_t wrows, int64_t k, int dtype,

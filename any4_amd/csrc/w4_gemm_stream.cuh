@@ -1,0 +1,273 @@
+// w4_gemm_stream.cuh -- the streaming W4A16 GEMM kernel for gfx950 ("lane owns group").
+//
+// Same contract and numerics as w4_gemm.cuh (the split-K latency kernel); this one is used whenever a
+// launch has enough 16-row tiles to give every wave its own tile or a large k-slice of one.
+//
+// Idea: the dequantised weight  w = RNE16( fma_f32(lut[row][code], scale[g,row], zero[g,row]) )
+// (reference MatrixLayoutB.cuh:1042-1046 / MatrixLayoutA.cuh:747-754) takes only 16 distinct
+// values per (row, quantisation group).  If ONE lane walks a contiguous k-span of ONE row, it can
+// compute those 16 final 16-bit values once per group -- bit-identical to the per-element fma --
+// park them in its private LDS column, and every weight element then costs exactly one v_perm_b32
+// (address) and one 16-bit LDS read that lands directly in the low / high half of the MFMA operand
+// register.  No per-element fma / cvt, no cross-lane traffic.
+//
+// Mapping: MFMA 16x16x32, W = A operand.  Lane (i = lane & 15, Q = lane >> 4) owns row i of the
+// tile and the Q-th quarter of the wave's k-slice, walked in units of 64 packed bytes (B: 128 k,
+// A: 64 k).  The K-slot of lane-row Q in every MFMA is "the next 8 k of quarter Q"; the X fragment
+// of lane (c, Q) is the matching 16 contiguous bytes of activation row c.
+#pragma once
+
+typedef const __attribute__((address_space(3))) uint16_t* lds_cu16ptr;
+typedef __attribute__((address_space(3))) uint16_t* lds_u16ptr;
+typedef const __attribute__((address_space(3))) uint32_t* lds_cu32ptr;
+typedef __attribute__((address_space(3))) uint32_t* lds_u32ptr;
+
+struct StreamParams {
+  const char* x;
+  const char* w;
+  const char* qinfo;
+  const char* lut;
+  char* y;
+  int32_t m, wrows, k;
+  int32_t ntiles;     // packed.size(0)
+  int32_t ksuper;     // packed.size(1)
+  int32_t gshift;     // log2(group)
+  int32_t ngroups;    // k / group
+  int32_t qtype;
+  int32_t splitk, sk_shift;
+  int32_t rowtiles;   // ceil(wrows / 16)
+  int32_t units_per_lane;  // NU: units walked by every lane (multiple of group / unit_k when that is > 1)
+  int64_t stride_x, stride_w, stride_qinfo, stride_lut, stride_y;
+};
+
+// WPL = packed words per (k super-tile, lane-row) entry: Bint4: I/2, Aint4: I
+template <typename DT, bool LAYOUT_A, int WPL, bool QMX, int WAVES, int MINW, int ABL = 0>
+__global__ void __launch_bounds__(WAVES * 64, MINW) w4_gemm_stream_kernel(const StreamParams p) {
+  constexpr int CHUNK = LAYOUT_A ? 16 : 32;  // k per chunk (one packed word per q)
+  constexpr int UNIT = 4 * CHUNK;            // k per unit = 64 packed bytes per lane
+  constexpr int NMMA = LAYOUT_A ? 2 : 4;     // MFMAs per chunk
+  constexpr int NP = 4 / WPL;                // 16*WPL-byte pieces per unit
+
+  __shared__ __attribute__((aligned(4096))) uint32_t s_tab[WAVES * 16 * 64];  // per wave [entry][lane]
+  __shared__ f32x4 s_red[WAVES * 64];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 15;
+  const int Q = lane >> 4;
+  const int r = i & 7;
+
+  const int slice = wave & (p.splitk - 1);
+  const int rt = blockIdx.x * (WAVES >> p.sk_shift) + (wave >> p.sk_shift);
+  const bool rt_ok = rt < p.rowtiles;
+  const int ct = blockIdx.y;
+  const int64_t b = blockIdx.z;
+  const char* xb = p.x + b * p.stride_x;
+  const char* wb = p.w + b * p.stride_w;
+  const char* qb = p.qinfo + b * p.stride_qinfo;
+  const char* lb = p.lut ? p.lut + b * p.stride_lut : nullptr;
+  char* yb = p.y + b * p.stride_y;
+
+  const int row0 = rt * 16;
+  const int row = row0 + i;
+  const int row_c = min(row, p.wrows - 1);
+  const int tile = LAYOUT_A ? rt : 2 * rt + (i >> 3);
+  const bool lane_ok = rt_ok && row < p.wrows && tile < p.ntiles;
+  const int tile_c = min(tile, p.ntiles - 1);
+
+  // packed-weight addressing: piece pc of unit U lives at k super-tile NP * U + pc
+  const uint32_t wrow = (uint32_t)((tile_c * p.ksuper * 32 + 4 * r) * WPL * 4);
+  const uint32_t wks = 32u * WPL * 4u;  // bytes per k super-tile
+  const int nunits = p.k / UNIT + (p.k % UNIT ? 1 : 0);
+  const int NU = p.units_per_lane;
+  const int u_first = (slice * 4 + Q) * NU;  // this lane's first unit
+
+  const int xrow = min(ct * 16 + i, p.m - 1);
+  const uint32_t xrowoff = (uint32_t)(xrow * p.k * 2);
+
+  // ---- raw LUT of this lane's row, as f32, in registers ----
+  float lutf[16];
+  if (p.qtype == TG_Q_INT4) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) lutf[e] = (float)(e - 8);
+  } else if (p.qtype == TG_Q_MX4) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e)
+      lutf[e] = (e & 8 ? -1.f : 1.f) * ((e & 7) < 5 ? 0.5f * (e & 7) : ((e & 7) == 5 ? 3.f : (e & 7) == 6 ? 4.f : 6.f));
+  } else {
+    const char* lrow = lb + (p.qtype == TG_Q_ANY4_ROWWISE ? (int64_t)row_c * 32 : 0);
+    const u32x4 l0 = reinterpret_cast<const u32x4*>(lrow)[0];
+    const u32x4 l1 = reinterpret_cast<const u32x4*>(lrow)[1];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const uint32_t pair = e < 8 ? l0[e >> 1] : l1[(e - 8) >> 1];
+      lutf[e] = (e & 1) ? DT::hi_f32(pair) : DT::lo_f32(pair);
+    }
+  }
+
+  uint32_t* tab = s_tab + wave * (16 * 64);
+  const uint32_t tabbase = (uint32_t)reinterpret_cast<uintptr_t>(tab);
+  const uint32_t lane4 = (uint32_t)lane * 4u | (tabbase & 0xffff0000u);
+  const uint32_t kmask = __builtin_amdgcn_readfirstlane(((tabbase >> 12) & 0xfu) * 0x10101010u);
+  const uint32_t sh = LAYOUT_A ? (uint32_t)(i >> 3) * 4u : 0u;
+  const uint32_t tabcol = tabbase + (uint32_t)lane * 4u;
+
+  // 16 final 16-bit weights of (row, group) -> this lane's LDS column
+  auto build_table = [&](uint32_t q, bool ok) {
+    float s, z;
+    if constexpr (QMX) {
+      s = u2f(q == 255u ? 0x7fc00000u : (q == 0u ? 0x00400000u : (q << 23)));  // Dequantization.cuh:331-339
+      z = 0.f;
+    } else {
+      s = DT::lo_f32(q);
+      z = DT::hi_f32(q);
+    }
+    if (!ok) s = z = 0.f;  // padding lanes contribute exact zeros
+#pragma unroll
+    for (int e = 0; e < 16; e += 2) {
+      const uint32_t pr = DT::pack2(__builtin_fmaf(lutf[e], s, z), __builtin_fmaf(lutf[e + 1], s, z));
+      *(lds_u32ptr)(tabcol + (uint32_t)e * 256u) = pr << 16;                // slot = value << 16
+      *(lds_u32ptr)(tabcol + (uint32_t)(e + 1) * 256u) = pr & 0xffff0000u;
+    }
+  };
+
+  auto load_q = [&](int k0) -> uint32_t {
+    const int g = min(k0, p.k - 1) >> p.gshift;
+    if constexpr (QMX) return reinterpret_cast<const uint8_t*>(qb)[(uint32_t)(row_c * p.ngroups + g)];
+    else return reinterpret_cast<const uint32_t*>(qb)[(uint32_t)(g * p.wrows + row_c)];
+  };
+
+  auto load_unit = [&](int U, u32x4 (&L)[4]) {
+    const int Uc = min(U, nunits - 1);
+#pragma unroll
+    for (int pc = 0; pc < NP; ++pc) {
+      const int ks = min(NP * Uc + pc, p.ksuper - 1);
+      const char* src = wb + (wrow + (uint32_t)ks * wks);
+#pragma unroll
+      for (int v = 0; v < WPL; ++v) {
+        if constexpr (ABL == 3 || ABL == 5) L[pc * WPL + v] = u32x4{(uint32_t)ks, 1u, 2u, (uint32_t)v};  // ablation: no weight stream
+        else L[pc * WPL + v] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src + 16 * v));
+      }
+    }
+  };
+
+  auto load_x = [&](int k0, u32x4 (&X)[NMMA]) {
+    const uint32_t off = xrowoff + (uint32_t)(min(k0, p.k - CHUNK) * 2);
+#pragma unroll
+    for (int h = 0; h < NMMA; ++h) {
+      if constexpr (ABL == 2) X[h] = u32x4{off, 0x3f803f80u, 2u, 3u};  // ablation: no X loads
+      else X[h] = *reinterpret_cast<const u32x4*>(xb + (off + 16u * h));
+    }
+  };
+
+  auto word = [&](const u32x4 (&L)[4], int q, int c) -> uint32_t {
+    if constexpr (WPL == 1) return L[c][q];
+    else if constexpr (WPL == 2) return L[2 * (c >> 1) + (q >> 1)][2 * (q & 1) + (c & 1)];
+    else return L[q][c];
+  };
+
+  // two lookups -> one operand register.  A table slot is the dword (value << 16): a 32-bit read
+  // yields the value already in the HIGH half, a 16-bit read at slot + 2 (folded into the DS offset
+  // field) yields it in the LOW half, so the merge is one VOP2 v_or_b32.
+  auto look2 = [&](uint32_t src, int byte_lo, int byte_hi) -> uint32_t {
+    const uint32_t a0 = __builtin_amdgcn_perm(src, lane4, 0x03020400u + ((uint32_t)byte_lo << 8));
+    const uint32_t a1 = __builtin_amdgcn_perm(src, lane4, 0x03020400u + ((uint32_t)byte_hi << 8));
+    if constexpr (ABL == 1 || ABL == 5) return a0 ^ a1;  // ablation: no LDS lookups
+    const uint32_t lo = *(lds_cu16ptr)(a0 + 2u);
+    const uint32_t hi = *(lds_cu32ptr)(a1);
+    return lo | hi;
+  };
+
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+
+  auto do_chunk = [&](const u32x4 (&L)[4], int c, const u32x4 (&X)[NMMA]) {
+    if constexpr (ABL == 4) {  // ablation: stream only
+      acc[0] += u2f(L[c][0] ^ L[c][1] ^ L[c][2] ^ L[c][3] ^ X[0][0] ^ X[NMMA - 1][3]);
+      return;
+    }
+    if constexpr (!LAYOUT_A) {
+      uint32_t wa[4], wb4[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const uint32_t w = word(L, q, c);
+        wa[q] = (w & 0x0f0f0f0fu) | kmask;          // bytes: v0 v4 v1 v5
+        wb4[q] = ((w >> 4) & 0x0f0f0f0fu) | kmask;  // bytes: v2 v6 v3 v7
+      }
+#pragma unroll
+      for (int h = 0; h < 4; ++h) {
+        u32x4 a;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const uint32_t src = (h & 1) ? wb4[q] : wa[q];
+          a[q] = look2(src, h >> 1, (h >> 1) + 2);  // k = 8h + 2q, 8h + 2q + 1
+        }
+        acc = DT::mfma(a, X[h], acc);
+      }
+    } else {
+      uint32_t ws[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) ws[q] = ((word(L, q, c) >> sh) & 0x0f0f0f0fu) | kmask;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        u32x4 a;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a[q] = look2(ws[q], h, h + 2);
+        acc = DT::mfma(a, X[h], acc);
+      }
+    }
+  };
+
+  // chunks per quantisation group (>= 1) and units per group (>= 1)
+  const int cpg_shift = max(p.gshift - (LAYOUT_A ? 4 : 5), 0);  // log2(chunks per group)
+
+  if (rt_ok) {
+    u32x4 L0[4], L1[4];   // packed words: unit in flight / unit being consumed (ping-pong)
+    u32x4 X0[NMMA], X1[NMMA];  // X fragments: chunk c uses X[c & 1], chunk c + 1 is in flight
+    uint32_t qn = load_q(u_first * UNIT);
+    load_unit(u_first, L0);
+    load_x(u_first * UNIT, X0);
+
+    auto do_unit = [&](int u, const u32x4 (&Lc)[4], u32x4 (&Ln)[4]) {
+      const int U = u_first + u;
+      const int k0 = U * UNIT;
+      if (u + 1 < NU) load_unit(U + 1, Ln);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        // new quantisation group?  wave-uniform: every lane starts group-aligned and walks in step
+        const int cglob = u * 4 + c;
+        if ((cglob & ((1 << cpg_shift) - 1)) == 0) {
+          const int kg = k0 + c * CHUNK;
+          build_table(qn, lane_ok && kg < p.k);
+          qn = load_q(kg + (CHUNK << cpg_shift));  // next group's scale|zero
+        }
+        const int kn = k0 + (c + 1) * CHUNK;  // next chunk (c == 3: first chunk of the next unit)
+        if (c & 1) {
+          load_x(kn, X0);
+          do_chunk(Lc, c, X1);
+        } else {
+          load_x(kn, X1);
+          do_chunk(Lc, c, X0);
+        }
+      }
+    };
+    for (int u = 0; u < NU; u += 2) {
+      do_unit(u, L0, L1);
+      if (u + 1 < NU) do_unit(u + 1, L1, L0);
+    }
+  }
+
+  // ---- split-K tail (identical to w4_gemm.cuh) ----
+  if (p.splitk > 1) {
+    s_red[wave * 64 + lane] = acc;
+    __syncthreads();
+    if (slice != 0) return;
+    for (int o = 1; o < p.splitk; ++o) acc += s_red[(wave + o) * 64 + lane];
+  }
+  const int col = ct * 16 + i;
+  const int rowg = row0 + 4 * Q;
+  if (rt_ok && col < p.m && rowg < p.wrows) {
+    u32x2 o = {DT::pack2(acc[0], acc[1]), DT::pack2(acc[2], acc[3])};
+    *reinterpret_cast<u32x2*>(yb + ((int64_t)col * p.wrows + rowg) * 2) = o;
+  }
+}

@@ -1,0 +1,243 @@
+#!/usr/bin/env python3
+"""bench.py -- any4 W4A16 small-batch GEMM on MI355X: achieved GB/s against the HBM roofline.
+
+Contract (one JSON line on rank 0):
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json configs[1]): any4 (per-row 16-entry bf16 LUT, g = 128) W4A16 GEMV, m = 1,
+n = k = 4096, weights packed on the B side with innerKTiles = 4 -- exactly what Any4Linear's default
+kernel `linear_y_f16RM_x_f16RM_W_any4TC` runs.  One STEP is one pass over a batch of L = 64
+independent such layers (distinct weights, activations and outputs: 580 MB, larger than L2 + Infinity
+Cache, so every step streams its weights from HBM) issued as ONE stacked launch of the C-ABI entry
+point tg_gemm_w4 (batch = L).  Inputs are resident in HBM before the timed region.
+
+`value` = algorithmic bytes of all ranks per step / max-over-ranks step time.
+Algorithmic bytes per layer: n*k/2 + (k/g)*n*4 + 32*n + m*k*2 + m*n*2 = 9 060 352 B.
+
+N > 1: the projection is row-sharded (rank r owns rows [r*n, (r+1)*n) of an [N*n, k] weight; the
+activation is replicated); every step ends with the RCCL all-gather of the partial outputs, inside
+the timed region.  Per-GPU work is fixed as N grows -> "scaling": "weak".
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 measured float4 copy
+
+
+def alg_bytes(m, n, k, g, lut_bytes):
+    return n * k // 2 + (k // g) * n * 4 + lut_bytes + m * k * 2 + m * n * 2
+
+
+def make_batch(L, m, n, k, g, inner, device, seed):
+    """Synthetic tensors of the SURVEY 8d recipe, generated on the device (packed words are uniformly
+    random nibbles, which is what packing uniformly random codes gives)."""
+    gen = torch.Generator(device=device).manual_seed(seed)
+    w = torch.randint(-2 ** 31, 2 ** 31 - 1, (L, n // 8, k // (16 * inner), 32, inner // 2), dtype=torch.int64,
+                      device=device, generator=gen).to(torch.int32)
+    x = torch.randn(L, m, k, device=device, generator=gen).to(torch.bfloat16)
+    scales = torch.rand(L, k // g, n, device=device, generator=gen) * 0.02 + 0.005
+    zeros = torch.randn(L, k // g, n, device=device, generator=gen) * 0.01
+    sz = torch.stack([scales, zeros], dim=3).to(torch.bfloat16).contiguous()
+    lut = torch.randn(L, n, 16, device=device, generator=gen).to(torch.bfloat16)
+    y = torch.empty(L, m, n, device=device, dtype=torch.bfloat16)
+    return w, x, sz, lut, y
+
+
+def cpu_baseline(m, n, k, g, budget_s=12.0):
+    """The oracle (a C port of the reference's dequant + matmul, oracle/tinygemm_oracle.c) timed on the
+    host cores on a bounded sample of the same workload: whole layers until ~budget_s have elapsed."""
+    import numpy as np
+
+    from oracle import oracle as orc
+
+    orc.build()
+    threads = os.cpu_count() or 1
+    orc.set_num_threads(threads)
+    rng = np.random.default_rng(0)
+    codes = rng.integers(0, 16, (n, k), dtype=np.int32)
+    lut = orc.bf16_bits(rng.standard_normal((n, 16)).astype(np.float32))
+    sz = orc.bf16_bits((rng.random((k // g, n, 2)) * 0.02).astype(np.float32))
+    x = orc.bf16_bits(rng.standard_normal((m, k)).astype(np.float32))
+    orc.linear(x, codes, g, orc.Q_ANY4_ROWWISE, sz, lut)  # warm-up
+    layers, t0 = 0, time.perf_counter()
+    while True:
+        orc.linear(x, codes, g, orc.Q_ANY4_ROWWISE, sz, lut)
+        layers += 1
+        dt = time.perf_counter() - t0
+        if dt >= budget_s or layers >= 2000:
+            break
+    gbps = layers * alg_bytes(m, n, k, g, 32 * n) / dt / 1e9
+    return {"value": round(gbps, 4), "unit": "GB/s", "cores": orc.num_threads(), "kind": "port",
+            "sample": f"{layers} layers of the bench workload (m={m}, n=k={n}, g={g}) in {dt:.1f} s, "
+                      f"OpenMP over weight rows, {dt / layers * 1e3:.1f} ms per layer"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--layers", type=int, default=64, help="independent layers per step (stacked launch)")
+    ap.add_argument("--m", type=int, default=1)
+    ap.add_argument("--n", type=int, default=4096)
+    ap.add_argument("--k", type=int, default=4096)
+    ap.add_argument("--group", type=int, default=128)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+
+    import torch.distributed as dist
+
+    if world > 1:
+        dist.init_process_group(backend="nccl")  # RCCL on ROCm
+
+    from any4_amd import _lib
+
+    lib = _lib.load()
+    L, m, n, k, g, inner = a.layers, a.m, a.n, a.k, a.group, 4
+    w, x, sz, lut, y = make_batch(L, m, n, k, g, inner, device, seed=1234 + rank)
+    if world > 1:
+        # replicated activations: every rank sees rank 0's x (as after the previous layer's all-gather)
+        dist.broadcast(x, src=0)
+        y_all = torch.empty(world, L, m, n, device=device, dtype=torch.bfloat16)
+
+    args = _lib.W4Gemm(
+        x=x.data_ptr(), w=w.data_ptr(), qinfo=sz.data_ptr(), lut=lut.data_ptr(), y=y.data_ptr(),
+        m=m, wrows=n, k=k, group=g, qtype=_lib.TG_Q_ANY4_ROWWISE, dtype=_lib.TG_BF16, w_on_right=1,
+        inner_k_tiles=inner, batch=L, stride_x=x.stride(0) * 2, stride_w=w.stride(0) * 4,
+        stride_qinfo=sz.stride(0) * 2, stride_lut=lut.stride(0) * 2, stride_y=y.stride(0) * 2)
+    stream = torch.cuda.current_stream()
+
+    def step():
+        _lib.check(lib.tg_gemm_w4(ctypes.byref(args), local_rank, stream.cuda_stream), "tg_gemm_w4")
+        if world > 1:
+            dist.all_gather_into_tensor(y_all, y)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    fence()
+    # kernel-only duration of the dominant kernel, measured live with HIP events on the launch stream
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    t0 = time.perf_counter()
+    for s in range(a.steps):
+        ev[s][0].record(stream)
+        _lib.check(lib.tg_gemm_w4(ctypes.byref(args), local_rank, stream.cuda_stream), "tg_gemm_w4")
+        ev[s][1].record(stream)
+        if world > 1:
+            dist.all_gather_into_tensor(y_all, y)
+    fence()
+    elapsed = time.perf_counter() - t0
+    kern_ms = sum(e0.elapsed_time(e1) for e0, e1 in ev) / a.steps
+
+    t = torch.tensor([elapsed, kern_ms], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed, kern_ms = float(t[0]), float(t[1])
+
+    bytes_layer = alg_bytes(m, n, k, g, 32 * n)
+    bytes_step_rank = L * bytes_layer
+    ms_per_step = elapsed / a.steps * 1e3
+    value = world * bytes_step_rank / (elapsed / a.steps) / 1e9
+    achieved = bytes_step_rank / (kern_ms * 1e-3) / 1e9
+
+    if rank == 0:
+        # single-layer launches (what one Any4Linear.forward issues), informational
+        single = _lib.W4Gemm.from_buffer_copy(args)
+        single.batch = 1
+        per = []
+        for b in range(L):
+            sa = _lib.W4Gemm.from_buffer_copy(single)
+            sa.x, sa.w, sa.qinfo = x[b].data_ptr(), w[b].data_ptr(), sz[b].data_ptr()
+            sa.lut, sa.y = lut[b].data_ptr(), y[b].data_ptr()
+            per.append(sa)
+        for sa in per:
+            lib.tg_gemm_w4(ctypes.byref(sa), local_rank, stream.cuda_stream)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(5):
+            for sa in per:
+                lib.tg_gemm_w4(ctypes.byref(sa), local_rank, stream.cuda_stream)
+        e1.record(stream)
+        torch.cuda.synchronize()
+        single_us = e0.elapsed_time(e1) * 1e3 / (5 * L)
+
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+
+        out = {
+            "metric": "any4 W4A16 GEMM achieved GB/s (m=1, n=k=4096, g=128)",
+            "value": round(value, 2),
+            "unit": "GB/s",
+            "n_gpus": world,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": round(ms_per_step, 5),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "bf16",
+            "data": "synthetic",
+            "config": {
+                "workload": f"any4 W4A16 GEMV m={m} n={n} k={k} g={g} per-row LUT, Bint4 innerKTiles=4; "
+                            f"one step = {L} independent layers (distinct cold weights) in one stacked launch"
+                            + (f"; rows sharded over {world} ranks + RCCL all-gather of y" if world > 1 else ""),
+                "layers_per_step": L, "m": m, "n": n, "k": k, "group": g,
+                "algorithmic_bytes_per_layer": bytes_layer,
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "w4_gemm_kernel<BF16, Bint4, innerK=4> (stacked, split-K 1)",
+                "achieved": round(achieved, 2),
+                "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                "traffic": traffic,
+                "launch_us": round(kern_ms * 1e3, 3),
+                "bytes_per_launch": bytes_step_rank,
+            },
+            "single_layer_launch": {
+                "us_per_launch": round(single_us, 3),
+                "GBps": round(bytes_layer / single_us / 1e3, 2),
+                "note": "back-to-back one-layer launches on one stream (split-K 16 latency kernel), event time / launches",
+            },
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(m, n, k, g)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,222 @@
+"""CPU suite, part 2: host logic, the C-ABI surface, the op/functional/module mirror and the row-shard
+all-gather (gloo, world_size 2).  No GPU, no HIP compute."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ---------------------------------------------------------------- C ABI
+
+def _declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "tinygemm_hip.h")).read()
+    return sorted(set(re.findall(r"TG_API\s+[\w\s\*]+?\b(tg_\w+)\s*\(", hdr)))
+
+
+def test_c_abi_exports_every_declared_symbol():
+    from any4_amd import _lib
+
+    syms = _declared_symbols()
+    assert len(syms) >= 11 and "tg_gemm_w4" in syms
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/tinygemm_hip.h but not exported"
+    assert set(syms) == set(_lib.SYMBOLS), "ctypes binding and header disagree"
+    assert _lib.load().tg_abi_version() == 1
+
+
+def test_c_abi_preconditions_fail_before_any_launch():
+    """Negative codes are returned by argument validation, which runs before the first HIP call."""
+    from any4_amd import _lib
+
+    L = _lib.load()
+    assert L.tg_convert_to_Bint4(None, 8, 64, 4, None, 0, None) == -1          # TG_E_NULL
+    buf = (ctypes.c_int32 * 64)()
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    assert L.tg_convert_to_Bint4(p, 8, 64, 3, p, 0, None) == -2                # bad innerKTiles
+    assert L.tg_convert_to_Bint4(p, 8, 96, 4, p, 0, None) == -3                # k % 64
+    assert L.tg_convert_to_Aint4(p, 8, 64, 8, p, 0, None) == -2
+    a = _lib.W4Gemm(x=p, w=p, qinfo=p, lut=p, y=p, m=1, wrows=16, k=128, group=48, qtype=2, dtype=0, w_on_right=1,
+                    inner_k_tiles=4, batch=1)
+    assert L.tg_gemm_w4(ctypes.byref(a), 0, None) == -4                         # bad group
+    a.group, a.qtype, a.dtype = 32, 3, 1
+    assert L.tg_gemm_w4(ctypes.byref(a), 0, None) == -5                         # mx4 + fp16
+    a.dtype, a.qtype, a.k = 0, 2, 144
+    assert L.tg_gemm_w4(ctypes.byref(a), 0, None) == -3                         # k % 32
+    a.k, a.lut = 128, None
+    assert L.tg_gemm_w4(ctypes.byref(a), 0, None) == -1                         # any4 without LUT
+    for code in range(-9, 1):
+        assert len(L.tg_error_string(code)) > 0
+    with pytest.raises(RuntimeError, match="qGroupSize"):
+        _lib.check(-4, "x")
+
+
+# ---------------------------------------------------------------- op surface
+
+REFERENCE_SCHEMAS = {  # tinygemm_lib/TinyGemm.cpp:17-122
+    "convert_matrix_to_m16n8k16_A_layout": "(Tensor t, int innerKTiles) -> Tensor",
+    "convert_matrix_to_m16n8k16_Aint4_layout": "(Tensor t, int innerKTiles) -> Tensor",
+    "convert_matrix_to_m16n8k16_Aint8_layout": "(Tensor t, int innerKTiles) -> Tensor",
+    "convert_matrix_from_m16n8k16_A_layout": "(Tensor t, int m, int k) -> Tensor",
+    "convert_matrix_to_m16n8k16_B_layout": "(Tensor t, int innerKTiles) -> Tensor",
+    "convert_matrix_to_m16n8k16_Bint4_layout": "(Tensor t, int innerKTiles) -> Tensor",
+    "convert_matrix_to_m16n8k16_Bint8_layout": "(Tensor t, int innerKTiles) -> Tensor",
+    "convert_matrix_from_m16n8k16_B_layout": "(Tensor t, int n, int k) -> Tensor",
+    "tinygemm_y_f16TC_x_f16TC_w_int4TC": "(Tensor A, Tensor B, int qGroupSize, Tensor qScaleAndZeros, bool weightOnRight) -> Tensor",
+    "tinygemm_y_f16RM_x_f16RM_w_int4TC": "(Tensor A, Tensor B, int qGroupSize, Tensor qScaleAndZeros, bool weightOnRight) -> Tensor",
+    "tinygemm_y_f16TC_x_f16TC_w_any4TC": "(Tensor A, Tensor B, int qGroupSize, Tensor qScaleAndZeros, Tensor int4DequantValues, bool weightOnRight) -> Tensor",
+    "tinygemm_y_f16RM_x_f16RM_w_any4TC": "(Tensor A, Tensor B, int qGroupSize, Tensor qScaleAndZeros, Tensor int4DequantValues, bool weightOnRight) -> Tensor",
+    "tinygemm_y_f16TC_x_f16TC_w_mx4TC": "(Tensor A, Tensor B, int qGroupSize, Tensor mx4Exponents, bool weightOnRight) -> Tensor",
+    "tinygemm_y_f16RM_x_f16RM_w_mx4TC": "(Tensor A, Tensor B, int qGroupSize, Tensor mx4Exponents, bool weightOnRight) -> Tensor",
+    "tinygemm_y_f16TC_x_f16TC_w_int8TC": "(Tensor A, Tensor B, int qGroupSize, Tensor qScaleAndZeros, bool weightOnRight) -> Tensor",
+    "tinygemm_y_f16RM_x_f16RM_w_int8TC": "(Tensor A, Tensor B, int qGroupSize, Tensor qScaleAndZeros, bool weightOnRight) -> Tensor",
+    "tinygemm_y_f16TC_x_f16TC_w_f16TC": "(Tensor A, Tensor B, bool weightOnRight) -> Tensor",
+    "tinygemm_y_f16RM_x_f16RM_w_f16TC": "(Tensor A, Tensor B, bool weightOnRight) -> Tensor",
+    "tinygemm_dequant_int4": "(Tensor t) -> Tensor",
+}
+
+
+def test_ops_registered_with_reference_schemas():
+    import tinygemm  # noqa: F401
+
+    for name, sig in REFERENCE_SCHEMAS.items():
+        op = getattr(torch.ops.tinygemm, name)
+        schema = str(op.default._schema)
+        assert schema == f"tinygemm::{name}{sig}", schema
+
+
+def test_no_cpu_fallback():
+    import tinygemm  # noqa: F401
+
+    with pytest.raises(NotImplementedError):
+        torch.ops.tinygemm.convert_matrix_to_m16n8k16_Bint4_layout(torch.zeros(8, 64, dtype=torch.int32), 4)
+    with pytest.raises(NotImplementedError):
+        torch.ops.tinygemm.tinygemm_y_f16RM_x_f16RM_w_int4TC(
+            torch.zeros(1, 64).bfloat16(), torch.zeros(1, 1, 32, 2, dtype=torch.int32), 32, torch.zeros(2, 8, 2).bfloat16(), True)
+
+
+def test_missing_library_fails_loudly(tmp_path, monkeypatch):
+    from any4_amd import _lib
+
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(ImportError, match="no CPU"):
+        _lib.load()
+
+
+def test_valid_tinygemm_kernel_call_truth_table():
+    import tinygemm_lib.functional as F
+
+    right = ["linear_y_f16RM_x_f16RM_W_any4TC", "linear_y_f16TC_x_f16TC_W_any4TC"]
+    left = ["linear_y_f16TC_W_any4TC_x_f16TC", "linear_y_f16RM_W_any4TC_x_f16RM"]
+    for w in (1, 2, 3, 4, 8, 16):
+        for api in right:
+            assert bool(F.valid_tinygemm_kernel_call(api, w)) == (w in (2, 4, 8))
+        for api in left:
+            assert bool(F.valid_tinygemm_kernel_call(api, w)) == (w in (1, 2, 4))
+    assert not F.valid_tinygemm_kernel_call("linear_y_f16RM_x_f16RM_W_int4TC", 4)
+    names = [n for n in dir(F) if n.startswith("linear_y_")]
+    assert len(names) == 16  # 4 int4 + 4 int8 + 4 any4 + 4 f16 (reference functional.py:20-259)
+
+
+def test_module_surface():
+    import modules
+
+    m = modules.Any4Linear(256, 64, bias=True, dtype=torch.bfloat16, group_size=128)
+    assert m.weight.shape == (64, 256) and m.weight.dtype == torch.int32 and not m.weight.requires_grad
+    assert m.scales_and_zeros.shape == (2, 64, 2) and m.lut.shape == (64, 16) and m.bias.shape == (64,)
+    assert m.kernel == "linear_y_f16RM_x_f16RM_W_any4TC" and m.w_inner_k == 4 and not m.weight_reshaped
+    assert m.per_row and m.n_bit == 4 and m.N_BIT == 4 and m.group_size == 128
+    assert set(m.state_dict()) == {"weight", "scales_and_zeros", "lut", "bias"}
+    assert "per_row=True" in repr(m)
+    g = modules.Any4Linear(256, 64, bias=False, per_row=False)
+    assert g.lut.shape == (16,) and g.bias is None
+    i4 = modules.Int4Linear(256, 64, dtype=torch.float16)
+    assert i4.kernel == "linear_y_f16RM_W_int4TC_x_f16RM" and i4.weight.abs().sum() == 0
+    assert set(i4.state_dict()) == {"weight", "scales_and_zeros", "bias"}
+    i8 = modules.Int8Linear(256, 64)
+    assert i8.w_inner_k == 2
+    bad = modules.Any4Linear(256, 64, kernel="linear_y_bogus")
+    with pytest.raises(ValueError, match="Unsupported kernel"):
+        bad.reshape_weight()
+    with pytest.raises(ValueError, match="Unsupported kernel"):
+        bad(torch.zeros(1, 256))
+
+
+def test_group_quantize_roundtrip():
+    from tinygemm_lib.utils import extract_scales_and_zeros, group_quantize_tensor
+
+    torch.manual_seed(0)
+    w = torch.randn(32, 256)
+    for g in (32, 64, 128):
+        codes, sz = group_quantize_tensor(w, 4, g)
+        assert codes.dtype == torch.int32 and codes.min() >= 0 and codes.max() <= 15
+        assert sz.shape == (256 // g, 32, 2)
+        s, z = extract_scales_and_zeros(sz, w.shape, g)
+        deq = (codes.float() - 8) * s + z
+        assert (deq - w).abs().max() <= s.max() * 0.5 + 1e-6
+
+
+# ---------------------------------------------------------------- row sharding over gloo (world_size 2)
+
+def _shard_worker(rank, world, port, results):
+    import torch.distributed as dist
+
+    from any4_amd.shard import RowShardedLinear, row_range, shard_any4_params
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        gen = torch.Generator().manual_seed(0)  # same full problem on every rank
+        n, k, g, m = 64, 128, 32, 3
+        codes = torch.randint(0, 16, (n, k), dtype=torch.int32, generator=gen)
+        lut = torch.randn(n, 16, generator=gen)
+        sz = torch.randn(k // g, n, 2, generator=gen) * 0.1
+        x = torch.randn(2, m, k, generator=gen)
+
+        def dequant(c, l, s):
+            sc = s[:, :, 0].t().repeat_interleave(g, dim=1)
+            zc = s[:, :, 1].t().repeat_interleave(g, dim=1)
+            return torch.gather(l, 1, c.long()) * sc + zc
+
+        y_full = x @ dequant(codes, lut, sz).t()
+        c, l, s = shard_any4_params(codes, lut, sz, rank, world)
+        lo, hi = row_range(n, rank, world)
+        assert c.shape == (n // world, k) and s.shape == (k // g, n // world, 2) and l.shape == (n // world, 16)
+
+        class Local(torch.nn.Module):  # stand-in for the rank-local Any4Linear (the HIP GEMM needs a GPU)
+            def forward(self, inp):
+                return inp @ dequant(c, l, s).t()
+
+        y = RowShardedLinear(Local(), n)(x)
+        ok = y.shape == y_full.shape and torch.allclose(y, y_full, atol=1e-5)
+        y_sharded = RowShardedLinear(Local(), n, gather_output=False)(x)
+        ok = ok and torch.allclose(y_sharded, y_full[..., lo:hi], atol=1e-5)
+        results[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_row_sharded_all_gather_gloo():
+    import torch.multiprocessing as mp
+
+    world = 2
+    port = 29500 + (os.getpid() % 2000)
+    mgr = mp.Manager()
+    results = mgr.dict()
+    mp.spawn(_shard_worker, args=(world, port, results), nprocs=world, join=True)
+    assert dict(results) == {0: True, 1: True}
+
+
+def test_row_range_validation():
+    from any4_amd.shard import row_range
+
+    assert row_range(4096, 3, 8) == (1536, 2048)
+    assert row_range(14336, 7, 8) == (12544, 14336)
+    with pytest.raises(ValueError):
+        row_range(100, 0, 8)

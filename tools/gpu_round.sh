@@ -1,0 +1,26 @@
+# One GPU-box visit: smoke, gpu tests, bench line, rocprof kernel stats + PMC traffic.  Writes gpurun_out/.
+set -u
+mkdir -p gpurun_out/prof
+R=$GRAFT_REPO_ROOT
+cd $R
+python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1; echo "smoke rc=$?"; tail -2 gpurun_out/smoke.log
+timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/gpu_tests.log 2>&1; echo "pytest rc=$?"; tail -3 gpurun_out/gpu_tests.log
+timeout 600 python bench.py > gpurun_out/bench.log 2> gpurun_out/bench.err; echo "bench rc=$?"; cat gpurun_out/bench.log; tail -3 gpurun_out/bench.err
+cd /tmp && export TMPDIR=/tmp
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof/stats -o bench -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $R/gpurun_out/prof/stats.log 2>&1
+timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/prof/pmc_fetch -o bench -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $R/gpurun_out/prof/pmc_fetch.log 2>&1
+timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/prof/pmc_write -o bench -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $R/gpurun_out/prof/pmc_write.log 2>&1
+cd $R
+find gpurun_out/prof -name "*.csv" | head -20
+head -4 gpurun_out/prof/stats/bench_kernel_stats.csv | cut -c1-260
+python - <<'PY'
+import csv, glob, collections
+for d in ("pmc_fetch", "pmc_write"):
+    for f in glob.glob(f"gpurun_out/prof/{d}/*counter_collection.csv"):
+        agg = collections.defaultdict(list)
+        for r in csv.DictReader(open(f)):
+            if "w4_gemm" in r["Kernel_Name"]:
+                agg[(r["Kernel_Name"][:60], r["Counter_Name"], r["Grid_Size"])].append(float(r["Counter_Value"]))
+        for k, v in agg.items():
+            print(d, k, "n=", len(v), "mean=", sum(v) / len(v))
+PY
