@@ -407,7 +407,8 @@ int launch_w4(GemmParams& p, int64_t coltiles, int64_t batch, hipStream_t st) {
     const int nunits = (p.k + UNIT - 1) / UNIT;
     const int upg = (1 << p.gshift) > UNIT ? (1 << p.gshift) / UNIT : 1;  // units per quantisation group
     int sk = g.splitk;
-    while (sk > 1 && nunits < 4 * sk * upg) sk >>= 1;
+    const int mrows = p.m < 16 ? p.m : 16;
+    while (sk > 1 && (nunits < 4 * sk * upg || mrows * sk > 16)) sk >>= 1;  // X slab: act rows * splitk <= 16
     int nu = (nunits + 4 * sk - 1) / (4 * sk);
     nu = (nu + upg - 1) / upg * upg;
     sp.splitk = sk;

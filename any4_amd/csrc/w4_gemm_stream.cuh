@@ -7,20 +7,26 @@
 // (reference MatrixLayoutB.cuh:1042-1046 / MatrixLayoutA.cuh:747-754) takes only 16 distinct
 // values per (row, quantisation group).  If ONE lane walks a contiguous k-span of ONE row, it can
 // compute those 16 final 16-bit values once per group -- bit-identical to the per-element fma --
-// park them in its private LDS column, and every weight element then costs exactly one v_perm_b32
-// (address) and one 16-bit LDS read that lands directly in the low / high half of the MFMA operand
-// register.  No per-element fma / cvt, no cross-lane traffic.
+// park them in its private LDS column, and every weight element then costs one v_perm_b32 (the LDS
+// address) and one LDS read; two reads are merged into an MFMA operand register by one v_or_b32.
+// No per-element fma / cvt, no cross-lane traffic.
 //
 // Mapping: MFMA 16x16x32, W = A operand.  Lane (i = lane & 15, Q = lane >> 4) owns row i of the
 // tile and the Q-th quarter of the wave's k-slice, walked in units of 64 packed bytes (B: 128 k,
 // A: 64 k).  The K-slot of lane-row Q in every MFMA is "the next 8 k of quarter Q"; the X fragment
 // of lane (c, Q) is the matching 16 contiguous bytes of activation row c.
+//
+// Activations go through LDS: every wave of a workgroup walks the same k sequence, so the X slab
+// of one unit-step ([act rows][quarters][UNIT] 16-bit) is staged once per workgroup, double
+// buffered, one barrier per unit.  This keeps X out of the in-order vector-memory return queue:
+// the only VM waits in the loop are for data requested one whole unit earlier.
 #pragma once
 
 typedef const __attribute__((address_space(3))) uint16_t* lds_cu16ptr;
-typedef __attribute__((address_space(3))) uint16_t* lds_u16ptr;
 typedef const __attribute__((address_space(3))) uint32_t* lds_cu32ptr;
 typedef __attribute__((address_space(3))) uint32_t* lds_u32ptr;
+typedef const __attribute__((address_space(3))) u32x4* lds_cu32x4ptr;
+typedef __attribute__((address_space(3))) u32x4* lds_u32x4ptr;
 
 struct StreamParams {
   const char* x;
@@ -36,7 +42,7 @@ struct StreamParams {
   int32_t qtype;
   int32_t splitk, sk_shift;
   int32_t rowtiles;   // ceil(wrows / 16)
-  int32_t units_per_lane;  // NU: units walked by every lane (multiple of group / unit_k when that is > 1)
+  int32_t units_per_lane;  // NU: units walked by every lane (a multiple of group / UNIT when that is > 1)
   int64_t stride_x, stride_w, stride_qinfo, stride_lut, stride_y;
 };
 
@@ -47,8 +53,14 @@ __global__ void __launch_bounds__(WAVES * 64, MINW) w4_gemm_stream_kernel(const 
   constexpr int UNIT = 4 * CHUNK;            // k per unit = 64 packed bytes per lane
   constexpr int NMMA = LAYOUT_A ? 2 : 4;     // MFMAs per chunk
   constexpr int NP = 4 / WPL;                // 16*WPL-byte pieces per unit
+  constexpr int XROW = UNIT * 2 + 16;        // bytes per staged X row; +16 rotates rows over the LDS banks
+  constexpr int PPR = UNIT * 2 / 16;         // 16-byte pieces per staged X row
+  constexpr int XROWS_MAX = 64;              // act rows (<= 16) x quarters (4) x splitk, host keeps it <= 64
+  constexpr int NTHREADS = WAVES * 64;
+  constexpr int XLOADS = XROWS_MAX * PPR / NTHREADS > 0 ? XROWS_MAX * PPR / NTHREADS : 1;
 
   __shared__ __attribute__((aligned(4096))) uint32_t s_tab[WAVES * 16 * 64];  // per wave [entry][lane]
+  __shared__ __attribute__((aligned(16))) char s_x[2 * XROWS_MAX * XROW];      // double-buffered X slab
   __shared__ f32x4 s_red[WAVES * 64];
 
   const int tid = threadIdx.x;
@@ -74,7 +86,7 @@ __global__ void __launch_bounds__(WAVES * 64, MINW) w4_gemm_stream_kernel(const 
   const int row_c = min(row, p.wrows - 1);
   const int tile = LAYOUT_A ? rt : 2 * rt + (i >> 3);
   const bool lane_ok = rt_ok && row < p.wrows && tile < p.ntiles;
-  const int tile_c = min(tile, p.ntiles - 1);
+  const int tile_c = min(max(tile, 0), p.ntiles - 1);
 
   // packed-weight addressing: piece pc of unit U lives at k super-tile NP * U + pc
   const uint32_t wrow = (uint32_t)((tile_c * p.ksuper * 32 + 4 * r) * WPL * 4);
@@ -83,8 +95,43 @@ __global__ void __launch_bounds__(WAVES * 64, MINW) w4_gemm_stream_kernel(const 
   const int NU = p.units_per_lane;
   const int u_first = (slice * 4 + Q) * NU;  // this lane's first unit
 
-  const int xrow = min(ct * 16 + i, p.m - 1);
-  const uint32_t xrowoff = (uint32_t)(xrow * p.k * 2);
+  // ---- X staging: thread -> (staged row, 16-byte piece); staged row = (act row c, slice, quarter) ----
+  const int mrows = min(p.m - ct * 16, 16);
+  const int xrows = mrows * 4 * p.splitk;
+  uint32_t xs_rowbase[XLOADS];  // global byte offset of the activation row this thread stages from
+  uint32_t xs_in[XLOADS];       // byte offset inside that row at unit-step 0
+  uint32_t xs_loff[XLOADS];     // LDS byte offset inside one buffer
+  bool xs_on[XLOADS];
+#pragma unroll
+  for (int j = 0; j < XLOADS; ++j) {
+    const int pid = tid + j * NTHREADS;
+    const int srow = pid / PPR, pc = pid % PPR;
+    xs_on[j] = srow < xrows;
+    const int sq = srow & 3, ssl = (srow >> 2) & (p.splitk - 1), sc = srow >> (2 + p.sk_shift);
+    const int xr = min(ct * 16 + sc, p.m - 1);
+    xs_rowbase[j] = (uint32_t)(xr * p.k * 2);
+    xs_in[j] = (uint32_t)((((ssl * 4 + sq) * NU) * UNIT + pc * 8) * 2);
+    xs_loff[j] = (uint32_t)(srow * XROW + pc * 16);
+  }
+  const uint32_t xrow_last = (uint32_t)((p.k - 8) * 2);  // clamp: last valid 16-byte piece of a row
+  auto stage_load = [&](int u, u32x4 (&R)[XLOADS]) {
+#pragma unroll
+    for (int j = 0; j < XLOADS; ++j) {
+      if (xs_on[j]) {
+        // clamp inside the activation row (padding units read valid memory; their weights are zero)
+        const uint32_t inrow = min(xs_in[j] + (uint32_t)(u * UNIT * 2), xrow_last);
+        R[j] = *reinterpret_cast<const u32x4*>(xb + (xs_rowbase[j] + inrow));
+      }
+    }
+  };
+  auto stage_store = [&](int buf, const u32x4 (&R)[XLOADS]) {
+#pragma unroll
+    for (int j = 0; j < XLOADS; ++j)
+      if (xs_on[j]) *(lds_u32x4ptr)((uint32_t)reinterpret_cast<uintptr_t>(s_x) + (uint32_t)(buf * XROWS_MAX * XROW) + xs_loff[j]) = R[j];
+  };
+  // this lane's fragment row in a staged slab
+  const int frow = ((min(i, mrows - 1) << p.sk_shift) + slice) * 4 + Q;
+  const uint32_t xfrag = (uint32_t)reinterpret_cast<uintptr_t>(s_x) + (uint32_t)(frow * XROW);
 
   // ---- raw LUT of this lane's row, as f32, in registers ----
   float lutf[16];
@@ -113,7 +160,7 @@ __global__ void __launch_bounds__(WAVES * 64, MINW) w4_gemm_stream_kernel(const 
   const uint32_t sh = LAYOUT_A ? (uint32_t)(i >> 3) * 4u : 0u;
   const uint32_t tabcol = tabbase + (uint32_t)lane * 4u;
 
-  // 16 final 16-bit weights of (row, group) -> this lane's LDS column
+  // 16 final 16-bit weights of (row, group) -> this lane's LDS column; slot = value << 16
   auto build_table = [&](uint32_t q, bool ok) {
     float s, z;
     if constexpr (QMX) {
@@ -127,7 +174,7 @@ __global__ void __launch_bounds__(WAVES * 64, MINW) w4_gemm_stream_kernel(const 
 #pragma unroll
     for (int e = 0; e < 16; e += 2) {
       const uint32_t pr = DT::pack2(__builtin_fmaf(lutf[e], s, z), __builtin_fmaf(lutf[e + 1], s, z));
-      *(lds_u32ptr)(tabcol + (uint32_t)e * 256u) = pr << 16;                // slot = value << 16
+      *(lds_u32ptr)(tabcol + (uint32_t)e * 256u) = pr << 16;
       *(lds_u32ptr)(tabcol + (uint32_t)(e + 1) * 256u) = pr & 0xffff0000u;
     }
   };
@@ -136,6 +183,13 @@ __global__ void __launch_bounds__(WAVES * 64, MINW) w4_gemm_stream_kernel(const 
     const int g = min(k0, p.k - 1) >> p.gshift;
     if constexpr (QMX) return reinterpret_cast<const uint8_t*>(qb)[(uint32_t)(row_c * p.ngroups + g)];
     else return reinterpret_cast<const uint32_t*>(qb)[(uint32_t)(g * p.wrows + row_c)];
+  };
+  // scale|zero words of the groups that START inside unit U (up to 4: group 32 on the B side)
+  const int gstep = 1 << p.gshift;
+  auto load_q4 = [&](int U, uint32_t (&q)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (j == 0 || j * gstep < UNIT) q[j] = load_q(U * UNIT + j * gstep);
   };
 
   auto load_unit = [&](int U, u32x4 (&L)[4]) {
@@ -146,18 +200,9 @@ __global__ void __launch_bounds__(WAVES * 64, MINW) w4_gemm_stream_kernel(const 
       const char* src = wb + (wrow + (uint32_t)ks * wks);
 #pragma unroll
       for (int v = 0; v < WPL; ++v) {
-        if constexpr (ABL == 3 || ABL == 5) L[pc * WPL + v] = u32x4{(uint32_t)ks, 1u, 2u, (uint32_t)v};  // ablation: no weight stream
+        if constexpr (ABL == 3) L[pc * WPL + v] = u32x4{(uint32_t)ks, 1u, 2u, (uint32_t)v};  // ablation: no weight stream
         else L[pc * WPL + v] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src + 16 * v));
       }
-    }
-  };
-
-  auto load_x = [&](int k0, u32x4 (&X)[NMMA]) {
-    const uint32_t off = xrowoff + (uint32_t)(min(k0, p.k - CHUNK) * 2);
-#pragma unroll
-    for (int h = 0; h < NMMA; ++h) {
-      if constexpr (ABL == 2) X[h] = u32x4{off, 0x3f803f80u, 2u, 3u};  // ablation: no X loads
-      else X[h] = *reinterpret_cast<const u32x4*>(xb + (off + 16u * h));
     }
   };
 
@@ -173,7 +218,7 @@ __global__ void __launch_bounds__(WAVES * 64, MINW) w4_gemm_stream_kernel(const 
   auto look2 = [&](uint32_t src, int byte_lo, int byte_hi) -> uint32_t {
     const uint32_t a0 = __builtin_amdgcn_perm(src, lane4, 0x03020400u + ((uint32_t)byte_lo << 8));
     const uint32_t a1 = __builtin_amdgcn_perm(src, lane4, 0x03020400u + ((uint32_t)byte_hi << 8));
-    if constexpr (ABL == 1 || ABL == 5) return a0 ^ a1;  // ablation: no LDS lookups
+    if constexpr (ABL == 1) return a0 ^ a1;  // ablation: no LDS lookups
     const uint32_t lo = *(lds_cu16ptr)(a0 + 2u);
     const uint32_t hi = *(lds_cu32ptr)(a1);
     return lo | hi;
@@ -181,9 +226,11 @@ __global__ void __launch_bounds__(WAVES * 64, MINW) w4_gemm_stream_kernel(const 
 
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 
-  auto do_chunk = [&](const u32x4 (&L)[4], int c, const u32x4 (&X)[NMMA]) {
+  // chunk c of the unit whose words are in L; X fragments come from the staged slab `xbuf`
+  auto do_chunk = [&](const u32x4 (&L)[4], int c, uint32_t xbuf) {
+    const uint32_t xa = xbuf + (uint32_t)(c * CHUNK * 2);
     if constexpr (ABL == 4) {  // ablation: stream only
-      acc[0] += u2f(L[c][0] ^ L[c][1] ^ L[c][2] ^ L[c][3] ^ X[0][0] ^ X[NMMA - 1][3]);
+      acc[0] += u2f(L[c][0] ^ L[c][1] ^ L[c][2] ^ L[c][3] ^ (*(lds_cu32ptr)(xa)));
       return;
     }
     if constexpr (!LAYOUT_A) {
@@ -202,7 +249,7 @@ __global__ void __launch_bounds__(WAVES * 64, MINW) w4_gemm_stream_kernel(const 
           const uint32_t src = (h & 1) ? wb4[q] : wa[q];
           a[q] = look2(src, h >> 1, (h >> 1) + 2);  // k = 8h + 2q, 8h + 2q + 1
         }
-        acc = DT::mfma(a, X[h], acc);
+        acc = DT::mfma(a, *(lds_cu32x4ptr)(xa + 16u * h), acc);
       }
     } else {
       uint32_t ws[4];
@@ -213,51 +260,51 @@ __global__ void __launch_bounds__(WAVES * 64, MINW) w4_gemm_stream_kernel(const 
         u32x4 a;
 #pragma unroll
         for (int q = 0; q < 4; ++q) a[q] = look2(ws[q], h, h + 2);
-        acc = DT::mfma(a, X[h], acc);
+        acc = DT::mfma(a, *(lds_cu32x4ptr)(xa + 16u * h), acc);
       }
     }
   };
 
-  // chunks per quantisation group (>= 1) and units per group (>= 1)
-  const int cpg_shift = max(p.gshift - (LAYOUT_A ? 4 : 5), 0);  // log2(chunks per group)
+  const int cpg_shift = max(p.gshift - (LAYOUT_A ? 4 : 5), 0);  // log2(chunks per quantisation group)
 
-  if (rt_ok) {
-    u32x4 L0[4], L1[4];   // packed words: unit in flight / unit being consumed (ping-pong)
-    u32x4 X0[NMMA], X1[NMMA];  // X fragments: chunk c uses X[c & 1], chunk c + 1 is in flight
-    uint32_t qn = load_q(u_first * UNIT);
-    load_unit(u_first, L0);
-    load_x(u_first * UNIT, X0);
+  // ---- prologue: unit 0 words + scales, X slab 0 staged, X slab 1 in registers ----
+  u32x4 L0[4], L1[4];      // packed words: unit being consumed / unit in flight (ping-pong)
+  uint32_t q0[4], q1[4];   // scale|zero words of the same two units
+  u32x4 XR[XLOADS];        // X pieces of the unit after next, on their way to LDS
+  load_unit(u_first, L0);
+  load_q4(u_first, q0);
+  stage_load(0, XR);
+  stage_store(0, XR);
+  if (NU > 1) stage_load(1, XR);
+  __syncthreads();
 
-    auto do_unit = [&](int u, const u32x4 (&Lc)[4], u32x4 (&Ln)[4]) {
-      const int U = u_first + u;
-      const int k0 = U * UNIT;
-      if (u + 1 < NU) load_unit(U + 1, Ln);
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        // new quantisation group?  wave-uniform: every lane starts group-aligned and walks in step
-        const int cglob = u * 4 + c;
-        if ((cglob & ((1 << cpg_shift) - 1)) == 0) {
-          const int kg = k0 + c * CHUNK;
-          build_table(qn, lane_ok && kg < p.k);
-          qn = load_q(kg + (CHUNK << cpg_shift));  // next group's scale|zero
-        }
-        const int kn = k0 + (c + 1) * CHUNK;  // next chunk (c == 3: first chunk of the next unit)
-        if (c & 1) {
-          load_x(kn, X0);
-          do_chunk(Lc, c, X1);
-        } else {
-          load_x(kn, X1);
-          do_chunk(Lc, c, X0);
-        }
-      }
-    };
-    for (int u = 0; u < NU; u += 2) {
-      do_unit(u, L0, L1);
-      if (u + 1 < NU) do_unit(u + 1, L1, L0);
+  // All control flow below is workgroup-uniform (NU, splitk, group size), barriers included.
+  auto do_unit = [&](int u, const u32x4 (&Lc)[4], const uint32_t (&qc)[4], u32x4 (&Ln)[4], uint32_t (&qn)[4]) {
+    const int U = u_first + u;
+    const int k0 = U * UNIT;
+    if (u + 1 < NU) {
+      load_unit(U + 1, Ln);
+      load_q4(U + 1, qn);
+      stage_store((u + 1) & 1, XR);            // slab u+1 (requested one unit ago) -> LDS
+      if (u + 2 < NU) stage_load(u + 2, XR);   // request slab u+2
     }
+    const uint32_t xbuf = xfrag + (uint32_t)((u & 1) * XROWS_MAX * XROW);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      if (((u * 4 + c) & ((1 << cpg_shift) - 1)) == 0) {  // a quantisation group starts here
+        const uint32_t qsel = cpg_shift == 0 ? qc[c] : (cpg_shift == 1 ? qc[c >> 1] : qc[0]);
+        build_table(qsel, lane_ok && (k0 + c * CHUNK) < p.k);
+      }
+      do_chunk(Lc, c, xbuf);
+    }
+    __syncthreads();  // slab u+1 visible to everyone; everyone done with slab u
+  };
+  for (int u = 0; u < NU; u += 2) {
+    do_unit(u, L0, q0, L1, q1);
+    if (u + 1 < NU) do_unit(u + 1, L1, q1, L0, q0);
   }
 
-  // ---- split-K tail (identical to w4_gemm.cuh) ----
+  // ---- split-K tail (as in w4_gemm.cuh) ----
   if (p.splitk > 1) {
     s_red[wave * 64 + lane] = acc;
     __syncthreads();
