@@ -83,6 +83,10 @@ __device__ const float kMX4Values[16] = {0.0f,  0.5f,  1.0f,  1.5f,  2.0f,  3.0f
 #include "w4_gemm.cuh"
 #include "w4_gemm_stream.cuh"
 
+#ifndef STREAM_MINW
+#define STREAM_MINW 4
+#endif
+
 // ---- 16-bit weights (reference TinyGemm_bf16.cu) ---------------------------------------------
 // Same tile/split-K structure; the A operand is gathered dword-wise from the fragment-order
 // tensor (each dword = two adjacent k of one row), no dequantisation.
@@ -386,6 +390,64 @@ inline Geometry pick_geometry(int64_t rowtiles, int64_t coltiles, int64_t batch,
   return g;
 }
 
+
+// ---- streaming kernel launch ---------------------------------------------------------------------
+template <typename DT, bool LAYOUT_A, int WPL, bool QMX, int SW>
+int launch_stream_sw(StreamParams& sp, int sk_want, int64_t coltiles, int64_t batch, hipStream_t st) {
+  constexpr int UNIT = LAYOUT_A ? 64 : 128;
+  const int nunits = (sp.k + UNIT - 1) / UNIT;
+  const int upg = (1 << sp.gshift) / UNIT;  // units per quantisation group (>= 1)
+  const int mrows = sp.m < 16 ? sp.m : 16;
+  int sk = sk_want < SW ? sk_want : SW;
+  while (sk > 1 && (nunits < 4 * sk * upg || mrows * sk > 16)) sk >>= 1;  // X slab: act rows * splitk <= 16
+  int nu = (nunits + 4 * sk - 1) / (4 * sk);
+  nu = (nu + upg - 1) / upg * upg;
+  sp.splitk = sk;
+  sp.sk_shift = 0;
+  while ((1 << sp.sk_shift) < sk) ++sp.sk_shift;
+  sp.units_per_lane = nu;
+  sp.upg_mask = upg - 1;
+  const int xrows = mrows * 4 * sk;
+  sp.xslab_bytes = xrows * (UNIT * 2 + 16);
+  const int pieces = xrows * (UNIT * 2 / 16);
+  const int xl = pieces <= SW * 64 ? 1 : (pieces <= 2 * SW * 64 ? 2 : 4);
+  const unsigned lds = SW * 4096u + SW * 1024u + 2u * (unsigned)sp.xslab_bytes;
+  const int tpb = SW / sk;
+  dim3 grid((unsigned)((sp.rowtiles + tpb - 1) / tpb), (unsigned)coltiles, (unsigned)batch);
+#define TG_LAUNCH_STREAM(XL)                                                                              \
+  do {                                                                                                    \
+    auto kern = w4_gemm_stream_kernel<DT, LAYOUT_A, WPL, QMX, SW, STREAM_MINW, XL>;                       \
+    if (lds > 64u * 1024u) {                                                                              \
+      static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),            \
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+      if (attr != hipSuccess) return (int)attr;                                                           \
+    }                                                                                                     \
+    hipLaunchKernelGGL(kern, grid, dim3(SW * 64), lds, st, sp);                                           \
+  } while (0)
+  if (xl == 1) TG_LAUNCH_STREAM(1);
+  else if (xl == 2) TG_LAUNCH_STREAM(2);
+  else TG_LAUNCH_STREAM(4);
+#undef TG_LAUNCH_STREAM
+  return launch_status();
+}
+
+template <typename DT, bool LAYOUT_A, int WPL, bool QMX>
+int launch_stream(const GemmParams& p, int sk_want, int64_t coltiles, int64_t batch, hipStream_t st) {
+  constexpr int UNIT = LAYOUT_A ? 64 : 128;
+  StreamParams sp;
+  sp.x = p.x; sp.w = p.w; sp.qinfo = p.qinfo; sp.lut = p.lut; sp.y = p.y;
+  sp.m = p.m; sp.wrows = p.wrows; sp.k = p.k; sp.ntiles = p.ntiles; sp.ksuper = p.ksuper;
+  sp.gshift = p.gshift; sp.ngroups = p.ngroups; sp.qtype = p.qtype; sp.rowtiles = p.rowtiles;
+  sp.stride_x = p.stride_x; sp.stride_w = p.stride_w; sp.stride_qinfo = p.stride_qinfo;
+  sp.stride_lut = p.stride_lut; sp.stride_y = p.stride_y;
+  // 4-wave workgroups unless their LDS footprint (tables + X slabs) would leave fewer than 16 waves per CU
+  const int mrows = p.m < 16 ? p.m : 16;
+  const int sk4 = sk_want < 4 ? sk_want : 4;
+  const unsigned lds4 = 4 * 5120u + 2u * (unsigned)(mrows * 4 * sk4 * (UNIT * 2 + 16));
+  if (160u * 1024u / lds4 >= 4) return launch_stream_sw<DT, LAYOUT_A, WPL, QMX, 4>(sp, sk_want, coltiles, batch, st);
+  return launch_stream_sw<DT, LAYOUT_A, WPL, QMX, 8>(sp, sk_want, coltiles, batch, st);
+}
+
 template <typename DT, bool LAYOUT_A, int CANON, bool QMX>
 int launch_w4(GemmParams& p, int64_t coltiles, int64_t batch, hipStream_t st) {
   constexpr int KSTEP = LAYOUT_A ? 64 : 128;
@@ -394,42 +456,12 @@ int launch_w4(GemmParams& p, int64_t coltiles, int64_t batch, hipStream_t st) {
   p.sk_shift = g.sk_shift;
   const int tpb = g.waves / g.splitk;
   dim3 grid((unsigned)((p.rowtiles + tpb - 1) / tpb), (unsigned)coltiles, (unsigned)batch);
-  static const int use_stream = getenv("TG_STREAM") ? atoi(getenv("TG_STREAM")) : 0;
-  if (use_stream && g.waves == 8) {
-    constexpr int WPL = CANON == CANON_NONE ? 1 : (CANON == CANON_PAIR ? 2 : 4);
-    constexpr int UNIT = LAYOUT_A ? 64 : 128;
-    StreamParams sp;
-    sp.x = p.x; sp.w = p.w; sp.qinfo = p.qinfo; sp.lut = p.lut; sp.y = p.y;
-    sp.m = p.m; sp.wrows = p.wrows; sp.k = p.k; sp.ntiles = p.ntiles; sp.ksuper = p.ksuper;
-    sp.gshift = p.gshift; sp.ngroups = p.ngroups; sp.qtype = p.qtype; sp.rowtiles = p.rowtiles;
-    sp.stride_x = p.stride_x; sp.stride_w = p.stride_w; sp.stride_qinfo = p.stride_qinfo;
-    sp.stride_lut = p.stride_lut; sp.stride_y = p.stride_y;
-    const int nunits = (p.k + UNIT - 1) / UNIT;
-    const int upg = (1 << p.gshift) > UNIT ? (1 << p.gshift) / UNIT : 1;  // units per quantisation group
-    int sk = g.splitk;
-    const int mrows = p.m < 16 ? p.m : 16;
-    while (sk > 1 && (nunits < 4 * sk * upg || mrows * sk > 16)) sk >>= 1;  // X slab: act rows * splitk <= 16
-    int nu = (nunits + 4 * sk - 1) / (4 * sk);
-    nu = (nu + upg - 1) / upg * upg;
-    sp.splitk = sk;
-    sp.sk_shift = 0;
-    while ((1 << sp.sk_shift) < sk) ++sp.sk_shift;
-    sp.units_per_lane = nu;
-    const int tpbs = 8 / sk;
-    dim3 sgrid((unsigned)((p.rowtiles + tpbs - 1) / tpbs), (unsigned)coltiles, (unsigned)batch);
-    if constexpr (std::is_same<DT, BF16>::value && !LAYOUT_A && CANON == CANON_PAIR && !QMX) {
-      static const int abl = getenv("TG_ABL") ? atoi(getenv("TG_ABL")) : 0;
-      if (abl) {
-        if (abl == 1) hipLaunchKernelGGL((w4_gemm_stream_kernel<DT, LAYOUT_A, WPL, QMX, 8, 4, 1>), sgrid, dim3(512), 0, st, sp);
-        if (abl == 2) hipLaunchKernelGGL((w4_gemm_stream_kernel<DT, LAYOUT_A, WPL, QMX, 8, 4, 2>), sgrid, dim3(512), 0, st, sp);
-        if (abl == 3) hipLaunchKernelGGL((w4_gemm_stream_kernel<DT, LAYOUT_A, WPL, QMX, 8, 4, 3>), sgrid, dim3(512), 0, st, sp);
-        if (abl == 4) hipLaunchKernelGGL((w4_gemm_stream_kernel<DT, LAYOUT_A, WPL, QMX, 8, 4, 4>), sgrid, dim3(512), 0, st, sp);
-        if (abl == 5) hipLaunchKernelGGL((w4_gemm_stream_kernel<DT, LAYOUT_A, WPL, QMX, 8, 4, 5>), sgrid, dim3(512), 0, st, sp);
-        return launch_status();
-      }
-    }
-    hipLaunchKernelGGL((w4_gemm_stream_kernel<DT, LAYOUT_A, WPL, QMX, 8, 4>), sgrid, dim3(512), 0, st, sp);
-    return launch_status();
+  // Streaming shapes go to the lane-owns-group kernel when the quantisation group covers at least one
+  // unit of its walk (Bint4: g >= 128, Aint4: g >= 64).  TG_STREAM=0 forces the split-K kernel.
+  static const int use_stream = getenv("TG_STREAM") ? atoi(getenv("TG_STREAM")) : 1;
+  constexpr int WPL = CANON == CANON_NONE ? 1 : (CANON == CANON_PAIR ? 2 : 4);
+  if (use_stream && g.waves == 8 && (1 << p.gshift) >= (LAYOUT_A ? 64 : 128)) {
+    return launch_stream<DT, LAYOUT_A, WPL, QMX>(p, g.splitk, coltiles, batch, st);
   }
   if (g.waves == 16) {
     hipLaunchKernelGGL((w4_gemm_kernel<DT, LAYOUT_A, CANON, QMX, 16, 2, 4>), grid, dim3(16 * 64), 0, st, p);

@@ -1,7 +1,8 @@
 // w4_gemm_stream.cuh -- the streaming W4A16 GEMM kernel for gfx950 ("lane owns group").
 //
 // Same contract and numerics as w4_gemm.cuh (the split-K latency kernel); this one is used whenever a
-// launch has enough 16-row tiles to give every wave its own tile or a large k-slice of one.
+// launch has enough 16-row tiles to give every wave its own tile or a large k-slice of one, and the
+// quantisation group is at least one unit (Bint4: g >= 128, Aint4: g >= 64).
 //
 // Idea: the dequantised weight  w = RNE16( fma_f32(lut[row][code], scale[g,row], zero[g,row]) )
 // (reference MatrixLayoutB.cuh:1042-1046 / MatrixLayoutA.cuh:747-754) takes only 16 distinct
@@ -17,9 +18,11 @@
 // of lane (c, Q) is the matching 16 contiguous bytes of activation row c.
 //
 // Activations go through LDS: every wave of a workgroup walks the same k sequence, so the X slab
-// of one unit-step ([act rows][quarters][UNIT] 16-bit) is staged once per workgroup, double
+// of one unit-step ([act rows][slices][quarters][UNIT] 16-bit) is staged once per workgroup, double
 // buffered, one barrier per unit.  This keeps X out of the in-order vector-memory return queue:
 // the only VM waits in the loop are for data requested one whole unit earlier.
+//
+// LDS (dynamic, sized by the host): [WAVES x 4 KiB tables][WAVES x 1 KiB split-K tiles][2 X slabs].
 #pragma once
 
 typedef const __attribute__((address_space(3))) uint16_t* lds_cu16ptr;
@@ -27,6 +30,8 @@ typedef const __attribute__((address_space(3))) uint32_t* lds_cu32ptr;
 typedef __attribute__((address_space(3))) uint32_t* lds_u32ptr;
 typedef const __attribute__((address_space(3))) u32x4* lds_cu32x4ptr;
 typedef __attribute__((address_space(3))) u32x4* lds_u32x4ptr;
+typedef const __attribute__((address_space(3))) f32x4* lds_cf32x4ptr;
+typedef __attribute__((address_space(3))) f32x4* lds_f32x4ptr;
 
 struct StreamParams {
   const char* x;
@@ -42,12 +47,15 @@ struct StreamParams {
   int32_t qtype;
   int32_t splitk, sk_shift;
   int32_t rowtiles;   // ceil(wrows / 16)
-  int32_t units_per_lane;  // NU: units walked by every lane (a multiple of group / UNIT when that is > 1)
+  int32_t units_per_lane;   // NU: units walked by every lane (a multiple of group / UNIT)
+  int32_t upg_mask;         // (units per quantisation group) - 1
+  int32_t xslab_bytes;      // bytes of one staged X slab = act rows * 4 * splitk * XROW
   int64_t stride_x, stride_w, stride_qinfo, stride_lut, stride_y;
 };
 
 // WPL = packed words per (k super-tile, lane-row) entry: Bint4: I/2, Aint4: I
-template <typename DT, bool LAYOUT_A, int WPL, bool QMX, int WAVES, int MINW, int ABL = 0>
+// XL  = 16-byte X pieces staged per thread and unit (host picks the smallest that covers the slab)
+template <typename DT, bool LAYOUT_A, int WPL, bool QMX, int WAVES, int MINW, int XL, int ABL = 0>
 __global__ void __launch_bounds__(WAVES * 64, MINW) w4_gemm_stream_kernel(const StreamParams p) {
   constexpr int CHUNK = LAYOUT_A ? 16 : 32;  // k per chunk (one packed word per q)
   constexpr int UNIT = 4 * CHUNK;            // k per unit = 64 packed bytes per lane
@@ -55,13 +63,12 @@ __global__ void __launch_bounds__(WAVES * 64, MINW) w4_gemm_stream_kernel(const 
   constexpr int NP = 4 / WPL;                // 16*WPL-byte pieces per unit
   constexpr int XROW = UNIT * 2 + 16;        // bytes per staged X row; +16 rotates rows over the LDS banks
   constexpr int PPR = UNIT * 2 / 16;         // 16-byte pieces per staged X row
-  constexpr int XROWS_MAX = 64;              // act rows (<= 16) x quarters (4) x splitk, host keeps it <= 64
   constexpr int NTHREADS = WAVES * 64;
-  constexpr int XLOADS = XROWS_MAX * PPR / NTHREADS > 0 ? XROWS_MAX * PPR / NTHREADS : 1;
 
-  __shared__ __attribute__((aligned(4096))) uint32_t s_tab[WAVES * 16 * 64];  // per wave [entry][lane]
-  __shared__ __attribute__((aligned(16))) char s_x[2 * XROWS_MAX * XROW];      // double-buffered X slab
-  __shared__ f32x4 s_red[WAVES * 64];
+  extern __shared__ __attribute__((aligned(4096))) char smem[];
+  const uint32_t lds0 = (uint32_t)reinterpret_cast<uintptr_t>(smem);  // LDS byte offset (4 KiB aligned)
+  const uint32_t lds_red = lds0 + WAVES * 4096u;
+  const uint32_t lds_x = lds_red + WAVES * 1024u;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -86,7 +93,7 @@ __global__ void __launch_bounds__(WAVES * 64, MINW) w4_gemm_stream_kernel(const 
   const int row_c = min(row, p.wrows - 1);
   const int tile = LAYOUT_A ? rt : 2 * rt + (i >> 3);
   const bool lane_ok = rt_ok && row < p.wrows && tile < p.ntiles;
-  const int tile_c = min(max(tile, 0), p.ntiles - 1);
+  const int tile_c = min(tile, p.ntiles - 1);
 
   // packed-weight addressing: piece pc of unit U lives at k super-tile NP * U + pc
   const uint32_t wrow = (uint32_t)((tile_c * p.ksuper * 32 + 4 * r) * WPL * 4);
@@ -98,12 +105,12 @@ __global__ void __launch_bounds__(WAVES * 64, MINW) w4_gemm_stream_kernel(const 
   // ---- X staging: thread -> (staged row, 16-byte piece); staged row = (act row c, slice, quarter) ----
   const int mrows = min(p.m - ct * 16, 16);
   const int xrows = mrows * 4 * p.splitk;
-  uint32_t xs_rowbase[XLOADS];  // global byte offset of the activation row this thread stages from
-  uint32_t xs_in[XLOADS];       // byte offset inside that row at unit-step 0
-  uint32_t xs_loff[XLOADS];     // LDS byte offset inside one buffer
-  bool xs_on[XLOADS];
+  uint32_t xs_rowbase[XL];  // global byte offset of the activation row this thread stages from
+  uint32_t xs_in[XL];       // byte offset inside that row at unit-step 0
+  uint32_t xs_loff[XL];     // LDS byte offset inside one slab
+  bool xs_on[XL];
 #pragma unroll
-  for (int j = 0; j < XLOADS; ++j) {
+  for (int j = 0; j < XL; ++j) {
     const int pid = tid + j * NTHREADS;
     const int srow = pid / PPR, pc = pid % PPR;
     xs_on[j] = srow < xrows;
@@ -114,9 +121,9 @@ __global__ void __launch_bounds__(WAVES * 64, MINW) w4_gemm_stream_kernel(const 
     xs_loff[j] = (uint32_t)(srow * XROW + pc * 16);
   }
   const uint32_t xrow_last = (uint32_t)((p.k - 8) * 2);  // clamp: last valid 16-byte piece of a row
-  auto stage_load = [&](int u, u32x4 (&R)[XLOADS]) {
+  auto stage_load = [&](int u, u32x4 (&R)[XL]) {
 #pragma unroll
-    for (int j = 0; j < XLOADS; ++j) {
+    for (int j = 0; j < XL; ++j) {
       if (xs_on[j]) {
         // clamp inside the activation row (padding units read valid memory; their weights are zero)
         const uint32_t inrow = min(xs_in[j] + (uint32_t)(u * UNIT * 2), xrow_last);
@@ -124,37 +131,40 @@ __global__ void __launch_bounds__(WAVES * 64, MINW) w4_gemm_stream_kernel(const 
       }
     }
   };
-  auto stage_store = [&](int buf, const u32x4 (&R)[XLOADS]) {
+  auto stage_store = [&](int buf, const u32x4 (&R)[XL]) {
 #pragma unroll
-    for (int j = 0; j < XLOADS; ++j)
-      if (xs_on[j]) *(lds_u32x4ptr)((uint32_t)reinterpret_cast<uintptr_t>(s_x) + (uint32_t)(buf * XROWS_MAX * XROW) + xs_loff[j]) = R[j];
+    for (int j = 0; j < XL; ++j)
+      if (xs_on[j]) *(lds_u32x4ptr)(lds_x + (uint32_t)(buf * p.xslab_bytes) + xs_loff[j]) = R[j];
   };
   // this lane's fragment row in a staged slab
   const int frow = ((min(i, mrows - 1) << p.sk_shift) + slice) * 4 + Q;
-  const uint32_t xfrag = (uint32_t)reinterpret_cast<uintptr_t>(s_x) + (uint32_t)(frow * XROW);
+  const uint32_t xfrag = lds_x + (uint32_t)(frow * XROW);
 
-  // ---- raw LUT of this lane's row, as f32, in registers ----
-  float lutf[16];
-  if (p.qtype == TG_Q_INT4) {
+  // ---- raw LUT of this lane's row: 16 x 16 bit, kept packed in 8 registers ----
+  u32x4 lut0, lut1;
+  if (p.qtype == TG_Q_INT4 || p.qtype == TG_Q_MX4) {
 #pragma unroll
-    for (int e = 0; e < 16; ++e) lutf[e] = (float)(e - 8);
-  } else if (p.qtype == TG_Q_MX4) {
-#pragma unroll
-    for (int e = 0; e < 16; ++e)
-      lutf[e] = (e & 8 ? -1.f : 1.f) * ((e & 7) < 5 ? 0.5f * (e & 7) : ((e & 7) == 5 ? 3.f : (e & 7) == 6 ? 4.f : 6.f));
+    for (int e = 0; e < 16; e += 2) {
+      float v0, v1;
+      if (p.qtype == TG_Q_INT4) {
+        v0 = (float)(e - 8);
+        v1 = (float)(e - 7);
+      } else {
+        const int e1 = e + 1;
+        v0 = (e & 8 ? -1.f : 1.f) * ((e & 7) < 5 ? 0.5f * (e & 7) : ((e & 7) == 5 ? 3.f : (e & 7) == 6 ? 4.f : 6.f));
+        v1 = (e1 & 8 ? -1.f : 1.f) * ((e1 & 7) < 5 ? 0.5f * (e1 & 7) : ((e1 & 7) == 5 ? 3.f : (e1 & 7) == 6 ? 4.f : 6.f));
+      }
+      const uint32_t pr = DT::pack2(v0, v1);  // exact: small integers / fp4 values
+      if (e < 8) lut0[e >> 1] = pr;
+      else lut1[(e - 8) >> 1] = pr;
+    }
   } else {
     const char* lrow = lb + (p.qtype == TG_Q_ANY4_ROWWISE ? (int64_t)row_c * 32 : 0);
-    const u32x4 l0 = reinterpret_cast<const u32x4*>(lrow)[0];
-    const u32x4 l1 = reinterpret_cast<const u32x4*>(lrow)[1];
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const uint32_t pair = e < 8 ? l0[e >> 1] : l1[(e - 8) >> 1];
-      lutf[e] = (e & 1) ? DT::hi_f32(pair) : DT::lo_f32(pair);
-    }
+    lut0 = reinterpret_cast<const u32x4*>(lrow)[0];
+    lut1 = reinterpret_cast<const u32x4*>(lrow)[1];
   }
 
-  uint32_t* tab = s_tab + wave * (16 * 64);
-  const uint32_t tabbase = (uint32_t)reinterpret_cast<uintptr_t>(tab);
+  const uint32_t tabbase = lds0 + (uint32_t)wave * 4096u;
   const uint32_t lane4 = (uint32_t)lane * 4u | (tabbase & 0xffff0000u);
   const uint32_t kmask = __builtin_amdgcn_readfirstlane(((tabbase >> 12) & 0xfu) * 0x10101010u);
   const uint32_t sh = LAYOUT_A ? (uint32_t)(i >> 3) * 4u : 0u;
@@ -173,23 +183,18 @@ __global__ void __launch_bounds__(WAVES * 64, MINW) w4_gemm_stream_kernel(const 
     if (!ok) s = z = 0.f;  // padding lanes contribute exact zeros
 #pragma unroll
     for (int e = 0; e < 16; e += 2) {
-      const uint32_t pr = DT::pack2(__builtin_fmaf(lutf[e], s, z), __builtin_fmaf(lutf[e + 1], s, z));
+      const uint32_t raw = e < 8 ? lut0[e >> 1] : lut1[(e - 8) >> 1];
+      const uint32_t pr = DT::pack2(__builtin_fmaf(DT::lo_f32(raw), s, z), __builtin_fmaf(DT::hi_f32(raw), s, z));
       *(lds_u32ptr)(tabcol + (uint32_t)e * 256u) = pr << 16;
       *(lds_u32ptr)(tabcol + (uint32_t)(e + 1) * 256u) = pr & 0xffff0000u;
     }
   };
 
-  auto load_q = [&](int k0) -> uint32_t {
-    const int g = min(k0, p.k - 1) >> p.gshift;
+  // scale|zero word of the group containing the first k of unit U
+  auto load_q = [&](int U) -> uint32_t {
+    const int g = min(U * UNIT, p.k - 1) >> p.gshift;
     if constexpr (QMX) return reinterpret_cast<const uint8_t*>(qb)[(uint32_t)(row_c * p.ngroups + g)];
     else return reinterpret_cast<const uint32_t*>(qb)[(uint32_t)(g * p.wrows + row_c)];
-  };
-  // scale|zero words of the groups that START inside unit U (up to 4: group 32 on the B side)
-  const int gstep = 1 << p.gshift;
-  auto load_q4 = [&](int U, uint32_t (&q)[4]) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      if (j == 0 || j * gstep < UNIT) q[j] = load_q(U * UNIT + j * gstep);
   };
 
   auto load_unit = [&](int U, u32x4 (&L)[4]) {
@@ -241,6 +246,53 @@ __global__ void __launch_bounds__(WAVES * 64, MINW) w4_gemm_stream_kernel(const 
         wa[q] = (w & 0x0f0f0f0fu) | kmask;          // bytes: v0 v4 v1 v5
         wb4[q] = ((w >> 4) & 0x0f0f0f0fu) | kmask;  // bytes: v2 v6 v3 v7
       }
+      if constexpr (ABL == 9) {
+        // experiment: addresses of two MFMA groups first, then their reads, then merges + MFMAs
+#pragma unroll
+        for (int hp = 0; hp < 4; hp += 2) {
+          uint32_t ad[16];
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int h = hp + hh;
+              const uint32_t src = (h & 1) ? wb4[q] : wa[q];
+              ad[hh * 8 + q * 2] = __builtin_amdgcn_perm(src, lane4, 0x03020400u + ((uint32_t)(h >> 1) << 8));
+              ad[hh * 8 + q * 2 + 1] = __builtin_amdgcn_perm(src, lane4, 0x03020400u + ((uint32_t)((h >> 1) + 2) << 8));
+            }
+          __builtin_amdgcn_sched_barrier(0);
+          uint32_t rd[16];
+#pragma unroll
+          for (int j = 0; j < 16; j += 2) {
+            rd[j] = *(lds_cu16ptr)(ad[j] + 2u);
+            rd[j + 1] = *(lds_cu32ptr)(ad[j + 1]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh) {
+            u32x4 a;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a[q] = rd[hh * 8 + q * 2] | rd[hh * 8 + q * 2 + 1];
+            acc = DT::mfma(a, *(lds_cu32x4ptr)(xa + 16u * (hp + hh)), acc);
+          }
+        }
+        return;
+      }
+      if constexpr (ABL == 8) {
+        // experiment: two MFMA groups of lookups in flight
+        u32x4 a[4];
+#pragma unroll
+        for (int h = 0; h < 4; ++h)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const uint32_t src = (h & 1) ? wb4[q] : wa[q];
+            a[h][q] = look2(src, h >> 1, (h >> 1) + 2);
+          }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int h = 0; h < 4; ++h) acc = DT::mfma(a[h], *(lds_cu32x4ptr)(xa + 16u * h), acc);
+        return;
+      }
 #pragma unroll
       for (int h = 0; h < 4; ++h) {
         u32x4 a;
@@ -265,38 +317,30 @@ __global__ void __launch_bounds__(WAVES * 64, MINW) w4_gemm_stream_kernel(const 
     }
   };
 
-  const int cpg_shift = max(p.gshift - (LAYOUT_A ? 4 : 5), 0);  // log2(chunks per quantisation group)
-
-  // ---- prologue: unit 0 words + scales, X slab 0 staged, X slab 1 in registers ----
-  u32x4 L0[4], L1[4];      // packed words: unit being consumed / unit in flight (ping-pong)
-  uint32_t q0[4], q1[4];   // scale|zero words of the same two units
-  u32x4 XR[XLOADS];        // X pieces of the unit after next, on their way to LDS
+  // ---- prologue: unit 0 words + scale, X slab 0 staged, X slab 1 in registers ----
+  u32x4 L0[4], L1[4];  // packed words: unit being consumed / unit in flight (ping-pong)
+  uint32_t q0, q1 = 0; // scale|zero word of the same two units
+  u32x4 XR[XL];        // X pieces of the unit after next, on their way to LDS
   load_unit(u_first, L0);
-  load_q4(u_first, q0);
+  q0 = load_q(u_first);
   stage_load(0, XR);
   stage_store(0, XR);
   if (NU > 1) stage_load(1, XR);
   __syncthreads();
 
   // All control flow below is workgroup-uniform (NU, splitk, group size), barriers included.
-  auto do_unit = [&](int u, const u32x4 (&Lc)[4], const uint32_t (&qc)[4], u32x4 (&Ln)[4], uint32_t (&qn)[4]) {
+  auto do_unit = [&](int u, const u32x4 (&Lc)[4], uint32_t qc, u32x4 (&Ln)[4], uint32_t& qn) {
     const int U = u_first + u;
-    const int k0 = U * UNIT;
     if (u + 1 < NU) {
       load_unit(U + 1, Ln);
-      load_q4(U + 1, qn);
-      stage_store((u + 1) & 1, XR);            // slab u+1 (requested one unit ago) -> LDS
-      if (u + 2 < NU) stage_load(u + 2, XR);   // request slab u+2
+      qn = load_q(U + 1);
+      stage_store((u + 1) & 1, XR);           // slab u+1 (requested one unit ago) -> LDS
+      if (u + 2 < NU) stage_load(u + 2, XR);  // request slab u+2
     }
-    const uint32_t xbuf = xfrag + (uint32_t)((u & 1) * XROWS_MAX * XROW);
+    if ((u & p.upg_mask) == 0) build_table(qc, lane_ok && U * UNIT < p.k);  // a quantisation group starts here
+    const uint32_t xbuf = xfrag + (uint32_t)((u & 1) * p.xslab_bytes);
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      if (((u * 4 + c) & ((1 << cpg_shift) - 1)) == 0) {  // a quantisation group starts here
-        const uint32_t qsel = cpg_shift == 0 ? qc[c] : (cpg_shift == 1 ? qc[c >> 1] : qc[0]);
-        build_table(qsel, lane_ok && (k0 + c * CHUNK) < p.k);
-      }
-      do_chunk(Lc, c, xbuf);
-    }
+    for (int c = 0; c < 4; ++c) do_chunk(Lc, c, xbuf);
     __syncthreads();  // slab u+1 visible to everyone; everyone done with slab u
   };
   for (int u = 0; u < NU; u += 2) {
@@ -306,10 +350,10 @@ __global__ void __launch_bounds__(WAVES * 64, MINW) w4_gemm_stream_kernel(const 
 
   // ---- split-K tail (as in w4_gemm.cuh) ----
   if (p.splitk > 1) {
-    s_red[wave * 64 + lane] = acc;
+    *(lds_f32x4ptr)(lds_red + (uint32_t)((wave * 64 + lane) * 16)) = acc;
     __syncthreads();
     if (slice != 0) return;
-    for (int o = 1; o < p.splitk; ++o) acc += s_red[(wave + o) * 64 + lane];
+    for (int o = 1; o < p.splitk; ++o) acc += *(lds_cf32x4ptr)(lds_red + (uint32_t)(((wave + o) * 64 + lane) * 16));
   }
   const int col = ct * 16 + i;
   const int rowg = row0 + 4 * Q;

@@ -216,7 +216,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "w4_gemm_kernel<BF16, Bint4, innerK=4> (stacked, split-K 1)",
+                "kernel": "w4_gemm_stream_kernel<BF16, Bint4 innerK=4> (stacked launch, one 16-row tile per wave)",
                 "achieved": round(achieved, 2),
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",

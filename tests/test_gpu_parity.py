@@ -483,3 +483,106 @@ def test_batched_launch_matches_single(T, oracle):
     for b in range(nb):
         y1 = T.tinygemm_y_f16RM_x_f16RM_w_any4TC(xs[b], packed[b], g, szs[b], luts[b], True)
         assert torch.equal(ys[b], y1)
+
+
+# ------------------------------------------------------------------------------------------------
+# streaming kernel ("lane owns group", any4_amd/csrc/w4_gemm_stream.cuh): reached when a launch has
+# more than 512 tiles -- here through stacked launches of many small problems
+# ------------------------------------------------------------------------------------------------
+
+def _stacked(T, probs, copies, g, qtype, on_right, inner, dtype=torch.bfloat16):
+    """Run len(probs) * copies problems in ONE tg_gemm_w4 launch; returns y [B][m][rows]."""
+    import ctypes
+
+    from any4_amd import _lib
+
+    L = _lib.load()
+    conv = T.convert_matrix_to_m16n8k16_Bint4_layout if on_right else T.convert_matrix_to_m16n8k16_Aint4_layout
+    packed = torch.stack([conv(p[0].to(DEV), inner) for p in probs]).repeat(copies, 1, 1, 1, 1).contiguous()
+    xs = torch.stack([p[1] for p in probs]).to(DEV).repeat(copies, 1, 1).contiguous()
+    qs = torch.stack([p[2] for p in probs]).to(DEV)
+    qs = qs.repeat(copies, *([1] * (qs.dim() - 1))).contiguous()
+    has_lut = probs[0][3] is not None
+    luts = torch.stack([p[3] for p in probs]).to(DEV) if has_lut else None
+    if has_lut:
+        luts = luts.repeat(copies, *([1] * (luts.dim() - 1))).contiguous()
+    B = packed.shape[0]
+    m, k = xs.shape[1], xs.shape[2]
+    rows = packed.shape[1] * (8 if on_right else 16)
+    ys = torch.full((B, m, rows), float("nan"), dtype=dtype, device=DEV)
+    qt = {"int4": _lib.TG_Q_INT4, "any4_global": _lib.TG_Q_ANY4_GLOBAL, "any4_rowwise": _lib.TG_Q_ANY4_ROWWISE, "mx4": _lib.TG_Q_MX4}[qtype]
+    args = _lib.W4Gemm(x=xs.data_ptr(), w=packed.data_ptr(), qinfo=qs.data_ptr(), lut=(luts.data_ptr() if has_lut else None),
+                       y=ys.data_ptr(), m=m, wrows=rows, k=k, group=g, qtype=qt,
+                       dtype=_lib.TG_BF16 if dtype == torch.bfloat16 else _lib.TG_F16, w_on_right=1 if on_right else 0,
+                       inner_k_tiles=inner, batch=B, stride_x=xs.stride(0) * 2, stride_w=packed.stride(0) * 4,
+                       stride_qinfo=qs.stride(0) * qs.element_size(), stride_lut=(luts.stride(0) * 2 if has_lut else 0),
+                       stride_y=ys.stride(0) * 2)
+    _lib.check(L.tg_gemm_w4(ctypes.byref(args), 0, torch.cuda.current_stream().cuda_stream), "stacked")
+    return ys
+
+
+@pytest.mark.parametrize("qtype,g", [("any4_rowwise", 128), ("any4_global", 256), ("int4", 128), ("mx4", 128), ("any4_rowwise", 64)])
+@pytest.mark.parametrize("on_right,inner", [(True, 2), (True, 4), (True, 8), (False, 1), (False, 2), (False, 4)])
+@pytest.mark.parametrize("m", [1, 5, 16])
+def test_stream_kernel_vs_oracle(T, oracle, qtype, g, on_right, inner, m):
+    """> 512 tiles in one launch -> w4_gemm_stream_kernel (when g >= its unit: 128 on the B side, 64 on the
+    A side; otherwise the same launch exercises the split-K-1 path of w4_gemm_kernel)."""
+    n, k = 48, 1024  # 3 tiles per problem; ragged last 16-row MFMA tile on the B side (6 x 8 rows)
+    nprob, copies = 4, 48  # 4 * 48 * 3 = 576 tiles
+    probs = [rand_problem(n, k, g, m, qtype, seed=1000 + 17 * b + m) for b in range(nprob)]
+    ys = _stacked(T, probs, copies, g, qtype, on_right, inner)
+    assert not torch.isnan(ys.float()).any()
+    for b in range(nprob):
+        w = oracle_weights(oracle, probs[b][0], g, qtype, probs[b][2], probs[b][3])
+        for cpy in (0, copies // 2, copies - 1):
+            assert_gemm_close(ys[cpy * nprob + b], probs[b][1], w)
+    # every copy of a problem gives the identical result
+    assert torch.equal(ys[:nprob], ys[-nprob:])
+
+
+@pytest.mark.parametrize("k", [128, 192, 640, 1152])
+@pytest.mark.parametrize("on_right,inner", [(True, 4), (False, 4), (True, 2), (False, 1)])
+def test_stream_kernel_ragged_k(T, oracle, k, on_right, inner):
+    """k that is not a multiple of the lanes' walk (4 quarters x units): padding units must contribute zeros."""
+    if k % (16 * inner):
+        pytest.skip("k not a multiple of 16*innerKTiles")
+    n, g, m = 32, 64 if not on_right else 128, 3
+    if k % g:
+        pytest.skip("group does not divide k")
+    probs = [rand_problem(n, k, g, m, "any4_rowwise", seed=k + b) for b in range(2)]
+    ys = _stacked(T, probs, 160, g, "any4_rowwise", on_right, inner)
+    for b in range(2):
+        w = oracle_weights(oracle, probs[b][0], g, "any4_rowwise", probs[b][2], probs[b][3])
+        assert_gemm_close(ys[b], probs[b][1], w)
+        assert_gemm_close(ys[-2 + b], probs[b][1], w)
+
+
+def test_stream_kernel_identity_and_fp16(T, oracle):
+    import any4_amd.utils as U
+
+    k, g = 512, 128
+    x = torch.randn(7, k, generator=torch.Generator().manual_seed(5)).bfloat16()
+    codes, sz = U.group_quantize_tensor(torch.eye(k, dtype=torch.bfloat16), 4, g)
+    lut = -(torch.arange(16, dtype=torch.bfloat16) - 8)
+    sz[:, :, 0] *= -1.0
+    for on_right, inner in ((True, 4), (False, 4)):
+        ys = _stacked(T, [(codes, x, sz, lut)], 20, g, "any4_global", on_right, inner)  # 32 tiles * 20 = 640
+        assert torch.equal(ys[0].cpu(), x) and torch.equal(ys[-1].cpu(), x)
+    probs = [rand_problem(64, 512, 128, 4, "any4_rowwise", dtype=torch.float16, seed=b) for b in range(2)]
+    ys = _stacked(T, probs, 80, 128, "any4_rowwise", True, 4, dtype=torch.float16)
+    for b in range(2):
+        w = oracle_weights(oracle, probs[b][0], 128, "any4_rowwise", probs[b][2], probs[b][3], torch.float16)
+        assert_gemm_close(ys[b], probs[b][1], w, torch.float16)
+
+
+def test_stream_kernel_mx4_nan_row(T):
+    import any4_amd.utils as U
+
+    k = 256
+    x = torch.randn(2, k, generator=torch.Generator().manual_seed(3)).bfloat16()
+    q, e = U.quantize_mx4(torch.eye(k), 128)
+    e[5, :] = 255
+    ys = _stacked(T, [(q, x, e, None)], 40, 128, "mx4", True, 4).cpu()  # 16 tiles * 40 = 640
+    assert torch.isnan(ys[:, :, 5]).all()
+    keep = [c for c in range(k) if c != 5]
+    assert torch.equal(ys[0][:, keep], x[:, keep]) and torch.equal(ys[-1][:, keep], x[:, keep])

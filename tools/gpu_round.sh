@@ -24,3 +24,5 @@ for d in ("pmc_fetch", "pmc_write"):
         for k, v in agg.items():
             print(d, k, "n=", len(v), "mean=", sum(v) / len(v))
 PY
+echo "== quick_bench default dispatch"; timeout 300 python tools/quick_bench.py --configs "1,4096,4096,1;8,4096,4096,1;16,4096,4096,1;1,4096,4096,0;8,8192,8192,0;1,8192,8192,1" --iters 3 2>&1 | grep -E "^m=|eager|stacked" | tee gpurun_out/qb_default.log
+for q in int4 any4_global mx4; do timeout 200 python tools/quick_bench.py --configs "1,4096,4096,1" --qtype $q --iters 3 2>&1 | grep -E "^m=|eager|stacked"; done | tee gpurun_out/qb_variants.log
