@@ -410,13 +410,16 @@ int launch_stream_sw(StreamParams& sp, int sk_want, int64_t coltiles, int64_t ba
   const int xrows = mrows * 4 * sk;
   sp.xslab_bytes = xrows * (UNIT * 2 + 16);
   const int pieces = xrows * (UNIT * 2 / 16);
-  const int xl = pieces <= SW * 64 ? 1 : (pieces <= 2 * SW * 64 ? 2 : 4);
-  const unsigned lds = SW * 4096u + SW * 1024u + 2u * (unsigned)sp.xslab_bytes;
+  // SW == 1: every wave stages its own X slab (no barrier in the kernel)
+  constexpr bool privx = SW == 1;
+  const int nstage = SW * 64;
+  const int xl = pieces <= nstage ? 1 : (pieces <= 2 * nstage ? 2 : 4);
+  const unsigned lds = SW * 5120u + 2u * (unsigned)sp.xslab_bytes;
   const int tpb = SW / sk;
   dim3 grid((unsigned)((sp.rowtiles + tpb - 1) / tpb), (unsigned)coltiles, (unsigned)batch);
 #define TG_LAUNCH_STREAM(XL)                                                                              \
   do {                                                                                                    \
-    auto kern = w4_gemm_stream_kernel<DT, LAYOUT_A, WPL, QMX, SW, STREAM_MINW, XL>;                       \
+    auto kern = w4_gemm_stream_kernel<DT, LAYOUT_A, WPL, QMX, SW, STREAM_MINW, XL, privx>;                \
     if (lds > 64u * 1024u) {                                                                              \
       static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),            \
                                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
@@ -424,9 +427,14 @@ int launch_stream_sw(StreamParams& sp, int sk_want, int64_t coltiles, int64_t ba
     }                                                                                                     \
     hipLaunchKernelGGL(kern, grid, dim3(SW * 64), lds, st, sp);                                           \
   } while (0)
-  if (xl == 1) TG_LAUNCH_STREAM(1);
-  else if (xl == 2) TG_LAUNCH_STREAM(2);
-  else TG_LAUNCH_STREAM(4);
+  if constexpr (SW == 1) {
+    if (xl == 1) TG_LAUNCH_STREAM(1);
+    else TG_LAUNCH_STREAM(2);
+  } else {
+    if (xl == 1) TG_LAUNCH_STREAM(1);
+    else if (xl == 2) TG_LAUNCH_STREAM(2);
+    else TG_LAUNCH_STREAM(4);
+  }
 #undef TG_LAUNCH_STREAM
   return launch_status();
 }
@@ -440,8 +448,10 @@ int launch_stream(const GemmParams& p, int sk_want, int64_t coltiles, int64_t ba
   sp.gshift = p.gshift; sp.ngroups = p.ngroups; sp.qtype = p.qtype; sp.rowtiles = p.rowtiles;
   sp.stride_x = p.stride_x; sp.stride_w = p.stride_w; sp.stride_qinfo = p.stride_qinfo;
   sp.stride_lut = p.stride_lut; sp.stride_y = p.stride_y;
-  // 4-wave workgroups unless their LDS footprint (tables + X slabs) would leave fewer than 16 waves per CU
   const int mrows = p.m < 16 ? p.m : 16;
+  // m == 1 and one tile per wave: single-wave workgroups, every wave stages its own X slab (no barriers)
+  if (mrows == 1 && sk_want == 1) return launch_stream_sw<DT, LAYOUT_A, WPL, QMX, 1>(sp, 1, coltiles, batch, st);
+  // otherwise 4-wave workgroups unless their LDS footprint (tables + X slabs) would leave fewer than 16 waves per CU
   const int sk4 = sk_want < 4 ? sk_want : 4;
   const unsigned lds4 = 4 * 5120u + 2u * (unsigned)(mrows * 4 * sk4 * (UNIT * 2 + 16));
   if (160u * 1024u / lds4 >= 4) return launch_stream_sw<DT, LAYOUT_A, WPL, QMX, 4>(sp, sk_want, coltiles, batch, st);

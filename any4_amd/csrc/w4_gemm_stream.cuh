@@ -17,12 +17,19 @@
 // A: 64 k).  The K-slot of lane-row Q in every MFMA is "the next 8 k of quarter Q"; the X fragment
 // of lane (c, Q) is the matching 16 contiguous bytes of activation row c.
 //
-// Activations go through LDS: every wave of a workgroup walks the same k sequence, so the X slab
-// of one unit-step ([act rows][slices][quarters][UNIT] 16-bit) is staged once per workgroup, double
-// buffered, one barrier per unit.  This keeps X out of the in-order vector-memory return queue:
-// the only VM waits in the loop are for data requested one whole unit earlier.
+// Activations go through LDS so that X never sits in the in-order vector-memory return queue (the
+// only VM waits in the loop are for data requested one whole unit earlier).  Two staging modes:
+//   PRIVX = false: every wave of a workgroup walks the same k sequence, so the X slab of one
+//                  unit-step ([act rows][slices][quarters][UNIT]) is staged once per workgroup,
+//                  double buffered, one barrier per unit;
+//   PRIVX = true : (m = 1, split-K 1, single-wave workgroups) every wave stages its own slab (one
+//                  16-byte load per lane per unit): no barrier anywhere in the kernel.
 //
-// LDS (dynamic, sized by the host): [WAVES x 4 KiB tables][WAVES x 1 KiB split-K tiles][2 X slabs].
+// LDS (dynamic, sized by the host, no static LDS so the base is 0):
+//   [WAVES x 4 KiB lookup tables][WAVES x 1 KiB split-K tiles][X slabs].
+// Wave w's table starts at byte w * 4096.  With WAVES == 1 (the PRIVX launches) the table sits at 0
+// and a lookup address is just (nibble << 8 | lane << 2); otherwise address bits 12..15 (the table
+// select) are OR-ed into the nibble bytes before the v_perm_b32.
 #pragma once
 
 typedef const __attribute__((address_space(3))) uint16_t* lds_cu16ptr;
@@ -49,13 +56,13 @@ struct StreamParams {
   int32_t rowtiles;   // ceil(wrows / 16)
   int32_t units_per_lane;   // NU: units walked by every lane (a multiple of group / UNIT)
   int32_t upg_mask;         // (units per quantisation group) - 1
-  int32_t xslab_bytes;      // bytes of one staged X slab = act rows * 4 * splitk * XROW
+  int32_t xslab_bytes;      // bytes of one staged X slab
   int64_t stride_x, stride_w, stride_qinfo, stride_lut, stride_y;
 };
 
 // WPL = packed words per (k super-tile, lane-row) entry: Bint4: I/2, Aint4: I
 // XL  = 16-byte X pieces staged per thread and unit (host picks the smallest that covers the slab)
-template <typename DT, bool LAYOUT_A, int WPL, bool QMX, int WAVES, int MINW, int XL, int ABL = 0>
+template <typename DT, bool LAYOUT_A, int WPL, bool QMX, int WAVES, int MINW, int XL, bool PRIVX, int ABL = 0>
 __global__ void __launch_bounds__(WAVES * 64, MINW) w4_gemm_stream_kernel(const StreamParams p) {
   constexpr int CHUNK = LAYOUT_A ? 16 : 32;  // k per chunk (one packed word per q)
   constexpr int UNIT = 4 * CHUNK;            // k per unit = 64 packed bytes per lane
@@ -63,12 +70,12 @@ __global__ void __launch_bounds__(WAVES * 64, MINW) w4_gemm_stream_kernel(const 
   constexpr int NP = 4 / WPL;                // 16*WPL-byte pieces per unit
   constexpr int XROW = UNIT * 2 + 16;        // bytes per staged X row; +16 rotates rows over the LDS banks
   constexpr int PPR = UNIT * 2 / 16;         // 16-byte pieces per staged X row
-  constexpr int NTHREADS = WAVES * 64;
+  constexpr int NSTAGE = PRIVX ? 64 : WAVES * 64;  // threads sharing one slab
 
   extern __shared__ __attribute__((aligned(4096))) char smem[];
-  const uint32_t lds0 = (uint32_t)reinterpret_cast<uintptr_t>(smem);  // LDS byte offset (4 KiB aligned)
-  const uint32_t lds_red = lds0 + WAVES * 4096u;
-  const uint32_t lds_x = lds_red + WAVES * 1024u;
+  if ((uint32_t)reinterpret_cast<uintptr_t>(smem) != 0u) __builtin_trap();  // the layout below assumes LDS base 0
+  constexpr uint32_t lds_red = WAVES * 4096u;
+  constexpr uint32_t lds_x0 = lds_red + WAVES * 1024u;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -105,13 +112,14 @@ __global__ void __launch_bounds__(WAVES * 64, MINW) w4_gemm_stream_kernel(const 
   // ---- X staging: thread -> (staged row, 16-byte piece); staged row = (act row c, slice, quarter) ----
   const int mrows = min(p.m - ct * 16, 16);
   const int xrows = mrows * 4 * p.splitk;
+  const uint32_t lds_x = PRIVX ? lds_x0 + (uint32_t)(wave * 2 * p.xslab_bytes) : lds_x0;
   uint32_t xs_rowbase[XL];  // global byte offset of the activation row this thread stages from
   uint32_t xs_in[XL];       // byte offset inside that row at unit-step 0
   uint32_t xs_loff[XL];     // LDS byte offset inside one slab
   bool xs_on[XL];
 #pragma unroll
   for (int j = 0; j < XL; ++j) {
-    const int pid = tid + j * NTHREADS;
+    const int pid = (PRIVX ? lane : tid) + j * NSTAGE;
     const int srow = pid / PPR, pc = pid % PPR;
     xs_on[j] = srow < xrows;
     const int sq = srow & 3, ssl = (srow >> 2) & (p.splitk - 1), sc = srow >> (2 + p.sk_shift);
@@ -164,31 +172,8 @@ __global__ void __launch_bounds__(WAVES * 64, MINW) w4_gemm_stream_kernel(const 
     lut1 = reinterpret_cast<const u32x4*>(lrow)[1];
   }
 
-  const uint32_t tabbase = lds0 + (uint32_t)wave * 4096u;
-  const uint32_t lane4 = (uint32_t)lane * 4u | (tabbase & 0xffff0000u);
-  const uint32_t kmask = __builtin_amdgcn_readfirstlane(((tabbase >> 12) & 0xfu) * 0x10101010u);
+  const uint32_t lane4 = (uint32_t)lane * 4u;
   const uint32_t sh = LAYOUT_A ? (uint32_t)(i >> 3) * 4u : 0u;
-  const uint32_t tabcol = tabbase + (uint32_t)lane * 4u;
-
-  // 16 final 16-bit weights of (row, group) -> this lane's LDS column; slot = value << 16
-  auto build_table = [&](uint32_t q, bool ok) {
-    float s, z;
-    if constexpr (QMX) {
-      s = u2f(q == 255u ? 0x7fc00000u : (q == 0u ? 0x00400000u : (q << 23)));  // Dequantization.cuh:331-339
-      z = 0.f;
-    } else {
-      s = DT::lo_f32(q);
-      z = DT::hi_f32(q);
-    }
-    if (!ok) s = z = 0.f;  // padding lanes contribute exact zeros
-#pragma unroll
-    for (int e = 0; e < 16; e += 2) {
-      const uint32_t raw = e < 8 ? lut0[e >> 1] : lut1[(e - 8) >> 1];
-      const uint32_t pr = DT::pack2(__builtin_fmaf(DT::lo_f32(raw), s, z), __builtin_fmaf(DT::hi_f32(raw), s, z));
-      *(lds_u32ptr)(tabcol + (uint32_t)e * 256u) = pr << 16;
-      *(lds_u32ptr)(tabcol + (uint32_t)(e + 1) * 256u) = pr & 0xffff0000u;
-    }
-  };
 
   // scale|zero word of the group containing the first k of unit U
   auto load_q = [&](int U) -> uint32_t {
@@ -217,135 +202,116 @@ __global__ void __launch_bounds__(WAVES * 64, MINW) w4_gemm_stream_kernel(const 
     else return L[q][c];
   };
 
-  // two lookups -> one operand register.  A table slot is the dword (value << 16): a 32-bit read
-  // yields the value already in the HIGH half, a 16-bit read at slot + 2 (folded into the DS offset
-  // field) yields it in the LOW half, so the merge is one VOP2 v_or_b32.
-  auto look2 = [&](uint32_t src, int byte_lo, int byte_hi) -> uint32_t {
-    const uint32_t a0 = __builtin_amdgcn_perm(src, lane4, 0x03020400u + ((uint32_t)byte_lo << 8));
-    const uint32_t a1 = __builtin_amdgcn_perm(src, lane4, 0x03020400u + ((uint32_t)byte_hi << 8));
-    if constexpr (ABL == 1) return a0 ^ a1;  // ablation: no LDS lookups
-    const uint32_t lo = *(lds_cu16ptr)(a0 + 2u);
-    const uint32_t hi = *(lds_cu32ptr)(a1);
-    return lo | hi;
-  };
-
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 
-  // chunk c of the unit whose words are in L; X fragments come from the staged slab `xbuf`
-  auto do_chunk = [&](const u32x4 (&L)[4], int c, uint32_t xbuf) {
-    const uint32_t xa = xbuf + (uint32_t)(c * CHUNK * 2);
-    if constexpr (ABL == 4) {  // ablation: stream only
-      acc[0] += u2f(L[c][0] ^ L[c][1] ^ L[c][2] ^ L[c][3] ^ (*(lds_cu32ptr)(xa)));
-      return;
-    }
-    if constexpr (!LAYOUT_A) {
-      uint32_t wa[4], wb4[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const uint32_t w = word(L, q, c);
-        wa[q] = (w & 0x0f0f0f0fu) | kmask;          // bytes: v0 v4 v1 v5
-        wb4[q] = ((w >> 4) & 0x0f0f0f0fu) | kmask;  // bytes: v2 v6 v3 v7
+  constexpr bool ONE = WAVES == 1;  // single-wave workgroup: table at LDS offset 0, no table-select bits
+  const uint32_t tabbase = ONE ? 0u : (uint32_t)wave * 4096u;
+  const uint32_t kmask = ONE ? 0u : __builtin_amdgcn_readfirstlane(((tabbase >> 12) & 0xfu) * 0x10101010u);
+  const uint32_t tabcol = tabbase + lane4;
+  {
+    // 16 final 16-bit weights of (row, group) -> this lane's LDS column; slot = value << 16
+    auto build_table = [&](uint32_t q, bool ok) {
+      float s, z;
+      if constexpr (QMX) {
+        s = u2f(q == 255u ? 0x7fc00000u : (q == 0u ? 0x00400000u : (q << 23)));  // Dequantization.cuh:331-339
+        z = 0.f;
+      } else {
+        s = DT::lo_f32(q);
+        z = DT::hi_f32(q);
       }
-      if constexpr (ABL == 9) {
-        // experiment: addresses of two MFMA groups first, then their reads, then merges + MFMAs
+      if (!ok) s = z = 0.f;  // padding lanes contribute exact zeros
 #pragma unroll
-        for (int hp = 0; hp < 4; hp += 2) {
-          uint32_t ad[16];
-#pragma unroll
-          for (int hh = 0; hh < 2; ++hh)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const int h = hp + hh;
-              const uint32_t src = (h & 1) ? wb4[q] : wa[q];
-              ad[hh * 8 + q * 2] = __builtin_amdgcn_perm(src, lane4, 0x03020400u + ((uint32_t)(h >> 1) << 8));
-              ad[hh * 8 + q * 2 + 1] = __builtin_amdgcn_perm(src, lane4, 0x03020400u + ((uint32_t)((h >> 1) + 2) << 8));
-            }
-          __builtin_amdgcn_sched_barrier(0);
-          uint32_t rd[16];
-#pragma unroll
-          for (int j = 0; j < 16; j += 2) {
-            rd[j] = *(lds_cu16ptr)(ad[j] + 2u);
-            rd[j + 1] = *(lds_cu32ptr)(ad[j + 1]);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int hh = 0; hh < 2; ++hh) {
-            u32x4 a;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) a[q] = rd[hh * 8 + q * 2] | rd[hh * 8 + q * 2 + 1];
-            acc = DT::mfma(a, *(lds_cu32x4ptr)(xa + 16u * (hp + hh)), acc);
-          }
-        }
+      for (int e = 0; e < 16; e += 2) {
+        const uint32_t raw = e < 8 ? lut0[e >> 1] : lut1[(e - 8) >> 1];
+        const uint32_t pr = DT::pack2(__builtin_fmaf(DT::lo_f32(raw), s, z), __builtin_fmaf(DT::hi_f32(raw), s, z));
+        *(lds_u32ptr)(tabcol + (uint32_t)e * 256u) = pr << 16;
+        *(lds_u32ptr)(tabcol + (uint32_t)(e + 1) * 256u) = pr & 0xffff0000u;
+      }
+    };
+
+    // two lookups -> one operand register.  A table slot is the dword (value << 16): a 32-bit read
+    // yields the value already in the HIGH half, a 16-bit read at slot + 2 yields it in the LOW half,
+    // so the merge is one VOP2 v_or_b32.  Address = (table select | nibble) << 8 | lane << 2.
+    auto look2 = [&](uint32_t src, int byte_lo, int byte_hi) -> uint32_t {
+      const uint32_t a0 = __builtin_amdgcn_perm(src, lane4, 0x0c0c0400u + ((uint32_t)byte_lo << 8));
+      const uint32_t a1 = __builtin_amdgcn_perm(src, lane4, 0x0c0c0400u + ((uint32_t)byte_hi << 8));
+      if constexpr (ABL == 1) return a0 ^ a1;  // ablation: no LDS lookups
+      const uint32_t lo = *(lds_cu16ptr)(a0 + 2u);
+      const uint32_t hi = *(lds_cu32ptr)(a1);
+      return lo | hi;
+    };
+
+    // chunk c of the unit whose words are in L; X fragments come from the staged slab `xbuf`
+    auto do_chunk = [&](const u32x4 (&L)[4], int c, uint32_t xbuf) {
+      const uint32_t xa = xbuf + (uint32_t)(c * CHUNK * 2);
+      if constexpr (ABL == 4) {  // ablation: stream only
+        acc[0] += u2f(L[c][0] ^ L[c][1] ^ L[c][2] ^ L[c][3] ^ (*(lds_cu32ptr)(xa)));
         return;
       }
-      if constexpr (ABL == 8) {
-        // experiment: two MFMA groups of lookups in flight
-        u32x4 a[4];
+      if constexpr (!LAYOUT_A) {
+        uint32_t wa[4], wb4[4];
 #pragma unroll
-        for (int h = 0; h < 4; ++h)
+        for (int q = 0; q < 4; ++q) {
+          const uint32_t w = word(L, q, c);
+          wa[q] = ONE ? (w & 0x0f0f0f0fu) : ((w & 0x0f0f0f0fu) | kmask);                 // bytes: v0 v4 v1 v5
+          wb4[q] = ONE ? ((w >> 4) & 0x0f0f0f0fu) : (((w >> 4) & 0x0f0f0f0fu) | kmask);  // bytes: v2 v6 v3 v7
+        }
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+          u32x4 a;
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const uint32_t src = (h & 1) ? wb4[q] : wa[q];
-            a[h][q] = look2(src, h >> 1, (h >> 1) + 2);
+            a[q] = look2(src, h >> 1, (h >> 1) + 2);  // k = 8h + 2q, 8h + 2q + 1
           }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int h = 0; h < 4; ++h) acc = DT::mfma(a[h], *(lds_cu32x4ptr)(xa + 16u * h), acc);
-        return;
-      }
-#pragma unroll
-      for (int h = 0; h < 4; ++h) {
-        u32x4 a;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const uint32_t src = (h & 1) ? wb4[q] : wa[q];
-          a[q] = look2(src, h >> 1, (h >> 1) + 2);  // k = 8h + 2q, 8h + 2q + 1
+          acc = DT::mfma(a, *(lds_cu32x4ptr)(xa + 16u * h), acc);
         }
-        acc = DT::mfma(a, *(lds_cu32x4ptr)(xa + 16u * h), acc);
+      } else {
+        uint32_t ws[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ws[q] = ONE ? ((word(L, q, c) >> sh) & 0x0f0f0f0fu) : (((word(L, q, c) >> sh) & 0x0f0f0f0fu) | kmask);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          u32x4 a;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) a[q] = look2(ws[q], h, h + 2);
+          acc = DT::mfma(a, *(lds_cu32x4ptr)(xa + 16u * h), acc);
+        }
       }
-    } else {
-      uint32_t ws[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) ws[q] = ((word(L, q, c) >> sh) & 0x0f0f0f0fu) | kmask;
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        u32x4 a;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) a[q] = look2(ws[q], h, h + 2);
-        acc = DT::mfma(a, *(lds_cu32x4ptr)(xa + 16u * h), acc);
+    };
+
+    // ---- prologue: unit 0 words + scale, X slab 0 staged, X slab 1 in registers ----
+    u32x4 L0[4], L1[4];   // packed words: unit being consumed / unit in flight (ping-pong)
+    uint32_t q0, q1 = 0;  // scale|zero word of the same two units
+    u32x4 XR[XL];         // X pieces of the unit after next, on their way to LDS
+    load_unit(u_first, L0);
+    q0 = load_q(u_first);
+    stage_load(0, XR);
+    stage_store(0, XR);
+    if (NU > 1) stage_load(1, XR);
+    if constexpr (!PRIVX) __syncthreads();
+
+    // All control flow below is workgroup-uniform (NU, splitk, group size), barriers included.
+    auto do_unit = [&](int u, const u32x4 (&Lc)[4], uint32_t qc, u32x4 (&Ln)[4], uint32_t& qn) {
+      const int U = u_first + u;
+      if (u + 1 < NU) {
+        load_unit(U + 1, Ln);
+        qn = load_q(U + 1);
+        stage_store((u + 1) & 1, XR);           // slab u+1 (requested one unit ago) -> LDS
+        if (u + 2 < NU) stage_load(u + 2, XR);  // request slab u+2
       }
-    }
-  };
-
-  // ---- prologue: unit 0 words + scale, X slab 0 staged, X slab 1 in registers ----
-  u32x4 L0[4], L1[4];  // packed words: unit being consumed / unit in flight (ping-pong)
-  uint32_t q0, q1 = 0; // scale|zero word of the same two units
-  u32x4 XR[XL];        // X pieces of the unit after next, on their way to LDS
-  load_unit(u_first, L0);
-  q0 = load_q(u_first);
-  stage_load(0, XR);
-  stage_store(0, XR);
-  if (NU > 1) stage_load(1, XR);
-  __syncthreads();
-
-  // All control flow below is workgroup-uniform (NU, splitk, group size), barriers included.
-  auto do_unit = [&](int u, const u32x4 (&Lc)[4], uint32_t qc, u32x4 (&Ln)[4], uint32_t& qn) {
-    const int U = u_first + u;
-    if (u + 1 < NU) {
-      load_unit(U + 1, Ln);
-      qn = load_q(U + 1);
-      stage_store((u + 1) & 1, XR);           // slab u+1 (requested one unit ago) -> LDS
-      if (u + 2 < NU) stage_load(u + 2, XR);  // request slab u+2
-    }
-    if ((u & p.upg_mask) == 0) build_table(qc, lane_ok && U * UNIT < p.k);  // a quantisation group starts here
-    const uint32_t xbuf = xfrag + (uint32_t)((u & 1) * p.xslab_bytes);
+      if ((u & p.upg_mask) == 0) build_table(qc, lane_ok && U * UNIT < p.k);  // a quantisation group starts here
+      const uint32_t xbuf = xfrag + (uint32_t)((u & 1) * p.xslab_bytes);
 #pragma unroll
-    for (int c = 0; c < 4; ++c) do_chunk(Lc, c, xbuf);
-    __syncthreads();  // slab u+1 visible to everyone; everyone done with slab u
-  };
-  for (int u = 0; u < NU; u += 2) {
-    do_unit(u, L0, q0, L1, q1);
-    if (u + 1 < NU) do_unit(u + 1, L1, q1, L0, q0);
+      for (int c = 0; c < 4; ++c) do_chunk(Lc, c, xbuf);
+      // shared slab: slab u+1 visible to everyone, everyone done with slab u.  Private slab: a wave's
+      // DS operations execute in order, nothing to wait for.
+      if constexpr (!PRIVX) __syncthreads();
+    };
+    for (int u = 0; u < NU; u += 2) {
+      do_unit(u, L0, q0, L1, q1);
+      if (u + 1 < NU) do_unit(u + 1, L1, q1, L0, q0);
+    }
   }
 
   // ---- split-K tail (as in w4_gemm.cuh) ----

@@ -1,3 +1,3 @@
 mkdir -p gpurun_out
-C="1,4096,4096,1"
-for a in 0 9 0 9; do echo "== STREAM ABL=$a"; TG_ABL=$a TG_STREAM=1 TG_VARIANT=801 timeout 120 python tools/quick_bench.py --configs "$C" --iters 5 2>&1 | grep -E "stacked"; done
+timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -4
+timeout 300 python tools/quick_bench.py --configs "1,4096,4096,1;2,4096,4096,1;4,4096,4096,1;8,4096,4096,1;16,4096,4096,1;1,4096,4096,0;8,8192,8192,0;1,8192,8192,1" --iters 5 2>&1 | grep -E "^m=|stacked"
