@@ -392,14 +392,22 @@ inline Geometry pick_geometry(int64_t rowtiles, int64_t coltiles, int64_t batch,
 
 
 // ---- streaming kernel launch ---------------------------------------------------------------------
+// LDS per workgroup: lookup tables (4 KiB per wave and row set) + two X slabs (+ split-K tiles).
+template <bool LAYOUT_A>
+inline unsigned stream_lds_bytes(int sw, int mrows, int sk) {
+  const unsigned nr = 1u;  // lookup tables per wave
+  const unsigned unit = LAYOUT_A ? 64u : 128u;
+  const unsigned slab = (unsigned)(mrows * 4 * sk) * (unit * 2u + 16u);
+  return (unsigned)sw * nr * 4096u + 2u * slab + (sk > 1 ? (unsigned)sw * nr * 1024u : 0u);
+}
+
 template <typename DT, bool LAYOUT_A, int WPL, bool QMX, int SW>
-int launch_stream_sw(StreamParams& sp, int sk_want, int64_t coltiles, int64_t batch, hipStream_t st) {
+int launch_stream_sw(StreamParams& sp, int sk, int64_t coltiles, int64_t batch, hipStream_t st) {
   constexpr int UNIT = LAYOUT_A ? 64 : 128;
+  constexpr unsigned NR = 1u;
   const int nunits = (sp.k + UNIT - 1) / UNIT;
   const int upg = (1 << sp.gshift) / UNIT;  // units per quantisation group (>= 1)
   const int mrows = sp.m < 16 ? sp.m : 16;
-  int sk = sk_want < SW ? sk_want : SW;
-  while (sk > 1 && (nunits < 4 * sk * upg || mrows * sk > 16)) sk >>= 1;  // X slab: act rows * splitk <= 16
   int nu = (nunits + 4 * sk - 1) / (4 * sk);
   nu = (nu + upg - 1) / upg * upg;
   sp.splitk = sk;
@@ -409,12 +417,13 @@ int launch_stream_sw(StreamParams& sp, int sk_want, int64_t coltiles, int64_t ba
   sp.upg_mask = upg - 1;
   const int xrows = mrows * 4 * sk;
   sp.xslab_bytes = xrows * (UNIT * 2 + 16);
+  sp.red_off = (int32_t)(SW * NR * 4096u + 2u * (unsigned)sp.xslab_bytes);
   const int pieces = xrows * (UNIT * 2 / 16);
   // SW == 1: every wave stages its own X slab (no barrier in the kernel)
   constexpr bool privx = SW == 1;
   const int nstage = SW * 64;
   const int xl = pieces <= nstage ? 1 : (pieces <= 2 * nstage ? 2 : 4);
-  const unsigned lds = SW * 5120u + 2u * (unsigned)sp.xslab_bytes;
+  const unsigned lds = stream_lds_bytes<LAYOUT_A>(SW, mrows, sk);
   const int tpb = SW / sk;
   dim3 grid((unsigned)((sp.rowtiles + tpb - 1) / tpb), (unsigned)coltiles, (unsigned)batch);
 #define TG_LAUNCH_STREAM(XL)                                                                              \
@@ -440,22 +449,30 @@ int launch_stream_sw(StreamParams& sp, int sk_want, int64_t coltiles, int64_t ba
 }
 
 template <typename DT, bool LAYOUT_A, int WPL, bool QMX>
-int launch_stream(const GemmParams& p, int sk_want, int64_t coltiles, int64_t batch, hipStream_t st) {
+int launch_stream(const GemmParams& p, int64_t coltiles, int64_t batch, hipStream_t st) {
   constexpr int UNIT = LAYOUT_A ? 64 : 128;
+  constexpr int RPW = 16;  // weight rows per wave
   StreamParams sp;
   sp.x = p.x; sp.w = p.w; sp.qinfo = p.qinfo; sp.lut = p.lut; sp.y = p.y;
   sp.m = p.m; sp.wrows = p.wrows; sp.k = p.k; sp.ntiles = p.ntiles; sp.ksuper = p.ksuper;
-  sp.gshift = p.gshift; sp.ngroups = p.ngroups; sp.qtype = p.qtype; sp.rowtiles = p.rowtiles;
+  sp.gshift = p.gshift; sp.ngroups = p.ngroups; sp.qtype = p.qtype;
+  sp.rowtiles = (p.wrows + RPW - 1) / RPW;
   sp.stride_x = p.stride_x; sp.stride_w = p.stride_w; sp.stride_qinfo = p.stride_qinfo;
   sp.stride_lut = p.stride_lut; sp.stride_y = p.stride_y;
   const int mrows = p.m < 16 ? p.m : 16;
+  const int nunits = (p.k + UNIT - 1) / UNIT;
+  const int upg = (1 << p.gshift) / UNIT;
+  // split-K: aim for at least two rounds of 16 waves on every CU; the X slab limits act rows * splitk to 16
+  const int64_t wave_tiles = (int64_t)sp.rowtiles * coltiles * batch;
+  int sk = 1;
+  while (sk < 8 && wave_tiles * sk < 2 * 256 * 16 && nunits >= 8 * sk * upg && mrows * sk * 2 <= 16) sk *= 2;
   // m == 1 and one tile per wave: single-wave workgroups, every wave stages its own X slab (no barriers)
-  if (mrows == 1 && sk_want == 1) return launch_stream_sw<DT, LAYOUT_A, WPL, QMX, 1>(sp, 1, coltiles, batch, st);
-  // otherwise 4-wave workgroups unless their LDS footprint (tables + X slabs) would leave fewer than 16 waves per CU
-  const int sk4 = sk_want < 4 ? sk_want : 4;
-  const unsigned lds4 = 4 * 5120u + 2u * (unsigned)(mrows * 4 * sk4 * (UNIT * 2 + 16));
-  if (160u * 1024u / lds4 >= 4) return launch_stream_sw<DT, LAYOUT_A, WPL, QMX, 4>(sp, sk_want, coltiles, batch, st);
-  return launch_stream_sw<DT, LAYOUT_A, WPL, QMX, 8>(sp, sk_want, coltiles, batch, st);
+  if (mrows == 1 && sk == 1) return launch_stream_sw<DT, LAYOUT_A, WPL, QMX, 1>(sp, 1, coltiles, batch, st);
+  // otherwise the smallest workgroup whose LDS footprint still lets 16 waves live on a CU
+  const int sk4 = sk < 4 ? sk : 4;
+  if (160u * 1024u / stream_lds_bytes<LAYOUT_A>(4, mrows, sk4) >= 4)
+    return launch_stream_sw<DT, LAYOUT_A, WPL, QMX, 4>(sp, sk4, coltiles, batch, st);
+  return launch_stream_sw<DT, LAYOUT_A, WPL, QMX, 8>(sp, sk, coltiles, batch, st);
 }
 
 template <typename DT, bool LAYOUT_A, int CANON, bool QMX>
@@ -471,7 +488,7 @@ int launch_w4(GemmParams& p, int64_t coltiles, int64_t batch, hipStream_t st) {
   static const int use_stream = getenv("TG_STREAM") ? atoi(getenv("TG_STREAM")) : 1;
   constexpr int WPL = CANON == CANON_NONE ? 1 : (CANON == CANON_PAIR ? 2 : 4);
   if (use_stream && g.waves == 8 && (1 << p.gshift) >= (LAYOUT_A ? 64 : 128)) {
-    return launch_stream<DT, LAYOUT_A, WPL, QMX>(p, g.splitk, coltiles, batch, st);
+    return launch_stream<DT, LAYOUT_A, WPL, QMX>(p, coltiles, batch, st);
   }
   if (g.waves == 16) {
     hipLaunchKernelGGL((w4_gemm_kernel<DT, LAYOUT_A, CANON, QMX, 16, 2, 4>), grid, dim3(16 * 64), 0, st, p);

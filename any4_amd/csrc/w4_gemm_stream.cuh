@@ -26,7 +26,7 @@
 //                  16-byte load per lane per unit): no barrier anywhere in the kernel.
 //
 // LDS (dynamic, sized by the host, no static LDS so the base is 0):
-//   [WAVES x 4 KiB lookup tables][WAVES x 1 KiB split-K tiles][X slabs].
+//   [WAVES x 4 KiB lookup tables][X slabs][split-K partial tiles, only when splitk > 1].
 // Wave w's table starts at byte w * 4096.  With WAVES == 1 (the PRIVX launches) the table sits at 0
 // and a lookup address is just (nibble << 8 | lane << 2); otherwise address bits 12..15 (the table
 // select) are OR-ed into the nibble bytes before the v_perm_b32.
@@ -57,6 +57,7 @@ struct StreamParams {
   int32_t units_per_lane;   // NU: units walked by every lane (a multiple of group / UNIT)
   int32_t upg_mask;         // (units per quantisation group) - 1
   int32_t xslab_bytes;      // bytes of one staged X slab
+  int32_t red_off;          // LDS byte offset of the split-K partial tiles (unused when splitk == 1)
   int64_t stride_x, stride_w, stride_qinfo, stride_lut, stride_y;
 };
 
@@ -74,8 +75,8 @@ __global__ void __launch_bounds__(WAVES * 64, MINW) w4_gemm_stream_kernel(const 
 
   extern __shared__ __attribute__((aligned(4096))) char smem[];
   if ((uint32_t)reinterpret_cast<uintptr_t>(smem) != 0u) __builtin_trap();  // the layout below assumes LDS base 0
-  constexpr uint32_t lds_red = WAVES * 4096u;
-  constexpr uint32_t lds_x0 = lds_red + WAVES * 1024u;
+  constexpr uint32_t lds_x0 = WAVES * 4096u;
+  const uint32_t lds_red = (uint32_t)p.red_off;  // split-K tiles live behind the X slabs (only allocated when splitk > 1)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
