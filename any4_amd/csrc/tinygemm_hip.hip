@@ -468,9 +468,10 @@ int launch_stream(const GemmParams& p, int64_t coltiles, int64_t batch, hipStrea
   while (sk < 8 && wave_tiles * sk < 2 * 256 * 16 && nunits >= 8 * sk * upg && mrows * sk * 2 <= 16) sk *= 2;
   // m == 1 and one tile per wave: single-wave workgroups, every wave stages its own X slab (no barriers)
   if (mrows == 1 && sk == 1) return launch_stream_sw<DT, LAYOUT_A, WPL, QMX, 1>(sp, 1, coltiles, batch, st);
-  // otherwise the smallest workgroup whose LDS footprint still lets 16 waves live on a CU
+  // otherwise 4-wave workgroups while their LDS footprint lets 16 waves live on a CU and the X slab is small;
+  // X slabs of 8 KiB or more per unit (Bint4: m >= 8, Aint4: m = 16): 8-wave workgroups halve the staging work per wave
   const int sk4 = sk < 4 ? sk : 4;
-  if (160u * 1024u / stream_lds_bytes<LAYOUT_A>(4, mrows, sk4) >= 4)
+  if (mrows * UNIT < 1024 && 160u * 1024u / stream_lds_bytes<LAYOUT_A>(4, mrows, sk4) >= 4)
     return launch_stream_sw<DT, LAYOUT_A, WPL, QMX, 4>(sp, sk4, coltiles, batch, st);
   return launch_stream_sw<DT, LAYOUT_A, WPL, QMX, 8>(sp, sk, coltiles, batch, st);
 }
