@@ -31,6 +31,13 @@ __global__ void __launch_bounds__(1024) k(uint32_t* out, uint64_t* cyc, int iter
       if (KIND == 3) { if (i & 1) { f32x2 a = {f[i - 1], f[i]}; v[i] = __builtin_bit_cast(uint32_t, __builtin_convertvector(a, bf16x2)); f[i] = __builtin_bit_cast(float, v[i]) ; } }
       if (KIND == 4) { uint32_t a = (v[i] & 0xf00u) | base; f[i] = *(lds_cfptr)(a); v[i] = __builtin_bit_cast(uint32_t, f[i]) + v[i]; }
       if (KIND == 5) v[i] = (v[i] & 0x0f0f0f0fu) | seed;
+      if (KIND == 7) { u32x4 r = *(volatile __attribute__((address_space(3))) u32x4*)(uintptr_t)(((wave * 1024 + lane * 4) * 4 + (i & 3) * 1024) & 0xffff); v[i] ^= r[0]; }
+      if (KIND == 8) { if ((lane & 15) == 0) { u32x4 r = *(volatile __attribute__((address_space(3))) u32x4*)(uintptr_t)(((wave * 1024 + lane * 4) * 4 + (i & 3) * 1024) & 0xffff); v[i] ^= r[0]; } }
+      if (KIND == 9) { u32x4 r = *(volatile __attribute__((address_space(3))) u32x4*)(uintptr_t)(((wave * 1024 + (lane >> 4) * 4) * 4 + (i & 3) * 1024) & 0xffff); v[i] ^= r[0]; }
+      if (KIND == 10) { if (lane < 16) { u32x4 r = *(volatile __attribute__((address_space(3))) u32x4*)(uintptr_t)(((wave * 1024 + lane * 4) * 4 + (i & 3) * 1024) & 0xffff); v[i] ^= r[0]; } }
+      if (KIND == 11) { if ((lane & 15) < 4) { u32x4 r = *(volatile __attribute__((address_space(3))) u32x4*)(uintptr_t)(((wave * 1024 + lane * 4) * 4 + (i & 3) * 1024) & 0xffff); v[i] ^= r[0]; } }
+      if (KIND == 12) { uint32_t r = *(volatile __attribute__((address_space(3))) uint32_t*)(uintptr_t)(((wave * 1024 + lane) * 4 + (i & 3) * 1024) & 0xffff); v[i] ^= r; }
+      if (KIND == 13) { if ((lane & 15) == 0) { uint32_t r = *(volatile __attribute__((address_space(3))) uint32_t*)(uintptr_t)(((wave * 1024 + lane) * 4 + (i & 3) * 1024) & 0xffff); v[i] ^= r; } }
       if (KIND == 6) { if ((i & 7) == 7) { u32x4 a = {v[i], v[i-1], v[i-2], v[i-3]}; u32x4 b = {v[i-4], v[i-5], v[i-6], v[i-7]}; acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0); } }
     }
   }
@@ -40,6 +47,54 @@ __global__ void __launch_bounds__(1024) k(uint32_t* out, uint64_t* cyc, int iter
   s += __builtin_bit_cast(uint32_t, acc[0] + acc[1] + acc[2] + acc[3]);
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
   if (lane == 0) cyc[blockIdx.x * 16 + wave] = t1 - t0;
+}
+
+// LDS read throughput: 16 independent reads in flight per wave, one s_waitcnt per block of 16.
+template <int WIDTH, int MASK>
+__global__ void __launch_bounds__(1024) kl(uint32_t* out, uint64_t* cyc, int iters, uint32_t seed) {
+  __shared__ float tab[16 * 64 * 16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int e = 0; e < 16; ++e) tab[wave * 1024 + e * 64 + lane] = (float)e;
+  __syncthreads();
+  uint32_t addr = (uint32_t)reinterpret_cast<uintptr_t>(&tab[0]) + wave * 4096;
+  if (MASK == 2) addr += (lane >> 4) * 16;            // broadcast within each 16-lane row
+  else addr += lane * (WIDTH == 128 ? 16 : WIDTH == 64 ? 8 : 4);
+  const bool on = MASK == 1 ? (lane & 15) == 0 : MASK == 3 ? lane < 16 : MASK == 4 ? (lane & 15) < 4 : true;
+  uint32_t s = 0;
+  uint64_t t0 = __builtin_readcyclecounter();
+  if (on) {
+    for (int it = 0; it < iters; ++it) {
+      u32x4 r[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        if (WIDTH == 128) asm volatile("ds_read_b128 %0, %1" : "=v"(r[i]) : "v"(addr + (i & 3) * 1024));
+        if (WIDTH == 64) { uint64_t t; asm volatile("ds_read_b64 %0, %1" : "=v"(t) : "v"(addr + (i & 3) * 1024)); r[i][0] = (uint32_t)t; }
+        if (WIDTH == 32) asm volatile("ds_read_b32 %0, %1" : "=v"(r[i][0]) : "v"(addr + (i & 3) * 1024));
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < 16; ++i) s ^= r[i][0];
+    }
+  }
+  uint64_t t1 = __builtin_readcyclecounter();
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+  if (lane == 0) cyc[blockIdx.x * 16 + wave] = t1 - t0;
+}
+
+template <int WIDTH, int MASK>
+void runl(const char* name) {
+  uint32_t* out; uint64_t* cyc;
+  const int blocks = 256, iters = 2000;
+  hipMalloc(&out, blocks * 1024 * 4); hipMalloc(&cyc, blocks * 16 * 8);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  hipLaunchKernelGGL((kl<WIDTH, MASK>), dim3(blocks), dim3(1024), 0, 0, out, cyc, 10, 3u);
+  hipEventRecord(e0);
+  hipLaunchKernelGGL((kl<WIDTH, MASK>), dim3(blocks), dim3(1024), 0, 0, out, cyc, iters, 3u);
+  hipEventRecord(e1); hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  double instr_per_cu = 16.0 * iters * 16;
+  printf("%-34s wall %.3f ms -> %.2f ns per wave-instr per CU\n", name, ms, ms * 1e6 / instr_per_cu);
+  hipFree(out); hipFree(cyc);
 }
 
 template <int KIND>
@@ -72,5 +127,14 @@ int main() {
   run<4>("and_or+ds_read_b32+add", 32);
   run<5>("v_and_or", 32);
   run<6>("mfma16x16x32bf16", 4);
+  runl<128, 0>("ds_read_b128 full");
+  runl<128, 1>("ds_read_b128 lanes%16==0");
+  runl<128, 2>("ds_read_b128 bcast per 16-lane row");
+  runl<128, 3>("ds_read_b128 lanes<16");
+  runl<128, 4>("ds_read_b128 lanes%16<4");
+  runl<64, 0>("ds_read_b64 full");
+  runl<64, 1>("ds_read_b64 lanes%16==0");
+  runl<32, 0>("ds_read_b32 full");
+  runl<32, 1>("ds_read_b32 lanes%16==0");
   return 0;
 }
