@@ -29,6 +29,10 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# the cpu_baseline leg runs the OpenMP oracle: without thread binding libgomp's workers pile onto a few cores
+# (measured: 93 ms vs 7 ms per layer on 8 cores); must be set before anything loads libgomp
+os.environ.setdefault("OMP_PROC_BIND", "true")
+
 import torch  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 measured float4 copy
@@ -186,6 +190,30 @@ def main():
         torch.cuda.synchronize()
         single_us = e0.elapsed_time(e1) * 1e3 / (5 * L)
 
+        def stacked_us(mm, layers, reps=10):
+            """Event time of `reps` stacked launches over `layers` layers at batch rows mm (same weights)."""
+            xx = x if mm == m else torch.randn(L, mm, k, device=device).to(torch.bfloat16)
+            yy = y if mm == m else torch.empty(L, mm, n, device=device, dtype=torch.bfloat16)
+            aa = _lib.W4Gemm.from_buffer_copy(args)
+            aa.x, aa.y, aa.m, aa.batch = xx.data_ptr(), yy.data_ptr(), mm, layers
+            aa.stride_x, aa.stride_y = xx.stride(0) * 2, yy.stride(0) * 2
+            for _ in range(3):
+                _lib.check(lib.tg_gemm_w4(ctypes.byref(aa), local_rank, stream.cuda_stream), "tg_gemm_w4")
+            a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a0.record(stream)
+            for _ in range(reps):
+                _lib.check(lib.tg_gemm_w4(ctypes.byref(aa), local_rank, stream.cuda_stream), "tg_gemm_w4")
+            a1.record(stream)
+            torch.cuda.synchronize()
+            return a0.elapsed_time(a1) * 1e3 / reps
+
+        # marginal rate (SURVEY 8d): slope of launch time over the number of stacked layers
+        t_half, t_full = stacked_us(m, L // 2), stacked_us(m, L)
+        slope_us = (t_full - t_half) / (L - L // 2)
+        # the metric's second point: m = 8 at the same n, k (same stacked launch, 8 activation rows)
+        m8_us = stacked_us(8, L) / L
+        m8_bytes = alg_bytes(8, n, k, g, 32 * n)
+
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
         if os.path.exists(pmc):
@@ -224,6 +252,19 @@ def main():
                 "traffic": traffic,
                 "launch_us": round(kern_ms * 1e3, 3),
                 "bytes_per_launch": bytes_step_rank,
+            },
+            "marginal": {
+                "us_per_layer": round(slope_us, 4),
+                "GBps": round(bytes_layer / slope_us / 1e3, 2),
+                "frac": round(bytes_layer / slope_us / 1e3 / HBM_PEAK_GBPS, 4),
+                "note": f"dT/dL between stacked launches of {L // 2} and {L} layers (launch overhead cancels)",
+            },
+            "m8": {
+                "us_per_layer": round(m8_us, 4),
+                "GBps": round(m8_bytes / m8_us / 1e3, 2),
+                "frac": round(m8_bytes / m8_us / 1e3 / HBM_PEAK_GBPS, 4),
+                "algorithmic_bytes_per_layer": m8_bytes,
+                "note": f"m=8, n=k={n}, g={g}: the metric's second point, same stacked launch of {L} layers",
             },
             "single_layer_launch": {
                 "us_per_launch": round(single_us, 3),
