@@ -397,7 +397,7 @@ template <bool LAYOUT_A>
 inline unsigned stream_lds_bytes(int sw, int mrows, int sk) {
   const unsigned nr = 1u;  // lookup tables per wave
   const unsigned unit = LAYOUT_A ? 64u : 128u;
-  const unsigned slab = (unsigned)(mrows * 4 * sk) * (unit * 2u + 16u);
+  const unsigned slab = (unsigned)(mrows * 4 * sk + 1) * (unit * 2u + 16u);  // + the all-zero row
   return (unsigned)sw * nr * 4096u + 2u * slab + (sk > 1 ? (unsigned)sw * nr * 1024u : 0u);
 }
 
@@ -416,7 +416,7 @@ int launch_stream_sw(StreamParams& sp, int sk, int64_t coltiles, int64_t batch, 
   sp.units_per_lane = nu;
   sp.upg_mask = upg - 1;
   const int xrows = mrows * 4 * sk;
-  sp.xslab_bytes = xrows * (UNIT * 2 + 16);
+  sp.xslab_bytes = (xrows + 1) * (UNIT * 2 + 16);
   sp.red_off = (int32_t)(SW * NR * 4096u + 2u * (unsigned)sp.xslab_bytes);
   const int pieces = xrows * (UNIT * 2 / 16);
   // SW == 1: every wave stages its own X slab (no barrier in the kernel)

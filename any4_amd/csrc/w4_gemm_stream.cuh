@@ -145,9 +145,15 @@ __global__ void __launch_bounds__(WAVES * 64, MINW) w4_gemm_stream_kernel(const 
     for (int j = 0; j < XL; ++j)
       if (xs_on[j]) *(lds_u32x4ptr)(lds_x + (uint32_t)(buf * p.xslab_bytes) + xs_loff[j]) = R[j];
   };
-  // this lane's fragment row in a staged slab
-  const int frow = ((min(i, mrows - 1) << p.sk_shift) + slice) * 4 + Q;
+  // this lane's fragment row in a staged slab.  MFMA columns >= m are never stored; they read the all-zero row
+  // behind the staged rows (zero operands keep the multipliers of the unused columns quiet -> less power, more clock).
+  const int frow = i < mrows ? ((i << p.sk_shift) + slice) * 4 + Q : xrows;
   const uint32_t xfrag = lds_x + (uint32_t)(frow * XROW);
+  {
+    const int zt = PRIVX ? lane : tid;
+    if (zt < 2 * (XROW / 16))
+      *(lds_u32x4ptr)(lds_x + (uint32_t)((zt / (XROW / 16)) * p.xslab_bytes + xrows * XROW + (zt % (XROW / 16)) * 16)) = u32x4{0, 0, 0, 0};
+  }
 
   // ---- raw LUT of this lane's row: 16 x 16 bit, kept packed in 8 registers ----
   u32x4 lut0, lut1;

@@ -7,10 +7,13 @@ Contract (one JSON line on rank 0):
 
 Workload (BASELINE.json configs[1]): any4 (per-row 16-entry bf16 LUT, g = 128) W4A16 GEMV, m = 1,
 n = k = 4096, weights packed on the B side with innerKTiles = 4 -- exactly what Any4Linear's default
-kernel `linear_y_f16RM_x_f16RM_W_any4TC` runs.  One STEP is one pass over a batch of L = 64
-independent such layers (distinct weights, activations and outputs: 580 MB, larger than L2 + Infinity
-Cache, so every step streams its weights from HBM) issued as ONE stacked launch of the C-ABI entry
-point tg_gemm_w4 (batch = L).  Inputs are resident in HBM before the timed region.
+kernel `linear_y_f16RM_x_f16RM_W_any4TC` runs.  One STEP is one pass over a batch of L = 512
+independent such layers (distinct weights, activations and outputs: 4.6 GB, far beyond L2 + Infinity
+Cache, so every step streams its weights from HBM; about the 4-bit weight volume of a Llama-3-8B
+decode step) issued as ONE stacked launch of the C-ABI entry point tg_gemm_w4 (batch = L).  Inputs are
+resident in HBM before the timed region.  A step is ~1 ms on purpose: the power controller needs ~30 ms
+of load to settle (it overshoots, throttles to ~75 % and recovers), so the warm-up steps must
+last that long for the timed steps to see the steady clock.
 
 `value` = algorithmic bytes of all ranks per step / max-over-ranks step time.
 Algorithmic bytes per layer: n*k/2 + (k/g)*n*4 + 32*n + m*k*2 + m*n*2 = 9 060 352 B.
@@ -89,9 +92,9 @@ def cpu_baseline(m, n, k, g, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--layers", type=int, default=64, help="independent layers per step (stacked launch)")
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--layers", type=int, default=512, help="independent layers per step (stacked launch)")
     ap.add_argument("--m", type=int, default=1)
     ap.add_argument("--n", type=int, default=4096)
     ap.add_argument("--k", type=int, default=4096)
@@ -183,12 +186,11 @@ def main():
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(stream)
-        for _ in range(5):
-            for sa in per:
-                lib.tg_gemm_w4(ctypes.byref(sa), local_rank, stream.cuda_stream)
+        for sa in per:
+            lib.tg_gemm_w4(ctypes.byref(sa), local_rank, stream.cuda_stream)
         e1.record(stream)
         torch.cuda.synchronize()
-        single_us = e0.elapsed_time(e1) * 1e3 / (5 * L)
+        single_us = e0.elapsed_time(e1) * 1e3 / L
 
         def stacked_us(mm, layers, reps=10):
             """Event time of `reps` stacked launches over `layers` layers at batch rows mm (same weights)."""
@@ -218,7 +220,9 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                # PMC passes are separate rocprofv3 runs of this same command (tools/gpu_round.sh); the committed
+                # summary holds HBM bytes per layer of the stacked launch, scaled here to this launch's layers
+                traffic = int(json.load(open(pmc))["hbm_bytes_per_layer"] * L)
             except Exception:
                 traffic = None
 

@@ -1,20 +1,29 @@
-mkdir -p gpurun_out/pmc3
-R=$GRAFT_REPO_ROOT
-cd /tmp && export TMPDIR=/tmp
-for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES" "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_INST_CYCLES_VMEM" "GRBM_GUI_ACTIVE GRBM_COUNT" "FETCH_SIZE" "MfmaUtil"; do
-  tag=$(echo $set | cut -d' ' -f1)
-  timeout 300 rocprofv3 --pmc $set --output-format csv -d $R/gpurun_out/pmc3/$tag -o q -- python $R/tools/quick_bench.py --configs "8,8192,8192,0;1,4096,4096,1" --iters 2 > /dev/null 2>&1
-done
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/pmc3/stats -o q -- python $R/tools/quick_bench.py --configs "8,8192,8192,0;1,4096,4096,1" --iters 3 > /dev/null 2>&1
-cd $R
 python - <<'PY'
-import csv, glob, collections
-agg = collections.defaultdict(list)
-for f in glob.glob("gpurun_out/pmc3/*/*counter_collection.csv"):
-    for r in csv.DictReader(open(f)):
-        if "w4_gemm_stream" in r["Kernel_Name"]:
-            agg[(r["Grid_Size"], r["Counter_Name"])].append(float(r["Counter_Value"]))
-for k in sorted(agg):
-    v = agg[k]; print(k, "n=%d mean=%.1f" % (len(v), sum(v) / len(v)))
+import ctypes, torch, sys, time
+sys.path.insert(0, '.')
+import bench
+from any4_amd import _lib
+lib = _lib.load()
+dev = torch.device('cuda', 0)
+L, m, n, k, g = 64, 1, 4096, 4096, 128
+w, x, sz, lut, y = bench.make_batch(L, m, n, k, g, 4, dev, 1)
+args = _lib.W4Gemm(x=x.data_ptr(), w=w.data_ptr(), qinfo=sz.data_ptr(), lut=lut.data_ptr(), y=y.data_ptr(), m=m, wrows=n, k=k, group=g,
+    qtype=_lib.TG_Q_ANY4_ROWWISE, dtype=_lib.TG_BF16, w_on_right=1, inner_k_tiles=4, batch=L, stride_x=x.stride(0)*2, stride_w=w.stride(0)*4,
+    stride_qinfo=sz.stride(0)*2, stride_lut=lut.stride(0)*2, stride_y=y.stride(0)*2)
+st = torch.cuda.current_stream()
+torch.cuda.synchronize()
+N = 600
+ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(N)]
+for s in range(N):
+    ev[s][0].record(st); lib.tg_gemm_w4(ctypes.byref(args), 0, st.cuda_stream); ev[s][1].record(st)
+torch.cuda.synchronize()
+ts = [a.elapsed_time(b) * 1e3 for a, b in ev]
+for i in range(0, N, 25):
+    seg = ts[i:i+25]; print(i, "avg %.1f min %.1f max %.1f us" % (sum(seg)/len(seg), min(seg), max(seg)))
+time.sleep(2)
+for s in range(50):
+    ev[s][0].record(st); lib.tg_gemm_w4(ctypes.byref(args), 0, st.cuda_stream); ev[s][1].record(st)
+torch.cuda.synchronize()
+ts = [a.elapsed_time(b) * 1e3 for a, b in ev[:50]]
+print("after 2 s idle:", " ".join("%.0f" % t for t in ts))
 PY
-grep w4_gemm gpurun_out/pmc3/stats/q_kernel_stats.csv | cut -c1-200
