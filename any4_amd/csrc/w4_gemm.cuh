@@ -117,6 +117,7 @@ __global__ void __launch_bounds__(WAVES * 64, MINW) w4_gemm_kernel(const GemmPar
   const uint32_t wstep = 32u * WPL * 4u;                                         // bytes per k super-tile
 
   const int xrow = min(ct * 16 + i, p.m - 1);
+  const bool xcol = ct * 16 + i < p.m;
   const uint32_t xlane = (uint32_t)((xrow * p.k + Q * CHUNK) * 2);
 
   const int nsteps_total = (p.k + KSTEP - 1) / KSTEP;
@@ -149,7 +150,8 @@ __global__ void __launch_bounds__(WAVES * 64, MINW) w4_gemm_kernel(const GemmPar
 #pragma unroll
     for (int h = 0; h < NMMA; ++h) {
       if constexpr (ABL == 2) sl.x[h] = u32x4{xo, 1u, 2u, 3u};  // ablation: no X loads
-      else sl.x[h] = *reinterpret_cast<const u32x4*>(xb + (xo + 16u * h));
+      else if (xcol) sl.x[h] = *reinterpret_cast<const u32x4*>(xb + (xo + 16u * h));
+      else sl.x[h] = u32x4{0u, 0u, 0u, 0u};  // unused MFMA column: zero operand (its output is never stored)
     }
   };
 

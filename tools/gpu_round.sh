@@ -5,11 +5,11 @@ R=$GRAFT_REPO_ROOT
 cd $R
 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1; echo "smoke rc=$?"; tail -2 gpurun_out/smoke.log
 timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/gpu_tests.log 2>&1; echo "pytest rc=$?"; tail -3 gpurun_out/gpu_tests.log
-timeout 600 python bench.py > gpurun_out/bench.log 2> gpurun_out/bench.err; echo "bench rc=$?"; cat gpurun_out/bench.log; tail -3 gpurun_out/bench.err
+timeout 600 python bench.py > gpurun_out/bench.log 2> gpurun_out/bench.err; echo "bench rc=$?"; cat gpurun_out/bench.log; tail -3 gpurun_out/bench.err; cp gpurun_out/bench.log gpurun_out/r01_bench_line.json
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof/stats -o bench -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $R/gpurun_out/prof/stats.log 2>&1
-timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/prof/pmc_fetch -o bench -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $R/gpurun_out/prof/pmc_fetch.log 2>&1
-timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/prof/pmc_write -o bench -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $R/gpurun_out/prof/pmc_write.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof/stats -o bench -- python $R/bench.py --roofline-only > $R/gpurun_out/prof/stats.log 2>&1
+timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/prof/pmc_fetch -o bench -- python $R/bench.py --steps 5 --warmup 2 --roofline-only > $R/gpurun_out/prof/pmc_fetch.log 2>&1
+timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/prof/pmc_write -o bench -- python $R/bench.py --steps 5 --warmup 2 --roofline-only > $R/gpurun_out/prof/pmc_write.log 2>&1
 cd $R
 find gpurun_out/prof -name "*.csv" | head -20
 head -4 gpurun_out/prof/stats/bench_kernel_stats.csv | cut -c1-260
@@ -32,7 +32,7 @@ rd = 2 * raw["FETCH_SIZE"][key]["mean_KB"] * 1024
 wr = raw["WRITE_SIZE"][key]["mean_KB"] * 1024
 alg = line["roofline"]["bytes_per_launch"]
 out = {
-    "command": "rocprofv3 --pmc FETCH_SIZE (and, in a separate pass, --pmc WRITE_SIZE) --output-format csv -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline   (tools/gpu_round.sh)",
+    "command": "rocprofv3 --pmc FETCH_SIZE (and, in a separate pass, --pmc WRITE_SIZE) --output-format csv -- python bench.py --steps 5 --warmup 2 --roofline-only   (tools/gpu_round.sh)",
     "kernel": line["roofline"]["kernel"], "layers_per_launch": L, "raw": raw,
     "correction": "gfx950 rocprofv3 FETCH_SIZE tallies the 128-B requests of 16-B/lane streaming reads at 64 B (MI355X_MICROARCH.md, HBM section): read bytes = 2 * FETCH_SIZE[KB] * 1024; WRITE_SIZE[KB] * 1024 as reported",
     "hbm_read_bytes_per_launch": int(rd), "hbm_write_bytes_per_launch": int(wr), "hbm_bytes_per_launch": int(rd + wr),
