@@ -39,6 +39,13 @@ SYMBOLS = {
     "tg_dequant_int4": [_vp, _i64, _vp, ctypes.c_int, _vp],
     "tg_gemm_w4": [ctypes.POINTER(W4Gemm), ctypes.c_int, _vp],
     "tg_gemm_f16": [_vp, _vp, _vp, _i64, _i64, _i64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp],
+    # include/decode_glue_hip.h (non-GEMM kernels of the decode harness)
+    "dg_add_rmsnorm": [_vp, _vp, _vp, _vp, _vp, _i64, _i64, ctypes.c_float, ctypes.c_int, ctypes.c_int, _vp],
+    "dg_rope_kv": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, ctypes.c_int, ctypes.c_int, ctypes.c_int, _i64,
+                   ctypes.c_int, ctypes.c_int, _vp],
+    "dg_decode_attn": [_vp, _vp, _vp, _vp, _vp, _i64, ctypes.c_int, ctypes.c_int, ctypes.c_int, _i64, ctypes.c_float,
+                       ctypes.c_int, ctypes.c_int, _vp],
+    "dg_swiglu": [_vp, _vp, _i64, _i64, ctypes.c_int, ctypes.c_int, _vp],
 }
 
 _lib = None

@@ -1,0 +1,244 @@
+// Non-GEMM kernels of one batch-1 decode step (include/decode_glue_hip.h).  Included at the end of
+// tinygemm_hip.hip: shares its type traits (BF16 / F16), DeviceScope and launch_status().
+//
+// These are small HBM/L2-latency-bound kernels (a few KiB to a few hundred KiB per launch); what matters is that
+// there are 5 of them per layer instead of ~45 torch launches, not their individual bandwidth.  Rounding points
+// mirror the torch formulation in any4_amd/decode.py so the two paths can be compared in tests.
+#include "../../include/decode_glue_hip.h"
+
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+// all threads of a 256-thread block get the reduction; `scratch` holds >= 4 floats and is reusable afterwards
+template <bool MAX>
+__device__ __forceinline__ float block_reduce(float v, float* scratch) {
+  v = MAX ? wave_max(v) : wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float r = scratch[0];
+#pragma unroll
+  for (int w = 1; w < 4; ++w) r = MAX ? fmaxf(r, scratch[w]) : r + scratch[w];
+  return r;
+}
+
+template <typename DT>
+__device__ __forceinline__ void unpack8(const u32x4& v, float (&f)[8]) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    f[2 * q] = DT::lo_f32(v[q]);
+    f[2 * q + 1] = DT::hi_f32(v[q]);
+  }
+}
+template <typename DT>
+__device__ __forceinline__ u32x4 pack8(const float (&f)[8]) {
+  return u32x4{DT::pack2(f[0], f[1]), DT::pack2(f[2], f[3]), DT::pack2(f[4], f[5]), DT::pack2(f[6], f[7])};
+}
+template <typename DT>
+__device__ __forceinline__ float round16(float a) { return DT::to_f32(DT::from_f32(a)); }
+
+// ---- residual add + RMSNorm: one 256-thread block per row ------------------------------------------
+template <typename DT>
+__global__ void __launch_bounds__(256) add_rmsnorm_kernel(const u32x4* h, const u32x4* __restrict__ delta,
+                                                          const u32x4* __restrict__ w, u32x4* h_out, u32x4* __restrict__ y,
+                                                          int dim8, float inv_dim, float eps) {
+  __shared__ float scratch[4];
+  const int64_t base = (int64_t)blockIdx.x * dim8;
+  float ss = 0.f;
+  for (int v = threadIdx.x; v < dim8; v += 256) {
+    float a[8];
+    unpack8<DT>(h[base + v], a);
+    if (delta) {
+      float d[8];
+      unpack8<DT>(delta[base + v], d);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a[e] = round16<DT>(a[e] + d[e]);
+    }
+    if (delta || h_out != h) h_out[base + v] = pack8<DT>(a);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ss += a[e] * a[e];
+  }
+  if (!y) return;
+  const float r = rsqrtf(block_reduce<false>(ss, scratch) * inv_dim + eps);
+  for (int v = threadIdx.x; v < dim8; v += 256) {
+    float a[8], g[8];
+    unpack8<DT>(h_out[base + v], a);  // written by this same thread above (or the untouched input)
+    unpack8<DT>(w[v], g);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[e] = round16<DT>(a[e] * r) * g[e];
+    y[base + v] = pack8<DT>(a);
+  }
+}
+
+// ---- rotary embedding + KV-cache write: block = one head of one sequence, thread = one rotation pair ----
+template <typename DT>
+__global__ void rope_kv_kernel(const uint16_t* __restrict__ qkv, const float* __restrict__ cos, const float* __restrict__ sin,
+                               const int64_t* __restrict__ pos_p, uint16_t* __restrict__ q_out, uint16_t* __restrict__ k_cache,
+                               uint16_t* __restrict__ v_cache, int hl, int kvl, int d, int64_t max_seq) {
+  const int b = blockIdx.x, head = blockIdx.y, j = threadIdx.x, d2 = d >> 1;
+  const int64_t pos = *pos_p;
+  const uint16_t* src = qkv + ((int64_t)b * (hl + 2 * kvl) + head) * d;
+  if (head >= hl + kvl) {  // v: plain copy into the cache
+    uint16_t* dst = v_cache + (((int64_t)b * kvl + (head - hl - kvl)) * max_seq + pos) * d;
+    dst[j] = src[j];
+    dst[j + d2] = src[j + d2];
+    return;
+  }
+  const float x1 = DT::to_f32(src[j]), x2 = DT::to_f32(src[j + d2]);
+  const float c1 = cos[pos * d + j], c2 = cos[pos * d + j + d2], s1 = sin[pos * d + j], s2 = sin[pos * d + j + d2];
+  // x * cos + rotate_half(x) * sin with each product and the sum rounded separately (as the torch ops do)
+  const float o1 = __fadd_rn(__fmul_rn(x1, c1), __fmul_rn(-x2, s1));
+  const float o2 = __fadd_rn(__fmul_rn(x2, c2), __fmul_rn(x1, s2));
+  uint16_t* dst = head < hl ? q_out + ((int64_t)b * hl + head) * d
+                            : k_cache + (((int64_t)b * kvl + (head - hl)) * max_seq + pos) * d;
+  dst[j] = DT::from_f32(o1);
+  dst[j + d2] = DT::from_f32(o2);
+}
+
+// ---- decode attention: block = one query head of one sequence --------------------------------------
+template <typename DT>
+__global__ void __launch_bounds__(256) decode_attn_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k_cache,
+                                                          const uint16_t* __restrict__ v_cache, const int64_t* __restrict__ pos_p,
+                                                          uint16_t* __restrict__ out, int hl, int kvl, int d, int64_t max_seq,
+                                                          float scale) {
+  extern __shared__ float sm[];  // [256 q] [4 scratch] [max_seq scores]; the partial outputs reuse the scores
+  float* qf = sm;
+  float* scratch = sm + 256;
+  float* sc = sm + 260;
+  const int b = blockIdx.x / hl, h = blockIdx.x % hl, kv = h / (hl / kvl), t = threadIdx.x;
+  const int S = (int)(*pos_p) + 1, d8 = d >> 3;
+  if (t < d) qf[t] = DT::to_f32(q[((int64_t)b * hl + h) * d + t]);
+  __syncthreads();
+  const u32x4* K = reinterpret_cast<const u32x4*>(k_cache + ((int64_t)b * kvl + kv) * max_seq * d);
+  const u32x4* V = reinterpret_cast<const u32x4*>(v_cache + ((int64_t)b * kvl + kv) * max_seq * d);
+  float mx = -INFINITY;
+  for (int s = t; s < S; s += 256) {
+    float acc = 0.f;
+    for (int v = 0; v < d8; ++v) {
+      float kf[8];
+      unpack8<DT>(K[(int64_t)s * d8 + v], kf);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc = fmaf(qf[v * 8 + e], kf[e], acc);
+    }
+    const float x = round16<DT>(acc) * scale;  // the score matrix is a 16-bit tensor in the torch formulation
+    sc[s] = x;
+    mx = fmaxf(mx, x);
+  }
+  mx = block_reduce<true>(mx, scratch);
+  float sum = 0.f;
+  for (int s = t; s < S; s += 256) {
+    const float e = __expf(sc[s] - mx);
+    sc[s] = e;
+    sum += e;
+  }
+  const float inv = 1.f / block_reduce<false>(sum, scratch);
+  __syncthreads();
+  // value contraction: thread = (8-wide column vc, position partition part)
+  const int vc = t % d8, part = t / d8, nparts = 256 / d8;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int s = part; s < S; s += nparts) {
+    const float p = round16<DT>(sc[s] * inv);  // probabilities are cast to 16 bit before the matmul
+    float vf[8];
+    unpack8<DT>(V[(int64_t)s * d8 + vc], vf);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = fmaf(p, vf[e], acc[e]);
+  }
+  __syncthreads();  // everyone is done reading the scores; reuse them as [nparts][d] partial outputs
+#pragma unroll
+  for (int e = 0; e < 8; ++e) sc[part * d + vc * 8 + e] = acc[e];
+  __syncthreads();
+  if (t < d) {
+    float o = 0.f;
+    for (int p = 0; p < nparts; ++p) o += sc[p * d + t];
+    out[((int64_t)b * hl + h) * d + t] = DT::from_f32(o);
+  }
+}
+
+// ---- SwiGLU ----------------------------------------------------------------------------------------
+template <typename DT>
+__global__ void __launch_bounds__(256) swiglu_kernel(const u32x4* __restrict__ gu, u32x4* __restrict__ out, int64_t il8, int64_t total8) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total8; i += (int64_t)gridDim.x * 256) {
+    const int64_t b = i / il8, j = i % il8;
+    float g[8], u[8];
+    unpack8<DT>(gu[b * 2 * il8 + j], g);
+    unpack8<DT>(gu[b * 2 * il8 + il8 + j], u);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) g[e] = round16<DT>(g[e] / (1.f + __expf(-g[e]))) * u[e];
+    out[i] = pack8<DT>(g);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int dg_add_rmsnorm(const void* h, const void* delta, const void* w, void* h_out, void* y, int64_t rows, int64_t dim,
+                   float eps, int dtype, int device, tg_stream_t stream) {
+  if (!h || !h_out || (y && !w)) return TG_E_NULL;
+  if (!(dtype == TG_BF16 || dtype == TG_F16)) return TG_E_DTYPE;
+  if (rows <= 0 || dim <= 0 || dim % 8 != 0 || dim > 16384 || rows > INT32_MAX) return TG_E_SHAPE;
+  if (!aligned16(h) || !aligned16(h_out) || (delta && !aligned16(delta)) || (y && (!aligned16(y) || !aligned16(w)))) return TG_E_ALIGN;
+  DeviceScope ds(device);
+  if (!ds.ok) return TG_E_DEVICE;
+  auto kern = dtype == TG_BF16 ? add_rmsnorm_kernel<BF16> : add_rmsnorm_kernel<F16>;
+  hipLaunchKernelGGL(kern, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, (const u32x4*)h, (const u32x4*)delta,
+                     (const u32x4*)w, (u32x4*)h_out, (u32x4*)y, (int)(dim / 8), 1.0f / (float)dim, eps);
+  return launch_status();
+}
+
+int dg_rope_kv(const void* qkv, const float* cos, const float* sin, const int64_t* pos, void* q_out, void* k_cache,
+               void* v_cache, int64_t bs, int hl, int kvl, int d, int64_t max_seq, int dtype, int device, tg_stream_t stream) {
+  if (!qkv || !cos || !sin || !pos || !q_out || !k_cache || !v_cache) return TG_E_NULL;
+  if (!(dtype == TG_BF16 || dtype == TG_F16)) return TG_E_DTYPE;
+  if (bs <= 0 || bs > 65535 || hl <= 0 || kvl <= 0 || hl % kvl != 0 || d <= 0 || d % 2 != 0 || d > 256 || max_seq <= 0) return TG_E_SHAPE;
+  DeviceScope ds(device);
+  if (!ds.ok) return TG_E_DEVICE;
+  auto kern = dtype == TG_BF16 ? rope_kv_kernel<BF16> : rope_kv_kernel<F16>;
+  hipLaunchKernelGGL(kern, dim3((unsigned)bs, (unsigned)(hl + 2 * kvl)), dim3(d / 2), 0, (hipStream_t)stream,
+                     (const uint16_t*)qkv, cos, sin, pos, (uint16_t*)q_out, (uint16_t*)k_cache, (uint16_t*)v_cache, hl, kvl, d, max_seq);
+  return launch_status();
+}
+
+int dg_decode_attn(const void* q, const void* k_cache, const void* v_cache, const int64_t* pos, void* out, int64_t bs,
+                   int hl, int kvl, int d, int64_t max_seq, float scale, int dtype, int device, tg_stream_t stream) {
+  if (!q || !k_cache || !v_cache || !pos || !out) return TG_E_NULL;
+  if (!(dtype == TG_BF16 || dtype == TG_F16)) return TG_E_DTYPE;
+  if (bs <= 0 || hl <= 0 || kvl <= 0 || hl % kvl != 0 || d < 8 || d % 8 != 0 || d > 256 || (256 % (d / 8)) != 0 ||
+      max_seq <= 0 || max_seq > 8192 || bs * hl > INT32_MAX)
+    return TG_E_SHAPE;
+  if (!aligned16(k_cache) || !aligned16(v_cache)) return TG_E_ALIGN;
+  DeviceScope ds(device);
+  if (!ds.ok) return TG_E_DEVICE;
+  const int64_t sc_floats = max_seq > (256 / (d / 8)) * (int64_t)d ? max_seq : (256 / (d / 8)) * (int64_t)d;
+  const unsigned lds = (unsigned)((260 + sc_floats) * sizeof(float));
+  auto kern = dtype == TG_BF16 ? decode_attn_kernel<BF16> : decode_attn_kernel<F16>;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(bs * hl)), dim3(256), lds, (hipStream_t)stream, (const uint16_t*)q,
+                     (const uint16_t*)k_cache, (const uint16_t*)v_cache, pos, (uint16_t*)out, hl, kvl, d, max_seq, scale);
+  return launch_status();
+}
+
+int dg_swiglu(const void* gu, void* out, int64_t bs, int64_t il, int dtype, int device, tg_stream_t stream) {
+  if (!gu || !out) return TG_E_NULL;
+  if (!(dtype == TG_BF16 || dtype == TG_F16)) return TG_E_DTYPE;
+  if (bs <= 0 || il <= 0 || il % 8 != 0) return TG_E_SHAPE;
+  if (!aligned16(gu) || !aligned16(out)) return TG_E_ALIGN;
+  DeviceScope ds(device);
+  if (!ds.ok) return TG_E_DEVICE;
+  const int64_t total8 = bs * (il / 8);
+  const int64_t blocks = cdiv(total8, 256);
+  auto kern = dtype == TG_BF16 ? swiglu_kernel<BF16> : swiglu_kernel<F16>;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, (hipStream_t)stream,
+                     (const u32x4*)gu, (u32x4*)out, il / 8, total8);
+  return launch_status();
+}
+
+}  // extern "C"

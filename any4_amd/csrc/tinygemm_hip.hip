@@ -394,14 +394,15 @@ inline Geometry pick_geometry(int64_t rowtiles, int64_t coltiles, int64_t batch,
 // ---- streaming kernel launch ---------------------------------------------------------------------
 // LDS per workgroup: lookup tables (4 KiB per wave and row set) + two X slabs (+ split-K tiles).
 template <bool LAYOUT_A>
-inline unsigned stream_lds_bytes(int sw, int mrows, int sk) {
+inline unsigned stream_lds_bytes(int sw, int mrows, int sk, bool privx = false) {
   const unsigned nr = 1u;  // lookup tables per wave
   const unsigned unit = LAYOUT_A ? 64u : 128u;
-  const unsigned slab = (unsigned)(mrows * 4 * sk + 1) * (unit * 2u + 16u);  // + the all-zero row
-  return (unsigned)sw * nr * 4096u + 2u * slab + (sk > 1 ? (unsigned)sw * nr * 1024u : 0u);
+  // shared slab: rows of all k-slices; private slabs: one per wave with the rows of its own slice; + the all-zero row
+  const unsigned slab = (unsigned)(mrows * 4 * (privx ? 1 : sk) + 1) * (unit * 2u + 16u);
+  return (unsigned)sw * nr * 4096u + 2u * slab * (privx ? (unsigned)sw : 1u) + (sk > 1 ? (unsigned)sw * nr * 1024u : 0u);
 }
 
-template <typename DT, bool LAYOUT_A, int WPL, bool QMX, int SW>
+template <typename DT, bool LAYOUT_A, int WPL, bool QMX, int SW, bool privx = (SW == 1)>
 int launch_stream_sw(StreamParams& sp, int sk, int64_t coltiles, int64_t batch, hipStream_t st) {
   constexpr int UNIT = LAYOUT_A ? 64 : 128;
   constexpr unsigned NR = 1u;
@@ -415,15 +416,14 @@ int launch_stream_sw(StreamParams& sp, int sk, int64_t coltiles, int64_t batch, 
   while ((1 << sp.sk_shift) < sk) ++sp.sk_shift;
   sp.units_per_lane = nu;
   sp.upg_mask = upg - 1;
-  const int xrows = mrows * 4 * sk;
+  const int xrows = mrows * 4 * (privx ? 1 : sk);
   sp.xslab_bytes = (xrows + 1) * (UNIT * 2 + 16);
-  sp.red_off = (int32_t)(SW * NR * 4096u + 2u * (unsigned)sp.xslab_bytes);
+  sp.red_off = (int32_t)(SW * NR * 4096u + 2u * (unsigned)sp.xslab_bytes * (privx ? SW : 1));
   const int pieces = xrows * (UNIT * 2 / 16);
-  // SW == 1: every wave stages its own X slab (no barrier in the kernel)
-  constexpr bool privx = SW == 1;
-  const int nstage = SW * 64;
+  // privx: every wave stages its own X slab (no barrier in the main loop)
+  const int nstage = privx ? 64 : SW * 64;
   const int xl = pieces <= nstage ? 1 : (pieces <= 2 * nstage ? 2 : 4);
-  const unsigned lds = stream_lds_bytes<LAYOUT_A>(SW, mrows, sk);
+  const unsigned lds = stream_lds_bytes<LAYOUT_A>(SW, mrows, sk, privx);
   const int tpb = SW / sk;
   dim3 grid((unsigned)((sp.rowtiles + tpb - 1) / tpb), (unsigned)coltiles, (unsigned)batch);
 #define TG_LAUNCH_STREAM(XL)                                                                              \
@@ -436,7 +436,10 @@ int launch_stream_sw(StreamParams& sp, int sk, int64_t coltiles, int64_t batch, 
     }                                                                                                     \
     hipLaunchKernelGGL(kern, grid, dim3(SW * 64), lds, st, sp);                                           \
   } while (0)
-  if constexpr (SW == 1) {
+  if constexpr (privx && SW > 1) {
+    if (xl != 1) return TG_E_SHAPE;  // private slabs with split-K are only instantiated for one piece per lane (m = 1)
+    TG_LAUNCH_STREAM(1);
+  } else if constexpr (SW == 1) {
     if (xl == 1) TG_LAUNCH_STREAM(1);
     else TG_LAUNCH_STREAM(2);
   } else {
@@ -465,9 +468,20 @@ int launch_stream(const GemmParams& p, int64_t coltiles, int64_t batch, hipStrea
   // split-K: aim for at least two rounds of 16 waves on every CU; the X slab limits act rows * splitk to 16
   const int64_t wave_tiles = (int64_t)sp.rowtiles * coltiles * batch;
   int sk = 1;
-  while (sk < 8 && wave_tiles * sk < 2 * 256 * 16 && nunits >= 8 * sk * upg && mrows * sk * 2 <= 16) sk *= 2;
-  // m == 1 and one tile per wave: single-wave workgroups, every wave stages its own X slab (no barriers)
-  if (mrows == 1 && sk == 1) return launch_stream_sw<DT, LAYOUT_A, WPL, QMX, 1>(sp, 1, coltiles, batch, st);
+  // (m = 1, private slabs: one round of 16 waves per CU is enough -- measured on the Llama-3-8B shapes)
+  const int64_t want = mrows == 1 ? 256 * 16 : 2 * 256 * 16;
+  while (sk < 8 && wave_tiles * sk < want && nunits >= 8 * sk * upg && mrows * sk * 2 <= 16) sk *= 2;
+  static const int sk_env = getenv("TG_SK") ? atoi(getenv("TG_SK")) : 0;  // developer override
+  if (sk_env > 0) sk = sk_env;
+  // m == 1: every wave stages its own X slab (no barrier in the main loop); a workgroup is the sk waves of one tile
+  if (mrows == 1) {
+    switch (sk) {
+      case 1: return launch_stream_sw<DT, LAYOUT_A, WPL, QMX, 1>(sp, 1, coltiles, batch, st);
+      case 2: return launch_stream_sw<DT, LAYOUT_A, WPL, QMX, 2, true>(sp, 2, coltiles, batch, st);
+      case 4: return launch_stream_sw<DT, LAYOUT_A, WPL, QMX, 4, true>(sp, 4, coltiles, batch, st);
+      default: return launch_stream_sw<DT, LAYOUT_A, WPL, QMX, 8, true>(sp, 8, coltiles, batch, st);
+    }
+  }
   // otherwise 4-wave workgroups while their LDS footprint lets 16 waves live on a CU and the X slab is small;
   // X slabs of 8 KiB or more per unit (Bint4: m >= 8, Aint4: m = 16): 8-wave workgroups halve the staging work per wave
   const int sk4 = sk < 4 ? sk : 4;
@@ -488,7 +502,8 @@ int launch_w4(GemmParams& p, int64_t coltiles, int64_t batch, hipStream_t st) {
   // unit of its walk (Bint4: g >= 128, Aint4: g >= 64).  TG_STREAM=0 forces the split-K kernel.
   static const int use_stream = getenv("TG_STREAM") ? atoi(getenv("TG_STREAM")) : 1;
   constexpr int WPL = CANON == CANON_NONE ? 1 : (CANON == CANON_PAIR ? 2 : 4);
-  if (use_stream && g.waves == 8 && (1 << p.gshift) >= (LAYOUT_A ? 64 : 128)) {
+  // m = 1 always streams: with private X slabs its split-K variants beat the latency kernel down to one matrix
+  if (use_stream && (g.waves == 8 || p.m == 1 || use_stream == 2) && (1 << p.gshift) >= (LAYOUT_A ? 64 : 128)) {
     return launch_stream<DT, LAYOUT_A, WPL, QMX>(p, coltiles, batch, st);
   }
   if (g.waves == 16) {
@@ -725,3 +740,5 @@ int tg_gemm_f16(const void* x, const void* w, void* y, int64_t m, int64_t wrows,
 }
 
 }  // extern "C"
+
+#include "decode_glue.cuh"

@@ -112,7 +112,8 @@ __global__ void __launch_bounds__(WAVES * 64, MINW) w4_gemm_stream_kernel(const 
 
   // ---- X staging: thread -> (staged row, 16-byte piece); staged row = (act row c, slice, quarter) ----
   const int mrows = min(p.m - ct * 16, 16);
-  const int xrows = mrows * 4 * p.splitk;
+  // shared slab: rows of every k-slice of the workgroup; private slab: only this wave's slice
+  const int xrows = PRIVX ? mrows * 4 : mrows * 4 * p.splitk;
   const uint32_t lds_x = PRIVX ? lds_x0 + (uint32_t)(wave * 2 * p.xslab_bytes) : lds_x0;
   uint32_t xs_rowbase[XL];  // global byte offset of the activation row this thread stages from
   uint32_t xs_in[XL];       // byte offset inside that row at unit-step 0
@@ -123,7 +124,9 @@ __global__ void __launch_bounds__(WAVES * 64, MINW) w4_gemm_stream_kernel(const 
     const int pid = (PRIVX ? lane : tid) + j * NSTAGE;
     const int srow = pid / PPR, pc = pid % PPR;
     xs_on[j] = srow < xrows;
-    const int sq = srow & 3, ssl = (srow >> 2) & (p.splitk - 1), sc = srow >> (2 + p.sk_shift);
+    const int sq = srow & 3;
+    const int ssl = PRIVX ? slice : (srow >> 2) & (p.splitk - 1);
+    const int sc = PRIVX ? srow >> 2 : srow >> (2 + p.sk_shift);
     const int xr = min(ct * 16 + sc, p.m - 1);
     xs_rowbase[j] = (uint32_t)(xr * p.k * 2);
     xs_in[j] = (uint32_t)((((ssl * 4 + sq) * NU) * UNIT + pc * 8) * 2);
@@ -147,7 +150,7 @@ __global__ void __launch_bounds__(WAVES * 64, MINW) w4_gemm_stream_kernel(const 
   };
   // this lane's fragment row in a staged slab.  MFMA columns >= m are never stored; they read the all-zero row
   // behind the staged rows (zero operands keep the multipliers of the unused columns quiet -> less power, more clock).
-  const int frow = i < mrows ? ((i << p.sk_shift) + slice) * 4 + Q : xrows;
+  const int frow = i >= mrows ? xrows : (PRIVX ? i * 4 + Q : ((i << p.sk_shift) + slice) * 4 + Q);
   const uint32_t xfrag = lds_x + (uint32_t)(frow * XROW);
   {
     const int zt = PRIVX ? lane : tid;

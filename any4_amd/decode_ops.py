@@ -1,0 +1,76 @@
+"""ctypes front-end of include/decode_glue_hip.h: the non-GEMM kernels of a batch-1 decode step.
+
+Every function takes torch tensors on a ROCm device, allocates the output with `torch.empty` (caching
+allocator, current stream) and launches on `torch.cuda.current_stream()`; they are legal inside
+`torch.cuda.graph` capture.  No CPU fallback: a CPU tensor raises.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+
+
+def _dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.bfloat16:
+        return _lib.TG_BF16
+    if t.dtype == torch.float16:
+        return _lib.TG_F16
+    raise RuntimeError(f"decode glue kernels need bf16 or fp16 tensors, got {t.dtype}")
+
+
+def _gpu(*ts):
+    for t in ts:
+        if t is not None and (not t.is_cuda or not t.is_contiguous()):
+            raise RuntimeError("decode glue kernels need contiguous tensors on a ROCm device (there is no CPU fallback)")
+
+
+def _stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def add_rmsnorm(h: torch.Tensor, delta, weight: torch.Tensor, eps: float, want_norm: bool = True):
+    """(h + delta, rmsnorm(h + delta) * weight); delta may be None.  h is updated IN PLACE when delta is given
+    (the residual stream is a running sum).  h [rows, dim]."""
+    _gpu(h, delta, weight)
+    rows, dim = h.shape
+    y = torch.empty_like(h) if want_norm else None
+    _lib.check(_lib.load().dg_add_rmsnorm(h.data_ptr(), None if delta is None else delta.data_ptr(), weight.data_ptr(),
+                                          h.data_ptr(), None if y is None else y.data_ptr(), rows, dim, float(eps),
+                                          _dt(h), h.device.index, _stream(h)), "dg_add_rmsnorm")
+    return h, y
+
+
+def rope_kv(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, pos: torch.Tensor, k_cache: torch.Tensor,
+            v_cache: torch.Tensor, hl: int, kvl: int, d: int) -> torch.Tensor:
+    """qkv [bs, (hl + 2 kvl) d] -> rotated q [bs, hl, d]; rotated k and v are written into the caches at `pos`."""
+    _gpu(qkv, cos, sin, pos, k_cache, v_cache)
+    if cos.dtype != torch.float32 or pos.dtype != torch.int64:
+        raise RuntimeError("rope tables must be float32 and pos int64")
+    bs, max_seq = qkv.shape[0], k_cache.shape[2]
+    q = torch.empty((bs, hl, d), dtype=qkv.dtype, device=qkv.device)
+    _lib.check(_lib.load().dg_rope_kv(qkv.data_ptr(), cos.data_ptr(), sin.data_ptr(), pos.data_ptr(), q.data_ptr(),
+                                      k_cache.data_ptr(), v_cache.data_ptr(), bs, hl, kvl, d, max_seq, _dt(qkv),
+                                      qkv.device.index, _stream(qkv)), "dg_rope_kv")
+    return q
+
+
+def decode_attn(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, pos: torch.Tensor, scale: float) -> torch.Tensor:
+    """q [bs, hl, d], caches [bs, kvl, max_seq, d] -> context [bs, hl * d] over positions 0..pos."""
+    _gpu(q, k_cache, v_cache, pos)
+    bs, hl, d = q.shape
+    kvl, max_seq = k_cache.shape[1], k_cache.shape[2]
+    out = torch.empty((bs, hl * d), dtype=q.dtype, device=q.device)
+    _lib.check(_lib.load().dg_decode_attn(q.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), pos.data_ptr(),
+                                          out.data_ptr(), bs, hl, kvl, d, max_seq, float(scale), _dt(q), q.device.index,
+                                          _stream(q)), "dg_decode_attn")
+    return out
+
+
+def swiglu(gu: torch.Tensor) -> torch.Tensor:
+    """gu [bs, 2 il] = [gate | up] -> silu(gate) * up [bs, il]."""
+    _gpu(gu)
+    bs, il = gu.shape[0], gu.shape[1] // 2
+    out = torch.empty((bs, il), dtype=gu.dtype, device=gu.device)
+    _lib.check(_lib.load().dg_swiglu(gu.data_ptr(), out.data_ptr(), bs, il, _dt(gu), gu.device.index, _stream(gu)), "dg_swiglu")
+    return out

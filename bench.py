@@ -292,7 +292,7 @@ def main():
             "single_layer_launch": {
                 "us_per_launch": round(single_us, 3),
                 "GBps": round(bytes_layer / single_us / 1e3, 2),
-                "note": "back-to-back one-layer launches on one stream (split-K 16 latency kernel), event time / launches",
+                "note": "back-to-back one-layer launches on one stream (streaming kernel, split-K 8, private X slabs), event time / launches",
             },
         }
         if world == 1 and not a.no_cpu_baseline:

@@ -1,0 +1,141 @@
+"""GPU suite: the decode harness (any4_amd/decode.py) on the HIP linears.
+
+A small Llama-shaped stack whose linears are `Any4Linear` modules built from known codes / LUTs / scales is
+compared with the SAME stack on 16-bit `nn.Linear`s holding the oracle's dequantised weights; eager, hipGraph
+replay and a k-means-free random `Any4Factory` stack are exercised."""
+import math
+
+import pytest
+import torch
+
+from tests.conftest import bits16, from_bits16
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+CFG = dict(hidden=256, inter=512, layers=2, heads=4, kv_heads=2, head_dim=64, vocab=128, max_seq=32, group_size=64)
+
+
+class _PairedFactories:
+    """any4(name, layer, k, rows) -> Any4Linear from explicit tensors; dense(...) -> nn.Linear with the oracle's
+    dequantisation of the same tensors."""
+
+    def __init__(self, oracle, cfg, kernel):
+        self.oracle, self.cfg, self.kernel, self.w = oracle, cfg, kernel, {}
+
+    def any4(self, name, layer, k, rows):
+        import modules
+
+        g = self.cfg.group_size
+        gen = torch.Generator().manual_seed(100 * layer + len(name))
+        codes = torch.randint(0, 16, (rows, k), dtype=torch.int32, generator=gen)
+        lut = torch.randn(rows, 16, generator=gen).to(torch.bfloat16)
+        std = 1.0 / math.sqrt(k)
+        scales = ((torch.rand(k // g, rows, generator=gen) * 0.4 + 0.8) * std).to(torch.bfloat16)
+        zeros = (torch.randn(k // g, rows, generator=gen) * 0.05 * std).to(torch.bfloat16)
+        sz = torch.stack([scales, zeros], dim=2).contiguous()
+        wb = self.oracle.dequant(codes.numpy(), g, self.oracle.Q_ANY4_ROWWISE, bits16(sz), bits16(lut), self.oracle.BF16)
+        self.w[(name, layer)] = from_bits16(wb, torch.bfloat16)
+        mod = modules.Any4Linear(k, rows, bias=False, device=DEV, dtype=torch.bfloat16, group_size=g, kernel=self.kernel)
+        mod.weight.data = codes.to(DEV)
+        mod.lut.data = lut.to(DEV)
+        mod.scales_and_zeros.data = sz.to(DEV)
+        mod.reshape_weight(4)
+        return mod
+
+    def dense(self, name, layer, k, rows):
+        lin = torch.nn.Linear(k, rows, bias=False, device=DEV, dtype=torch.bfloat16)
+        lin.weight.data = self.w[(name, layer)].to(DEV)
+        return lin
+
+
+@pytest.mark.parametrize("kernel", ["linear_y_f16RM_x_f16RM_W_any4TC", "linear_y_f16RM_W_any4TC_x_f16RM"])
+@pytest.mark.parametrize("bs", [1, 3])
+@pytest.mark.parametrize("fused", [False, True])
+def test_decode_any4_vs_dense_dequantised(oracle, kernel, bs, fused):
+    from any4_amd.decode import DecodeConfig, DecodeStack
+
+    cfg = DecodeConfig(**CFG)
+    fac = _PairedFactories(oracle, cfg, kernel)
+    q = DecodeStack(cfg, fac.any4, DEV, torch.bfloat16, bs=bs, seed=5, fused=fused)
+    d = DecodeStack(cfg, fac.dense, DEV, torch.bfloat16, bs=bs, seed=5, fused=False)  # plain torch ops throughout
+    toks = torch.randint(0, cfg.vocab, (6, bs), generator=torch.Generator().manual_seed(1)).to(DEV)
+    for i, t in enumerate(toks):
+        a, b = q.decode(t, i).float(), d.decode(t, i).float()
+        assert torch.isfinite(a).all()
+        # same weights, same 16-bit pipeline; only the fp32 summation order inside the GEMMs differs
+        assert (a - b).abs().max() <= 0.03 * b.abs().max() + 1e-3, (i, (a - b).abs().max(), b.abs().max())
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_glue_kernels_vs_torch(dtype):
+    """Each HIP glue kernel against the torch formulation it replaces (any4_amd/decode.py), same rounding points."""
+    from any4_amd import decode_ops as G
+    from any4_amd.decode import RMSNorm, _rope, _rope_tables, DecodeConfig
+
+    gen = torch.Generator(device=DEV).manual_seed(0)
+    ulp = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+
+    def close(a, b, k=2.0):
+        a, b = a.float(), b.float()
+        return bool(((a - b).abs() <= k * ulp * b.abs().clamp_min(1e-2)).all())
+
+    # residual add + rmsnorm
+    bs, dim = 3, 1024
+    h = torch.randn(bs, dim, device=DEV, generator=gen).to(dtype)
+    dl = torch.randn(bs, dim, device=DEV, generator=gen).to(dtype)
+    norm = RMSNorm(dim, 1e-5, DEV, dtype)
+    norm.weight.data = (torch.rand(dim, device=DEV, generator=gen) + 0.5).to(dtype)
+    want_h = h + dl
+    want_y = norm(want_h)
+    got_h, got_y = G.add_rmsnorm(h.clone(), dl, norm.weight, 1e-5)
+    assert torch.equal(got_h, want_h) and close(got_y, want_y)
+    _, y0 = G.add_rmsnorm(h.clone(), None, norm.weight, 1e-5)
+    assert close(y0, norm(h))
+
+    # rope + cache write, attention
+    cfg = DecodeConfig(hidden=256, heads=4, kv_heads=2, head_dim=64, max_seq=48)
+    hl, kvl, d, S = 4, 2, 64, 48
+    cos, sin = _rope_tables(cfg, DEV)
+    kc = torch.randn(bs, kvl, S, d, device=DEV, generator=gen).to(dtype)
+    vc = torch.randn(bs, kvl, S, d, device=DEV, generator=gen).to(dtype)
+    for p in (0, 1, 17, 47):
+        pos = torch.tensor([p], device=DEV)
+        qkv = torch.randn(bs, (hl + 2 * kvl) * d, device=DEV, generator=gen).to(dtype)
+        c, s_ = cos[p].view(1, 1, -1), sin[p].view(1, 1, -1)
+        want_q = _rope(qkv[:, : hl * d].reshape(bs, hl, d), c, s_)
+        want_k = _rope(qkv[:, hl * d: (hl + kvl) * d].reshape(bs, kvl, d), c, s_)
+        want_v = qkv[:, (hl + kvl) * d:].reshape(bs, kvl, d)
+        kc2, vc2 = kc.clone(), vc.clone()
+        got_q = G.rope_kv(qkv, cos, sin, pos, kc2, vc2, hl, kvl, d)
+        assert torch.equal(got_q, want_q) and torch.equal(kc2[:, :, p], want_k) and torch.equal(vc2[:, :, p], want_v)
+        keep = torch.arange(S, device=DEV) != p
+        assert torch.equal(kc2[:, :, keep], kc[:, :, keep]) and torch.equal(vc2[:, :, keep], vc[:, :, keep])
+        # attention over positions 0..p
+        scale = 1.0 / math.sqrt(d)
+        qg = got_q.reshape(bs, kvl, hl // kvl, d)
+        att = torch.matmul(qg, kc2.transpose(2, 3)).float() * scale
+        att = att.masked_fill((torch.arange(S, device=DEV) > p).view(1, 1, 1, -1), float("-inf")).softmax(-1).to(dtype)
+        want = torch.matmul(att, vc2).reshape(bs, hl * d)
+        got = G.decode_attn(got_q, kc2, vc2, pos, scale)
+        assert (got.float() - want.float()).abs().max() <= 4 * ulp * want.float().abs().max(), p
+
+    # swiglu
+    gu = torch.randn(bs, 2 * 512, device=DEV, generator=gen).to(dtype) * 3
+    want = torch.nn.functional.silu(gu[:, :512]) * gu[:, 512:]
+    assert close(G.swiglu(gu), want)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        G.swiglu(gu.cpu())
+
+
+def test_decode_graph_replay_equals_eager():
+    from any4_amd.decode import Any4Factory, DecodeConfig, DecodeStack
+
+    cfg = DecodeConfig(**CFG)
+    eager = DecodeStack(cfg, Any4Factory(cfg, DEV, seed=3), DEV, bs=2, seed=9)
+    graph = DecodeStack(cfg, Any4Factory(cfg, DEV, seed=3), DEV, bs=2, seed=9)
+    graph.capture()
+    assert graph._graph is not None
+    toks = torch.randint(0, cfg.vocab, (5, 2), generator=torch.Generator().manual_seed(2)).to(DEV)
+    # capture's warm-up steps wrote position 0 of the cache with token 0; decoding from position 0 overwrites it
+    for i, t in enumerate(toks):
+        assert torch.equal(eager.decode(t, i), graph.decode(t, i).clone()), i

@@ -13,8 +13,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # ---------------------------------------------------------------- C ABI
 
 def _declared_symbols():
-    hdr = open(os.path.join(ROOT, "include", "tinygemm_hip.h")).read()
-    return sorted(set(re.findall(r"TG_API\s+[\w\s\*]+?\b(tg_\w+)\s*\(", hdr)))
+    syms = set()
+    for name in sorted(os.listdir(os.path.join(ROOT, "include"))):  # every header of the C ABI
+        if name.endswith(".h"):
+            hdr = open(os.path.join(ROOT, "include", name)).read()
+            syms |= set(re.findall(r"TG_API\s+[\w\s\*]+?\b((?:tg|dg)_\w+)\s*\(", hdr))
+    return sorted(syms)
 
 
 def test_c_abi_exports_every_declared_symbol():
@@ -24,7 +28,7 @@ def test_c_abi_exports_every_declared_symbol():
     assert len(syms) >= 11 and "tg_gemm_w4" in syms
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for s in syms:
-        assert hasattr(lib, s), f"{s} declared in include/tinygemm_hip.h but not exported"
+        assert hasattr(lib, s), f"{s} declared in include/*.h but not exported"
     assert set(syms) == set(_lib.SYMBOLS), "ctypes binding and header disagree"
     assert _lib.load().tg_abi_version() == 1
 

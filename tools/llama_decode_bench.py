@@ -1,0 +1,112 @@
+#!/usr/bin/env python3
+"""Model-level decode benchmark (BASELINE config 5; counterpart of the reference's benchmark.py:113-215).
+
+    python tools/llama_decode_bench.py --config llama3_8b --baseline
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29511 \
+        tools/llama_decode_bench.py --config llama3_8b                   # TP=8, rows sharded, RCCL all-gathers
+
+Random-initialised weights of the named architecture (no checkpoints here), random token ids, one new token per
+sequence per step over a static KV cache.  Prints one JSON line on rank 0: ms per token, tokens/s, and the rate at which
+the 4-bit weights stream (algorithmic bytes of the quantized linears / step time).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+
+def time_steps(stack, steps, warmup, start_pos):
+    tok = torch.randint(0, stack.cfg.vocab, (stack.bs,), device=stack.tokens.device)
+    for i in range(warmup):
+        stack.decode(tok, start_pos + i)
+    if stack.world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        stack.decode(tok, start_pos + warmup + i)
+    if stack.world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default="llama3_8b", choices=["llama3_8b", "llama2_7b", "tiny"])
+    ap.add_argument("--layers", type=int, default=None, help="override the number of decoder layers")
+    ap.add_argument("--bs", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--max-seq", type=int, default=1024)
+    ap.add_argument("--start-pos", type=int, default=128, help="sequence position of the first timed token")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--baseline", action="store_true", help="also time the same stack with 16-bit nn.Linear")
+    ap.add_argument("--kernel", default="linear_y_f16RM_x_f16RM_W_any4TC")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl")
+
+    from any4_amd.decode import Any4Factory, DecodeConfig, DecodeStack, DenseFactory, memory_allocated_mb
+
+    if a.config == "tiny":
+        cfg = DecodeConfig(hidden=512, inter=1024, layers=2, heads=8, kv_heads=8, head_dim=64, vocab=1024, max_seq=a.max_seq)
+    else:
+        cfg = getattr(DecodeConfig, a.config)(max_seq=a.max_seq)
+    if a.layers is not None:
+        cfg.layers = a.layers
+
+    def run(factory_cls, label):
+        torch.cuda.reset_peak_memory_stats(device)
+        fac = factory_cls(cfg, device, torch.bfloat16, seed=1 + rank) if factory_cls is DenseFactory else \
+            factory_cls(cfg, device, torch.bfloat16, seed=1 + rank, kernel=a.kernel)
+        stack = DecodeStack(cfg, fac, device, torch.bfloat16, bs=a.bs, rank=rank, world=world)
+        graph = False
+        if not a.no_graph:
+            try:
+                stack.capture()
+                graph = True
+            except Exception as e:  # noqa: BLE001  (symmetric across ranks: same code, same shapes)
+                if rank == 0:
+                    print(f"[{label}] graph capture failed ({type(e).__name__}: {e}); timing eager", file=sys.stderr)
+                stack._graph = None
+        dt = time_steps(stack, a.steps, a.warmup, a.start_pos)
+        out = {"linears": label, "ms_per_token": round(dt * 1e3, 4), "tokens_per_s": round(a.bs / dt, 1),
+               "hipgraph": graph, "peak_mem_mib": round(memory_allocated_mb(device), 1)}
+        if label == "any4":
+            out["weight_stream_GBps_all_ranks"] = round(cfg.weight_bytes_4bit() / dt / 1e9, 1)
+        del stack, fac
+        torch.cuda.empty_cache()
+        return out
+
+    res = {"config": a.config, "layers": cfg.layers, "bs": a.bs, "tp": world, "max_seq": cfg.max_seq,
+           "steps": a.steps, "warmup": a.warmup, "data": "synthetic (random weights, random tokens)",
+           "algorithmic_4bit_bytes_per_token": cfg.weight_bytes_4bit()}
+    res["any4"] = run(Any4Factory, "any4")
+    if a.baseline:
+        res["bf16"] = run(DenseFactory, "bf16")
+        res["speedup_vs_bf16"] = round(res["bf16"]["ms_per_token"] / res["any4"]["ms_per_token"], 3)
+    if rank == 0:
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
