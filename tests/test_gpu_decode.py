@@ -139,3 +139,63 @@ def test_decode_graph_replay_equals_eager():
     # capture's warm-up steps wrote position 0 of the cache with token 0; decoding from position 0 overwrites it
     for i, t in enumerate(toks):
         assert torch.equal(eager.decode(t, i), graph.decode(t, i).clone()), i
+
+
+# ---------------------------------------------------------------- quantizer -> modules on the HIP kernels (N1)
+
+def test_anyq_and_intq_layer_real_kernels(oracle):
+    from any4_amd import quantize as Q
+
+    torch.manual_seed(4)
+    lin = torch.nn.Linear(512, 256, bias=True, device=DEV, dtype=torch.bfloat16)
+    x = torch.randn(5, 512, device=DEV).to(torch.bfloat16)
+    y_dense = lin(x).float()
+    for layer_fn, kw in ((Q.anyq_layer, dict(group_size=128)), (Q.anyq_layer, dict(group_size=64, per_row=False)),
+                         (Q.intq_layer, dict(group_size=128))):
+        import copy
+
+        src = copy.deepcopy(lin)
+        q = layer_fn(src, name="lin", **kw)
+        assert type(q).__name__ in ("Any4Linear", "Int4Linear") and q.weight.dim() == 4 and q.weight_reshaped
+        # the fake-quantized twin: same quantizer, weights reconstructed in place of the dense ones
+        twin = layer_fn(copy.deepcopy(lin), name="lin", pseudo=True, **kw)
+        y_q, y_t = q(x).float(), twin(x).float()
+        assert (y_q - y_t).abs().max() <= 0.02 * y_t.abs().max() + 1e-2, (layer_fn.__name__, kw)
+        assert (y_q - y_dense).abs().max() <= 0.25 * y_dense.abs().max()       # 4-bit, still the same layer
+    # any4 is the better 4-bit grid on the same groups
+    e_any = (Q.anyq_layer(copy.deepcopy(lin), pseudo=True, group_size=128).weight - lin.weight).float().pow(2).mean()
+    e_int = (Q.intq_layer(copy.deepcopy(lin), pseudo=True, group_size=128, unsigned=True).weight - lin.weight).float().pow(2).mean()
+    assert e_any < e_int
+
+
+def test_kmeans_on_gpu_matches_cpu():
+    from any4_amd import quantize as Q
+
+    torch.manual_seed(6)
+    w = torch.randn(64, 2048)
+    wg = Q.group_q(w, 4, 128)[0]
+    a_c, c_c = Q.kmeans_rows(wg, 16)
+    a_g, c_g = Q.kmeans_rows(wg.to(DEV), 16)
+    sse = lambda a, c: ((c.gather(1, a.long()) - wg.to(c.device)) ** 2).sum(1).cpu()
+    assert torch.allclose(sse(a_g, c_g), sse(a_c, c_c), rtol=2e-3)
+    codes, lut, sz = Q.anyq_quantize_tensor(w.to(torch.bfloat16), device=DEV)   # CPU checkpoint, clustered on the GPU
+    assert codes.device.type == "cpu" and lut.device.type == "cpu" and lut.dtype == torch.bfloat16
+
+
+def test_quantize_model_decode_stack():
+    """quantize_model over a dense decode stack: every nn.Linear but the LM head becomes an Any4Linear and the
+    logits stay close to the dense model's."""
+    from any4_amd import quantize as Q
+    from any4_amd.decode import DecodeConfig, DecodeStack, DenseFactory
+
+    cfg = DecodeConfig(**CFG)
+    stack = DecodeStack(cfg, DenseFactory(cfg, DEV, seed=2), DEV, bs=2, seed=4)
+    dense = DecodeStack(cfg, DenseFactory(cfg, DEV, seed=2), DEV, bs=2, seed=4)
+    Q.quantize_model(stack, layer_to=Q.anyq_layer, group_size=cfg.group_size)
+    kinds = {type(m).__name__ for m in stack.modules()}
+    assert "Any4Linear" in kinds and type(stack.lm_head).__name__ == "Linear"
+    assert sum(type(m).__name__ == "Any4Linear" for m in stack.modules()) == 4 * cfg.layers
+    toks = torch.randint(0, cfg.vocab, (4, 2), generator=torch.Generator().manual_seed(8)).to(DEV)
+    for i, t in enumerate(toks):
+        a, b = stack.decode(t, i).float(), dense.decode(t, i).float()
+        assert torch.isfinite(a).all() and (a - b).abs().max() <= 0.35 * b.abs().max(), i
