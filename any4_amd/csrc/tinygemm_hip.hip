@@ -451,6 +451,18 @@ int launch_stream_sw(StreamParams& sp, int sk, int64_t coltiles, int64_t batch, 
   return launch_status();
 }
 
+// Resident-X launch: 16-wave workgroups, the whole [mrows][k] activation block staged once per workgroup.
+template <typename DT, bool LAYOUT_A, int WPL, bool QMX>
+int launch_stream_xres(StreamParams& sp, int64_t coltiles, int64_t batch, unsigned lds, hipStream_t st) {
+  auto kern = w4_gemm_stream_kernel<DT, LAYOUT_A, WPL, QMX, 16, STREAM_MINW, 1, false, 0, true>;
+  static const hipError_t attr =
+      hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (attr != hipSuccess) return (int)attr;
+  dim3 grid((unsigned)((sp.rowtiles + 15) / 16), (unsigned)coltiles, (unsigned)batch);
+  hipLaunchKernelGGL(kern, grid, dim3(16 * 64), lds, st, sp);
+  return launch_status();
+}
+
 template <typename DT, bool LAYOUT_A, int WPL, bool QMX>
 int launch_stream(const GemmParams& p, int64_t coltiles, int64_t batch, hipStream_t st) {
   constexpr int UNIT = LAYOUT_A ? 64 : 128;
@@ -474,12 +486,27 @@ int launch_stream(const GemmParams& p, int64_t coltiles, int64_t batch, hipStrea
   static const int sk_env = getenv("TG_SK") ? atoi(getenv("TG_SK")) : 0;  // developer override
   if (sk_env > 0) sk = sk_env;
   // m == 1: every wave stages its own X slab (no barrier in the main loop); a workgroup is the sk waves of one tile
-  if (mrows == 1) {
+  static const int xres_env = getenv("TG_XRES") ? atoi(getenv("TG_XRES")) : 1;  // developer knob: 0 off, 2 also for m = 1
+  if (mrows == 1 && xres_env != 2) {
     switch (sk) {
       case 1: return launch_stream_sw<DT, LAYOUT_A, WPL, QMX, 1>(sp, 1, coltiles, batch, st);
       case 2: return launch_stream_sw<DT, LAYOUT_A, WPL, QMX, 2, true>(sp, 2, coltiles, batch, st);
       case 4: return launch_stream_sw<DT, LAYOUT_A, WPL, QMX, 4, true>(sp, 4, coltiles, batch, st);
       default: return launch_stream_sw<DT, LAYOUT_A, WPL, QMX, 8, true>(sp, 8, coltiles, batch, st);
+    }
+  }
+  // m >= 2, one tile per wave: keep the whole activation block resident in LDS when it fits next to 16 lookup
+  // tables (m = 8 at k = 4096 does: 66 KiB + 64 KiB) -- one barrier per workgroup instead of one per unit
+  // (measured: wins for m >= 8 at k = 4096 and for m >= 2 at k = 8192; the 16-wave workgroup costs ~15 % in tile-granularity
+  //  tail against 4-wave workgroups, which the small slabs of m <= 4 at k = 4096 do not pay back)
+  if (sk == 1 && xres_env && (mrows * UNIT >= 1024 || sp.k >= 8192 || xres_env == 2)) {
+    const int nu = (int)(((nunits + 3) / 4 + upg - 1) / upg * upg);
+    const unsigned xrow = (unsigned)(nu * UNIT * 2 + 16);
+    const unsigned lds = 16u * 4096u + (unsigned)(mrows * 4) * xrow + (unsigned)(UNIT * 2 + 16);
+    if (lds <= 160u * 1024u) {
+      sp.splitk = 1; sp.sk_shift = 0; sp.units_per_lane = nu; sp.upg_mask = upg - 1;
+      sp.xslab_bytes = (int32_t)xrow; sp.red_off = 0;
+      return launch_stream_xres<DT, LAYOUT_A, WPL, QMX>(sp, coltiles, batch, lds, st);
     }
   }
   // otherwise 4-wave workgroups while their LDS footprint lets 16 waves live on a CU and the X slab is small;

@@ -22,8 +22,11 @@
 //   PRIVX = false: every wave of a workgroup walks the same k sequence, so the X slab of one
 //                  unit-step ([act rows][slices][quarters][UNIT]) is staged once per workgroup,
 //                  double buffered, one barrier per unit;
-//   PRIVX = true : (m = 1, split-K 1, single-wave workgroups) every wave stages its own slab (one
-//                  16-byte load per lane per unit): no barrier anywhere in the kernel.
+//   PRIVX = true : (m = 1) every wave stages its own slab (one 16-byte load per lane per unit): no barrier in
+//                  the main loop; the waves of a workgroup are the k-slices of one tile (split-K 1..8);
+//   XRES  = true : (m >= 2, split-K 1, m * k * 2 <= ~96 KiB) the whole activation block is staged ONCE per
+//                  workgroup ([act rows][quarters][k / 4], p.xslab_bytes = bytes per row) and stays resident
+//                  while the 16 waves walk their tiles: one barrier per workgroup instead of one per unit.
 //
 // LDS (dynamic, sized by the host, no static LDS so the base is 0):
 //   [WAVES x 4 KiB lookup tables][X slabs][split-K partial tiles, only when splitk > 1].
@@ -63,7 +66,7 @@ struct StreamParams {
 
 // WPL = packed words per (k super-tile, lane-row) entry: Bint4: I/2, Aint4: I
 // XL  = 16-byte X pieces staged per thread and unit (host picks the smallest that covers the slab)
-template <typename DT, bool LAYOUT_A, int WPL, bool QMX, int WAVES, int MINW, int XL, bool PRIVX, int ABL = 0>
+template <typename DT, bool LAYOUT_A, int WPL, bool QMX, int WAVES, int MINW, int XL, bool PRIVX, int ABL = 0, bool XRES = false>
 __global__ void __launch_bounds__(WAVES * 64, MINW) w4_gemm_stream_kernel(const StreamParams p) {
   constexpr int CHUNK = LAYOUT_A ? 16 : 32;  // k per chunk (one packed word per q)
   constexpr int UNIT = 4 * CHUNK;            // k per unit = 64 packed bytes per lane
@@ -113,7 +116,7 @@ __global__ void __launch_bounds__(WAVES * 64, MINW) w4_gemm_stream_kernel(const 
   // ---- X staging: thread -> (staged row, 16-byte piece); staged row = (act row c, slice, quarter) ----
   const int mrows = min(p.m - ct * 16, 16);
   // shared slab: rows of every k-slice of the workgroup; private slab: only this wave's slice
-  const int xrows = PRIVX ? mrows * 4 : mrows * 4 * p.splitk;
+  const int xrows = (PRIVX || XRES) ? mrows * 4 : mrows * 4 * p.splitk;
   const uint32_t lds_x = PRIVX ? lds_x0 + (uint32_t)(wave * 2 * p.xslab_bytes) : lds_x0;
   uint32_t xs_rowbase[XL];  // global byte offset of the activation row this thread stages from
   uint32_t xs_in[XL];       // byte offset inside that row at unit-step 0
@@ -150,9 +153,21 @@ __global__ void __launch_bounds__(WAVES * 64, MINW) w4_gemm_stream_kernel(const 
   };
   // this lane's fragment row in a staged slab.  MFMA columns >= m are never stored; they read the all-zero row
   // behind the staged rows (zero operands keep the multipliers of the unused columns quiet -> less power, more clock).
-  const int frow = i >= mrows ? xrows : (PRIVX ? i * 4 + Q : ((i << p.sk_shift) + slice) * 4 + Q);
-  const uint32_t xfrag = lds_x + (uint32_t)(frow * XROW);
-  {
+  const int frow = i >= mrows ? xrows : ((PRIVX || XRES) ? i * 4 + Q : ((i << p.sk_shift) + slice) * 4 + Q);
+  const uint32_t xfrag = lds_x + (uint32_t)(frow * (XRES ? p.xslab_bytes : XROW));
+  if constexpr (XRES) {
+    // resident X: stage every (act row, quarter) k-span once; the zero row (one unit long) sits behind them
+    const int ppr = NU * (UNIT / 8);  // 16-byte pieces per staged row
+    for (int pid = tid; pid < xrows * ppr; pid += WAVES * 64) {
+      const int srow = pid / ppr, pc = pid - srow * ppr;
+      const int xr = min(ct * 16 + (srow >> 2), p.m - 1);
+      const uint32_t inrow = min((uint32_t)((((srow & 3) * NU) * UNIT + pc * 8) * 2), xrow_last);
+      *(lds_u32x4ptr)(lds_x + (uint32_t)(srow * p.xslab_bytes + pc * 16)) =
+          *reinterpret_cast<const u32x4*>(xb + ((uint32_t)(xr * p.k * 2) + inrow));
+    }
+    if (tid < XROW / 16) *(lds_u32x4ptr)(lds_x + (uint32_t)(xrows * p.xslab_bytes + tid * 16)) = u32x4{0, 0, 0, 0};
+    __syncthreads();
+  } else {
     const int zt = PRIVX ? lane : tid;
     if (zt < 2 * (XROW / 16))
       *(lds_u32x4ptr)(lds_x + (uint32_t)((zt / (XROW / 16)) * p.xslab_bytes + xrows * XROW + (zt % (XROW / 16)) * 16)) = u32x4{0, 0, 0, 0};
@@ -296,10 +311,12 @@ __global__ void __launch_bounds__(WAVES * 64, MINW) w4_gemm_stream_kernel(const 
     u32x4 XR[XL];         // X pieces of the unit after next, on their way to LDS
     load_unit(u_first, L0);
     q0 = load_q(u_first);
-    stage_load(0, XR);
-    stage_store(0, XR);
-    if (NU > 1) stage_load(1, XR);
-    if constexpr (!PRIVX) __syncthreads();
+    if constexpr (!XRES) {
+      stage_load(0, XR);
+      stage_store(0, XR);
+      if (NU > 1) stage_load(1, XR);
+      if constexpr (!PRIVX) __syncthreads();
+    }
 
     // All control flow below is workgroup-uniform (NU, splitk, group size), barriers included.
     auto do_unit = [&](int u, const u32x4 (&Lc)[4], uint32_t qc, u32x4 (&Ln)[4], uint32_t& qn) {
@@ -307,16 +324,19 @@ __global__ void __launch_bounds__(WAVES * 64, MINW) w4_gemm_stream_kernel(const 
       if (u + 1 < NU) {
         load_unit(U + 1, Ln);
         qn = load_q(U + 1);
-        stage_store((u + 1) & 1, XR);           // slab u+1 (requested one unit ago) -> LDS
-        if (u + 2 < NU) stage_load(u + 2, XR);  // request slab u+2
+        if constexpr (!XRES) {
+          stage_store((u + 1) & 1, XR);           // slab u+1 (requested one unit ago) -> LDS
+          if (u + 2 < NU) stage_load(u + 2, XR);  // request slab u+2
+        }
       }
       if ((u & p.upg_mask) == 0) build_table(qc, lane_ok && U * UNIT < p.k);  // a quantisation group starts here
-      const uint32_t xbuf = xfrag + (uint32_t)((u & 1) * p.xslab_bytes);
+      // resident X: unit u of this lane's k-span (the zero row is only one unit long)
+      const uint32_t xbuf = XRES ? xfrag + (i < mrows ? (uint32_t)(u * UNIT * 2) : 0u) : xfrag + (uint32_t)((u & 1) * p.xslab_bytes);
 #pragma unroll
       for (int c = 0; c < 4; ++c) do_chunk(Lc, c, xbuf);
       // shared slab: slab u+1 visible to everyone, everyone done with slab u.  Private slab: a wave's
       // DS operations execute in order, nothing to wait for.
-      if constexpr (!PRIVX) __syncthreads();
+      if constexpr (!PRIVX && !XRES) __syncthreads();
     };
     for (int u = 0; u < NU; u += 2) {
       do_unit(u, L0, q0, L1, q1);

@@ -49,6 +49,8 @@ def main():
             shape = (L, n // 16, k // (16 * inner), 32, inner)
         w = torch.randint(-2**31, 2**31 - 1, shape, dtype=torch.int64, device=dev, generator=gen).to(torch.int32)
         x = torch.randn(L, m, k, device=dev, generator=gen).bfloat16()
+        if os.environ.get("QB_XZERO"):  # power experiment: only activation row 0 carries data
+            x[:, 1:] = 0
         if a.qtype == "mx4":
             q = torch.randint(120, 131, (L, n, k // g), dtype=torch.uint8, device=dev, generator=gen)
             qstride = q.stride(0)
