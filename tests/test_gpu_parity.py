@@ -586,3 +586,33 @@ def test_stream_kernel_mx4_nan_row(T):
     assert torch.isnan(ys[:, :, 5]).all()
     keep = [c for c in range(k) if c != 5]
     assert torch.equal(ys[0][:, keep], x[:, keep]) and torch.equal(ys[-1][:, keep], x[:, keep])
+
+
+@pytest.mark.parametrize("k,expect_sk", [(1024, 2), (2048, 4), (4096, 8)])
+@pytest.mark.parametrize("on_right,inner", [(True, 4), (False, 4), (True, 8), (False, 1)])
+@pytest.mark.parametrize("qtype", ["any4_rowwise", "int4"])
+def test_stream_private_slab_splitk(T, oracle, k, expect_sk, on_right, inner, qtype):
+    """m = 1 single launches: streaming kernel, private X slabs, the `expect_sk` waves of a workgroup are the
+    k-slices of one tile (reduction in LDS, fixed order)."""
+    n, g = 80, 128
+    codes, x, qinfo, lut = rand_problem(n, k, g, 1, qtype, seed=k + inner)
+    y = run_rm(T, codes, x, qinfo, lut, g, qtype, on_right, inner)
+    assert_gemm_close(y[:, :n], x, oracle_weights(oracle, codes, g, qtype, qinfo, lut))
+    y2 = run_rm(T, codes, x, qinfo, lut, g, qtype, on_right, inner)
+    assert torch.equal(y, y2)  # deterministic
+
+
+@pytest.mark.parametrize("on_right,inner,m", [(True, 4, 8), (True, 2, 11), (False, 4, 16), (False, 2, 16)])
+def test_stream_resident_x(T, oracle, on_right, inner, m):
+    """>= 8192 wave-tiles with m >= 8 (B side) / 16 (A side): the activation block is staged once per 16-wave
+    workgroup (XRES variant of w4_gemm_stream_kernel)."""
+    n, k, g = 48, 1024, 128
+    nprob, copies = 4, 700  # 4 * 700 * 3 = 8400 tiles
+    probs = [rand_problem(n, k, g, m, "any4_rowwise", seed=77 + 3 * b + m) for b in range(nprob)]
+    ys = _stacked(T, probs, copies, g, "any4_rowwise", on_right, inner)
+    assert not torch.isnan(ys.float()).any()
+    for b in range(nprob):
+        w = oracle_weights(oracle, probs[b][0], g, "any4_rowwise", probs[b][2], probs[b][3])
+        for cpy in (0, copies - 1):
+            assert_gemm_close(ys[cpy * nprob + b], probs[b][1], w)
+    assert torch.equal(ys[:nprob], ys[-nprob:])
