@@ -34,6 +34,7 @@ sys.path.insert(0, ROOT)
 
 # the cpu_baseline leg runs the OpenMP oracle: without thread binding libgomp's workers pile onto a few cores
 # (measured: 93 ms vs 7 ms per layer on 8 cores); must be set before anything loads libgomp
+_SCHEDULABLE_CPUS = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)  # before binding
 os.environ.setdefault("OMP_PROC_BIND", "true")
 
 import torch  # noqa: E402
@@ -75,7 +76,7 @@ def cpu_baseline(m, n, k, g, budget_s=12.0):
     x = orc.bf16_bits(rng.standard_normal((m, k)).astype(np.float32))
     # thread count: the box may expose more logical CPUs than its cgroup lets run (256 threads on a quota of a
     # few cores is ~10x slower than 8), so probe powers of two up to the affinity mask and keep the fastest
-    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    avail = _SCHEDULABLE_CPUS  # taken at import: OMP_PROC_BIND pins the main thread, which shrinks the mask seen later
     cands = sorted({min(avail, 1 << i) for i in range(0, 10)} | {avail})
     best, best_t = 1, float("inf")
     for t in cands:

@@ -44,3 +44,21 @@ print("traffic/algorithmic", out["traffic_over_algorithmic"])
 PY
 echo "== quick_bench default dispatch"; timeout 300 python tools/quick_bench.py --configs "1,4096,4096,1;8,4096,4096,1;16,4096,4096,1;1,4096,4096,0;8,8192,8192,0;1,8192,8192,1" --iters 3 2>&1 | grep -E "^m=|eager|stacked|steady" | tee gpurun_out/qb_default.log
 for q in int4 any4_global mx4; do timeout 200 python tools/quick_bench.py --configs "1,4096,4096,1" --qtype $q --iters 3 2>&1 | grep -E "^m=|eager|stacked|steady"; done | tee gpurun_out/qb_variants.log
+# MFMA utilisation / HBM traffic at m = 8 and 16 (north_star: "MFMA utilisation at m=8/16"), separate --pmc passes
+cd /tmp
+for c in MfmaUtil FETCH_SIZE; do
+  timeout 300 rocprofv3 --pmc $c --output-format csv -d $R/gpurun_out/prof/pmc_m8_$c -o q -- python $R/tools/quick_bench.py --configs "8,4096,4096,1;16,4096,4096,1;8,8192,8192,0" --iters 2 --settle 0 > /dev/null 2>&1
+done
+cd $R
+python - <<'PY'
+import csv, glob, collections, json
+agg = collections.defaultdict(list)
+for f in glob.glob("gpurun_out/prof/pmc_m8_*/*counter_collection.csv"):
+    for r in csv.DictReader(open(f)):
+        if "w4_gemm_stream" in r["Kernel_Name"]:
+            agg[(r["Kernel_Name"].split("w4_gemm_stream_kernel")[1][:60], r["Grid_Size"], r["Counter_Name"])].append(float(r["Counter_Value"]))
+out = {f"{k[0]} grid={k[1]} {k[2]}": {"n": len(v), "mean": sum(v) / len(v)} for k, v in sorted(agg.items())}
+json.dump(out, open("gpurun_out/r01_pmc_m8_m16.json", "w"), indent=1)
+for k, v in out.items():
+    print(k, v)
+PY
