@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libtinygemm_hip.so")
 
 TG_BF16, TG_F16 = 0, 1
-TG_Q_INT4, TG_Q_ANY4_GLOBAL, TG_Q_ANY4_ROWWISE, TG_Q_MX4 = 0, 1, 2, 3
+TG_Q_INT4, TG_Q_ANY4_GLOBAL, TG_Q_ANY4_ROWWISE, TG_Q_MX4, TG_Q_INT8 = 0, 1, 2, 3, 4
 
 _i32, _i64, _vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p
 
@@ -39,6 +39,9 @@ SYMBOLS = {
     "tg_dequant_int4": [_vp, _i64, _vp, ctypes.c_int, _vp],
     "tg_gemm_w4": [ctypes.POINTER(W4Gemm), ctypes.c_int, _vp],
     "tg_gemm_f16": [_vp, _vp, _vp, _i64, _i64, _i64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp],
+    "tg_convert_to_Bint8": [_vp, _i64, _i64, ctypes.c_int, _vp, ctypes.c_int, _vp],
+    "tg_convert_to_Aint8": [_vp, _i64, _i64, ctypes.c_int, _vp, ctypes.c_int, _vp],
+    "tg_gemm_w8": [ctypes.POINTER(W4Gemm), ctypes.c_int, _vp],
     # include/decode_glue_hip.h (non-GEMM kernels of the decode harness)
     "dg_add_rmsnorm": [_vp, _vp, _vp, _vp, _vp, _i64, _i64, ctypes.c_float, ctypes.c_int, ctypes.c_int, _vp],
     "dg_rope_kv": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, ctypes.c_int, ctypes.c_int, ctypes.c_int, _i64,
@@ -63,7 +66,10 @@ def load() -> ctypes.CDLL:
         )
     lib = ctypes.CDLL(LIB_PATH)
     for name, argtypes in SYMBOLS.items():
-        fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:  # a stale build: the header declares a symbol the .so does not export
+            raise ImportError(f"{LIB_PATH} does not export {name}; rebuild with `python -m any4_amd.build`") from e
         fn.argtypes = argtypes
         fn.restype = ctypes.c_char_p if name == "tg_error_string" else ctypes.c_int
     if lib.tg_abi_version() != 1:

@@ -82,6 +82,7 @@ __device__ const float kMX4Values[16] = {0.0f,  0.5f,  1.0f,  1.5f,  2.0f,  3.0f
 
 #include "w4_gemm.cuh"
 #include "w4_gemm_stream.cuh"
+#include "w8_gemm.cuh"
 
 #ifndef STREAM_MINW
 #define STREAM_MINW 4
@@ -390,6 +391,60 @@ inline Geometry pick_geometry(int64_t rowtiles, int64_t coltiles, int64_t batch,
   return g;
 }
 
+
+// ---- int8 packers (reference TinyGemmConvertB.cu:366-411, TinyGemmConvertA.cu:337-397): one thread per output word.
+// The OR of the shifted 32-bit inputs is kept exactly as written there (inputs above 255 bleed into higher bytes).
+template <int I>
+__global__ void __launch_bounds__(256) pack_Bint8_kernel(const int32_t* __restrict__ in, int32_t* __restrict__ out, int64_t n,
+                                                         int64_t k, int64_t ksuper, int64_t total) {
+  for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (int64_t)gridDim.x * 256) {
+    const int j = (int)(o % I), t = (int)((o / I) % 32);
+    const int64_t ks_ = (o / (I * 32)) % ksuper, nt = o / (I * 32 * ksuper);
+    const int64_t n0 = nt * 8 + t / 4, kb = (ks_ * I + j) * 16 + (t % 4) * 2;
+    uint32_t v[4] = {0u, 0u, 0u, 0u};
+    if (n0 < n) {
+      const int32_t* r = in + n0 * k;
+      if (kb < k) v[0] = (uint32_t)r[kb];
+      if (kb + 1 < k) v[1] = (uint32_t)r[kb + 1];
+      if (kb + 8 < k) v[2] = (uint32_t)r[kb + 8];
+      if (kb + 9 < k) v[3] = (uint32_t)r[kb + 9];
+    }
+    out[o] = (int32_t)((v[3] << 24) | (v[1] << 16) | (v[2] << 8) | v[0]);
+  }
+}
+
+template <int I>
+__global__ void __launch_bounds__(256) pack_Aint8_kernel(const int32_t* __restrict__ in, int32_t* __restrict__ out, int64_t m,
+                                                         int64_t k, int64_t kouter, int64_t total) {
+  for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (int64_t)gridDim.x * 256) {
+    const int w = (int)(o % 2), j = (int)((o / 2) % I), t = (int)((o / (2 * I)) % 32);
+    const int64_t ko = (o / (2 * I * 32)) % kouter, mt = o / (2 * I * 32 * kouter);
+    const int64_t m0 = mt * 16 + t / 4, m1 = m0 + 8;
+    const int64_t ka = (ko * I + j) * 16 + (t % 4) * 2 + 8 * w;  // word 0: k0, k0+1; word 1: k0+8, k0+9
+    uint32_t v0 = 0u, v1 = 0u, v2 = 0u, v3 = 0u;                 // (m0,ka) (m0,ka+1) (m1,ka) (m1,ka+1)
+    if (m0 < m && ka < k) v0 = (uint32_t)in[m0 * k + ka];
+    if (m0 < m && ka + 1 < k) v1 = (uint32_t)in[m0 * k + ka + 1];
+    if (m1 < m && ka < k) v2 = (uint32_t)in[m1 * k + ka];
+    if (m1 < m && ka + 1 < k) v3 = (uint32_t)in[m1 * k + ka + 1];
+    out[o] = (int32_t)((v3 << 24) | (v1 << 16) | (v2 << 8) | v0);
+  }
+}
+
+template <typename DT, bool LAYOUT_A, int I>
+int launch_w8(GemmParams& p, int64_t coltiles, int64_t batch, hipStream_t st) {
+  constexpr int WAVES = 8;
+  const int64_t tiles = (int64_t)p.rowtiles * coltiles * batch;
+  const int nsteps = (p.k / 16 + 3) / 4;
+  int sk = 1;
+  while (sk < WAVES && tiles * sk < 256 * 16 && sk * 2 <= nsteps) sk *= 2;
+  p.splitk = sk;
+  p.sk_shift = 0;
+  while ((1 << p.sk_shift) < sk) ++p.sk_shift;
+  const int tpb = WAVES / sk;
+  dim3 grid((unsigned)((p.rowtiles + tpb - 1) / tpb), (unsigned)coltiles, (unsigned)batch);
+  hipLaunchKernelGGL((w8_gemm_kernel<DT, LAYOUT_A, I, WAVES>), grid, dim3(WAVES * 64), 0, st, p);
+  return launch_status();
+}
 
 // ---- streaming kernel launch ---------------------------------------------------------------------
 // LDS per workgroup: lookup tables (4 KiB per wave and row set) + two X slabs (+ split-K tiles).
@@ -731,6 +786,83 @@ int tg_gemm_w4(const tg_w4_gemm* a, int device, tg_stream_t stream) {
     return on_right ? launch_w4_c<BF16, false>(p, canon, coltiles, batch, st) : launch_w4_c<BF16, true>(p, canon, coltiles, batch, st);
   }
   return on_right ? launch_w4_c<F16, false>(p, canon, coltiles, batch, st) : launch_w4_c<F16, true>(p, canon, coltiles, batch, st);
+}
+
+int tg_convert_to_Bint8(const int32_t* in, int64_t n, int64_t k, int I, int32_t* out, int device, tg_stream_t stream) {
+  if (!in || !out) return TG_E_NULL;
+  if (!(I == 1 || I == 2 || I == 4)) return TG_E_INNER_K;  // ConvertB.cu:428
+  if (n <= 0 || k <= 0) return TG_E_SHAPE;
+  if (k % (I * 16) != 0) return TG_E_K_DIV;                // ConvertB.cu:438
+  DeviceScope ds(device);
+  if (!ds.ok) return TG_E_DEVICE;
+  const int64_t ksuper = k / (I * 16), total = cdiv(n, 8) * ksuper * 32 * I;
+  const unsigned blocks = (unsigned)(cdiv(total, 256) < 8192 ? cdiv(total, 256) : 8192);
+  hipStream_t st = (hipStream_t)stream;
+  if (I == 1) hipLaunchKernelGGL(pack_Bint8_kernel<1>, dim3(blocks), dim3(256), 0, st, in, out, n, k, ksuper, total);
+  else if (I == 2) hipLaunchKernelGGL(pack_Bint8_kernel<2>, dim3(blocks), dim3(256), 0, st, in, out, n, k, ksuper, total);
+  else hipLaunchKernelGGL(pack_Bint8_kernel<4>, dim3(blocks), dim3(256), 0, st, in, out, n, k, ksuper, total);
+  return launch_status();
+}
+
+int tg_convert_to_Aint8(const int32_t* in, int64_t m, int64_t k, int I, int32_t* out, int device, tg_stream_t stream) {
+  if (!in || !out) return TG_E_NULL;
+  if (!(I == 1 || I == 2)) return TG_E_INNER_K;  // ConvertA.cu:413
+  if (m <= 0 || k <= 0) return TG_E_SHAPE;
+  DeviceScope ds(device);
+  if (!ds.ok) return TG_E_DEVICE;
+  const int64_t kouter = cdiv(cdiv(k, 16), I), total = cdiv(m, 16) * kouter * 32 * I * 2;
+  const unsigned blocks = (unsigned)(cdiv(total, 256) < 8192 ? cdiv(total, 256) : 8192);
+  hipStream_t st = (hipStream_t)stream;
+  if (I == 1) hipLaunchKernelGGL(pack_Aint8_kernel<1>, dim3(blocks), dim3(256), 0, st, in, out, m, k, kouter, total);
+  else hipLaunchKernelGGL(pack_Aint8_kernel<2>, dim3(blocks), dim3(256), 0, st, in, out, m, k, kouter, total);
+  return launch_status();
+}
+
+int tg_gemm_w8(const tg_w4_gemm* a, int device, tg_stream_t stream) {
+  if (!a || !a->x || !a->w || !a->qinfo || !a->y) return TG_E_NULL;
+  if (a->qtype != TG_Q_INT8) return TG_E_QTYPE;
+  if (!(a->dtype == TG_BF16 || a->dtype == TG_F16)) return TG_E_DTYPE;
+  if (a->m <= 0 || a->wrows <= 0 || a->k <= 0 || a->m > INT32_MAX || a->wrows > INT32_MAX || a->k > INT32_MAX) return TG_E_SHAPE;
+  const int I = a->inner_k_tiles;
+  const bool on_right = a->w_on_right != 0;
+  if (on_right ? !(I == 1 || I == 2 || I == 4) : !(I == 1 || I == 2)) return TG_E_INNER_K;  // TinyGemm_int8.cu:262, 286
+  if (a->k % 32 != 0 || a->k % (16 * I) != 0) return TG_E_K_DIV;                            // TinyGemmImpl.cuh:370-376
+  const int g = a->group;
+  if (!(g == 32 || g == 64 || g == 128 || g == 256) || a->k % g != 0) return TG_E_GROUP;     // TinyGemm_int8.cu:293-301
+  const int rows_per_tile = on_right ? 8 : 16;
+  if (a->wrows % rows_per_tile != 0) return TG_E_SHAPE;
+  if ((reinterpret_cast<uintptr_t>(a->x) & 3u) || (reinterpret_cast<uintptr_t>(a->w) & 3u) ||
+      (reinterpret_cast<uintptr_t>(a->qinfo) & 3u) || (reinterpret_cast<uintptr_t>(a->y) & 7u))
+    return TG_E_ALIGN;
+  const int batch = a->batch > 1 ? a->batch : 1;
+  GemmParams p;
+  p.x = (const char*)a->x; p.w = (const char*)a->w; p.qinfo = (const char*)a->qinfo; p.lut = nullptr; p.y = (char*)a->y;
+  p.m = (int32_t)a->m; p.wrows = (int32_t)a->wrows; p.k = (int32_t)a->k;
+  p.ntiles = (int32_t)(a->wrows / rows_per_tile);
+  p.ksuper = (int32_t)(a->k / (16 * I));
+  p.gshift = g == 32 ? 5 : g == 64 ? 6 : g == 128 ? 7 : 8;
+  p.ngroups = (int32_t)(a->k / g);
+  p.qtype = a->qtype; p.dbg = 0;
+  p.stride_x = batch > 1 ? a->stride_x : 0; p.stride_w = batch > 1 ? a->stride_w : 0;
+  p.stride_qinfo = batch > 1 ? a->stride_qinfo : 0; p.stride_lut = 0; p.stride_y = batch > 1 ? a->stride_y : 0;
+  DeviceScope ds(device);
+  if (!ds.ok) return TG_E_DEVICE;
+  hipStream_t st = (hipStream_t)stream;
+  p.rowtiles = (int32_t)cdiv(a->wrows, 16);
+  const int64_t coltiles = cdiv(a->m, 16);
+#define TG_W8(DTT)                                                                                    \
+  do {                                                                                                \
+    if (on_right) {                                                                                   \
+      if (I == 1) return launch_w8<DTT, false, 1>(p, coltiles, batch, st);                           \
+      if (I == 2) return launch_w8<DTT, false, 2>(p, coltiles, batch, st);                           \
+      return launch_w8<DTT, false, 4>(p, coltiles, batch, st);                                       \
+    }                                                                                                 \
+    if (I == 1) return launch_w8<DTT, true, 1>(p, coltiles, batch, st);                              \
+    return launch_w8<DTT, true, 2>(p, coltiles, batch, st);                                          \
+  } while (0)
+  if (a->dtype == TG_BF16) TG_W8(BF16);
+  TG_W8(F16);
+#undef TG_W8
 }
 
 int tg_gemm_f16(const void* x, const void* w, void* y, int64_t m, int64_t wrows, int64_t k, int dtype,

@@ -1,0 +1,112 @@
+// w8_gemm.cuh -- W8A16 small-batch GEMM for gfx950 (included by tinygemm_hip.hip).
+//
+// Replaces {A,B}Layout_TC_int8 (reference MatrixLayoutA.cuh int8 layout, MatrixLayoutB.cuh:1104-1327) and
+// convert_i8x4_to_f16x2x2 (Dequantization.cuh:262-330) under tinygemm_m16n8k16_chunk_kernel: the stored byte b
+// means b - 128, w = RNE16(fma(b - 128, scale, zero)), contraction in fp32 on the MFMA.
+//
+// Packed words are consumed as stored (bit-identical to the reference's layouts):
+//   Bint8 [nT][kS][32][I]  : lane t, k-tile kt -> ONE word, bytes = k 2q, 2q+8, 2q+1, 2q+9 (q = t % 4) of row t / 4
+//   Aint8 [mT][kO][32][2I] : lane t, k-tile kt -> TWO words, bytes = (m0,k0)(m1,k0)(m0,k0+1)(m1,k0+1) and the same at
+//                            k0 + 8 (m0 = t / 4, m1 = m0 + 8, k0 = 2q)
+// Mapping: MFMA 16x16x32, W = A operand.  Lane (i = lane & 15, Q = lane >> 4) owns row i of the 16-row tile and
+// the q = Q words; one K-slot = two k-tiles = the 8 k values {2Q, 2Q+1, 2Q+8, 2Q+9} + {0, 16}, so the matching X
+// fragment of lane (c, Q) is four dwords of activation row c at byte offsets 4Q + {0, 16, 32, 48} of the slot.
+// A step = 4 k-tiles (64 k, two K-slots): 16 B (B side, I = 4) or 2 x 16 B (A side, I = 2) of packed bytes per lane.
+// Same wave-tile / split-K / no-predication structure as w4_gemm.cuh (clamped addresses; out-of-range lanes get
+// scale = zero = 0 and contribute exact zeros).  A correct, HBM-streaming kernel; not tuned like the 4-bit path.
+#pragma once
+
+template <typename DT, bool LAYOUT_A, int I, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64, 2) w8_gemm_kernel(const GemmParams p) {
+  __shared__ f32x4 s_red[WAVES * 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, Q = lane >> 4;
+
+  const int slice = wave & (p.splitk - 1);
+  const int rt = blockIdx.x * (WAVES >> p.sk_shift) + (wave >> p.sk_shift);
+  const bool rt_ok = rt < p.rowtiles;
+  const int ct = blockIdx.y;
+  const int64_t b = blockIdx.z;
+  const char* xb = p.x + b * p.stride_x;
+  const uint32_t* wb = reinterpret_cast<const uint32_t*>(p.w + b * p.stride_w);
+  const uint32_t* qb = reinterpret_cast<const uint32_t*>(p.qinfo + b * p.stride_qinfo);
+  char* yb = p.y + b * p.stride_y;
+
+  const int row0 = rt * 16, row = row0 + i;
+  const int row_c = min(row, p.wrows - 1);
+  // packed tile and lane-in-tile of this row
+  const int tile = LAYOUT_A ? rt : 2 * rt + (i >> 3);
+  const int tile_c = min(tile, p.ntiles - 1);
+  const int t = 4 * (i & 7) + Q;
+  const bool row_ok = rt_ok && row < p.wrows && tile < p.ntiles;
+  constexpr int WPT = LAYOUT_A ? 2 : 1;  // words per k-tile and lane
+  const int ktiles = p.k >> 4;           // k % 32 == 0 is checked by the host
+  const uint32_t lane_words = (uint32_t)((tile_c * p.ksuper * 32 + t) * (I * WPT));  // word index of (tile, super 0, t)
+
+  const int xrow = min(ct * 16 + i, p.m - 1);
+  const bool xcol = ct * 16 + i < p.m;
+  const char* xlane = xb + ((int64_t)xrow * p.k) * 2 + 4 * Q;
+
+  const int nsteps_total = (ktiles + 3) >> 2;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (rt_ok) {
+    for (int s = slice; s < nsteps_total; s += p.splitk) {
+      // ---- the 4 k-tiles of this step: packed words (1 per k-tile on the B side, 2 on the A side) ----
+      uint32_t w0[4], w1[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int kt = min(4 * s + j, ktiles - 1);
+        const uint32_t idx = lane_words + (uint32_t)((kt / I) * 32 * I * WPT + (kt % I) * WPT);
+        w0[j] = __builtin_nontemporal_load(wb + idx);
+        if constexpr (LAYOUT_A) w1[j] = __builtin_nontemporal_load(wb + idx + 1);
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {  // two K-slots of two k-tiles each
+        const int kt0 = 4 * s + 2 * h;
+        const bool ok = row_ok && kt0 < ktiles;
+        const int kt0_c = min(kt0, ktiles - 2);
+        uint32_t q = qb[(uint32_t)(((kt0_c << 4) >> p.gshift) * p.wrows + row_c)];
+        q = ok ? q : 0u;  // scale = zero = 0: this lane contributes exact zeros
+        const float sc = DT::lo_f32(q), zp = DT::hi_f32(q);
+        u32x4 xf = {0u, 0u, 0u, 0u};
+        if (xcol) {
+          const char* xp = xlane + (int64_t)kt0_c * 32;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) xf[e] = *reinterpret_cast<const uint32_t*>(xp + 16 * e);
+        }
+        u32x4 a;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          // the four bytes of this lane's row in k-tile kt0 + j, in k order 2Q, 2Q+1, 2Q+8, 2Q+9
+          uint32_t b0, b1, b2, b3;
+          if constexpr (LAYOUT_A) {
+            const uint32_t u0 = w0[2 * h + j] >> ((i >> 3) * 8), u1 = w1[2 * h + j] >> ((i >> 3) * 8);
+            b0 = u0 & 0xffu; b1 = (u0 >> 16) & 0xffu; b2 = u1 & 0xffu; b3 = (u1 >> 16) & 0xffu;
+          } else {
+            const uint32_t u = w0[2 * h + j];
+            b0 = u & 0xffu; b1 = (u >> 16) & 0xffu; b2 = (u >> 8) & 0xffu; b3 = u >> 24;
+          }
+          const float f0 = __builtin_fmaf((float)b0 - 128.f, sc, zp), f1 = __builtin_fmaf((float)b1 - 128.f, sc, zp);
+          const float f2 = __builtin_fmaf((float)b2 - 128.f, sc, zp), f3 = __builtin_fmaf((float)b3 - 128.f, sc, zp);
+          a[2 * j] = DT::pack2(f0, f1);
+          a[2 * j + 1] = DT::pack2(f2, f3);
+        }
+        acc = DT::mfma(a, xf, acc);
+      }
+    }
+  }
+
+  // ---- split-K tail (as in w4_gemm.cuh): lane (c = lane & 15, Q) holds y[act row c][rows row0 + 4Q .. +3] ----
+  if (p.splitk > 1) {
+    s_red[wave * 64 + lane] = acc;
+    __syncthreads();
+    if (slice != 0) return;
+    for (int o = 1; o < p.splitk; ++o) acc += s_red[(wave + o) * 64 + lane];
+  }
+  const int col = ct * 16 + i;
+  const int rowg = row0 + 4 * Q;
+  if (rt_ok && col < p.m && rowg < p.wrows) {
+    u32x2 o = {DT::pack2(acc[0], acc[1]), DT::pack2(acc[2], acc[3])};
+    *reinterpret_cast<u32x2*>(yb + ((int64_t)col * p.wrows + rowg) * 2) = o;
+  }
+}

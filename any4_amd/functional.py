@@ -80,7 +80,7 @@ def linear_y_f16RM_W_int4TC_x_f16RM(x, w_int32, w_scales_and_zeros, q_group, w_i
     return _T.tinygemm_y_f16RM_x_f16RM_w_int4TC(wa, x, q_group, w_scales_and_zeros, False)
 
 
-# -- int8 (schemas only in this build; the ops raise) ------------------------------------------------
+# -- int8 (byte codes, value = byte - 128; tinygemm_lib/functional.py:86-137) -----------------------
 
 def linear_y_f16TC_x_f16TC_W_int8TC(x, w_int32, w_scales_and_zeros, q_group, w_inner_k=4, reshape_weight=True):
     xa = _T.convert_matrix_to_m16n8k16_A_layout(x, 1)

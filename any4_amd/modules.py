@@ -88,7 +88,7 @@ class Int4Linear(_PackedLinear):
 
 
 class Int8Linear(_PackedLinear):
-    """API parity only: the int8 kernels are not part of this build, the ops raise."""
+    """int8 weights (modules.py:85-152): codes 0..255 from group_quantize_tensor(n_bit=8), value = code - 128."""
     _PACKERS = {
         "linear_y_f16RM_x_f16RM_W_int8TC": "convert_matrix_to_m16n8k16_Bint8_layout",
         "linear_y_f16RM_W_int8TC_x_f16RM": "convert_matrix_to_m16n8k16_Aint8_layout",

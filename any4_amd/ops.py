@@ -316,22 +316,108 @@ def tinygemm_y_f16TC_x_f16TC_w_f16TC(A, B, weightOnRight):
 
 
 # ---------------------------------------------------------------------------------------------
-# int8 weights: out of this build's scope.  The schemas exist so
-# that callers see a clear error instead of an AttributeError.
+# int8 weights
 # ---------------------------------------------------------------------------------------------
 
-def _int8_unbuilt(*_args, **_kw):
-    raise RuntimeError("tinygemm: the int8-weight path is not built in this MI355X library (int4/any4/mx4/f16 only)")
+def convert_matrix_to_m16n8k16_Bint8_layout(t: torch.Tensor, innerKTiles: int) -> torch.Tensor:
+    """TinyGemmConvertB.cu:415-465: int32 [n][k] byte codes -> [ceil(n/8)][k/(16 I)][32][I]."""
+    _check(t.dim() == 2 and t.dtype == torch.int32 and t.is_contiguous(), "Bint8 layout: input must be a contiguous 2-D int32 matrix")
+    _check(innerKTiles in (1, 2, 4), "Bint8 layout: innerKTiles must be 1, 2 or 4")
+    n, k = t.shape
+    _check(k % (innerKTiles * 16) == 0, "Bint8 layout: k must be a multiple of innerKTiles * 16")
+    out = torch.empty((_cdiv(n, 8), k // (innerKTiles * 16), 32, innerKTiles), dtype=torch.int32, device=t.device)
+    _lib.check(_L.tg_convert_to_Bint8(t.data_ptr(), n, k, innerKTiles, out.data_ptr(), _dev(t), _stream(t)),
+               "convert_matrix_to_m16n8k16_Bint8_layout")
+    return out
+
+
+def convert_matrix_to_m16n8k16_Aint8_layout(t: torch.Tensor, innerKTiles: int) -> torch.Tensor:
+    """TinyGemmConvertA.cu:400-440: int32 [m][k] byte codes -> [ceil(m/16)][ceil(ceil(k/16)/I)][32][2 I]."""
+    _check(t.dim() == 2 and t.dtype == torch.int32 and t.is_contiguous(), "Aint8 layout: input must be a contiguous 2-D int32 matrix")
+    _check(innerKTiles in (1, 2), "Aint8 layout: innerKTiles must be 1 or 2")
+    m, k = t.shape
+    out = torch.empty((_cdiv(m, 16), _cdiv(_cdiv(k, 16), innerKTiles), 32, 2 * innerKTiles), dtype=torch.int32, device=t.device)
+    _lib.check(_L.tg_convert_to_Aint8(t.data_ptr(), m, k, innerKTiles, out.data_ptr(), _dev(t), _stream(t)),
+               "convert_matrix_to_m16n8k16_Aint8_layout")
+    return out
+
+
+def tinygemm_y_f16RM_x_f16RM_w_int8TC(A, B, qGroupSize, qScaleAndZeros, weightOnRight):
+    """Row-major activations / output with int8 weights (TinyGemm_int8.cu:216-399)."""
+    opname = "tinygemm_y_f16RM_x_f16RM_w_int8TC"
+    _check(A.device == B.device and A.device == qScaleAndZeros.device, "A, B and qScaleAndZeros must be on the same device")
+    if weightOnRight:
+        x, w = A, B
+        _check(x.dim() == 2 and x.is_contiguous(), "activations must be a contiguous 2-D matrix")
+        _check(w.dim() == 4 and w.dtype == torch.int32 and w.is_contiguous(), "weights must be a contiguous 4-D int32 tensor")
+        inner = w.size(3)
+        _check(inner in (1, 2, 4), "Bint8 weights: innermost dim must be 1, 2 or 4")
+        wrows = w.size(0) * 8
+    else:
+        w, x = A, B
+        _check(w.dim() == 4 and w.dtype == torch.int32 and w.is_contiguous(), "weights must be a contiguous 4-D int32 tensor")
+        _check(x.dim() == 2 and x.is_contiguous(), "activations must be a contiguous 2-D matrix")
+        _check(w.size(3) % 2 == 0, "Aint8 weights: innermost dim must be even")
+        inner = w.size(3) // 2
+        _check(inner in (1, 2), "Aint8 weights: innermost dim must be 2 or 4")
+        wrows = w.size(0) * 16
+    m, k = x.shape
+    k_tiles = _cdiv(k, 16)
+    _check(w.size(1) == _cdiv(k_tiles, inner), "weights: k super-tiles do not match the activations' k")
+    _check(w.size(2) == 32, "weights: dim 2 must be 32")
+    _check(x.dtype in _F16_TYPES, "activation dtype must be bfloat16 or float16")
+    _check(qGroupSize in (32, 64, 128, 256), "qGroupSize must be 32, 64, 128 or 256")
+    qinfo = qScaleAndZeros
+    _check(qinfo.dim() == 3, "qScaleAndZeros must be 3-D [k / qGroupSize][weight rows][2]")
+    _check(k_tiles * 16 >= qGroupSize and (k_tiles * 16) % qGroupSize == 0, "qGroupSize must divide k")
+    _check(qinfo.size(0) == (k_tiles * 16) // qGroupSize, "qScaleAndZeros.size(0) must equal k / qGroupSize")
+    _check(qinfo.size(1) == wrows, "qScaleAndZeros.size(1) must equal the tile-padded weight rows")
+    _check(qinfo.size(2) == 2, "qScaleAndZeros.size(2) must be 2")
+    _check(qinfo.dtype == x.dtype, "qScaleAndZeros dtype must match the activations")
+    _check(k % 32 == 0 and k_tiles % inner == 0, "k must be a multiple of 32 and of innerKTiles * 16")
+    qinfo = qinfo.contiguous()
+    y = torch.empty((m, wrows), dtype=x.dtype, device=x.device)
+    if m == 0:
+        return y
+    args = W4Gemm(x=x.data_ptr(), w=w.data_ptr(), qinfo=qinfo.data_ptr(), lut=None, y=y.data_ptr(), m=m, wrows=wrows, k=k,
+                  group=qGroupSize, qtype=_lib.TG_Q_INT8, dtype=_dt(x), w_on_right=1 if weightOnRight else 0,
+                  inner_k_tiles=inner, batch=1)
+    _lib.check(_L.tg_gemm_w8(ctypes.byref(args), _dev(x), _stream(x)), opname)
+    return y
+
+
+def tinygemm_y_f16TC_x_f16TC_w_int8TC(A, B, qGroupSize, qScaleAndZeros, weightOnRight):
+    """Fragment-order activations / output (TinyGemm_int8.cu:23-214): un-layout -> row-major GEMM -> re-layout."""
+    _check(A.dim() == 4 and A.is_contiguous() and A.size(2) == 32, "A must be a contiguous 4-D tensor-core layout tensor")
+    _check(B.dim() == 4 and B.is_contiguous() and B.size(2) == 32, "B must be a contiguous 4-D tensor-core layout tensor")
+    if weightOnRight:
+        _check(A.size(3) == 8, "activations (A layout) must have innermost dim 8")
+        _check(B.size(3) in (1, 2, 4) and B.dtype == torch.int32, "weights (Bint8 layout) must be int32 with innermost dim 1, 2 or 4")
+        k_tiles_a, k_tiles_b = A.size(1), B.size(1) * B.size(3)
+        _check(k_tiles_a == k_tiles_b, "A and B disagree on k")
+        m_pad, k = A.size(0) * 16, k_tiles_a * 16
+        x = convert_matrix_from_m16n8k16_A_layout(A, m_pad, k)
+        y = tinygemm_y_f16RM_x_f16RM_w_int8TC(x, B, qGroupSize, qScaleAndZeros, True)
+        return convert_matrix_to_m16n8k16_A_layout(y, 1)
+    _check(A.size(3) in (2, 4) and A.dtype == torch.int32, "weights (Aint8 layout) must be int32 with innermost dim 2 or 4")
+    _check(B.size(3) in (4, 8), "activations (B layout) must have innermost dim 4 or 8")
+    b_inner = B.size(3) // 4
+    k_tiles_a, k_tiles_b = A.size(1) * (A.size(3) // 2), B.size(1) * b_inner
+    _check(k_tiles_a == k_tiles_b, "A and B disagree on k")
+    n_pad, k = B.size(0) * 8, k_tiles_b * 16
+    x = convert_matrix_from_m16n8k16_B_layout(B, n_pad, k)
+    y = tinygemm_y_f16RM_x_f16RM_w_int8TC(A, x, qGroupSize, qScaleAndZeros, False)
+    return convert_matrix_to_m16n8k16_B_layout(y, b_inner)
 
 
 _IMPLS = {
     "convert_matrix_to_m16n8k16_A_layout": convert_matrix_to_m16n8k16_A_layout,
     "convert_matrix_to_m16n8k16_Aint4_layout": convert_matrix_to_m16n8k16_Aint4_layout,
-    "convert_matrix_to_m16n8k16_Aint8_layout": _int8_unbuilt,
+    "convert_matrix_to_m16n8k16_Aint8_layout": convert_matrix_to_m16n8k16_Aint8_layout,
     "convert_matrix_from_m16n8k16_A_layout": convert_matrix_from_m16n8k16_A_layout,
     "convert_matrix_to_m16n8k16_B_layout": convert_matrix_to_m16n8k16_B_layout,
     "convert_matrix_to_m16n8k16_Bint4_layout": convert_matrix_to_m16n8k16_Bint4_layout,
-    "convert_matrix_to_m16n8k16_Bint8_layout": _int8_unbuilt,
+    "convert_matrix_to_m16n8k16_Bint8_layout": convert_matrix_to_m16n8k16_Bint8_layout,
     "convert_matrix_from_m16n8k16_B_layout": convert_matrix_from_m16n8k16_B_layout,
     "tinygemm_y_f16TC_x_f16TC_w_int4TC": tinygemm_y_f16TC_x_f16TC_w_int4TC,
     "tinygemm_y_f16RM_x_f16RM_w_int4TC": tinygemm_y_f16RM_x_f16RM_w_int4TC,
@@ -339,8 +425,8 @@ _IMPLS = {
     "tinygemm_y_f16RM_x_f16RM_w_any4TC": tinygemm_y_f16RM_x_f16RM_w_any4TC,
     "tinygemm_y_f16TC_x_f16TC_w_mx4TC": tinygemm_y_f16TC_x_f16TC_w_mx4TC,
     "tinygemm_y_f16RM_x_f16RM_w_mx4TC": tinygemm_y_f16RM_x_f16RM_w_mx4TC,
-    "tinygemm_y_f16TC_x_f16TC_w_int8TC": _int8_unbuilt,
-    "tinygemm_y_f16RM_x_f16RM_w_int8TC": _int8_unbuilt,
+    "tinygemm_y_f16TC_x_f16TC_w_int8TC": tinygemm_y_f16TC_x_f16TC_w_int8TC,
+    "tinygemm_y_f16RM_x_f16RM_w_int8TC": tinygemm_y_f16RM_x_f16RM_w_int8TC,
     "tinygemm_y_f16TC_x_f16TC_w_f16TC": tinygemm_y_f16TC_x_f16TC_w_f16TC,
     "tinygemm_y_f16RM_x_f16RM_w_f16TC": tinygemm_y_f16RM_x_f16RM_w_f16TC,
     "tinygemm_dequant_int4": tinygemm_dequant_int4,

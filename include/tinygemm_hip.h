@@ -51,7 +51,8 @@ enum {
   TG_Q_INT4 = 0,         /* uniform int4: value = code - 8                                  */
   TG_Q_ANY4_GLOBAL = 1,  /* one 16-entry LUT for the whole matrix (the reference's NF4 path) */
   TG_Q_ANY4_ROWWISE = 2, /* one 16-entry LUT per weight row (any4)                         */
-  TG_Q_MX4 = 3           /* fp4-e2m1 codes with an e8m0 exponent per group                 */
+  TG_Q_MX4 = 3,          /* fp4-e2m1 codes with an e8m0 exponent per group                 */
+  TG_Q_INT8 = 4          /* tg_gemm_w8 only: uniform int8, value = byte - 128              */
 };
 
 /* precondition failures (wording of the matching TORCH_CHECK is in tg_error_string) */
@@ -134,6 +135,23 @@ typedef struct tg_w4_gemm {
 } tg_w4_gemm;
 
 TG_API int tg_gemm_w4(const tg_w4_gemm* args, int device, tg_stream_t stream);
+
+/*
+ * int8 weights.
+ * tg_convert_to_Bint8 replaces convert_matrix_to_m16n8k16_Bint8_layout (TinyGemmConvertB.cu:415-465, kernel 366-411):
+ *   in int32 [n][k] (byte codes) -> out int32 [ceil(n/8)][k/(16 I)][32][I], I in {1,2,4}, k % (16 I) == 0.
+ * tg_convert_to_Aint8 replaces convert_matrix_to_m16n8k16_Aint8_layout (TinyGemmConvertA.cu:400-440, kernel 337-397):
+ *   in int32 [m][k] -> out int32 [ceil(m/16)][ceil(ceil(k/16)/I)][32][2 I], I in {1,2}.
+ * Both are bit-identical to the reference's words.
+ * tg_gemm_w8 replaces tinygemm_y_f16RM_x_f16RM_w_int8TC (TinyGemm_int8.cu:216-399, 430-458): same argument struct as
+ *   tg_gemm_w4 with qtype = TG_Q_INT8, inner_k_tiles = I of the packed layout (B: 1,2,4; A: 1,2 = size(3)/2), lut unused;
+ *   w = RNE16(fma(byte - 128, scale, zero)) (Dequantization.cuh:262-330, MatrixLayoutB.cuh:1296-1316).
+ */
+TG_API int tg_convert_to_Bint8(const int32_t* in, int64_t n, int64_t k, int inner_k_tiles, int32_t* out, int device,
+                               tg_stream_t stream);
+TG_API int tg_convert_to_Aint8(const int32_t* in, int64_t m, int64_t k, int inner_k_tiles, int32_t* out, int device,
+                               tg_stream_t stream);
+TG_API int tg_gemm_w8(const tg_w4_gemm* args, int device, tg_stream_t stream);
 
 /*
  * replaces tinygemm_y_f16RM_x_f16RM_w_f16TC (TinyGemm_bf16.cu:163-327): un-quantised 16-bit

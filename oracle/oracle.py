@@ -19,7 +19,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "_build", "libtinygemm_oracle.so")
 
 BF16, F16 = 0, 1
-Q_INT4, Q_ANY4_GLOBAL, Q_ANY4_ROWWISE, Q_MX4 = 0, 1, 2, 3
+Q_INT4, Q_ANY4_GLOBAL, Q_ANY4_ROWWISE, Q_MX4, Q_INT8 = 0, 1, 2, 3, 4
 
 
 def build(force: bool = False) -> str:
@@ -44,6 +44,8 @@ def lib() -> ctypes.CDLL:
         L.tgo_unpack_Bint4.argtypes = [vp, i64, i64, i32, vp]
         L.tgo_pack_Aint4.argtypes = [vp, i64, i64, i32, vp]
         L.tgo_unpack_Aint4.argtypes = [vp, i64, i64, i32, vp]
+        L.tgo_pack_Bint8.argtypes = [vp, i64, i64, i32, vp]
+        L.tgo_pack_Aint8.argtypes = [vp, i64, i64, i32, vp]
         L.tgo_to_A16.argtypes = [vp, i64, i64, vp]
         L.tgo_from_A16.argtypes = [vp, i64, i64, vp]
         L.tgo_to_B16.argtypes = [vp, i64, i64, i32, vp]
@@ -108,6 +110,30 @@ def pack_Aint4(codes: np.ndarray, inner_k_tiles: int) -> np.ndarray:
         raise ValueError("Aint4: innerKTiles must be 1/2/4")
     out = np.empty((_cdiv(m, 16), _cdiv(k, 16 * I), 32, I), np.int32)
     _check(lib().tgo_pack_Aint4(_p(codes), m, k, I, _p(out)), "pack_Aint4")
+    return out
+
+
+def pack_Bint8(codes: np.ndarray, inner_k_tiles: int) -> np.ndarray:
+    """int32 [n][k] (byte codes 0..255) -> [ceil(n/8)][k/(16 I)][32][I] (TinyGemmConvertB.cu:366-411)."""
+    codes = _c(codes, np.int32)
+    n, k = codes.shape
+    I = inner_k_tiles
+    if I not in (1, 2, 4) or k % (16 * I):
+        raise ValueError("Bint8: innerKTiles must be 1/2/4 and k a multiple of 16*innerKTiles")
+    out = np.empty((_cdiv(n, 8), k // (16 * I), 32, I), np.int32)
+    _check(lib().tgo_pack_Bint8(_p(codes), n, k, I, _p(out)), "pack_Bint8")
+    return out
+
+
+def pack_Aint8(codes: np.ndarray, inner_k_tiles: int) -> np.ndarray:
+    """int32 [m][k] -> [ceil(m/16)][ceil(ceil(k/16)/I)][32][2 I] (TinyGemmConvertA.cu:337-397)."""
+    codes = _c(codes, np.int32)
+    m, k = codes.shape
+    I = inner_k_tiles
+    if I not in (1, 2):
+        raise ValueError("Aint8: innerKTiles must be 1/2")
+    out = np.empty((_cdiv(m, 16), _cdiv(_cdiv(k, 16), I), 32, 2 * I), np.int32)
+    _check(lib().tgo_pack_Aint8(_p(codes), m, k, I, _p(out)), "pack_Aint8")
     return out
 
 

@@ -9,6 +9,7 @@ What is captured (inputs + the reference's own outputs; data only, no reference 
 
   group_quant.npz   tinygemm_lib/utils.py:27-67 group_quantize_tensor on seeded bf16 weights,
                     g in {32,64,128,256}: codes + scales_and_zeros bit patterns.           (Q1)
+  group_quant_int8.npz  the same function at n_bit = 8 (inputs of the int8 kernels, row N3).
   mx4.npz           tinygemm_lib/utils.py:137-232 quantize_mx4 / dequantize_mx4, g=32.       (Q2)
   any4_n1024_k1024_g128_seed1234.npz
                     quantize.py:523-637 anyq_quantize_tensor (sklearn k-means, per-row LUT)
@@ -72,6 +73,17 @@ def main():
     out["eye256_codes_g64"] = codes.numpy().astype("uint8")
     out["eye256_sz_bits_g64"] = _bits16(sz)
     np.savez_compressed(os.path.join(HERE, "group_quant.npz"), **out)
+
+    # ---------------------------------------------------------------- group_quant_int8.npz (Q1 at n_bit = 8, row N3)
+    out8 = {"w_bits": _bits16(w)}
+    for g in (32, 128):
+        codes, sz = ref_utils.group_quantize_tensor(w, 8, g)
+        out8[f"codes_g{g}"] = codes.numpy().astype("uint8")
+        out8[f"sz_bits_g{g}"] = _bits16(sz)
+    codes, sz = ref_utils.group_quantize_tensor(eye, 8, 64)  # identity case of test_tinygemm_int8.py:23-50
+    out8["eye256_codes_g64"] = codes.numpy().astype("uint8")
+    out8["eye256_sz_bits_g64"] = _bits16(sz)
+    np.savez_compressed(os.path.join(HERE, "group_quant_int8.npz"), **out8)
 
     # ---------------------------------------------------------------- mx4.npz (Q2)
     out = {}

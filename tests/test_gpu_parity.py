@@ -426,7 +426,7 @@ def test_errors(T):
     with pytest.raises(RuntimeError):
         T.tinygemm_y_f16RM_x_f16RM_w_mx4TC(x.half(), w2, 32, torch.zeros(16, 4, dtype=torch.uint8, device=DEV), True)
     with pytest.raises(RuntimeError):
-        T.tinygemm_y_f16RM_x_f16RM_w_int8TC(x, w2, 128, sz, True)            # int8 not built
+        T.tinygemm_y_f16RM_x_f16RM_w_int8TC(x, w2, 128, sz, True)            # a Bint4 tensor is not a Bint8 one (k mismatch)
     with pytest.raises((RuntimeError, NotImplementedError)):
         T.convert_matrix_to_m16n8k16_Bint4_layout(codes.cpu(), 4)            # no CPU fallback
 
@@ -616,3 +616,89 @@ def test_stream_resident_x(T, oracle, on_right, inner, m):
         for cpy in (0, copies - 1):
             assert_gemm_close(ys[cpy * nprob + b], probs[b][1], w)
     assert torch.equal(ys[:nprob], ys[-nprob:])
+
+
+# ------------------------------------------------------------------------------------------------
+# int8 weights: packers bit-exact, GEMM vs the oracle, identity bit-exact
+# ------------------------------------------------------------------------------------------------
+
+def _rand_int8_problem(n, k, g, m, dtype=torch.bfloat16, seed=0):
+    gen = torch.Generator().manual_seed(seed)
+    codes = torch.randint(0, 256, (n, k), dtype=torch.int32, generator=gen)
+    x = torch.randn(m, k, generator=gen).to(dtype)
+    scales = (torch.rand(k // g, n, generator=gen) * 0.002 + 0.0005).to(dtype)
+    zeros = (torch.randn(k // g, n, generator=gen) * 0.01).to(dtype)
+    return codes, x, torch.stack([scales, zeros], dim=2).contiguous()
+
+
+@pytest.mark.parametrize("n,k", [(8, 64), (19, 256), (100, 640), (256, 4096)])
+def test_pack_int8_bit_exact(T, oracle, n, k):
+    codes = torch.randint(0, 256, (n, k), dtype=torch.int32, generator=torch.Generator().manual_seed(n + k))
+    codes[0, 0] = 0x1234567  # the packers OR the shifted 32-bit inputs without masking (ConvertB.cu:404)
+    for inner in (1, 2, 4):
+        if k % (16 * inner) == 0:
+            got = T.convert_matrix_to_m16n8k16_Bint8_layout(codes.to(DEV), inner).cpu().numpy()
+            assert np.array_equal(got, oracle.pack_Bint8(codes.numpy(), inner)), ("B", inner)
+    for inner in (1, 2):
+        got = T.convert_matrix_to_m16n8k16_Aint8_layout(codes.to(DEV), inner).cpu().numpy()
+        assert np.array_equal(got, oracle.pack_Aint8(codes.numpy(), inner)), ("A", inner)
+
+
+@pytest.mark.parametrize("on_right,inner", [(True, 1), (True, 2), (True, 4), (False, 1), (False, 2)])
+@pytest.mark.parametrize("g", [32, 128])
+@pytest.mark.parametrize("m,n,k", [(1, 64, 256), (5, 48, 1024), (16, 200, 512), (33, 24, 4096)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_gemm_int8_vs_oracle(T, oracle, on_right, inner, g, m, n, k, dtype):
+    if k % (16 * inner) or (dtype == torch.float16 and (g, m) != (128, 5)):
+        pytest.skip("covered elsewhere")
+    codes, x, sz = _rand_int8_problem(n, k, g, m, dtype, seed=n + k + m)
+    d = lambda t: t.to(DEV)
+    if on_right:
+        w2 = T.convert_matrix_to_m16n8k16_Bint8_layout(d(codes), inner)
+        n_pad = w2.size(0) * 8
+    else:
+        w2 = T.convert_matrix_to_m16n8k16_Aint8_layout(d(codes), inner)
+        n_pad = w2.size(0) * 16
+    szp = torch.zeros(k // g, n_pad, 2, dtype=dtype)
+    szp[:, :n] = sz
+    y = T.tinygemm_y_f16RM_x_f16RM_w_int8TC(d(x), w2, g, d(szp), True) if on_right else \
+        T.tinygemm_y_f16RM_x_f16RM_w_int8TC(w2, d(x), g, d(szp), False)
+    assert y.shape == (m, n_pad)
+    w = oracle.dequant(codes.numpy(), g, oracle.Q_INT8, bits16(sz), None, oracle.BF16 if dtype == torch.bfloat16 else oracle.F16)
+    assert_gemm_close(y[:, :n], x, w, dtype)
+    assert (y[:, n:] == 0).all()  # padded rows: zero codes... with scale = zero = 0 they dequantise to 0
+
+
+@pytest.mark.parametrize("api", ["RM_right", "RM_left", "TC_right", "TC_left"])
+@pytest.mark.parametrize("k,g,inner", [(256, 32, 1), (1024, 64, 2), (2048, 256, 2), (1024, 128, 4)])
+def test_int8_identity_bit_exact(T, api, k, g, inner):
+    """test_tinygemm_int8.py:23-50: w = eye(k) through group_quantize_tensor(n_bit=8) -> y == x bit for bit (bf16)."""
+    import tinygemm_lib.functional as F
+    from tinygemm_lib.utils import group_quantize_tensor
+
+    if api.endswith("left") and inner == 4:
+        pytest.skip("Aint8 has innerKTiles 1, 2")
+    x = torch.randn(29, k, generator=torch.Generator().manual_seed(k)).to(torch.bfloat16).to(DEV)
+    w = torch.eye(k, dtype=torch.bfloat16, device=DEV)
+    w_int32, sz = group_quantize_tensor(w, n_bit=8, q_group_size=g)
+    fn = {"RM_right": F.linear_y_f16RM_x_f16RM_W_int8TC, "RM_left": F.linear_y_f16RM_W_int8TC_x_f16RM,
+          "TC_right": F.linear_y_f16TC_x_f16TC_W_int8TC, "TC_left": F.linear_y_f16TC_W_int8TC_x_f16TC}[api]
+    y = fn(x, w_int32, sz, g, inner)
+    assert torch.equal(y, x @ w.t())
+
+
+def test_int8linear_module(T, oracle):
+    import modules
+
+    n, k, g = 96, 512, 128
+    codes, x, sz = _rand_int8_problem(n, k, g, 7, seed=5)
+    for kernel in ("linear_y_f16RM_x_f16RM_W_int8TC", "linear_y_f16RM_W_int8TC_x_f16RM"):
+        mod = modules.Int8Linear(k, n, bias=True, device=DEV, dtype=torch.bfloat16, group_size=g, kernel=kernel)
+        mod.weight.data = codes.to(DEV)
+        mod.scales_and_zeros.data = sz.to(DEV)
+        mod.bias.data = torch.zeros(n, dtype=torch.bfloat16, device=DEV)
+        mod.reshape_weight()
+        assert mod.weight.dim() == 4 and mod.weight_reshaped
+        y = mod(x.to(DEV).view(1, 7, k))
+        assert y.shape == (1, 7, n)
+        assert_gemm_close(y.view(7, n), x, oracle.dequant(codes.numpy(), g, oracle.Q_INT8, bits16(sz), None))

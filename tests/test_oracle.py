@@ -76,6 +76,51 @@ def test_group_quantize_matches_reference_fixture():
     assert np.array_equal(bits16(sz), g["eye256_sz_bits_g64"])
 
 
+def test_group_quantize_int8_matches_reference_fixture(oracle):
+    """n_bit = 8 (inputs of the int8 kernels): codes 0..255, zero = min + 128 scale."""
+    g = load_golden("group_quant_int8.npz")
+    w = from_bits16(g["w_bits"], torch.bfloat16)
+    for gs in (32, 128):
+        codes, sz = U.group_quantize_tensor(w, 8, gs)
+        assert np.array_equal(codes.numpy().astype(np.uint8), g[f"codes_g{gs}"]) and int(codes.max()) <= 255
+        assert np.array_equal(bits16(sz), g[f"sz_bits_g{gs}"])
+        # oracle dequant (byte - 128) * scale + zero reproduces w to half a grid step
+        wd = from_bits16(oracle.dequant(codes.numpy(), gs, oracle.Q_INT8, bits16(sz), None), torch.bfloat16).float()
+        scale = from_bits16(bits16(sz), torch.bfloat16).float()[:, :, 0].t().repeat_interleave(gs, dim=1)
+        assert ((wd - w.float()).abs() <= scale * 0.5 + 2.0 ** -8 * w.float().abs().max()).all()
+    codes, sz = U.group_quantize_tensor(torch.eye(256, dtype=torch.bfloat16), 8, 64)
+    assert np.array_equal(codes.numpy().astype(np.uint8), g["eye256_codes_g64"])
+    assert np.array_equal(bits16(sz), g["eye256_sz_bits_g64"])
+    # the identity known-answer case: dequantised eye is exactly eye (test_tinygemm_int8.py:23-50 relies on it)
+    wd = from_bits16(oracle.dequant(codes.numpy(), 64, oracle.Q_INT8, bits16(sz), None), torch.bfloat16)
+    assert torch.equal(wd, torch.eye(256, dtype=torch.bfloat16))
+
+
+def test_pack_int8_layout_formulas(oracle):
+    """Bint8 / Aint8 words against the index formulas of TinyGemmConvertB.cu:366-411 / TinyGemmConvertA.cu:337-397."""
+    rng = np.random.default_rng(3)
+    n, k = 20, 192
+    codes = rng.integers(0, 256, (n, k), dtype=np.int32)
+    for inner in (1, 2, 4):
+        out = oracle.pack_Bint8(codes, inner).view(np.uint32)
+        assert out.shape == ((n + 7) // 8, k // (16 * inner), 32, inner)
+        for (a, b, t, j) in [(0, 0, 0, 0), (1, 1, 13, inner - 1), (2, k // (16 * inner) - 1, 31, 0)]:
+            n0, kb = a * 8 + t // 4, (b * inner + j) * 16 + (t % 4) * 2
+            v = [int(codes[n0, kk]) if n0 < n else 0 for kk in (kb, kb + 1, kb + 8, kb + 9)]
+            assert out[a, b, t, j] == ((v[3] << 24) | (v[1] << 16) | (v[2] << 8) | v[0])
+    for inner in (1, 2):
+        out = oracle.pack_Aint8(codes, inner).view(np.uint32)
+        assert out.shape == ((n + 15) // 16, (k // 16 + inner - 1) // inner, 32, 2 * inner)
+        for (a, kt, t) in [(0, 0, 0), (1, 5, 9), (1, k // 16 - 1, 31)]:
+            m0, m1, k0 = a * 16 + t // 4, a * 16 + t // 4 + 8, kt * 16 + (t % 4) * 2
+            gv = lambda mm, kk: int(codes[mm, kk]) if mm < n else 0
+            w0 = (gv(m1, k0 + 1) << 24) | (gv(m0, k0 + 1) << 16) | (gv(m1, k0) << 8) | gv(m0, k0)
+            w1 = (gv(m1, k0 + 9) << 24) | (gv(m0, k0 + 9) << 16) | (gv(m1, k0 + 8) << 8) | gv(m0, k0 + 8)
+            assert out[a, kt // inner, t, (kt % inner) * 2] == w0 and out[a, kt // inner, t, (kt % inner) * 2 + 1] == w1
+    with pytest.raises(Exception):
+        oracle.pack_Bint8(codes, 8)
+
+
 def test_mx4_quantizer_matches_reference_fixture(oracle):
     g = load_golden("mx4.npz")
     w = torch.from_numpy(g["w"])

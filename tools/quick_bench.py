@@ -16,9 +16,9 @@ from any4_amd import _lib
 
 
 def alg_bytes(m, n, k, g, qtype):
-    lut = {"any4_rowwise": 32 * n, "any4_global": 32, "int4": 0, "mx4": 0}[qtype]
+    lut = {"any4_rowwise": 32 * n, "any4_global": 32, "int4": 0, "mx4": 0, "int8": 0}[qtype]
     q = n * k // 32 if qtype == "mx4" else (k // g) * n * 4
-    return n * k // 2 + q + lut + m * k * 2 + m * n * 2
+    return (n * k if qtype == "int8" else n * k // 2) + q + lut + m * k * 2 + m * n * 2
 
 
 def main():
@@ -36,14 +36,18 @@ def main():
     T = None
     import tinygemm  # noqa
     T = torch.ops.tinygemm
-    qt = {"int4": 0, "any4_global": 1, "any4_rowwise": 2, "mx4": 3}[a.qtype]
+    qt = {"int4": 0, "any4_global": 1, "any4_rowwise": 2, "mx4": 3, "int8": 4}[a.qtype]
+    gemm = L_.tg_gemm_w8 if a.qtype == "int8" else L_.tg_gemm_w4
     for cfg in a.configs.split(";"):
         m, n, k, on_right = [int(v) for v in cfg.split(",")]
         L = a.L if n * k <= 4096 * 4096 else max(a.L // 4, 12)
         g = 32 if a.qtype == "mx4" else a.g
         gen = torch.Generator(device=dev).manual_seed(0)
         inner = a.inner
-        if on_right:
+        if a.qtype == "int8":
+            inner = min(inner, 4 if on_right else 2)
+            shape = (L, n // 8, k // (16 * inner), 32, inner) if on_right else (L, n // 16, k // (16 * inner), 32, 2 * inner)
+        elif on_right:
             shape = (L, n // 8, k // (16 * inner), 32, inner // 2)
         else:
             shape = (L, n // 16, k // (16 * inner), 32, inner)
@@ -72,11 +76,11 @@ def main():
 
         def run_eager():
             for s in singles:
-                rc = L_.tg_gemm_w4(ctypes.byref(s), 0, torch.cuda.current_stream().cuda_stream)
+                rc = gemm(ctypes.byref(s), 0, torch.cuda.current_stream().cuda_stream)
                 assert rc == 0, rc
 
         def run_stacked():
-            rc = L_.tg_gemm_w4(ctypes.byref(stacked), 0, torch.cuda.current_stream().cuda_stream)
+            rc = gemm(ctypes.byref(stacked), 0, torch.cuda.current_stream().cuda_stream)
             assert rc == 0, rc
 
         def timeit(fn, iters):
