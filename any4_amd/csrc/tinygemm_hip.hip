@@ -509,11 +509,16 @@ int launch_stream_sw(StreamParams& sp, int sk, int64_t coltiles, int64_t batch, 
 // Resident-X launch: 16-wave workgroups, the whole [mrows][k] activation block staged once per workgroup.
 template <typename DT, bool LAYOUT_A, int WPL, bool QMX>
 int launch_stream_xres(StreamParams& sp, int64_t coltiles, int64_t batch, unsigned lds, hipStream_t st) {
+  // one workgroup walks up to 4 consecutive groups of 16 tiles of its layer (X staged once, tile-granularity tail
+  // amortised) as long as that leaves at least two workgroups per CU
+  int tpw = 4;
+  while (tpw > 1 && ((sp.rowtiles + 16 * tpw - 1) / (16 * tpw)) * coltiles * batch < 512) tpw >>= 1;
+  sp.tiles_per_wave = tpw;
   auto kern = w4_gemm_stream_kernel<DT, LAYOUT_A, WPL, QMX, 16, STREAM_MINW, 1, false, 0, true>;
   static const hipError_t attr =
       hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (attr != hipSuccess) return (int)attr;
-  dim3 grid((unsigned)((sp.rowtiles + 15) / 16), (unsigned)coltiles, (unsigned)batch);
+  dim3 grid((unsigned)((sp.rowtiles + 16 * tpw - 1) / (16 * tpw)), (unsigned)coltiles, (unsigned)batch);
   hipLaunchKernelGGL(kern, grid, dim3(16 * 64), lds, st, sp);
   return launch_status();
 }
@@ -527,6 +532,7 @@ int launch_stream(const GemmParams& p, int64_t coltiles, int64_t batch, hipStrea
   sp.m = p.m; sp.wrows = p.wrows; sp.k = p.k; sp.ntiles = p.ntiles; sp.ksuper = p.ksuper;
   sp.gshift = p.gshift; sp.ngroups = p.ngroups; sp.qtype = p.qtype;
   sp.rowtiles = (p.wrows + RPW - 1) / RPW;
+  sp.tiles_per_wave = 1;
   sp.stride_x = p.stride_x; sp.stride_w = p.stride_w; sp.stride_qinfo = p.stride_qinfo;
   sp.stride_lut = p.stride_lut; sp.stride_y = p.stride_y;
   const int mrows = p.m < 16 ? p.m : 16;

@@ -61,6 +61,7 @@ struct StreamParams {
   int32_t upg_mask;         // (units per quantisation group) - 1
   int32_t xslab_bytes;      // bytes of one staged X slab
   int32_t red_off;          // LDS byte offset of the split-K partial tiles (unused when splitk == 1)
+  int32_t tiles_per_wave;   // resident-X launches: consecutive tile groups walked by one workgroup (else 1)
   int64_t stride_x, stride_w, stride_qinfo, stride_lut, stride_y;
 };
 
@@ -89,8 +90,6 @@ __global__ void __launch_bounds__(WAVES * 64, MINW) w4_gemm_stream_kernel(const 
   const int r = i & 7;
 
   const int slice = wave & (p.splitk - 1);
-  const int rt = blockIdx.x * (WAVES >> p.sk_shift) + (wave >> p.sk_shift);
-  const bool rt_ok = rt < p.rowtiles;
   const int ct = blockIdx.y;
   const int64_t b = blockIdx.z;
   const char* xb = p.x + b * p.stride_x;
@@ -99,15 +98,6 @@ __global__ void __launch_bounds__(WAVES * 64, MINW) w4_gemm_stream_kernel(const 
   const char* lb = p.lut ? p.lut + b * p.stride_lut : nullptr;
   char* yb = p.y + b * p.stride_y;
 
-  const int row0 = rt * 16;
-  const int row = row0 + i;
-  const int row_c = min(row, p.wrows - 1);
-  const int tile = LAYOUT_A ? rt : 2 * rt + (i >> 3);
-  const bool lane_ok = rt_ok && row < p.wrows && tile < p.ntiles;
-  const int tile_c = min(tile, p.ntiles - 1);
-
-  // packed-weight addressing: piece pc of unit U lives at k super-tile NP * U + pc
-  const uint32_t wrow = (uint32_t)((tile_c * p.ksuper * 32 + 4 * r) * WPL * 4);
   const uint32_t wks = 32u * WPL * 4u;  // bytes per k super-tile
   const int nunits = p.k / UNIT + (p.k % UNIT ? 1 : 0);
   const int NU = p.units_per_lane;
@@ -172,6 +162,21 @@ __global__ void __launch_bounds__(WAVES * 64, MINW) w4_gemm_stream_kernel(const 
     if (zt < 2 * (XROW / 16))
       *(lds_u32x4ptr)(lds_x + (uint32_t)((zt / (XROW / 16)) * p.xslab_bytes + xrows * XROW + (zt % (XROW / 16)) * 16)) = u32x4{0, 0, 0, 0};
   }
+
+  // ---- tile loop: a resident-X workgroup walks p.tiles_per_wave consecutive groups of WAVES tiles (the X block
+  // stays in LDS, waves do not wait for each other between tiles); every other mode handles one tile per wave ----
+  const int tiles_per_wave = XRES ? p.tiles_per_wave : 1;
+  for (int tt = 0; tt < tiles_per_wave; ++tt) {
+  const int rt = (blockIdx.x * tiles_per_wave + tt) * (WAVES >> p.sk_shift) + (wave >> p.sk_shift);
+  const bool rt_ok = rt < p.rowtiles;
+  const int row0 = rt * 16;
+  const int row = row0 + i;
+  const int row_c = min(row, p.wrows - 1);
+  const int tile = LAYOUT_A ? rt : 2 * rt + (i >> 3);
+  const bool lane_ok = rt_ok && row < p.wrows && tile < p.ntiles;
+  const int tile_c = min(tile, p.ntiles - 1);
+  // packed-weight addressing: piece pc of unit U lives at k super-tile NP * U + pc
+  const uint32_t wrow = (uint32_t)((tile_c * p.ksuper * 32 + 4 * r) * WPL * 4);
 
   // ---- raw LUT of this lane's row: 16 x 16 bit, kept packed in 8 registers ----
   u32x4 lut0, lut1;
@@ -357,4 +362,5 @@ __global__ void __launch_bounds__(WAVES * 64, MINW) w4_gemm_stream_kernel(const 
     u32x2 o = {DT::pack2(acc[0], acc[1]), DT::pack2(acc[2], acc[3])};
     *reinterpret_cast<u32x2*>(yb + ((int64_t)col * p.wrows + rowg) * 2) = o;
   }
+  }  // tile loop
 }
