@@ -199,3 +199,32 @@ def test_quantize_model_decode_stack():
     for i, t in enumerate(toks):
         a, b = stack.decode(t, i).float(), dense.decode(t, i).float()
         assert torch.isfinite(a).all() and (a - b).abs().max() <= 0.35 * b.abs().max(), i
+
+
+def test_hf_llama_quantize_model_real_vs_pseudo():
+    """The reference's model-level path (benchmark.py / eval.py): a HuggingFace Llama, every nn.Linear but the LM
+    head swapped by quantize_model.  Real kernels (Any4Linear on HIP) and fake quantization (reconstructed weights in
+    nn.Linear) of the SAME deterministic quantizer must give the same logits up to 16-bit summation order."""
+    import copy
+
+    transformers = pytest.importorskip("transformers")
+    from any4_amd import quantize as Q
+
+    torch.manual_seed(0)
+    cfg = transformers.LlamaConfig(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4,
+                                   num_key_value_heads=2, vocab_size=512, max_position_embeddings=64)
+    base = transformers.AutoModelForCausalLM.from_config(cfg, dtype=torch.bfloat16).to(DEV).eval()
+    real, fake = copy.deepcopy(base), copy.deepcopy(base)
+    Q.quantize_model(real, layer_to=Q.anyq_layer, pseudo=False, group_size=64)
+    Q.quantize_model(fake, layer_to=Q.anyq_layer, pseudo=True, group_size=64)
+    assert sum(type(m).__name__ == "Any4Linear" for m in real.modules()) == 7 * cfg.num_hidden_layers
+    assert type(real.lm_head).__name__ == "Linear"
+    ids = torch.randint(0, cfg.vocab_size, (2, 5), generator=torch.Generator().manual_seed(1)).to(DEV)
+    with torch.no_grad():
+        yb = base(input_ids=ids, use_cache=False).logits.float()
+        yr = real(input_ids=ids, use_cache=False).logits.float()
+        yf = fake(input_ids=ids, use_cache=False).logits.float()
+    assert torch.isfinite(yr).all()
+    assert (yr - yf).abs().max() <= 0.03 * yf.abs().max() + 1e-3, ((yr - yf).abs().max(), yf.abs().max())
+    assert (yf - yb).abs().max() > 0      # it is quantized...
+    assert (yr - yb).abs().max() <= 0.5 * yb.abs().max()  # ...and still the same model

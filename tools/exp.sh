@@ -1,3 +1,5 @@
-timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "stream or gemm_m_sweep or full_size" 2>&1 | tail -3
-C="8,4096,4096,1;16,2048,2048,1;4,8192,8192,1;8,4096,4096,0"
-timeout 300 python tools/quick_bench.py --configs "$C" --iters 3 --L 128 2>&1 | grep -E "^m=|steady"
+timeout 600 python -m pytest tests/test_gpu_decode.py -x -q -k hf_llama 2>&1 | tail -5
+timeout 600 python tools/microbenchmark.py --quantize anyq 2>&1 | grep -v amdgpu | tail -6
+timeout 600 python tools/microbenchmark.py --quantize intq 2>&1 | tail -5
+timeout 600 python tools/microbenchmark.py --quantize int8 2>&1 | tail -5
+timeout 1500 python tools/hf_benchmark.py --arch llama3_8b --layers 8 2>&1 | tail -9

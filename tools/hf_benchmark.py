@@ -1,0 +1,93 @@
+#!/usr/bin/env python3
+"""HuggingFace causal LM forward: 16-bit baseline vs `quantize_model(..., pseudo=False)` (counterpart of the reference's
+benchmark.py:113-215, same protocol: random input_ids[bs, seqlen], warm-up / iterations, wall-clock and device-only
+time, model size, peak memory).  There is no hub access here, so the model is built from a LlamaConfig with random
+weights (`--arch llama3_8b|llama2_7b|tiny`, `--layers N` to shorten); with a local checkpoint directory use
+`--model-path`.
+
+    python tools/hf_benchmark.py --arch llama3_8b --layers 8 --quantize anyq
+"""
+import argparse
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+import torch  # noqa: E402
+
+ARCH = {
+    "llama3_8b": dict(hidden_size=4096, intermediate_size=14336, num_hidden_layers=32, num_attention_heads=32,
+                      num_key_value_heads=8, vocab_size=128256, rope_theta=500000.0, max_position_embeddings=8192),
+    "llama2_7b": dict(hidden_size=4096, intermediate_size=11008, num_hidden_layers=32, num_attention_heads=32,
+                      num_key_value_heads=32, vocab_size=32000, max_position_embeddings=4096),
+    "tiny": dict(hidden_size=512, intermediate_size=1024, num_hidden_layers=2, num_attention_heads=8,
+                 num_key_value_heads=4, vocab_size=1024, max_position_embeddings=512),
+}
+
+
+def model_size_bytes(model) -> int:
+    return sum(p.numel() * p.element_size() for p in model.parameters()) + sum(b.numel() * b.element_size() for b in model.buffers())
+
+
+@torch.no_grad()
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--arch", default="llama3_8b", choices=sorted(ARCH))
+    ap.add_argument("--model-path", default=None, help="local HF checkpoint directory (optional)")
+    ap.add_argument("--layers", type=int, default=None)
+    ap.add_argument("--batch-size", type=int, default=1)
+    ap.add_argument("--seqlen", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--iters", type=int, default=50)
+    ap.add_argument("--quantize", default="anyq", choices=["anyq", "intq"])
+    ap.add_argument("--group-size", type=int, default=128)
+    a = ap.parse_args()
+    if not torch.cuda.is_available():
+        raise SystemExit("needs a GPU (no CPU fallback)")
+    from transformers import AutoModelForCausalLM, LlamaConfig
+
+    from any4_amd import quantize as Q
+    from any4_amd.bench_utils import benchmark_cuda_only_in_ms, benchmark_in_ms, memory_allocated_mb
+
+    torch.manual_seed(0)
+    if a.model_path:
+        model = AutoModelForCausalLM.from_pretrained(a.model_path, dtype=torch.bfloat16, local_files_only=True)
+    else:
+        cfg = dict(ARCH[a.arch])
+        if a.layers is not None:
+            cfg["num_hidden_layers"] = a.layers
+        model = AutoModelForCausalLM.from_config(LlamaConfig(**cfg), dtype=torch.bfloat16)
+    model = model.to("cuda").eval()
+    ids = torch.randint(0, model.config.vocab_size, (a.batch_size, a.seqlen), device="cuda")
+    mask = torch.ones_like(ids)
+    f = lambda m: m(input_ids=ids, attention_mask=mask, use_cache=False)
+
+    torch.cuda.reset_peak_memory_stats()
+    t, tc = benchmark_in_ms(f, a.warmup, a.iters, model), benchmark_cuda_only_in_ms(f, a.warmup, a.iters, model)
+    size0, peak0 = model_size_bytes(model), memory_allocated_mb()
+    ref = f(model).logits.float()
+
+    t0 = time.perf_counter()
+    layer_to = Q.anyq_layer if a.quantize == "anyq" else Q.intq_layer
+    Q.quantize_model(model, layer_from=torch.nn.Linear, layer_to=layer_to, pseudo=False, group_size=a.group_size)
+    torch.cuda.synchronize()
+    tq_quant = time.perf_counter() - t0
+    torch.cuda.reset_peak_memory_stats()
+    qt, qtc = benchmark_in_ms(f, a.warmup, a.iters, model), benchmark_cuda_only_in_ms(f, a.warmup, a.iters, model)
+    out = f(model).logits.float()
+    n_q = sum(type(m).__name__ in ("Any4Linear", "Int4Linear") for m in model.modules())
+
+    print(f"Model: {a.model_path or a.arch}  layers={model.config.num_hidden_layers}  bs={a.batch_size} seqlen={a.seqlen}")
+    print("Baseline:")
+    print(f"\tModel Size:\t{size0 / 2**30:.2f} GB\tPeak: {peak0:.0f} MB")
+    print(f"\tModel:\tTotal {t:.3f} ms\tCUDA {tc:.3f} ms")
+    print(f"Quantized ({a.quantize}, {n_q} linears swapped in {tq_quant:.1f} s):")
+    print(f"\tModel Size:\t{model_size_bytes(model) / 2**30:.2f} GB\tPeak: {memory_allocated_mb():.0f} MB")
+    print(f"\tModel:\tTotal {qt:.3f} ms\tCUDA {qtc:.3f} ms")
+    print(f"Speedup:\tTotal {t / qt:.2f}x\tCUDA {tc / qtc:.2f}x")
+    print(f"logits: max |quantized - baseline| = {(out - ref).abs().max():.3f} at max |baseline| = {ref.abs().max():.3f}")
+
+
+if __name__ == "__main__":
+    main()

@@ -38,6 +38,9 @@ __global__ void __launch_bounds__(1024) k(uint32_t* out, uint64_t* cyc, int iter
       if (KIND == 11) { if ((lane & 15) < 4) { u32x4 r = *(volatile __attribute__((address_space(3))) u32x4*)(uintptr_t)(((wave * 1024 + lane * 4) * 4 + (i & 3) * 1024) & 0xffff); v[i] ^= r[0]; } }
       if (KIND == 12) { uint32_t r = *(volatile __attribute__((address_space(3))) uint32_t*)(uintptr_t)(((wave * 1024 + lane) * 4 + (i & 3) * 1024) & 0xffff); v[i] ^= r; }
       if (KIND == 13) { if ((lane & 15) == 0) { uint32_t r = *(volatile __attribute__((address_space(3))) uint32_t*)(uintptr_t)(((wave * 1024 + lane) * 4 + (i & 3) * 1024) & 0xffff); v[i] ^= r; } }
+      if (KIND == 14) asm volatile("v_mov_b32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2" : "+v"(v[i]) : "v"(v[(i + 1) % N_UNROLL]));
+      if (KIND == 15) asm volatile("v_or_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(v[i]) : "v"(v[i]), "v"(base));
+      if (KIND == 16) asm volatile("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(v[i]) : "v"(8u), "v"(v[i]));
       if (KIND == 6) { if ((i & 7) == 7) { u32x4 a = {v[i], v[i-1], v[i-2], v[i-3]}; u32x4 b = {v[i-4], v[i-5], v[i-6], v[i-7]}; acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0); } }
     }
   }
@@ -127,6 +130,9 @@ int main() {
   run<4>("and_or+ds_read_b32+add", 32);
   run<5>("v_and_or", 32);
   run<6>("mfma16x16x32bf16", 4);
+  run<14>("v_mov_b32_sdwa preserve", 32);
+  run<15>("v_or_b32_sdwa byte sel", 32);
+  run<16>("v_lshlrev_b32_sdwa byte sel", 32);
   runl<128, 0>("ds_read_b128 full");
   runl<128, 1>("ds_read_b128 lanes%16==0");
   runl<128, 2>("ds_read_b128 bcast per 16-lane row");
