@@ -45,5 +45,28 @@ def benchmark_cuda_only_in_ms(f, warmup: int, iters: int, *args, **kwargs) -> fl
     return sum(e0.elapsed_time(e1) for e0, e1 in ev) / iters
 
 
+def benchmark_kernels_only_in_ms(f, warmup: int, iters: int, *args, **kwargs) -> float:
+    """Sum of the device kernels' own durations per call (torch.profiler / roctracer), cache flushed between calls.
+    An empty HIP-event pair already measures ~4.3 us on MI355X (tools/ubench/cold_launch.hip), which is comparable to
+    a whole 4-bit 4096x4096 GEMV; this number leaves that bracket out."""
+    global _flush
+    if _flush is None:
+        _flush = torch.empty(1 << 28, dtype=torch.float32, device="cuda")
+    for _ in range(warmup):
+        f(*args, **kwargs)
+    torch.cuda.synchronize()
+    with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CUDA]) as prof:
+        for _ in range(iters):
+            _flush.zero_()
+            f(*args, **kwargs)
+        torch.cuda.synchronize()
+    total_us = 0.0
+    for ev in prof.key_averages():
+        if "fill" in ev.key.lower() or "memset" in ev.key.lower():  # the flush
+            continue
+        total_us += getattr(ev, "self_device_time_total", 0.0) or getattr(ev, "self_cuda_time_total", 0.0)
+    return total_us / 1e3 / iters
+
+
 def memory_allocated_mb(device=None) -> float:
     return torch.cuda.max_memory_allocated(device) / 2 ** 20

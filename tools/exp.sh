@@ -1,5 +1,2 @@
-timeout 600 python -m pytest tests/test_gpu_decode.py -x -q -k hf_llama 2>&1 | tail -5
-timeout 600 python tools/microbenchmark.py --quantize anyq 2>&1 | grep -v amdgpu | tail -6
-timeout 600 python tools/microbenchmark.py --quantize intq 2>&1 | tail -5
-timeout 600 python tools/microbenchmark.py --quantize int8 2>&1 | tail -5
-timeout 1500 python tools/hf_benchmark.py --arch llama3_8b --layers 8 2>&1 | tail -9
+for d in 4096 8192; do for q in anyq intq; do echo "== $d $q"; timeout 300 python tools/microbenchmark.py --input-dim $d --output-dim $d --quantize $q 2>&1 | grep -v amdgpu | tail -5; done; done
+echo "== nf4-style global LUT"; timeout 300 python tools/microbenchmark.py --quantize anyq --quantize-args per_row=False 2>&1 | tail -3

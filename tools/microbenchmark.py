@@ -39,14 +39,15 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("needs a GPU (no CPU fallback)")
     from any4_amd import quantize as Q
-    from any4_amd.bench_utils import benchmark_cuda_only_in_ms, benchmark_in_ms
+    from any4_amd.bench_utils import benchmark_cuda_only_in_ms, benchmark_in_ms, benchmark_kernels_only_in_ms
 
     dtype = getattr(torch, a.dtype)
     x = torch.randn(a.batch_size * a.seqlen, a.input_dim, dtype=dtype, device="cuda")
     linear = torch.nn.Linear(a.input_dim, a.output_dim, dtype=dtype, device="cuda", bias=False)
     t, tc = benchmark_in_ms(linear, a.warmup, a.iters, x), benchmark_cuda_only_in_ms(linear, a.warmup, a.iters, x)
+    tk = benchmark_kernels_only_in_ms(linear, a.warmup, a.iters, x)
     print("Baseline:")
-    print(f"\tTotal: {t:.4f} ms\tCUDA: {tc:.4f} ms")
+    print(f"\tTotal: {t:.4f} ms\tCUDA: {tc:.4f} ms\tkernels only: {tk:.4f} ms")
     if a.quantize != "none":
         kw = parse_kv(a.quantize_args)
         if a.quantize == "anyq":
@@ -62,9 +63,10 @@ def main():
             q.weight.data, q.scales_and_zeros.data = group_quantize_tensor(linear.weight, 8, g)
             q.reshape_weight()
         qt, qtc = benchmark_in_ms(q, a.warmup, a.iters, x), benchmark_cuda_only_in_ms(q, a.warmup, a.iters, x)
+        qtk = benchmark_kernels_only_in_ms(q, a.warmup, a.iters, x)
         print("Quantized:")
-        print(f"\tTotal: {qt:.4f} ms\tCUDA: {qtc:.4f} ms")
-        print(f"Speedup:\tTotal {t / qt:.2f}x\tCUDA {tc / qtc:.2f}x")
+        print(f"\tTotal: {qt:.4f} ms\tCUDA: {qtc:.4f} ms\tkernels only: {qtk:.4f} ms")
+        print(f"Speedup:\tTotal {t / qt:.2f}x\tCUDA {tc / qtc:.2f}x\tkernels only {tk / qtk:.2f}x")
 
 
 if __name__ == "__main__":
