@@ -103,7 +103,7 @@ __global__ void __launch_bounds__(WAVES * 64, MINW) w4_gemm_stream_kernel(const 
   const int NU = p.units_per_lane;
   const int u_first = (slice * 4 + Q) * NU;  // this lane's first unit
 
-  // ---- X staging: thread -> (staged row, 16-byte piece); staged row = (act row c, slice, quarter) ----
+  // ---- X staging: thread -> (staged row, 16-byte piece); staged row = (quarter, slice, act row c) ----
   const int mrows = min(p.m - ct * 16, 16);
   // shared slab: rows of every k-slice of the workgroup; private slab: only this wave's slice
   const int xrows = (PRIVX || XRES) ? mrows * 4 : mrows * 4 * p.splitk;
@@ -117,9 +117,12 @@ __global__ void __launch_bounds__(WAVES * 64, MINW) w4_gemm_stream_kernel(const 
     const int pid = (PRIVX ? lane : tid) + j * NSTAGE;
     const int srow = pid / PPR, pc = pid % PPR;
     xs_on[j] = srow < xrows;
-    const int sq = srow & 3;
-    const int ssl = PRIVX ? slice : (srow >> 2) & (p.splitk - 1);
-    const int sc = PRIVX ? srow >> 2 : srow >> (2 + p.sk_shift);
+    // staged row order [quarter][slice][act row]: the 16 lanes (c = 0..15) of one lane-row read CONSECUTIVE slab rows,
+    // whose +16-byte rotation spreads them over the LDS banks (measured: halves SQ_LDS_BANK_CONFLICT of the Aint4
+    // shared-slab launches against the [act row][quarter] order)
+    const int sc = srow % mrows, st_ = srow / mrows;
+    const int ssl = PRIVX ? slice : st_ & (p.splitk - 1);
+    const int sq = PRIVX ? st_ : st_ >> p.sk_shift;
     const int xr = min(ct * 16 + sc, p.m - 1);
     xs_rowbase[j] = (uint32_t)(xr * p.k * 2);
     xs_in[j] = (uint32_t)((((ssl * 4 + sq) * NU) * UNIT + pc * 8) * 2);
@@ -143,15 +146,15 @@ __global__ void __launch_bounds__(WAVES * 64, MINW) w4_gemm_stream_kernel(const 
   };
   // this lane's fragment row in a staged slab.  MFMA columns >= m are never stored; they read the all-zero row
   // behind the staged rows (zero operands keep the multipliers of the unused columns quiet -> less power, more clock).
-  const int frow = i >= mrows ? xrows : ((PRIVX || XRES) ? i * 4 + Q : ((i << p.sk_shift) + slice) * 4 + Q);
+  const int frow = i >= mrows ? xrows : ((PRIVX || XRES) ? Q * mrows + i : ((Q << p.sk_shift) + slice) * mrows + i);
   const uint32_t xfrag = lds_x + (uint32_t)(frow * (XRES ? p.xslab_bytes : XROW));
   if constexpr (XRES) {
     // resident X: stage every (act row, quarter) k-span once; the zero row (one unit long) sits behind them
     const int ppr = NU * (UNIT / 8);  // 16-byte pieces per staged row
     for (int pid = tid; pid < xrows * ppr; pid += WAVES * 64) {
-      const int srow = pid / ppr, pc = pid - srow * ppr;
-      const int xr = min(ct * 16 + (srow >> 2), p.m - 1);
-      const uint32_t inrow = min((uint32_t)((((srow & 3) * NU) * UNIT + pc * 8) * 2), xrow_last);
+      const int srow = pid / ppr, pc = pid - srow * ppr;  // srow = quarter * mrows + act row
+      const int xr = min(ct * 16 + srow % mrows, p.m - 1);
+      const uint32_t inrow = min((uint32_t)((((srow / mrows) * NU) * UNIT + pc * 8) * 2), xrow_last);
       *(lds_u32x4ptr)(lds_x + (uint32_t)(srow * p.xslab_bytes + pc * 16)) =
           *reinterpret_cast<const u32x4*>(xb + ((uint32_t)(xr * p.k * 2) + inrow));
     }
