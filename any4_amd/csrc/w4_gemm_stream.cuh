@@ -120,9 +120,10 @@ __global__ void __launch_bounds__(WAVES * 64, MINW) w4_gemm_stream_kernel(const 
     // staged row order [quarter][slice][act row]: the 16 lanes (c = 0..15) of one lane-row read CONSECUTIVE slab rows,
     // whose +16-byte rotation spreads them over the LDS banks (measured: halves SQ_LDS_BANK_CONFLICT of the Aint4
     // shared-slab launches against the [act row][quarter] order)
-    const int sc = srow % mrows, st_ = srow / mrows;
+    // (private slabs exist for m = 1 only, where both orders coincide: keep the shift-only form there)
+    const int sc = PRIVX ? srow >> 2 : srow % mrows, st_ = PRIVX ? 0 : srow / mrows;
     const int ssl = PRIVX ? slice : st_ & (p.splitk - 1);
-    const int sq = PRIVX ? st_ : st_ >> p.sk_shift;
+    const int sq = PRIVX ? srow & 3 : st_ >> p.sk_shift;
     const int xr = min(ct * 16 + sc, p.m - 1);
     xs_rowbase[j] = (uint32_t)(xr * p.k * 2);
     xs_in[j] = (uint32_t)((((ssl * 4 + sq) * NU) * UNIT + pc * 8) * 2);
@@ -146,7 +147,7 @@ __global__ void __launch_bounds__(WAVES * 64, MINW) w4_gemm_stream_kernel(const 
   };
   // this lane's fragment row in a staged slab.  MFMA columns >= m are never stored; they read the all-zero row
   // behind the staged rows (zero operands keep the multipliers of the unused columns quiet -> less power, more clock).
-  const int frow = i >= mrows ? xrows : ((PRIVX || XRES) ? Q * mrows + i : ((Q << p.sk_shift) + slice) * mrows + i);
+  const int frow = i >= mrows ? xrows : (PRIVX ? i * 4 + Q : (XRES ? Q * mrows + i : ((Q << p.sk_shift) + slice) * mrows + i));
   const uint32_t xfrag = lds_x + (uint32_t)(frow * (XRES ? p.xslab_bytes : XROW));
   if constexpr (XRES) {
     // resident X: stage every (act row, quarter) k-span once; the zero row (one unit long) sits behind them
