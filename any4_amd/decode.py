@@ -226,11 +226,15 @@ class DecodeStack(torch.nn.Module):
 
     def __init__(self, cfg: DecodeConfig, linear_factory: Callable, device, dtype=torch.bfloat16, bs: int = 1,
                  rank: int = 0, world: int = 1, group=None, seed: int = 0, lm_head: bool = True,
-                 fused: Optional[bool] = None):
+                 fused: Optional[bool] = None, emulate_gather: bool = False):
         """fused: run the non-GEMM parts on the HIP glue kernels (default on a GPU) or as plain torch ops
-        (the formulation the glue kernels are tested against; also what runs in the CPU plumbing tests)."""
+        (the formulation the glue kernels are tested against; also what runs in the CPU plumbing tests).
+        emulate_gather: TIMING ONLY -- build rank `rank` of `world` in a single process and replace every all-gather
+        by a local copy of the rank's shard into all `world` slots (the values are meaningless): the per-GPU compute
+        of a TP=world decode step, without the interconnect."""
         super().__init__()
         self.cfg, self.bs, self.rank, self.world, self.group = cfg, bs, rank, world, group
+        self.emulate_gather = emulate_gather
         self.fused = torch.device(device).type == "cuda" if fused is None else fused
         gen = torch.Generator(device=device).manual_seed(seed)
         self.embed = torch.nn.Embedding(cfg.vocab, cfg.hidden, device=device, dtype=dtype)
@@ -260,6 +264,8 @@ class DecodeStack(torch.nn.Module):
         if self.world == 1:
             return y
         y = y.contiguous()
+        if self.emulate_gather:
+            return y.repeat(1, self.world)
         parts = torch.empty((self.world,) + tuple(y.shape), dtype=y.dtype, device=y.device)
         if dist.get_backend(self.group) == "nccl":
             dist.all_gather_into_tensor(parts, y, group=self.group)

@@ -26,13 +26,13 @@ def time_steps(stack, steps, warmup, start_pos):
     tok = torch.randint(0, stack.cfg.vocab, (stack.bs,), device=stack.tokens.device)
     for i in range(warmup):
         stack.decode(tok, start_pos + i)
-    if stack.world > 1:
+    if dist.is_initialized():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(steps):
         stack.decode(tok, start_pos + warmup + i)
-    if stack.world > 1:
+    if dist.is_initialized():
         dist.barrier()
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / steps
@@ -50,6 +50,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--baseline", action="store_true", help="also time the same stack with 16-bit nn.Linear")
     ap.add_argument("--kernel", default="linear_y_f16RM_x_f16RM_W_any4TC")
+    ap.add_argument("--emulate-tp", type=int, default=0,
+                    help="single process, timing only: build rank 0 of a TP=N model and replace the all-gathers by local "
+                         "copies -> per-GPU compute time of a TP=N step without the interconnect")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -75,7 +78,10 @@ def main():
         torch.cuda.reset_peak_memory_stats(device)
         fac = factory_cls(cfg, device, torch.bfloat16, seed=1 + rank) if factory_cls is DenseFactory else \
             factory_cls(cfg, device, torch.bfloat16, seed=1 + rank, kernel=a.kernel)
-        stack = DecodeStack(cfg, fac, device, torch.bfloat16, bs=a.bs, rank=rank, world=world)
+        if a.emulate_tp > 1:
+            stack = DecodeStack(cfg, fac, device, torch.bfloat16, bs=a.bs, rank=0, world=a.emulate_tp, emulate_gather=True)
+        else:
+            stack = DecodeStack(cfg, fac, device, torch.bfloat16, bs=a.bs, rank=rank, world=world)
         graph = False
         if not a.no_graph:
             try:
@@ -94,7 +100,7 @@ def main():
         torch.cuda.empty_cache()
         return out
 
-    res = {"config": a.config, "layers": cfg.layers, "bs": a.bs, "tp": world, "max_seq": cfg.max_seq,
+    res = {"config": a.config, "layers": cfg.layers, "bs": a.bs, "tp": world, "emulated_tp_compute_only": a.emulate_tp or None, "max_seq": cfg.max_seq,
            "steps": a.steps, "warmup": a.warmup, "data": "synthetic (random weights, random tokens)",
            "algorithmic_4bit_bytes_per_token": cfg.weight_bytes_4bit()}
     res["any4"] = run(Any4Factory, "any4")
