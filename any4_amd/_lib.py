@@ -48,6 +48,11 @@ SYMBOLS = {
                    ctypes.c_int, ctypes.c_int, _vp],
     "dg_decode_attn": [_vp, _vp, _vp, _vp, _vp, _i64, ctypes.c_int, ctypes.c_int, ctypes.c_int, _i64, ctypes.c_float,
                        ctypes.c_int, ctypes.c_int, _vp],
+    "dg_rope_attn": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, ctypes.c_int, ctypes.c_int, ctypes.c_int, _i64, ctypes.c_float,
+                     ctypes.c_int, ctypes.c_int, _vp],
+    "dg_rope_attn_split_scratch_bytes": [_i64, ctypes.c_int, ctypes.c_int, ctypes.c_int],
+    "dg_rope_attn_split": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, ctypes.c_int, ctypes.c_int, ctypes.c_int, _i64,
+                           ctypes.c_float, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp],
     "dg_swiglu": [_vp, _vp, _i64, _i64, ctypes.c_int, ctypes.c_int, _vp],
 }
 
@@ -71,7 +76,8 @@ def load() -> ctypes.CDLL:
         except AttributeError as e:  # a stale build: the header declares a symbol the .so does not export
             raise ImportError(f"{LIB_PATH} does not export {name}; rebuild with `python -m any4_amd.build`") from e
         fn.argtypes = argtypes
-        fn.restype = ctypes.c_char_p if name == "tg_error_string" else ctypes.c_int
+        fn.restype = (ctypes.c_char_p if name == "tg_error_string" else
+                      ctypes.c_int64 if name == "dg_rope_attn_split_scratch_bytes" else ctypes.c_int)
     if lib.tg_abi_version() != 1:
         raise ImportError(f"{LIB_PATH}: ABI version {lib.tg_abi_version()} != 1; rebuild")
     _lib = lib

@@ -79,6 +79,61 @@ __global__ void __launch_bounds__(256) add_rmsnorm_kernel(const u32x4* h, const 
   }
 }
 
+// q . K[s] over d = 8 * d8 elements, fp32, in element order; the 16-byte loads are issued eight at a time (a
+// position's key row is one dependent L2 round trip otherwise).
+template <typename DT>
+__device__ __forceinline__ float qk_dot(const float* qf, const u32x4* __restrict__ Krow, int d8) {
+  float acc = 0.f;
+  for (int v0 = 0; v0 < d8; v0 += 8) {
+    u32x4 kk[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (v0 + u < d8) kk[u] = Krow[v0 + u];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (v0 + u < d8) {
+        float kf[8];
+        unpack8<DT>(kk[u], kf);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc = fmaf(qf[(v0 + u) * 8 + e], kf[e], acc);
+      }
+    }
+  }
+  return acc;
+}
+
+// value contraction of one thread: acc[e] += p[s] * V[s][vc*8 + e] over s = part, part + nparts, ... (ascending).
+// Eight independent 16-byte loads are kept in flight: the loop is latency-bound (one L2 round trip per position).
+// `vnew` (LDS, may be null) supplies position S - 1 when the cache row was written by this very launch.
+template <typename DT>
+__device__ __forceinline__ void pv_accumulate(const u32x4* __restrict__ V, const float* vnew, const float* sc, float inv,
+                                              int S, int d8, int vc, int part, int nparts, float (&acc)[8], int first = 0) {
+  for (int s0 = part + first; s0 < S; s0 += nparts * 8) {
+    u32x4 vv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int s = s0 + u * nparts;
+      if (s < S && !(vnew && s == S - 1)) vv[u] = V[(int64_t)s * d8 + vc];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int s = s0 + u * nparts;
+      if (s < S) {
+        const float p = round16<DT>(sc[s] * inv);  // probabilities are cast to 16 bit before the matmul
+        float vf[8];
+        if (vnew && s == S - 1) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) vf[e] = vnew[vc * 8 + e];
+        } else {
+          unpack8<DT>(vv[u], vf);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = fmaf(p, vf[e], acc[e]);
+      }
+    }
+  }
+}
+
 // ---- rotary embedding + KV-cache write: block = one head of one sequence, thread = one rotation pair ----
 template <typename DT>
 __global__ void rope_kv_kernel(const uint16_t* __restrict__ qkv, const float* __restrict__ cos, const float* __restrict__ sin,
@@ -122,13 +177,7 @@ __global__ void __launch_bounds__(256) decode_attn_kernel(const uint16_t* __rest
   const u32x4* V = reinterpret_cast<const u32x4*>(v_cache + ((int64_t)b * kvl + kv) * max_seq * d);
   float mx = -INFINITY;
   for (int s = t; s < S; s += 256) {
-    float acc = 0.f;
-    for (int v = 0; v < d8; ++v) {
-      float kf[8];
-      unpack8<DT>(K[(int64_t)s * d8 + v], kf);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) acc = fmaf(qf[v * 8 + e], kf[e], acc);
-    }
+    const float acc = qk_dot<DT>(qf, K + (int64_t)s * d8, d8);
     const float x = round16<DT>(acc) * scale;  // the score matrix is a 16-bit tensor in the torch formulation
     sc[s] = x;
     mx = fmaxf(mx, x);
@@ -145,13 +194,7 @@ __global__ void __launch_bounds__(256) decode_attn_kernel(const uint16_t* __rest
   // value contraction: thread = (8-wide column vc, position partition part)
   const int vc = t % d8, part = t / d8, nparts = 256 / d8;
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  for (int s = part; s < S; s += nparts) {
-    const float p = round16<DT>(sc[s] * inv);  // probabilities are cast to 16 bit before the matmul
-    float vf[8];
-    unpack8<DT>(V[(int64_t)s * d8 + vc], vf);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) acc[e] = fmaf(p, vf[e], acc[e]);
-  }
+  pv_accumulate<DT>(V, nullptr, sc, inv, S, d8, vc, part, nparts, acc);
   __syncthreads();  // everyone is done reading the scores; reuse them as [nparts][d] partial outputs
 #pragma unroll
   for (int e = 0; e < 8; ++e) sc[part * d + vc * 8 + e] = acc[e];
@@ -161,6 +204,231 @@ __global__ void __launch_bounds__(256) decode_attn_kernel(const uint16_t* __rest
     for (int p = 0; p < nparts; ++p) o += sc[p * d + t];
     out[((int64_t)b * hl + h) * d + t] = DT::from_f32(o);
   }
+}
+
+// ---- RoPE + KV-cache write + decode attention in one launch: block = one query head of one sequence ----
+// Every block rotates its own q head and the k head of its KV group, writes k / v of the new token into the caches
+// (the hl/kvl blocks of a group write identical bytes) and uses its LDS copy for position *pos, so nothing is read
+// back from global memory within the launch.  Same arithmetic, in the same order, as rope_kv_kernel + decode_attn_kernel.
+template <typename DT>
+__global__ void __launch_bounds__(256) rope_attn_kernel(const uint16_t* __restrict__ qkv, const float* __restrict__ cos,
+                                                        const float* __restrict__ sin, const int64_t* __restrict__ pos_p,
+                                                        uint16_t* __restrict__ k_cache, uint16_t* __restrict__ v_cache,
+                                                        uint16_t* __restrict__ out, int hl, int kvl, int d, int64_t max_seq,
+                                                        float scale) {
+  extern __shared__ float sm[];  // [256 q] [256 k_new] [256 v_new] [4 scratch] [scores]
+  float* qf = sm;
+  float* kn = sm + 256;
+  float* vn = sm + 512;
+  float* scratch = sm + 768;
+  float* sc = sm + 772;
+  const int b = blockIdx.x / hl, h = blockIdx.x % hl, kv = h / (hl / kvl), t = threadIdx.x;
+  const int64_t pos = *pos_p;
+  const int S = (int)pos + 1, d8 = d >> 3, d2 = d >> 1;
+  const uint16_t* row = qkv + (int64_t)b * (hl + 2 * kvl) * d;
+  uint16_t* kdst = k_cache + (((int64_t)b * kvl + kv) * max_seq + pos) * d;
+  uint16_t* vdst = v_cache + (((int64_t)b * kvl + kv) * max_seq + pos) * d;
+  // Issue every cache read this thread will need first -- its key row and the first eight value vectors of its
+  // partition -- so that the HBM round trips of qkv / K / V overlap instead of following each other (the KV cache of a
+  // layer is cold: ~4 GB of weights have streamed through the caches since the previous token).
+  const u32x4* K = reinterpret_cast<const u32x4*>(k_cache + ((int64_t)b * kvl + kv) * max_seq * d);
+  const u32x4* V = reinterpret_cast<const u32x4*>(v_cache + ((int64_t)b * kvl + kv) * max_seq * d);
+  const int vc = t % d8, part = t / d8, nparts = 256 / d8;
+  const bool kpre = d8 <= 16 && t < S - 1;
+  u32x4 kreg[16], vpre[8];
+  if (kpre) {
+#pragma unroll
+    for (int v = 0; v < 16; ++v)
+      if (v < d8) kreg[v] = K[(int64_t)t * d8 + v];
+  }
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int sv = part + u * nparts;
+    if (sv < S - 1) vpre[u] = V[(int64_t)sv * d8 + vc];
+  }
+  if (t < d) {  // threads 0..d2-1 rotate q, d2..d-1 rotate k (one rotation pair each)
+    const bool isk = t >= d2;
+    const int j = isk ? t - d2 : t;
+    const uint16_t* src = row + (isk ? (hl + kv) * d : h * d);
+    const float x1 = DT::to_f32(src[j]), x2 = DT::to_f32(src[j + d2]);
+    const float c1 = cos[pos * d + j], c2 = cos[pos * d + j + d2], s1 = sin[pos * d + j], s2 = sin[pos * d + j + d2];
+    const uint16_t o1 = DT::from_f32(__fadd_rn(__fmul_rn(x1, c1), __fmul_rn(-x2, s1)));
+    const uint16_t o2 = DT::from_f32(__fadd_rn(__fmul_rn(x2, c2), __fmul_rn(x1, s2)));
+    float* dstf = isk ? kn : qf;
+    dstf[j] = DT::to_f32(o1);
+    dstf[j + d2] = DT::to_f32(o2);
+    if (isk) { kdst[j] = o1; kdst[j + d2] = o2; }
+    const uint16_t vraw = row[(hl + kvl + kv) * d + t];
+    vn[t] = DT::to_f32(vraw);
+    vdst[t] = vraw;
+  }
+  __syncthreads();
+  float mx = -INFINITY;
+  for (int s = t; s < S; s += 256) {
+    float acc = 0.f;
+    if (s == S - 1) {
+      for (int e = 0; e < d; ++e) acc = fmaf(qf[e], kn[e], acc);
+    } else if (kpre && s == t) {
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        if (v < d8) {
+          float kf[8];
+          unpack8<DT>(kreg[v], kf);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc = fmaf(qf[v * 8 + e], kf[e], acc);
+        }
+      }
+    } else {
+      acc = qk_dot<DT>(qf, K + (int64_t)s * d8, d8);
+    }
+    const float x = round16<DT>(acc) * scale;
+    sc[s] = x;
+    mx = fmaxf(mx, x);
+  }
+  mx = block_reduce<true>(mx, scratch);
+  float sum = 0.f;
+  for (int s = t; s < S; s += 256) {
+    const float e = __expf(sc[s] - mx);
+    sc[s] = e;
+    sum += e;
+  }
+  const float inv = 1.f / block_reduce<false>(sum, scratch);
+  __syncthreads();
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {  // first batch: the prefetched vectors (same order as pv_accumulate)
+    const int sv = part + u * nparts;
+    if (sv < S) {
+      const float p = round16<DT>(sc[sv] * inv);
+      float vf[8];
+      if (sv == S - 1) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) vf[e] = vn[vc * 8 + e];
+      } else {
+        unpack8<DT>(vpre[u], vf);
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] = fmaf(p, vf[e], acc[e]);
+    }
+  }
+  pv_accumulate<DT>(V, vn, sc, inv, S, d8, vc, part, nparts, acc, nparts * 8);
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < 8; ++e) sc[part * d + vc * 8 + e] = acc[e];
+  __syncthreads();
+  if (t < d) {
+    float o = 0.f;
+    for (int p = 0; p < nparts; ++p) o += sc[p * d + t];
+    out[((int64_t)b * hl + h) * d + t] = DT::from_f32(o);
+  }
+}
+
+// ---- split-S variant of rope_attn_kernel: grid (bs * hl, NS); block (bh, c) handles positions [c * CS, (c + 1) * CS)
+// with CS = ceil((*pos + 1) / NS), writes (max, sum, unnormalised output) of its chunk to `part`, and the LAST block of a
+// head to arrive (atomic counter, self-resetting, so the launch is replayable in a graph) combines the NS partials.
+// One block per head leaves 7/8 of the CUs idle and walks a long context at ~40 ns per position; this one fills the GPU.
+// Softmax statistics are combined flash-decoding style, so probabilities are normalised AFTER the value contraction
+// (the single-block kernels round normalised probabilities to 16 bit first): same result within 16-bit rounding.
+template <typename DT>
+__global__ void __launch_bounds__(256) rope_attn_split_kernel(const uint16_t* __restrict__ qkv, const float* __restrict__ cos,
+                                                              const float* __restrict__ sin, const int64_t* __restrict__ pos_p,
+                                                              uint16_t* __restrict__ k_cache, uint16_t* __restrict__ v_cache,
+                                                              uint16_t* __restrict__ out, float* part, int* counters, int hl,
+                                                              int kvl, int d, int64_t max_seq, float scale) {
+  extern __shared__ float sm[];  // [256 q] [256 k_new] [256 v_new] [4 scratch] [scores / partial outputs]
+  float* qf = sm;
+  float* kn = sm + 256;
+  float* vn = sm + 512;
+  float* scratch = sm + 768;
+  float* sc = sm + 772;
+  __shared__ int s_last;
+  const int bh = blockIdx.x, c = blockIdx.y, NS = gridDim.y;
+  const int b = bh / hl, h = bh % hl, kv = h / (hl / kvl), t = threadIdx.x;
+  const int64_t pos = *pos_p;
+  const int S = (int)pos + 1, d8 = d >> 3, d2 = d >> 1;
+  const int CS = (S + NS - 1) / NS;
+  const int c0 = c * CS, c1 = min(S, c0 + CS);  // may be empty
+  const bool owner = c0 <= (int)pos && (int)pos < c1;  // this block's chunk holds the new token
+  const uint16_t* row = qkv + (int64_t)b * (hl + 2 * kvl) * d;
+  if (t < d) {
+    const bool isk = t >= d2;
+    const int j = isk ? t - d2 : t;
+    const uint16_t* src = row + (isk ? (hl + kv) * d : h * d);
+    const float x1 = DT::to_f32(src[j]), x2 = DT::to_f32(src[j + d2]);
+    const float cs1 = cos[pos * d + j], cs2 = cos[pos * d + j + d2], s1 = sin[pos * d + j], s2 = sin[pos * d + j + d2];
+    const uint16_t o1 = DT::from_f32(__fadd_rn(__fmul_rn(x1, cs1), __fmul_rn(-x2, s1)));
+    const uint16_t o2 = DT::from_f32(__fadd_rn(__fmul_rn(x2, cs2), __fmul_rn(x1, s2)));
+    float* dstf = isk ? kn : qf;
+    dstf[j] = DT::to_f32(o1);
+    dstf[j + d2] = DT::to_f32(o2);
+    const uint16_t vraw = row[(hl + kvl + kv) * d + t];
+    vn[t] = DT::to_f32(vraw);
+    if (owner) {
+      uint16_t* kdst = k_cache + (((int64_t)b * kvl + kv) * max_seq + pos) * d;
+      uint16_t* vdst = v_cache + (((int64_t)b * kvl + kv) * max_seq + pos) * d;
+      if (isk) { kdst[j] = o1; kdst[j + d2] = o2; }
+      vdst[t] = vraw;
+    }
+  }
+  __syncthreads();
+  const u32x4* K = reinterpret_cast<const u32x4*>(k_cache + ((int64_t)b * kvl + kv) * max_seq * d);
+  const u32x4* V = reinterpret_cast<const u32x4*>(v_cache + ((int64_t)b * kvl + kv) * max_seq * d);
+  float mx = -INFINITY;
+  for (int s = c0 + t; s < c1; s += 256) {
+    float acc = 0.f;
+    if (s == S - 1) {
+      for (int e = 0; e < d; ++e) acc = fmaf(qf[e], kn[e], acc);
+    } else {
+      acc = qk_dot<DT>(qf, K + (int64_t)s * d8, d8);
+    }
+    const float x = round16<DT>(acc) * scale;
+    sc[s - c0] = x;
+    mx = fmaxf(mx, x);
+  }
+  mx = block_reduce<true>(mx, scratch);
+  float sum = 0.f;
+  for (int s = c0 + t; s < c1; s += 256) {
+    const float e = __expf(sc[s - c0] - mx);
+    sc[s - c0] = e;
+    sum += e;
+  }
+  sum = block_reduce<false>(sum, scratch);
+  __syncthreads();
+  const int vc = t % d8, prt = t / d8, nparts = 256 / d8;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  // positions are chunk-relative inside pv_accumulate: shift the row pointer, the new token is the chunk's last row
+  pv_accumulate<DT>(V + (int64_t)c0 * d8, owner ? vn : nullptr, sc, 1.0f, c1 > c0 ? c1 - c0 : 0, d8, vc, prt, nparts, acc);
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < 8; ++e) sc[prt * d + vc * 8 + e] = acc[e];
+  __syncthreads();
+  float* mine = part + ((int64_t)bh * NS + c) * (d + 2);
+  if (t < d) {
+    float o = 0.f;
+    for (int p = 0; p < nparts; ++p) o += sc[p * d + t];
+    mine[2 + t] = o;
+  }
+  if (t == 0) { mine[0] = mx; mine[1] = sum; }
+  __threadfence();
+  __syncthreads();
+  if (t == 0) s_last = atomicAdd(&counters[bh], 1) == NS - 1;
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  if (t < d) {
+    const float* base = part + (int64_t)bh * NS * (d + 2);
+    float M = -INFINITY;
+    for (int i = 0; i < NS; ++i) M = fmaxf(M, __hip_atomic_load(base + i * (d + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    float L = 0.f, o = 0.f;
+    for (int i = 0; i < NS; ++i) {
+      const float mi = __hip_atomic_load(base + i * (d + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const float w = mi == -INFINITY ? 0.f : __expf(mi - M);
+      L += w * __hip_atomic_load(base + i * (d + 2) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      o += w * __hip_atomic_load(base + i * (d + 2) + 2 + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    out[((int64_t)b * hl + h) * d + t] = DT::from_f32(o / L);
+  }
+  if (t == 0) counters[bh] = 0;  // ready for the next launch / graph replay
 }
 
 // ---- SwiGLU ----------------------------------------------------------------------------------------
@@ -224,6 +492,53 @@ int dg_decode_attn(const void* q, const void* k_cache, const void* v_cache, cons
   hipLaunchKernelGGL(kern, dim3((unsigned)(bs * hl)), dim3(256), lds, (hipStream_t)stream, (const uint16_t*)q,
                      (const uint16_t*)k_cache, (const uint16_t*)v_cache, pos, (uint16_t*)out, hl, kvl, d, max_seq, scale);
   return launch_status();
+}
+
+int dg_rope_attn(const void* qkv, const float* cos, const float* sin, const int64_t* pos, void* k_cache, void* v_cache,
+                 void* out, int64_t bs, int hl, int kvl, int d, int64_t max_seq, float scale, int dtype, int device,
+                 tg_stream_t stream) {
+  if (!qkv || !cos || !sin || !pos || !k_cache || !v_cache || !out) return TG_E_NULL;
+  if (!(dtype == TG_BF16 || dtype == TG_F16)) return TG_E_DTYPE;
+  if (bs <= 0 || hl <= 0 || kvl <= 0 || hl % kvl != 0 || d < 8 || d % 8 != 0 || d > 256 || (256 % (d / 8)) != 0 ||
+      max_seq <= 0 || max_seq > 8192 || bs * hl > INT32_MAX)
+    return TG_E_SHAPE;
+  if (!aligned16(k_cache) || !aligned16(v_cache)) return TG_E_ALIGN;
+  DeviceScope ds(device);
+  if (!ds.ok) return TG_E_DEVICE;
+  const int64_t sc_floats = max_seq > (256 / (d / 8)) * (int64_t)d ? max_seq : (256 / (d / 8)) * (int64_t)d;
+  const unsigned lds = (unsigned)((772 + sc_floats) * sizeof(float));
+  auto kern = dtype == TG_BF16 ? rope_attn_kernel<BF16> : rope_attn_kernel<F16>;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(bs * hl)), dim3(256), lds, (hipStream_t)stream, (const uint16_t*)qkv, cos, sin, pos,
+                     (uint16_t*)k_cache, (uint16_t*)v_cache, (uint16_t*)out, hl, kvl, d, max_seq, scale);
+  return launch_status();
+}
+
+int dg_rope_attn_split(const void* qkv, const float* cos, const float* sin, const int64_t* pos, void* k_cache, void* v_cache,
+                       void* out, void* scratch, int64_t scratch_bytes, int64_t bs, int hl, int kvl, int d, int64_t max_seq,
+                       float scale, int nsplit, int dtype, int device, tg_stream_t stream) {
+  if (!qkv || !cos || !sin || !pos || !k_cache || !v_cache || !out || !scratch) return TG_E_NULL;
+  if (!(dtype == TG_BF16 || dtype == TG_F16)) return TG_E_DTYPE;
+  if (bs <= 0 || hl <= 0 || kvl <= 0 || hl % kvl != 0 || d < 8 || d % 8 != 0 || d > 256 || (256 % (d / 8)) != 0 ||
+      max_seq <= 0 || max_seq > 65536 || bs * hl > INT32_MAX || nsplit < 1 || nsplit > 64)
+    return TG_E_SHAPE;
+  if (scratch_bytes < dg_rope_attn_split_scratch_bytes(bs, hl, d, nsplit)) return TG_E_SHAPE;
+  if (!aligned16(k_cache) || !aligned16(v_cache) || !aligned16(scratch)) return TG_E_ALIGN;
+  DeviceScope ds(device);
+  if (!ds.ok) return TG_E_DEVICE;
+  const int64_t cs = (max_seq + nsplit - 1) / nsplit;
+  const int64_t sc_floats = cs > (256 / (d / 8)) * (int64_t)d ? cs : (256 / (d / 8)) * (int64_t)d;
+  const unsigned lds = (unsigned)((772 + sc_floats) * sizeof(float));
+  if (lds > 64u * 1024u) return TG_E_SHAPE;
+  int* counters = reinterpret_cast<int*>(scratch);
+  float* part = reinterpret_cast<float*>(reinterpret_cast<char*>(scratch) + ((bs * hl * 4 + 15) / 16) * 16);
+  auto kern = dtype == TG_BF16 ? rope_attn_split_kernel<BF16> : rope_attn_split_kernel<F16>;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(bs * hl), (unsigned)nsplit), dim3(256), lds, (hipStream_t)stream, (const uint16_t*)qkv,
+                     cos, sin, pos, (uint16_t*)k_cache, (uint16_t*)v_cache, (uint16_t*)out, part, counters, hl, kvl, d, max_seq, scale);
+  return launch_status();
+}
+
+int64_t dg_rope_attn_split_scratch_bytes(int64_t bs, int hl, int d, int nsplit) {
+  return ((bs * hl * 4 + 15) / 16) * 16 + bs * hl * (int64_t)nsplit * (d + 2) * 4;
 }
 
 int dg_swiglu(const void* gu, void* out, int64_t bs, int64_t il, int dtype, int device, tg_stream_t stream) {

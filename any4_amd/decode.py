@@ -207,15 +207,19 @@ class DecodeLayer(torch.nn.Module):
         act = torch.nn.functional.silu(gu[:, :il]) * gu[:, il:]
         return h + gather(self.down(gather(act)))
 
-    def forward_fused(self, h, delta, pos, cos_tab, sin_tab, gather):
-        """Same layer on the HIP glue kernels (include/decode_glue_hip.h): 5 launches + 4 GEMMs.  `h` is the
+    def forward_fused(self, h, delta, pos, cos_tab, sin_tab, gather, attn_scratch=None, attn_split=1):
+        """Same layer on the HIP glue kernels (include/decode_glue_hip.h): 4 launches + 4 GEMMs.  `h` is the
         residual stream (updated in place), `delta` the previous layer's not-yet-added MLP output."""
         from . import decode_ops as G
 
         cfg, d = self.cfg, self.cfg.head_dim
         h, y = G.add_rmsnorm(h, delta, self.norm1.weight, self.norm1.eps)
-        q = G.rope_kv(self.qkv(y), cos_tab, sin_tab, pos, self.k_cache, self.v_cache, self.hl, self.kvl, d)
-        ctx = G.decode_attn(q, self.k_cache, self.v_cache, pos, 1.0 / math.sqrt(d))
+        if attn_scratch is not None:
+            ctx = G.rope_attn_split(self.qkv(y), cos_tab, sin_tab, pos, self.k_cache, self.v_cache, self.hl, self.kvl, d,
+                                    1.0 / math.sqrt(d), attn_scratch, attn_split)
+        else:
+            ctx = G.rope_attn(self.qkv(y), cos_tab, sin_tab, pos, self.k_cache, self.v_cache, self.hl, self.kvl, d,
+                              1.0 / math.sqrt(d))
         h, y = G.add_rmsnorm(h, gather(self.o(gather(ctx))), self.norm2.weight, self.norm2.eps)
         return h, gather(self.down(gather(G.swiglu(self.gate_up(y)))))
 
@@ -258,6 +262,16 @@ class DecodeStack(torch.nn.Module):
         self.register_buffer("pos", torch.zeros(1, dtype=torch.long, device=device), persistent=False)
         self._graph = None
         self._out = None
+        # split-sequence attention: enough blocks per head to fill the 256 CUs (one scratch buffer, launches are stream-ordered)
+        self._attn_scratch, self._attn_split = None, 1
+        if self.fused:
+            from . import decode_ops as G
+
+            hl = cfg.heads // world
+            # (the cross-block combine needs device-scope fences, ~15 us on the 8-XCD part: it only pays for long caches)
+            self._attn_split = max(1, min(8, 256 // max(1, bs * hl))) if cfg.max_seq > 2048 else 1
+            if self._attn_split > 1:
+                self._attn_scratch = G.rope_attn_split_scratch(bs, hl, cfg.head_dim, self._attn_split, device)
 
     # [bs, n/G] on every rank -> [bs, n], rank-major feature order (== row order of the unsharded weight)
     def _gather(self, y):
@@ -283,7 +297,7 @@ class DecodeStack(torch.nn.Module):
         if self.fused:
             h, delta = self.embed(self.tokens), None
             for layer in self.layers:
-                h, delta = layer.forward_fused(h, delta, pos, self.cos, self.sin, self._gather)
+                h, delta = layer.forward_fused(h, delta, pos, self.cos, self.sin, self._gather, self._attn_scratch, self._attn_split)
             from . import decode_ops as G
 
             _, y = G.add_rmsnorm(h, delta, self.norm.weight, self.norm.eps)

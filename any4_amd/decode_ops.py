@@ -67,6 +67,41 @@ def decode_attn(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, p
     return out
 
 
+def rope_attn(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, pos: torch.Tensor, k_cache: torch.Tensor,
+              v_cache: torch.Tensor, hl: int, kvl: int, d: int, scale: float) -> torch.Tensor:
+    """rope_kv + decode_attn in one launch: qkv [bs, (hl + 2 kvl) d] -> context [bs, hl * d]; caches updated at `pos`."""
+    _gpu(qkv, cos, sin, pos, k_cache, v_cache)
+    if cos.dtype != torch.float32 or pos.dtype != torch.int64:
+        raise RuntimeError("rope tables must be float32 and pos int64")
+    bs, max_seq = qkv.shape[0], k_cache.shape[2]
+    out = torch.empty((bs, hl * d), dtype=qkv.dtype, device=qkv.device)
+    _lib.check(_lib.load().dg_rope_attn(qkv.data_ptr(), cos.data_ptr(), sin.data_ptr(), pos.data_ptr(), k_cache.data_ptr(),
+                                        v_cache.data_ptr(), out.data_ptr(), bs, hl, kvl, d, max_seq, float(scale), _dt(qkv),
+                                        qkv.device.index, _stream(qkv)), "dg_rope_attn")
+    return out
+
+
+def rope_attn_split_scratch(bs: int, hl: int, d: int, nsplit: int, device) -> torch.Tensor:
+    """Zeroed scratch buffer for rope_attn_split (counters + per-chunk partials); reusable by stream-ordered launches."""
+    n = _lib.load().dg_rope_attn_split_scratch_bytes(bs, hl, d, nsplit)
+    return torch.zeros((n + 3) // 4, dtype=torch.int32, device=device)
+
+
+def rope_attn_split(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, pos: torch.Tensor, k_cache: torch.Tensor,
+                    v_cache: torch.Tensor, hl: int, kvl: int, d: int, scale: float, scratch: torch.Tensor, nsplit: int) -> torch.Tensor:
+    """rope_attn with the sequence split over `nsplit` blocks per head (fills the GPU at batch 1 / long contexts)."""
+    _gpu(qkv, cos, sin, pos, k_cache, v_cache, scratch)
+    if cos.dtype != torch.float32 or pos.dtype != torch.int64:
+        raise RuntimeError("rope tables must be float32 and pos int64")
+    bs, max_seq = qkv.shape[0], k_cache.shape[2]
+    out = torch.empty((bs, hl * d), dtype=qkv.dtype, device=qkv.device)
+    _lib.check(_lib.load().dg_rope_attn_split(qkv.data_ptr(), cos.data_ptr(), sin.data_ptr(), pos.data_ptr(), k_cache.data_ptr(),
+                                              v_cache.data_ptr(), out.data_ptr(), scratch.data_ptr(), scratch.numel() * 4, bs, hl,
+                                              kvl, d, max_seq, float(scale), nsplit, _dt(qkv), qkv.device.index, _stream(qkv)),
+               "dg_rope_attn_split")
+    return out
+
+
 def swiglu(gu: torch.Tensor) -> torch.Tensor:
     """gu [bs, 2 il] = [gate | up] -> silu(gate) * up [bs, il]."""
     _gpu(gu)

@@ -9,6 +9,7 @@
  *   dg_add_rmsnorm   h' = h + delta;  y = rmsnorm(h') * w          (residual add + LlamaRMSNorm)
  *   dg_rope_kv       rotary embedding of q and k, k/v written into the static KV cache at *pos
  *   dg_decode_attn   grouped-query attention of one new token against cache[0 .. *pos]
+ *   dg_rope_attn     the two above fused (what the decode harness launches)
  *   dg_swiglu        silu(gate) * up
  *
  * Conventions are those of include/tinygemm_hip.h: raw device pointers, caller-owned outputs, explicit
@@ -42,10 +43,27 @@ TG_API int dg_rope_kv(const void* qkv, const float* cos, const float* sin, const
 
 /* out[b][h][:] = softmax_s( to16(q[b][h] . k_cache[b][h / (hl/kvl)][s]) * scale ) over s <= *pos, applied to
  * v_cache; probabilities rounded to 16 bit before the value contraction, fp32 accumulation, one rounding of
- * the output.  d % 8 == 0, d <= 256, max_seq <= 16384. */
+ * the output.  d % 8 == 0, d <= 256, max_seq <= 8192. */
 TG_API int dg_decode_attn(const void* q, const void* k_cache, const void* v_cache, const int64_t* pos, void* out,
                           int64_t bs, int hl, int kvl, int d, int64_t max_seq, float scale, int dtype, int device,
                           tg_stream_t stream);
+
+/* dg_rope_kv followed by dg_decode_attn in ONE launch (a hipGraph of dependent kernels advances at ~5 us per node on
+ * MI355X): same arguments, same arithmetic in the same order, bit-identical results; q is not
+ * materialised.  d % 8 == 0, d <= 256, max_seq <= 8192. */
+TG_API int dg_rope_attn(const void* qkv, const float* cos, const float* sin, const int64_t* pos, void* k_cache,
+                        void* v_cache, void* out, int64_t bs, int hl, int kvl, int d, int64_t max_seq, float scale,
+                        int dtype, int device, tg_stream_t stream);
+
+/* dg_rope_attn with the sequence split over `nsplit` blocks per head (flash-decoding style combine by the last block to
+ * arrive): fills the GPU at batch 1 and long contexts.  `scratch`: dg_rope_attn_split_scratch_bytes(...) bytes, 16-byte
+ * aligned, ZEROED ONCE by the caller before the first launch (the kernel leaves its counters at zero again); launches
+ * sharing a scratch buffer must be stream-ordered.  Probabilities are normalised after the value contraction, so results
+ * agree with dg_rope_attn within 16-bit rounding, not bit for bit.  max_seq / nsplit <= ~15000. */
+TG_API int64_t dg_rope_attn_split_scratch_bytes(int64_t bs, int hl, int d, int nsplit);
+TG_API int dg_rope_attn_split(const void* qkv, const float* cos, const float* sin, const int64_t* pos, void* k_cache,
+                              void* v_cache, void* out, void* scratch, int64_t scratch_bytes, int64_t bs, int hl, int kvl,
+                              int d, int64_t max_seq, float scale, int nsplit, int dtype, int device, tg_stream_t stream);
 
 /* out[b][j] = to16(silu(gu[b][j])) * gu[b][il + j], j < il; gu [bs][2 il]; il % 8 == 0. */
 TG_API int dg_swiglu(const void* gu, void* out, int64_t bs, int64_t il, int dtype, int device, tg_stream_t stream);
