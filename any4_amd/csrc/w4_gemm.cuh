@@ -132,6 +132,8 @@ __global__ void __launch_bounds__(WAVES * 64, MINW) w4_gemm_kernel(const GemmPar
     else ks = s;
     ks = min(ks, p.ksuper - 1);
     if constexpr (ABL == 3 || ABL == 9) sl.w = u32x4{(uint32_t)ks, 1u, 2u, 3u};  // ablation: no weight stream
+    // (Aint4: lanes i and i + 8 read the same words -- keep them cacheable, see w4_gemm_stream.cuh)
+    else if constexpr (LAYOUT_A) sl.w = *reinterpret_cast<const u32x4*>(wb + (wlane + (uint32_t)ks * wstep));
     else sl.w = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wb + (wlane + (uint32_t)ks * wstep)));
     const int kk = s * KSTEP + Q * CHUNK;  // first k of this lane's canonical chunk
     const bool ok = tile_ok && row_ok && kk < p.k;
