@@ -49,50 +49,83 @@ __global__ void __launch_bounds__(WAVES * 64, 2) w8_gemm_kernel(const GemmParams
 
   const int nsteps_total = (ktiles + 3) >> 2;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  if (rt_ok) {
+  // everything one step needs, so that the loads of step s + splitk are in flight while step s is computed
+  struct Step {
+    uint32_t w0[4], w1[4];  // packed words of the 4 k-tiles (1 per k-tile on the B side, 2 on the A side)
+    uint32_t q[2];          // scale|zero of the two K-slots
+    u32x4 x[2];             // X fragments of the two K-slots
+  };
+  auto load_step = [&](int s, Step& st) {
+    // one vector load per k super-tile (I k-tiles, I * WPT consecutive words of this lane); a clamped (repeated) super-tile
+    // only feeds K-slots whose scale is forced to zero below
+    constexpr int WPS = I * WPT;   // words per super-tile and lane: 1, 2 or 4
+    constexpr int SPS = 4 / I;     // super-tiles per step (I = 4: 1, I = 2: 2, I = 1: 4)
+    uint32_t w[4 * WPT];
+#pragma unroll
+    for (int u = 0; u < SPS; ++u) {
+      const int sup = min(s * SPS + u, p.ksuper - 1);
+      const uint32_t* src = wb + lane_words + (uint32_t)(sup * 32 * WPS);
+      if constexpr (WPS == 4) {
+        const u32x4 v = LAYOUT_A ? *reinterpret_cast<const u32x4*>(src) : __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src));
+        w[u * 4 + 0] = v[0]; w[u * 4 + 1] = v[1]; w[u * 4 + 2] = v[2]; w[u * 4 + 3] = v[3];
+      } else if constexpr (WPS == 2) {
+        const u32x2 v = LAYOUT_A ? *reinterpret_cast<const u32x2*>(src) : __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(src));
+        w[u * 2 + 0] = v[0]; w[u * 2 + 1] = v[1];
+      } else {
+        w[u] = __builtin_nontemporal_load(src);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {  // k-tile j of the step: word j (B side) or words 2j, 2j + 1 (A side)
+      st.w0[j] = w[j * WPT];
+      if constexpr (LAYOUT_A) st.w1[j] = w[j * WPT + 1];
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int kt0 = 4 * s + 2 * h;
+      const int kt0_c = min(kt0, ktiles - 2);
+      const uint32_t q = qb[(uint32_t)(((kt0_c << 4) >> p.gshift) * p.wrows + row_c)];
+      st.q[h] = (row_ok && kt0 < ktiles) ? q : 0u;  // scale = zero = 0: this lane contributes exact zeros
+      st.x[h] = u32x4{0u, 0u, 0u, 0u};
+      if (xcol) {
+        const char* xp = xlane + (int64_t)kt0_c * 32;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) st.x[h][e] = *reinterpret_cast<const uint32_t*>(xp + 16 * e);
+      }
+    }
+  };
+  auto compute_step = [&](const Step& st) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {  // two K-slots of two k-tiles each
+      const float sc = DT::lo_f32(st.q[h]), zp = DT::hi_f32(st.q[h]);
+      u32x4 a;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        // the four bytes of this lane's row in k-tile 2h + j of the step, in k order 2Q, 2Q+1, 2Q+8, 2Q+9
+        uint32_t b0, b1, b2, b3;
+        if constexpr (LAYOUT_A) {
+          const uint32_t u0 = st.w0[2 * h + j] >> ((i >> 3) * 8), u1 = st.w1[2 * h + j] >> ((i >> 3) * 8);
+          b0 = u0 & 0xffu; b1 = (u0 >> 16) & 0xffu; b2 = u1 & 0xffu; b3 = (u1 >> 16) & 0xffu;
+        } else {
+          const uint32_t u = st.w0[2 * h + j];
+          b0 = u & 0xffu; b1 = (u >> 16) & 0xffu; b2 = (u >> 8) & 0xffu; b3 = u >> 24;
+        }
+        const float f0 = __builtin_fmaf((float)b0 - 128.f, sc, zp), f1 = __builtin_fmaf((float)b1 - 128.f, sc, zp);
+        const float f2 = __builtin_fmaf((float)b2 - 128.f, sc, zp), f3 = __builtin_fmaf((float)b3 - 128.f, sc, zp);
+        a[2 * j] = DT::pack2(f0, f1);
+        a[2 * j + 1] = DT::pack2(f2, f3);
+      }
+      acc = DT::mfma(a, st.x[h], acc);
+    }
+  };
+  if (rt_ok && slice < nsteps_total) {
+    Step cur, nxt;
+    load_step(slice, cur);
     for (int s = slice; s < nsteps_total; s += p.splitk) {
-      // ---- the 4 k-tiles of this step: packed words (1 per k-tile on the B side, 2 on the A side) ----
-      uint32_t w0[4], w1[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int kt = min(4 * s + j, ktiles - 1);
-        const uint32_t idx = lane_words + (uint32_t)((kt / I) * 32 * I * WPT + (kt % I) * WPT);
-        w0[j] = __builtin_nontemporal_load(wb + idx);
-        if constexpr (LAYOUT_A) w1[j] = __builtin_nontemporal_load(wb + idx + 1);
-      }
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {  // two K-slots of two k-tiles each
-        const int kt0 = 4 * s + 2 * h;
-        const bool ok = row_ok && kt0 < ktiles;
-        const int kt0_c = min(kt0, ktiles - 2);
-        uint32_t q = qb[(uint32_t)(((kt0_c << 4) >> p.gshift) * p.wrows + row_c)];
-        q = ok ? q : 0u;  // scale = zero = 0: this lane contributes exact zeros
-        const float sc = DT::lo_f32(q), zp = DT::hi_f32(q);
-        u32x4 xf = {0u, 0u, 0u, 0u};
-        if (xcol) {
-          const char* xp = xlane + (int64_t)kt0_c * 32;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) xf[e] = *reinterpret_cast<const uint32_t*>(xp + 16 * e);
-        }
-        u32x4 a;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          // the four bytes of this lane's row in k-tile kt0 + j, in k order 2Q, 2Q+1, 2Q+8, 2Q+9
-          uint32_t b0, b1, b2, b3;
-          if constexpr (LAYOUT_A) {
-            const uint32_t u0 = w0[2 * h + j] >> ((i >> 3) * 8), u1 = w1[2 * h + j] >> ((i >> 3) * 8);
-            b0 = u0 & 0xffu; b1 = (u0 >> 16) & 0xffu; b2 = u1 & 0xffu; b3 = (u1 >> 16) & 0xffu;
-          } else {
-            const uint32_t u = w0[2 * h + j];
-            b0 = u & 0xffu; b1 = (u >> 16) & 0xffu; b2 = (u >> 8) & 0xffu; b3 = u >> 24;
-          }
-          const float f0 = __builtin_fmaf((float)b0 - 128.f, sc, zp), f1 = __builtin_fmaf((float)b1 - 128.f, sc, zp);
-          const float f2 = __builtin_fmaf((float)b2 - 128.f, sc, zp), f3 = __builtin_fmaf((float)b3 - 128.f, sc, zp);
-          a[2 * j] = DT::pack2(f0, f1);
-          a[2 * j + 1] = DT::pack2(f2, f3);
-        }
-        acc = DT::mfma(a, xf, acc);
-      }
+      const bool more = s + p.splitk < nsteps_total;
+      if (more) load_step(s + p.splitk, nxt);
+      compute_step(cur);
+      if (more) cur = nxt;
     }
   }
 

@@ -1,9 +1,2 @@
-C="1,4096,4096,1;8,4096,4096,1;1,4096,4096,0;8,4096,4096,0;8,8192,8192,0;16,4096,4096,0"
-cp any4_amd/lib/libtinygemm_hip.so /tmp/base.so
-for v in base v2 base v2; do
-  if [ $v = base ]; then cp /tmp/base.so any4_amd/lib/libtinygemm_hip.so; else cp gpurun_out_variants/lib_$v.so any4_amd/lib/libtinygemm_hip.so; fi
-  echo "== $v: $(timeout 300 python tools/quick_bench.py --configs "$C" --iters 3 2>&1 | grep -E "steady" | awk '{print $2}' | tr '\n' ' ')"
-done
-cp /tmp/base.so any4_amd/lib/libtinygemm_hip.so
-timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q 2>&1 | tail -2
-for q in anyq intq; do timeout 300 python tools/microbenchmark.py --quantize $q 2>&1 | tail -1; done
+timeout 300 python tools/quick_bench.py --configs "1,4096,4096,1;1,4096,4096,0;8,4096,4096,0" --qtype int8 --iters 3 2>&1 | grep -E "^m=|steady"
+timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k int8 2>&1 | tail -2
