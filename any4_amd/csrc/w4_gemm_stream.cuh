@@ -20,17 +20,17 @@
 // Activations go through LDS so that X never sits in the in-order vector-memory return queue (the
 // only VM waits in the loop are for data requested one whole unit earlier).  Two staging modes:
 //   PRIVX = false: every wave of a workgroup walks the same k sequence, so the X slab of one
-//                  unit-step ([act rows][slices][quarters][UNIT]) is staged once per workgroup,
+//                  unit-step ([quarters][slices][act rows][UNIT]) is staged once per workgroup,
 //                  double buffered, one barrier per unit;
 //   PRIVX = true : (m = 1) every wave stages its own slab (one 16-byte load per lane per unit): no barrier in
 //                  the main loop; the waves of a workgroup are the k-slices of one tile (split-K 1..8);
 //   XRES  = true : (m >= 2, split-K 1, m * k * 2 <= ~96 KiB) the whole activation block is staged ONCE per
-//                  workgroup ([act rows][quarters][k / 4], p.xslab_bytes = bytes per row) and stays resident
-//                  while the 16 waves walk their tiles: one barrier per workgroup instead of one per unit.
+//                  workgroup ([quarters][act rows][k / 4], p.xslab_bytes = bytes per row) and stays resident
+//                  while the 16 waves walk p.tiles_per_wave tiles each: one barrier per workgroup instead of one per unit.
 //
 // LDS (dynamic, sized by the host, no static LDS so the base is 0):
 //   [WAVES x 4 KiB lookup tables][X slabs][split-K partial tiles, only when splitk > 1].
-// Wave w's table starts at byte w * 4096.  With WAVES == 1 (the PRIVX launches) the table sits at 0
+// Wave w's table starts at byte w * 4096.  With WAVES == 1 (the stacked m = 1 launches) the table sits at 0
 // and a lookup address is just (nibble << 8 | lane << 2); otherwise address bits 12..15 (the table
 // select) are OR-ed into the nibble bytes before the v_perm_b32.
 #pragma once
