@@ -1,5 +1,6 @@
-timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q 2>&1 | tail -2
-C="1,6144,4096,1;1,4096,4096,1;1,28672,4096,1;1,4096,14336,1;1,8192,8192,1"
-echo "== sk<=16"; timeout 300 python tools/quick_bench.py --configs "$C" --iters 3 --settle 0 --L 32 2>&1 | grep -E "graph" | awk '{print $2}' | tr '\n' ' '; echo
-echo "== sk=8";  TG_SK=8 timeout 300 python tools/quick_bench.py --configs "$C" --iters 3 --settle 0 --L 32 2>&1 | grep -E "graph" | awk '{print $2}' | tr '\n' ' '; echo
-timeout 900 python tools/llama_decode_bench.py --config llama3_8b 2>&1 | tail -1 | cut -c260-420
+# Scratch pad for one-off GPU experiments (run as: gpurun -- 'bash tools/exp.sh').  Kept in the tree because the profiles
+# under profiles/ name it as their origin; the reproducible flow is tools/gpu_round.sh.  Example: A/B two builds of the
+# library on ONE box (boxes differ by +-3 %, and the m = 1 kernel is sensitive to code generation):
+#   cp any4_amd/lib/libtinygemm_hip.so /tmp/base.so
+#   for v in base variant base variant; do cp /tmp/$v.so any4_amd/lib/libtinygemm_hip.so; python tools/quick_bench.py --configs "1,4096,4096,1" --iters 3 | grep steady; done
+timeout 300 python tools/quick_bench.py --configs "1,4096,4096,1;8,4096,4096,1" --iters 3 2>&1 | grep -E "^m=|steady"
