@@ -137,3 +137,48 @@ class Any4Linear(_PackedLinear):
 
     def extra_repr(self) -> str:
         return super().extra_repr() + f", per_row={self.per_row}"
+
+
+# NF4 code book of QLoRA / bitsandbytes (the reference's kmeans.py:17 carries the same 16 values), ascending
+NF4_VALUES = (-1.0, -0.6961928009986877, -0.5250730514526367, -0.39491748809814453, -0.28444138169288635,
+              -0.18477343022823334, -0.09105003625154495, 0.0, 0.07958029955625534, 0.16093020141124725,
+              0.24611230194568634, 0.33791524171829224, 0.44070982933044434, 0.5626170039176941, 0.7229568362236023, 1.0)
+
+
+class NF4Linear(Any4Linear):
+    """One of the modules the reference lists as TODO (modules.py:10): NormalFloat4 weights on the any4 kernel with ONE
+    16-entry LUT for the whole matrix (the reference's "NF4" benchmark rows are exactly this, README.md:448-455).
+    weight = codes 0..15, scales_and_zeros = [k/g][n][(absmax, 0)], lut = NF4_VALUES: w = lut[code] * absmax."""
+
+    def __init__(self, in_features: int, out_features: int, bias: bool = True, device=None, dtype=None,
+                 group_size: int = 128, kernel: str = "linear_y_f16RM_x_f16RM_W_any4TC", w_inner_k: int = 4) -> None:
+        super().__init__(in_features, out_features, bias=bias, device=device, dtype=dtype, group_size=group_size,
+                         kernel=kernel, w_inner_k=w_inner_k, per_row=False)
+        self.lut.data = torch.tensor(NF4_VALUES, device=device, dtype=dtype)
+
+
+class MX4Linear(_PackedLinear):
+    """The other TODO of modules.py:10: MX4 (fp4-e2m1 codes, one e8m0 exponent per group of 32) on
+    tinygemm_y_f16RM_x_f16RM_w_mx4TC (bf16 only, TinyGemm_int4.cu:758).  Parameters: weight (codes, packed by
+    reshape_weight), exponents uint8 [out][in / group_size]."""
+    _PACKERS = {
+        "linear_y_f16RM_x_f16RM_W_mx4TC": "convert_matrix_to_m16n8k16_Bint4_layout",
+        "linear_y_f16RM_W_mx4TC_x_f16RM": "convert_matrix_to_m16n8k16_Aint4_layout",
+    }
+
+    def __init__(self, in_features: int, out_features: int, bias: bool = True, device=None, dtype=None,
+                 group_size: int = 32, kernel: str = "linear_y_f16RM_x_f16RM_W_mx4TC", w_inner_k: int = 4) -> None:
+        super().__init__()
+        self._make_common(in_features, out_features, bias, device, dtype, group_size, kernel, w_inner_k, zero_init=True)
+        del self.scales_and_zeros
+        self.exponents = torch.nn.Parameter(torch.full((out_features, in_features // group_size), 127, dtype=torch.uint8, device=device),
+                                            requires_grad=False)
+
+    def _gemm(self, x):
+        if self.kernel not in self._PACKERS:
+            raise ValueError(f"Unsupported kernel type {self.kernel}")
+        if not self.weight_reshaped:
+            self.reshape_weight(self.w_inner_k)
+        on_right = self.kernel == "linear_y_f16RM_x_f16RM_W_mx4TC"
+        a, b = (x, self.weight) if on_right else (self.weight, x)
+        return _T.tinygemm_y_f16RM_x_f16RM_w_mx4TC(a, b, self.group_size, self.exponents, on_right)

@@ -329,6 +329,60 @@ def intq_layer(module: torch.nn.Module, name: str = "", n_bit: int = 4, group_si
     return q
 
 
+@torch.no_grad()
+def nf4_quantize_tensor(W: torch.Tensor, q_group_size: int = 128):
+    """NormalFloat4 with absmax group scaling (what bitsandbytes' quantize_nf4 does, quantize.py:923-937 uses it for the
+    pseudo path): -> (int32 codes [n][k], lut [16] = NF4 code book, scales_and_zeros [k/g][n][(absmax, 0)])."""
+    from .modules import NF4_VALUES
+
+    n, k = W.shape
+    grp = W.float().reshape(-1, q_group_size)
+    absmax = grp.abs().amax(dim=1, keepdim=True).clamp_min(1e-12)
+    book = torch.tensor(NF4_VALUES, device=W.device, dtype=torch.float32)
+    mid = ((book[1:] + book[:-1]) * 0.5).contiguous()
+    codes = torch.searchsorted(mid, (grp / absmax).contiguous()).to(torch.int32).reshape(n, k)
+    sz = pack_scales_and_zeros(absmax, torch.zeros_like(absmax), W.shape)
+    return codes, book.to(W.dtype), sz.to(W.dtype)
+
+
+def nf4_layer(module: torch.nn.Module, name: str = "", n_bit: int = 4, group_size: int = 128, pseudo: Optional[bool] = None,
+              kernel: str = "linear_y_f16RM_x_f16RM_W_any4TC", w_inner_k: int = 4, **_) -> torch.nn.Module:
+    """nn.Linear -> NF4Linear (real kernels) or fake-quantized weights in place (pseudo=True)."""
+    assert n_bit == 4, "nf4 only supports 4-bit"
+    w = module.weight
+    codes, lut, sz = nf4_quantize_tensor(w, q_group_size=group_size)
+    if pseudo:
+        s, _ = extract_scales_and_zeros(sz.float(), w.shape, group_size)
+        module.weight.data = (lut.float()[codes.long()] * s).to(w.dtype)
+        return module
+    from .modules import NF4Linear
+
+    q = NF4Linear(module.in_features, module.out_features, bias=module.bias is not None, device=w.device, dtype=w.dtype,
+                  group_size=group_size, kernel=kernel, w_inner_k=w_inner_k)
+    q.weight.data, q.scales_and_zeros.data, q.bias = codes.to(w.device), sz.to(w.device), module.bias
+    q.reshape_weight(w_inner_k)
+    return q
+
+
+def mx4_layer(module: torch.nn.Module, name: str = "", group_size: int = 32, pseudo: Optional[bool] = None,
+              kernel: str = "linear_y_f16RM_x_f16RM_W_mx4TC", w_inner_k: int = 4, **_) -> torch.nn.Module:
+    """nn.Linear (bf16) -> MX4Linear, or fake-quantized weights in place (pseudo=True)."""
+    from .utils import dequantize_mx4, quantize_mx4
+
+    w = module.weight
+    codes, exps = quantize_mx4(w.float(), group_size)
+    if pseudo:
+        module.weight.data = dequantize_mx4(codes, exps).to(w.dtype)
+        return module
+    from .modules import MX4Linear
+
+    q = MX4Linear(module.in_features, module.out_features, bias=module.bias is not None, device=w.device, dtype=w.dtype,
+                  group_size=group_size, kernel=kernel, w_inner_k=w_inner_k)
+    q.weight.data, q.exponents.data, q.bias = codes.to(w.device), exps.to(w.device), module.bias
+    q.reshape_weight(w_inner_k)
+    return q
+
+
 def quantize_model(model: torch.nn.Module, layer_from=torch.nn.Linear, layer_to: Callable = anyq_layer, skip_modules=None,
                    **kwargs) -> torch.nn.Module:
     """Replace every `layer_from` submodule by `layer_to(module, name=..., **kwargs)`, in place.

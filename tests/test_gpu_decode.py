@@ -251,3 +251,32 @@ def test_hf_llama_quantize_model_real_vs_pseudo():
     assert (yr - yf).abs().max() <= 0.03 * yf.abs().max() + 1e-3, ((yr - yf).abs().max(), yf.abs().max())
     assert (yf - yb).abs().max() > 0      # it is quantized...
     assert (yr - yb).abs().max() <= 0.5 * yb.abs().max()  # ...and still the same model
+
+
+def test_nf4_and_mx4_modules():
+    """NF4Linear / MX4Linear (the reference's modules.py:10 TODO) on the any4-global-LUT and mx4 kernels: real kernels
+    vs the fake-quantized weights of the same quantizer."""
+    import copy
+
+    from any4_amd import quantize as Q
+
+    torch.manual_seed(11)
+    lin = torch.nn.Linear(512, 192, bias=True, device=DEV, dtype=torch.bfloat16)
+    x = torch.randn(6, 512, device=DEV).to(torch.bfloat16)
+    for layer_fn, kw, cls in ((Q.nf4_layer, dict(group_size=64), "NF4Linear"), (Q.mx4_layer, dict(group_size=32), "MX4Linear"),
+                              (Q.mx4_layer, dict(group_size=32, kernel="linear_y_f16RM_W_mx4TC_x_f16RM"), "MX4Linear")):
+        q = layer_fn(copy.deepcopy(lin), **kw)
+        twin = layer_fn(copy.deepcopy(lin), pseudo=True, **kw)
+        assert type(q).__name__ == cls and q.weight.dim() == 4
+        yq, yt = q(x).float(), twin(x).float()
+        assert (yq - yt).abs().max() <= 0.02 * yt.abs().max() + 1e-2, (cls, kw)
+        assert (yq - lin(x).float()).abs().max() <= 0.3 * yt.abs().max()
+    # NF4 codes are the nearest code-book entries of w / absmax(group)
+    from any4_amd.modules import NF4_VALUES
+
+    codes, book, sz = Q.nf4_quantize_tensor(lin.weight, 64)
+    g = lin.weight.float().reshape(-1, 64)
+    scaled = g / g.abs().amax(1, keepdim=True)
+    ref = (scaled[..., None] - torch.tensor(NF4_VALUES, device=DEV)).abs().argmin(-1).reshape(lin.weight.shape)
+    assert (codes.long() != ref).float().mean() < 1e-4   # exact ties aside
+    assert book.dtype == torch.bfloat16 and sz.shape == (512 // 64, 192, 2) and bool((sz[..., 1] == 0).all())
