@@ -702,3 +702,28 @@ def test_int8linear_module(T, oracle):
         y = mod(x.to(DEV).view(1, 7, k))
         assert y.shape == (1, 7, n)
         assert_gemm_close(y.view(7, n), x, oracle.dequant(codes.numpy(), g, oracle.Q_INT8, bits16(sz), None))
+
+
+@pytest.mark.parametrize("on_right,inner", [(True, 4), (False, 2)])
+@pytest.mark.parametrize("m,copies", [(33, 50), (20, 700)])
+def test_stream_kernel_several_column_tiles(T, oracle, on_right, inner, m, copies):
+    """m > 16: the launch has several 16-row activation tiles (grid.y); the last one is ragged (33 = 16 + 16 + 1,
+    20 = 16 + 4), so workgroups of one launch see different numbers of live MFMA columns.  copies = 50: shared-slab
+    variant with split-K; copies = 700 (>= 8192 wave-tiles): resident-X variant."""
+    n, k, g = 48, 1024, 128
+    probs = [rand_problem(n, k, g, m, "any4_rowwise", seed=500 + 7 * b + m) for b in range(4)]
+    ys = _stacked(T, probs, copies, g, "any4_rowwise", on_right, inner)
+    assert not torch.isnan(ys.float()).any()
+    for b in range(4):
+        w = oracle_weights(oracle, probs[b][0], g, "any4_rowwise", probs[b][2], probs[b][3])
+        assert_gemm_close(ys[b], probs[b][1], w)
+        assert_gemm_close(ys[(copies - 1) * 4 + b], probs[b][1], w)
+
+
+@pytest.mark.parametrize("k", [1024, 4096])
+def test_stream_private_slab_splitk_fp16(T, oracle, k):
+    n, g = 80, 128
+    for on_right, inner in ((True, 4), (False, 4)):
+        codes, x, qinfo, lut = rand_problem(n, k, g, 1, "any4_rowwise", dtype=torch.float16, seed=k)
+        y = run_rm(T, codes, x, qinfo, lut, g, "any4_rowwise", on_right, inner)
+        assert_gemm_close(y[:, :n], x, oracle_weights(oracle, codes, g, "any4_rowwise", qinfo, lut, torch.float16), torch.float16)
