@@ -109,31 +109,43 @@ __global__ void __launch_bounds__(WAVES * 64) f16_gemm_kernel(const F16GemmParam
   const int rt = blockIdx.x, ct = blockIdx.y;
   const int row0 = rt * 16, row = row0 + i;
   const bool row_ok = row < p.wrows;
+  // Lane (i, Q) reads the fragment words of ITS OWN lane slot t = 4 (i & 7) + Q of the m16n8k16 layouts, as stored:
+  // per k-tile the dwords (k0,k1) and (k0+8,k0+9) with k0 = 2Q, so one K-slot (two k-tiles) is the 8 k values
+  // {2Q, 2Q+1, 2Q+8, 2Q+9} + {0, 16} and the X fragment is four dwords at byte offsets 4Q + {0, 16, 32, 48} of the slot
+  // (the mapping of w8_gemm.cuh).  One 16-byte (A16, B16 I = 2) or 8-byte (B16 I = 1) load per k-tile pair / k-tile.
   const uint32_t* wd = reinterpret_cast<const uint32_t*>(p.w);
   const int xrow = min(ct * 16 + i, p.m - 1);
-  const int nsteps_total = (p.k + 31) / 32;
+  const bool xcol = ct * 16 + i < p.m;
+  const int ktiles = p.k >> 4;  // k % 32 == 0
+  const int nsteps_total = ktiles >> 1;
+  const int t = 4 * r + Q;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   for (int s = wave; s < nsteps_total; s += WAVES) {
-    // lane (i, Q): k = 32 s + 8 Q + 0..7  = k-tile kt, half hh
-    const int kt = 2 * s + (Q >> 1), hh = Q & 1;
-    const bool k_ok = (32 * s + 8 * Q) < p.k && kt < p.ktiles_padded;
     u32x4 a = {0, 0, 0, 0}, xv = {0, 0, 0, 0};
-    if (k_ok && row_ok) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        int64_t idx;
-        if constexpr (LAYOUT_A) {
-          // [mT][kT][32][8 halfs] = 4 dwords: d0=(m0;k0,k1) d1=(m1;k0,k1) d2=(m0;k2,k3) d3=(m1;k2,k3)
-          idx = (((int64_t)rt * p.ktiles_padded + kt) * 32 + 4 * r + q) * 4 + 2 * hh + (i >> 3);
+    if (row_ok) {
+      if constexpr (LAYOUT_A) {
+        // [mT][kT][32][8 halfs] = 4 dwords per lane slot: (m0;k0,k1) (m1;k0,k1) (m0;k8,k9) (m1;k8,k9)
+        const u32x4 v0 = *reinterpret_cast<const u32x4*>(wd + (((int64_t)rt * p.ktiles_padded + 2 * s) * 32 + t) * 4);
+        const u32x4 v1 = *reinterpret_cast<const u32x4*>(wd + (((int64_t)rt * p.ktiles_padded + 2 * s + 1) * 32 + t) * 4);
+        const int h = i >> 3;
+        a = u32x4{h ? v0[1] : v0[0], h ? v0[3] : v0[2], h ? v1[1] : v1[0], h ? v1[3] : v1[2]};
+      } else {
+        // [nT][kT/I][32][4 I halfs]: per k-tile the dwords (k0,k1) (k8,k9)
+        const int tile = 2 * rt + (i >> 3);
+        if (p.inner == 2) {
+          a = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wd + (((int64_t)tile * (p.ktiles_padded / 2) + s) * 32 + t) * 4));
         } else {
-          // [nT][kT/I][32][4 I halfs]: per k-tile 2 dwords d0=(k0,k1) d1=(k2,k3)
-          const int tile = 2 * rt + (i >> 3);
-          idx = ((((int64_t)tile * (p.ktiles_padded / p.inner) + kt / p.inner) * 32 + 4 * r + q) * p.inner + (kt % p.inner)) * 2 + hh;
+          const u32x2 v0 = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(wd + (((int64_t)tile * p.ktiles_padded + 2 * s) * 32 + t) * 2));
+          const u32x2 v1 = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(wd + (((int64_t)tile * p.ktiles_padded + 2 * s + 1) * 32 + t) * 2));
+          a = u32x4{v0[0], v0[1], v1[0], v1[1]};
         }
-        a[q] = wd[idx];
       }
     }
-    if (k_ok) xv = *reinterpret_cast<const u32x4*>(p.x + ((int64_t)xrow * p.k + 32 * s + 8 * Q) * 2);
+    if (xcol) {
+      const char* xp = p.x + ((int64_t)xrow * p.k + 32 * s) * 2 + 4 * Q;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) xv[e] = *reinterpret_cast<const uint32_t*>(xp + 16 * e);
+    }
     acc = DT::mfma(a, xv, acc);
   }
   s_red[wave * 64 + lane] = acc;
