@@ -224,3 +224,19 @@ def test_row_range_validation():
     assert row_range(14336, 7, 8) == (12544, 14336)
     with pytest.raises(ValueError):
         row_range(100, 0, 8)
+
+
+# ---------------------------------------------------------------- bench.py pieces that run without a GPU
+
+def test_bench_cpu_baseline_leg_and_byte_formula():
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    # config 2 = 9 060 352 B, m = 8 -> 9 175 040 B
+    assert bench.alg_bytes(1, 4096, 4096, 128, 32 * 4096) == 9060352
+    assert bench.alg_bytes(8, 4096, 4096, 128, 32 * 4096) == 9175040
+    cb = bench.cpu_baseline(1, 512, 512, 128, budget_s=0.2)
+    assert cb["kind"] == "port" and cb["unit"] == "GB/s" and cb["value"] > 0 and cb["cores"] >= 1
+    assert "layers of the bench workload" in cb["sample"]
