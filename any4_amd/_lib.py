@@ -10,6 +10,9 @@ LIB_PATH = os.path.join(_HERE, "lib", "libtinygemm_hip.so")
 
 TG_BF16, TG_F16 = 0, 1
 TG_Q_INT4, TG_Q_ANY4_GLOBAL, TG_Q_ANY4_ROWWISE, TG_Q_MX4, TG_Q_INT8 = 0, 1, 2, 3, 4
+TG_NUM_FAST, TG_NUM_REFERENCE = 0, 1
+TG_ABI_VERSION = 2
+TG_PLAN_SPLITK, TG_PLAN_STREAM, TG_PLAN_PAIR = 1, 2, 3
 
 _i32, _i64, _vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p
 
@@ -23,6 +26,7 @@ class W4Gemm(ctypes.Structure):
         ("group", _i32), ("qtype", _i32), ("dtype", _i32), ("w_on_right", _i32), ("inner_k_tiles", _i32),
         ("batch", _i32),
         ("stride_x", _i64), ("stride_w", _i64), ("stride_qinfo", _i64), ("stride_lut", _i64), ("stride_y", _i64),
+        ("numerics", _i32), ("reserved", _i32), ("bias", _vp), ("stride_bias", _i64),
     ]
 
 
@@ -38,6 +42,7 @@ SYMBOLS = {
     "tg_convert_from_B16": [_vp, _i64, _i64, ctypes.c_int, _vp, ctypes.c_int, _vp],
     "tg_dequant_int4": [_vp, _i64, _vp, ctypes.c_int, _vp],
     "tg_gemm_w4": [ctypes.POINTER(W4Gemm), ctypes.c_int, _vp],
+    "tg_gemm_w4_plan": [ctypes.POINTER(W4Gemm), ctypes.c_int],
     "tg_gemm_f16": [_vp, _vp, _vp, _i64, _i64, _i64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp],
     "tg_convert_to_Bint8": [_vp, _i64, _i64, ctypes.c_int, _vp, ctypes.c_int, _vp],
     "tg_convert_to_Aint8": [_vp, _i64, _i64, ctypes.c_int, _vp, ctypes.c_int, _vp],
@@ -78,8 +83,8 @@ def load() -> ctypes.CDLL:
         fn.argtypes = argtypes
         fn.restype = (ctypes.c_char_p if name == "tg_error_string" else
                       ctypes.c_int64 if name == "dg_rope_attn_split_scratch_bytes" else ctypes.c_int)
-    if lib.tg_abi_version() != 1:
-        raise ImportError(f"{LIB_PATH}: ABI version {lib.tg_abi_version()} != 1; rebuild")
+    if lib.tg_abi_version() != TG_ABI_VERSION:
+        raise ImportError(f"{LIB_PATH}: ABI version {lib.tg_abi_version()} != {TG_ABI_VERSION}; rebuild")
     _lib = lib
     return lib
 

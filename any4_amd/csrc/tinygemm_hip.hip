@@ -29,6 +29,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <atomic>
 #include <type_traits>
 
 #include "../../include/tinygemm_hip.h"
@@ -80,8 +81,22 @@ struct F16 {
 __device__ const float kMX4Values[16] = {0.0f,  0.5f,  1.0f,  1.5f,  2.0f,  3.0f,  4.0f,  6.0f,
                                          -0.0f, -0.5f, -1.0f, -1.5f, -2.0f, -3.0f, -4.0f, -6.0f};
 
+// Output store of four consecutive weight rows of one activation row.  With a bias the sum is first rounded to 16 bits and
+// the bias added in a second rounded step: bit-identical to the reference module's separate `y + bias` (modules.py:221-222).
+template <typename DT>
+__device__ __forceinline__ void store_rows4(char* yb, const char* bias, int64_t elem, int rowg, f32x4 acc) {
+  u32x2 o = {DT::pack2(acc[0], acc[1]), DT::pack2(acc[2], acc[3])};
+  if (bias) {
+    const u32x2 bv = *reinterpret_cast<const u32x2*>(bias + (int64_t)rowg * 2);
+    o[0] = DT::pack2(DT::lo_f32(o[0]) + DT::lo_f32(bv[0]), DT::hi_f32(o[0]) + DT::hi_f32(bv[0]));
+    o[1] = DT::pack2(DT::lo_f32(o[1]) + DT::lo_f32(bv[1]), DT::hi_f32(o[1]) + DT::hi_f32(bv[1]));
+  }
+  *reinterpret_cast<u32x2*>(yb + elem * 2) = o;
+}
+
 #include "w4_gemm.cuh"
 #include "w4_gemm_stream.cuh"
+#include "w4_gemm_pair.cuh"
 #include "w8_gemm.cuh"
 
 #ifndef STREAM_MINW
@@ -172,7 +187,9 @@ template <int I>
 __global__ void __launch_bounds__(256) pack_Bint4_kernel(const int32_t* __restrict__ in, int32_t* __restrict__ out,
                                                         int64_t n, int64_t k, int64_t ksuper) {
   constexpr int KB = 512;  // k per workgroup; multiple of 16*I for I <= 8
-  __shared__ uint8_t s_codes[8][KB + 16];
+  // codes are staged as full 32-bit values: the reference ORs the shifted UNMASKED inputs (TinyGemmConvertB.cu:302-303),
+  // so out-of-range codes must reach the pack expression untouched for the words to stay bit-identical
+  __shared__ uint32_t s_codes[8][KB + 4];
   const int tid = threadIdx.x;
   const int64_t nT = blockIdx.y;
   const int64_t kb0 = (int64_t)blockIdx.x * KB;
@@ -182,12 +199,9 @@ __global__ void __launch_bounds__(256) pack_Bint4_kernel(const int32_t* __restri
     const int idx = it * 256 + tid;
     const int rr = idx >> 7, c4 = idx & 127;
     const int64_t row = nT * 8 + rr, kk = kb0 + c4 * 4;
-    uint32_t pk = 0;
-    if (row < n && kk < k) {  // k % 32 == 0 -> whole int4 in range
-      const int4 v = *reinterpret_cast<const int4*>(in + row * k + kk);
-      pk = ((uint32_t)v.x & 0xffu) | (((uint32_t)v.y & 0xffu) << 8) | (((uint32_t)v.z & 0xffu) << 16) | ((uint32_t)v.w << 24);
-    }
-    *reinterpret_cast<uint32_t*>(&s_codes[rr][c4 * 4]) = pk;
+    int4 v = {0, 0, 0, 0};
+    if (row < n && kk < k) v = *reinterpret_cast<const int4*>(in + row * k + kk);  // k % 32 == 0 -> whole int4 in range
+    *reinterpret_cast<int4*>(&s_codes[rr][c4 * 4]) = v;
   }
   __syncthreads();
   // words of this tile: [kS_local][t][j], KB/(16 I) super-tiles x 32 x I/2 = KB words
@@ -202,13 +216,12 @@ __global__ void __launch_bounds__(256) pack_Bint4_kernel(const int32_t* __restri
     if (ks >= ksuper) continue;
     const int rr = t >> 2, q = t & 3;
     const int kl = (ksl * I + 2 * j) * 16 + 2 * q;
-    const uint8_t* src = &s_codes[rr][kl];
+    const uint32_t* src = &s_codes[rr][kl];
     uint32_t v[8];
 #pragma unroll
     for (int pr = 0; pr < 4; ++pr) {
-      const uint32_t two = *reinterpret_cast<const uint16_t*>(src + 8 * pr);
-      v[2 * pr] = two & 0xffu;
-      v[2 * pr + 1] = two >> 8;
+      v[2 * pr] = src[8 * pr];
+      v[2 * pr + 1] = src[8 * pr + 1];
     }
     const uint32_t pack = (v[7] << 28) | (v[5] << 24) | (v[3] << 20) | (v[1] << 16) | (v[6] << 12) | (v[4] << 8) | (v[2] << 4) | v[0];
     out[((nT * ksuper + ks) * 32 + t) * (I / 2) + j] = (int32_t)pack;
@@ -220,7 +233,7 @@ template <int I>
 __global__ void __launch_bounds__(256) pack_Aint4_kernel(const int32_t* __restrict__ in, int32_t* __restrict__ out,
                                                         int64_t m, int64_t k, int64_t ksuper) {
   constexpr int KB = 256;
-  __shared__ uint8_t s_codes[16][KB + 16];
+  __shared__ uint32_t s_codes[16][KB + 4];  // full 32-bit codes, see pack_Bint4_kernel
   const int tid = threadIdx.x;
   const int64_t mT = blockIdx.y;
   const int64_t kb0 = (int64_t)blockIdx.x * KB;
@@ -230,18 +243,18 @@ __global__ void __launch_bounds__(256) pack_Aint4_kernel(const int32_t* __restri
     const int idx = it * 256 + tid;
     const int rr = idx >> 6, c4 = idx & 63;
     const int64_t row = mT * 16 + rr, kk = kb0 + c4 * 4;
-    uint32_t pk = 0;
+    int4 v = {0, 0, 0, 0};
     if (row < m) {
       if (vec_ok && kk + 3 < k) {
-        const int4 v = *reinterpret_cast<const int4*>(in + row * k + kk);
-        pk = ((uint32_t)v.x & 0xffu) | (((uint32_t)v.y & 0xffu) << 8) | (((uint32_t)v.z & 0xffu) << 16) | ((uint32_t)v.w << 24);
+        v = *reinterpret_cast<const int4*>(in + row * k + kk);
       } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (kk + e < k) pk |= ((uint32_t)in[row * k + kk + e] & 0xffu) << (8 * e);
+        if (kk < k) v.x = in[row * k + kk];
+        if (kk + 1 < k) v.y = in[row * k + kk + 1];
+        if (kk + 2 < k) v.z = in[row * k + kk + 2];
+        if (kk + 3 < k) v.w = in[row * k + kk + 3];
       }
     }
-    *reinterpret_cast<uint32_t*>(&s_codes[rr][c4 * 4]) = pk;
+    *reinterpret_cast<int4*>(&s_codes[rr][c4 * 4]) = v;
   }
   __syncthreads();
   // words of this tile: [kS_local][t][inner]: KB/16 k-tiles x 32 = 512 words
@@ -256,12 +269,10 @@ __global__ void __launch_bounds__(256) pack_Aint4_kernel(const int32_t* __restri
     if (ks >= ksuper) continue;
     const int m0 = t >> 2, q = t & 3;
     const int kl = (ksl * I + inner) * 16 + 2 * q;
-    const uint32_t a0 = *reinterpret_cast<const uint16_t*>(&s_codes[m0][kl]);          // (m0,k0) (m0,k1)
-    const uint32_t b0 = *reinterpret_cast<const uint16_t*>(&s_codes[m0 + 8][kl]);      // (m1,k0) (m1,k1)
-    const uint32_t a1 = *reinterpret_cast<const uint16_t*>(&s_codes[m0][kl + 8]);      // (m0,k2) (m0,k3)
-    const uint32_t b1 = *reinterpret_cast<const uint16_t*>(&s_codes[m0 + 8][kl + 8]);  // (m1,k2) (m1,k3)
-    const uint32_t v0 = a0 & 0xffu, v1 = a0 >> 8, v2 = b0 & 0xffu, v3 = b0 >> 8;
-    const uint32_t v4 = a1 & 0xffu, v5 = a1 >> 8, v6 = b1 & 0xffu, v7 = b1 >> 8;
+    const uint32_t v0 = s_codes[m0][kl], v1 = s_codes[m0][kl + 1];              // (m0,k0) (m0,k1)
+    const uint32_t v2 = s_codes[m0 + 8][kl], v3 = s_codes[m0 + 8][kl + 1];      // (m1,k0) (m1,k1)
+    const uint32_t v4 = s_codes[m0][kl + 8], v5 = s_codes[m0][kl + 9];          // (m0,k2) (m0,k3)
+    const uint32_t v6 = s_codes[m0 + 8][kl + 8], v7 = s_codes[m0 + 8][kl + 9];  // (m1,k2) (m1,k3)
     const uint32_t pack = (v7 << 28) | (v5 << 24) | (v3 << 20) | (v1 << 16) | (v6 << 12) | (v4 << 8) | (v2 << 4) | v0;
     out[((mT * ksuper + ks) * 32 + t) * I + inner] = (int32_t)pack;
   }
@@ -372,7 +383,30 @@ inline int launch_status() {
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// Kernels that address LDS from offset 0 (lookup tables at the start of the dynamic region) and / or need more than 64 KiB
+// of dynamic LDS: once per device, check that the kernel has no static LDS (the dynamic region then starts at 0) and raise
+// its dynamic-LDS limit.  State = one write-once bit per device and kernel; racing threads repeat the same idempotent calls.
+template <auto KERN>
+int prepare_lds_kernel() {
+  static std::atomic<uint64_t> done{0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return TG_E_DEVICE;
+  if (dev >= 0 && dev < 64 && ((done.load(std::memory_order_relaxed) >> dev) & 1u)) return 0;
+  hipFuncAttributes fa;
+  hipError_t e = hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(KERN));
+  if (e != hipSuccess) return (int)e;
+  if (fa.sharedSizeBytes != 0) return TG_E_INTERNAL;
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(KERN), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e != hipSuccess) return (int)e;
+  if (dev >= 0 && dev < 64) done.fetch_or(1ull << dev, std::memory_order_relaxed);
+  return 0;
+}
+
+#ifdef TG_DEV  // developer builds only (-DTG_DEV): geometry override through the environment, never in the shipped library
 int g_dbg_variant = 0;
+#else
+constexpr int g_dbg_variant = 0;
+#endif
 
 // Launch geometry.  Streaming shapes (many tiles) use 8-wave workgroups, two per CU, and the
 // smallest split-K that still puts >= ~16 waves on every CU; a single small matrix (one tile per
@@ -495,12 +529,10 @@ int launch_stream_sw(StreamParams& sp, int sk, int64_t coltiles, int64_t batch, 
   dim3 grid((unsigned)((sp.rowtiles + tpb - 1) / tpb), (unsigned)coltiles, (unsigned)batch);
 #define TG_LAUNCH_STREAM(XL)                                                                              \
   do {                                                                                                    \
-    auto kern = w4_gemm_stream_kernel<DT, LAYOUT_A, WPL, QMX, SW, STREAM_MINW, XL, privx>;                \
-    if (lds > 64u * 1024u) {                                                                              \
-      static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),            \
-                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-      if (attr != hipSuccess) return (int)attr;                                                           \
-    }                                                                                                     \
+    constexpr auto kern = w4_gemm_stream_kernel<DT, LAYOUT_A, WPL, QMX, SW, STREAM_MINW, XL, privx>;      \
+    if (sp.dry) return TG_PLAN_STREAM;                                                                    \
+    const int prc = prepare_lds_kernel<kern>();                                                           \
+    if (prc != 0) return prc;                                                                             \
     hipLaunchKernelGGL(kern, grid, dim3(SW * 64), lds, st, sp);                                           \
   } while (0)
   if constexpr (privx && SW > 1) {
@@ -526,10 +558,10 @@ int launch_stream_xres(StreamParams& sp, int64_t coltiles, int64_t batch, unsign
   int tpw = 4;
   while (tpw > 1 && ((sp.rowtiles + 16 * tpw - 1) / (16 * tpw)) * coltiles * batch < 512) tpw >>= 1;
   sp.tiles_per_wave = tpw;
-  auto kern = w4_gemm_stream_kernel<DT, LAYOUT_A, WPL, QMX, 16, STREAM_MINW, 1, false, 0, true>;
-  static const hipError_t attr =
-      hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  if (attr != hipSuccess) return (int)attr;
+  constexpr auto kern = w4_gemm_stream_kernel<DT, LAYOUT_A, WPL, QMX, 16, STREAM_MINW, 1, false, 0, true>;
+  if (sp.dry) return TG_PLAN_STREAM;
+  const int prc = prepare_lds_kernel<kern>();
+  if (prc != 0) return prc;
   dim3 grid((unsigned)((sp.rowtiles + 16 * tpw - 1) / (16 * tpw)), (unsigned)coltiles, (unsigned)batch);
   hipLaunchKernelGGL(kern, grid, dim3(16 * 64), lds, st, sp);
   return launch_status();
@@ -547,6 +579,7 @@ int launch_stream(const GemmParams& p, int64_t coltiles, int64_t batch, hipStrea
   sp.tiles_per_wave = 1;
   sp.stride_x = p.stride_x; sp.stride_w = p.stride_w; sp.stride_qinfo = p.stride_qinfo;
   sp.stride_lut = p.stride_lut; sp.stride_y = p.stride_y;
+  sp.bias = p.bias; sp.stride_bias = p.stride_bias; sp.dry = p.dry;
   const int mrows = p.m < 16 ? p.m : 16;
   const int nunits = (p.k + UNIT - 1) / UNIT;
   const int upg = (1 << p.gshift) / UNIT;
@@ -556,10 +589,16 @@ int launch_stream(const GemmParams& p, int64_t coltiles, int64_t batch, hipStrea
   // (m = 1, private slabs: one round of 16 waves per CU is enough -- measured on the Llama-3-8B shapes)
   const int64_t want = mrows == 1 ? 256 * 16 : 2 * 256 * 16;
   while (sk < 8 && wave_tiles * sk < want && nunits >= 8 * sk * upg && mrows * sk * 2 <= 16) sk *= 2;
+#ifdef TG_DEV
   static const int sk_env = getenv("TG_SK") ? atoi(getenv("TG_SK")) : 0;  // developer override
   if (sk_env > 0) sk = sk_env;
+#endif
   // m == 1: every wave stages its own X slab (no barrier in the main loop); a workgroup is the sk waves of one tile
+#ifdef TG_DEV
   static const int xres_env = getenv("TG_XRES") ? atoi(getenv("TG_XRES")) : 1;  // developer knob: 0 off, 2 also for m = 1
+#else
+  constexpr int xres_env = 1;
+#endif
   if (mrows == 1 && xres_env != 2) {
     switch (sk) {
       case 1: return launch_stream_sw<DT, LAYOUT_A, WPL, QMX, 1>(sp, 1, coltiles, batch, st);
@@ -590,6 +629,96 @@ int launch_stream(const GemmParams& p, int64_t coltiles, int64_t batch, hipStrea
   return launch_stream_sw<DT, LAYOUT_A, WPL, QMX, 8>(sp, sk, coltiles, batch, st);
 }
 
+
+// ---- pair-table kernel launch (w4_gemm_pair.cuh) ---------------------------------------------------
+// Returns TG_PAIR_NA when the shape does not fit this kernel's LDS plan (the caller then takes another kernel).
+enum { TG_PAIR_NA = -100 };
+
+#ifndef TG_PAIR_R
+#define TG_PAIR_R 2
+#endif
+#ifndef TG_PAIR_ABL
+#define TG_PAIR_ABL 0
+#endif
+#ifndef TG_PAIR_SB
+#define TG_PAIR_SB 1
+#endif
+#ifndef TG_PAIR_WGS
+#define TG_PAIR_WGS 512  // persistent workgroups: two per CU
+#endif
+template <typename DT, int I, int GPS, int MREGS, bool QMX>
+int launch_pair_k(PairParams& pp, unsigned lds, hipStream_t st) {
+#ifdef TG_DEV_MIN  // developer builds: only the headline instantiation (fast A/B builds)
+  if constexpr (!(std::is_same<DT, BF16>::value && I == 4 && GPS == 1 && MREGS == 4 && !QMX)) return TG_PAIR_NA;
+  else {
+#endif
+  constexpr auto kern = w4_gemm_pair_kernel<DT, I, GPS, MREGS, QMX, TG_PAIR_R, TG_PAIR_ABL, TG_PAIR_SB>;
+  if (pp.dry) return TG_PLAN_PAIR;
+  const int prc = prepare_lds_kernel<kern>();
+  if (prc != 0) return prc;
+  const unsigned wgs = (unsigned)(pp.items < TG_PAIR_WGS ? pp.items : TG_PAIR_WGS);
+  hipLaunchKernelGGL(kern, dim3(wgs), dim3(512), lds, st, pp);
+  return launch_status();
+#ifdef TG_DEV_MIN
+  }
+#endif
+}
+
+template <typename DT, int I, bool QMX>
+int launch_pair(const GemmParams& p, int64_t batch, hipStream_t st) {
+  constexpr int RW = 64;
+  const int g = 1 << p.gshift;
+  const int gps = g >= 16 * I ? 1 : (16 * I) / g;
+  const int mregs = p.m <= 8 ? 4 : (p.m <= 16 ? 8 : 16);
+  const int ma = 2 * mregs;
+  PairParams pp;
+  pp.x = p.x; pp.w = p.w; pp.qinfo = p.qinfo; pp.lut = p.lut; pp.y = p.y;
+  pp.m = p.m; pp.wrows = p.wrows; pp.k = p.k; pp.ntiles = p.ntiles; pp.ksuper = p.ksuper;
+  pp.gshift = p.gshift; pp.ngroups = p.ngroups; pp.qtype = p.qtype;
+  const int nsg = g >= 16 * I ? g / (16 * I) : 1;  // super-tiles per group
+  const int units = p.ksuper / nsg;
+  pp.spw = ((units + 7) / 8) * nsg;
+  pp.nsg_shift = 0;
+  while ((1 << pp.nsg_shift) < nsg) ++pp.nsg_shift;
+  pp.gch_mask = g / 32 - 1;
+  const int mrows = p.m < ma ? p.m : ma;
+  pp.rused = mrows < 4 ? mrows : mregs;
+  pp.xs_rows = mrows <= 4 ? 4 : ma;
+  pp.red_lanes = mrows <= 4 ? 32 : 64;
+  pp.x_pitch = p.k * 2 + 16;
+  pp.lds_x = 65536;
+  pp.lds_xs = (pp.lds_x + mrows * pp.x_pitch + 32 + 15) & ~15;
+  pp.lds_red = (pp.lds_xs + p.ngroups * pp.xs_rows * 4 + 15) & ~15;
+  pp.red_alias = mrows > 4;  // 16 KiB and more of partial sums: reuse the table's LDS instead
+  unsigned lds = (unsigned)pp.lds_red + (unsigned)(8 * 2 * pp.rused * pp.red_lanes * 4);
+  if (pp.red_alias) {
+    lds = (unsigned)pp.lds_red;
+    pp.lds_red = 0;
+  }
+  if (lds > 80u * 1024u) return TG_PAIR_NA;  // two workgroups per CU
+  pp.rblocks = (p.wrows + RW - 1) / RW;
+  pp.cblocks = (p.m + ma - 1) / ma;
+  const int64_t items = (int64_t)pp.rblocks * pp.cblocks * batch;
+  if (items > INT32_MAX) return TG_PAIR_NA;
+  pp.items = (int32_t)items;
+  pp.stride_x = p.stride_x; pp.stride_w = p.stride_w; pp.stride_qinfo = p.stride_qinfo;
+  pp.stride_lut = p.stride_lut; pp.stride_y = p.stride_y;
+  pp.bias = p.bias; pp.stride_bias = p.stride_bias; pp.dry = p.dry;
+#define TG_PAIR_M(GPS_)                                                        \
+  (mregs == 4 ? launch_pair_k<DT, I, GPS_, 4, QMX>(pp, lds, st)               \
+              : mregs == 8 ? launch_pair_k<DT, I, GPS_, 8, QMX>(pp, lds, st)  \
+                           : launch_pair_k<DT, I, GPS_, 16, QMX>(pp, lds, st))
+  if (gps == 1) return TG_PAIR_M(1);
+  if constexpr (I >= 4) {
+    if (gps == 2) return TG_PAIR_M(2);
+  }
+  if constexpr (I >= 8) {
+    if (gps == 4) return TG_PAIR_M(4);
+  }
+#undef TG_PAIR_M
+  return TG_PAIR_NA;
+}
+
 template <typename DT, bool LAYOUT_A, int CANON, bool QMX>
 int launch_w4(GemmParams& p, int64_t coltiles, int64_t batch, hipStream_t st) {
   constexpr int KSTEP = LAYOUT_A ? 64 : 128;
@@ -600,12 +729,24 @@ int launch_w4(GemmParams& p, int64_t coltiles, int64_t batch, hipStream_t st) {
   dim3 grid((unsigned)((p.rowtiles + tpb - 1) / tpb), (unsigned)coltiles, (unsigned)batch);
   // Streaming shapes go to the lane-owns-group kernel when the quantisation group covers at least one
   // unit of its walk (Bint4: g >= 128, Aint4: g >= 64).  TG_STREAM=0 forces the split-K kernel.
+#ifdef TG_DEV
   static const int use_stream = getenv("TG_STREAM") ? atoi(getenv("TG_STREAM")) : 1;
+#else
+  constexpr int use_stream = 1;
+#endif
   constexpr int WPL = CANON == CANON_NONE ? 1 : (CANON == CANON_PAIR ? 2 : 4);
+  // TG_NUM_FAST, weights on the B side: the pair-table kernel (group-scaled numerics) whenever its LDS plan fits
+  if constexpr (!LAYOUT_A) {
+    if (p.numerics == TG_NUM_FAST) {
+      const int rc = launch_pair<DT, 2 * WPL, QMX>(p, batch, st);
+      if (rc != TG_PAIR_NA) return rc;
+    }
+  }
   // m = 1 always streams: with private X slabs its split-K variants beat the latency kernel down to one matrix
   if (use_stream && (g.waves == 8 || p.m == 1 || use_stream == 2) && (1 << p.gshift) >= (LAYOUT_A ? 64 : 128)) {
     return launch_stream<DT, LAYOUT_A, WPL, QMX>(p, coltiles, batch, st);
   }
+  if (p.dry) return TG_PLAN_SPLITK;
   if (g.waves == 16) {
     hipLaunchKernelGGL((w4_gemm_kernel<DT, LAYOUT_A, CANON, QMX, 16, 2, 4>), grid, dim3(16 * 64), 0, st, p);
   } else {
@@ -647,6 +788,8 @@ const char* tg_error_string(int code) {
     case TG_E_SHAPE: return "inconsistent or non-positive sizes";
     case TG_E_ALIGN: return "device buffers must be 16-byte aligned";
     case TG_E_DEVICE: return "could not select the requested device";
+    case TG_E_SIZE: return "an operand is too large for the kernels' 32-bit byte offsets (activations, packed weights or quantisation info of one problem must stay below 2 GiB; at most 65535 16-row activation tiles)";
+    case TG_E_INTERNAL: return "internal error: a kernel that addresses LDS from offset 0 was built with static LDS";
     default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown tinygemm error";
   }
 }
@@ -746,7 +889,7 @@ int tg_dequant_int4(const int32_t* in, int64_t count, void* out_bf16, int device
   return launch_status();
 }
 
-int tg_gemm_w4(const tg_w4_gemm* a, int device, tg_stream_t stream) {
+static int gemm_w4_impl(const tg_w4_gemm* a, int device, tg_stream_t stream, int dry) {
   if (!a || !a->x || !a->w || !a->qinfo || !a->y) return TG_E_NULL;
   if (a->qtype < TG_Q_INT4 || a->qtype > TG_Q_MX4) return TG_E_QTYPE;
   if ((a->qtype == TG_Q_ANY4_GLOBAL || a->qtype == TG_Q_ANY4_ROWWISE) && !a->lut) return TG_E_NULL;
@@ -763,8 +906,16 @@ int tg_gemm_w4(const tg_w4_gemm* a, int device, tg_stream_t stream) {
   const int rows_per_tile = on_right ? 8 : 16;
   if (a->wrows % rows_per_tile != 0) return TG_E_SHAPE;
   if (!aligned16(a->x) || !aligned16(a->w) || (reinterpret_cast<uintptr_t>(a->qinfo) & 3u)) return TG_E_ALIGN;
+  if (a->lut && !aligned16(a->lut)) return TG_E_ALIGN;          // LUT rows are read as two 16-byte vectors
+  if (a->bias && (reinterpret_cast<uintptr_t>(a->bias) & 7u)) return TG_E_ALIGN;
+  if (!(a->numerics == TG_NUM_FAST || a->numerics == TG_NUM_REFERENCE) || a->reserved != 0) return TG_E_SHAPE;
   const int batch = a->batch > 1 ? a->batch : 1;
-  if (batch > 1 && ((a->stride_x | a->stride_w) & 15)) return TG_E_ALIGN;
+  if (batch > 1 && ((a->stride_x | a->stride_w | a->stride_lut) & 15)) return TG_E_ALIGN;
+  if (batch > 1 && a->bias && (a->stride_bias & 7)) return TG_E_ALIGN;
+  // the kernels address one problem's operands with 32-bit byte offsets
+  if (a->m * a->k * 2 >= (int64_t)1 << 31 || a->wrows * a->k / 2 >= (int64_t)1 << 31 ||
+      (a->k / a->group) * a->wrows * 4 >= (int64_t)1 << 31 || cdiv(a->m, 16) > 65535)
+    return TG_E_SIZE;
 
   GemmParams p;
   p.x = (const char*)a->x;
@@ -780,20 +931,27 @@ int tg_gemm_w4(const tg_w4_gemm* a, int device, tg_stream_t stream) {
   p.gshift = g == 32 ? 5 : g == 64 ? 6 : g == 128 ? 7 : 8;
   p.ngroups = (int32_t)(a->k / g);
   p.qtype = a->qtype;
+  p.dbg = 0;
+  p.dry = dry;
+  p.numerics = a->numerics;
+#ifdef TG_DEV
   {
     static const int env_dbg = getenv("TG_DBG") ? atoi(getenv("TG_DBG")) : 0;
     static const int env_var = getenv("TG_VARIANT") ? atoi(getenv("TG_VARIANT")) : 0;
     p.dbg = env_dbg;
     g_dbg_variant = env_var;
   }
+#endif
+  p.bias = (const char*)a->bias;
+  p.stride_bias = batch > 1 ? a->stride_bias : 0;
   p.stride_x = batch > 1 ? a->stride_x : 0;
   p.stride_w = batch > 1 ? a->stride_w : 0;
   p.stride_qinfo = batch > 1 ? a->stride_qinfo : 0;
   p.stride_lut = batch > 1 ? a->stride_lut : 0;
   p.stride_y = batch > 1 ? a->stride_y : 0;
 
-  DeviceScope ds(device);
-  if (!ds.ok) return TG_E_DEVICE;
+  DeviceScope ds(dry ? -1 : device);
+  if (!dry && !ds.ok) return TG_E_DEVICE;
   hipStream_t st = (hipStream_t)stream;
   p.rowtiles = (int32_t)cdiv(a->wrows, 16);
   const int64_t coltiles = cdiv(a->m, 16);
@@ -805,6 +963,10 @@ int tg_gemm_w4(const tg_w4_gemm* a, int device, tg_stream_t stream) {
   }
   return on_right ? launch_w4_c<F16, false>(p, canon, coltiles, batch, st) : launch_w4_c<F16, true>(p, canon, coltiles, batch, st);
 }
+
+int tg_gemm_w4(const tg_w4_gemm* a, int device, tg_stream_t stream) { return gemm_w4_impl(a, device, stream, 0); }
+
+int tg_gemm_w4_plan(const tg_w4_gemm* a, int device) { return gemm_w4_impl(a, device, nullptr, 1); }
 
 int tg_convert_to_Bint8(const int32_t* in, int64_t n, int64_t k, int I, int32_t* out, int device, tg_stream_t stream) {
   if (!in || !out) return TG_E_NULL;
@@ -852,15 +1014,22 @@ int tg_gemm_w8(const tg_w4_gemm* a, int device, tg_stream_t stream) {
   if ((reinterpret_cast<uintptr_t>(a->x) & 3u) || (reinterpret_cast<uintptr_t>(a->w) & 3u) ||
       (reinterpret_cast<uintptr_t>(a->qinfo) & 3u) || (reinterpret_cast<uintptr_t>(a->y) & 7u))
     return TG_E_ALIGN;
+  if (a->bias && (reinterpret_cast<uintptr_t>(a->bias) & 7u)) return TG_E_ALIGN;
+  if (a->reserved != 0) return TG_E_SHAPE;
+  if (a->m * a->k * 2 >= (int64_t)1 << 31 || a->wrows * a->k >= (int64_t)1 << 31 ||
+      (a->k / a->group) * a->wrows * 4 >= (int64_t)1 << 31 || cdiv(a->m, 16) > 65535)
+    return TG_E_SIZE;
   const int batch = a->batch > 1 ? a->batch : 1;
+  if (batch > 1 && a->bias && (a->stride_bias & 7)) return TG_E_ALIGN;
   GemmParams p;
   p.x = (const char*)a->x; p.w = (const char*)a->w; p.qinfo = (const char*)a->qinfo; p.lut = nullptr; p.y = (char*)a->y;
+  p.bias = (const char*)a->bias; p.stride_bias = batch > 1 ? a->stride_bias : 0; p.numerics = TG_NUM_REFERENCE;
   p.m = (int32_t)a->m; p.wrows = (int32_t)a->wrows; p.k = (int32_t)a->k;
   p.ntiles = (int32_t)(a->wrows / rows_per_tile);
   p.ksuper = (int32_t)(a->k / (16 * I));
   p.gshift = g == 32 ? 5 : g == 64 ? 6 : g == 128 ? 7 : 8;
   p.ngroups = (int32_t)(a->k / g);
-  p.qtype = a->qtype; p.dbg = 0;
+  p.qtype = a->qtype; p.dbg = 0; p.dry = 0;
   p.stride_x = batch > 1 ? a->stride_x : 0; p.stride_w = batch > 1 ? a->stride_w : 0;
   p.stride_qinfo = batch > 1 ? a->stride_qinfo : 0; p.stride_lut = 0; p.stride_y = batch > 1 ? a->stride_y : 0;
   DeviceScope ds(device);

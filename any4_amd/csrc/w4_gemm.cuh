@@ -36,7 +36,11 @@ struct GemmParams {
   int32_t sk_shift;  // log2(splitk)
   int32_t rowtiles;  // ceil(wrows / 16)
   int32_t dbg;       // developer ablation flags (0 in production)
+  int32_t numerics;  // TG_NUM_* (host-side dispatch only)
+  int32_t dry;       // host-side only: report the kernel family instead of launching (tg_gemm_w4_plan)
   int64_t stride_x, stride_w, stride_qinfo, stride_lut, stride_y;
+  const char* bias;   // optional [wrows] 16-bit, added after the first rounding (see store_rows4)
+  int64_t stride_bias;
 };
 
 enum { CANON_NONE = 0, CANON_PAIR = 1, CANON_QUAD = 2 };
@@ -310,7 +314,6 @@ __global__ void __launch_bounds__(WAVES * 64, MINW) w4_gemm_kernel(const GemmPar
   const int col = ct * 16 + i;
   const int rowg = row0 + 4 * Q;
   if (rt_ok && col < p.m && rowg < p.wrows) {  // wrows % 8 == 0 and rowg % 4 == 0: all four rows valid
-    u32x2 o = {DT::pack2(acc[0], acc[1]), DT::pack2(acc[2], acc[3])};
-    *reinterpret_cast<u32x2*>(yb + ((int64_t)col * p.wrows + rowg) * 2) = o;
+    store_rows4<DT>(yb, p.bias ? p.bias + b * p.stride_bias : nullptr, (int64_t)col * p.wrows + rowg, rowg, acc);
   }
 }

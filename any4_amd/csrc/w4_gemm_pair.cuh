@@ -1,0 +1,495 @@
+// w4_gemm_pair.cuh -- the "pair-table" W4A16 GEMM kernel for gfx950 (weights on the B side, Bint4 layout).
+//
+// Same contract as w4_gemm.cuh / w4_gemm_stream.cuh (reference TinyGemmImpl.cuh:23-345 with BLayout_TC_int4,
+// MatrixLayoutB.cuh:686-1101, and the converters of Dequantization.cuh:55-178, 331-351), with the "group-scaled"
+// numerics described below.
+//
+// Why another kernel: a per-element LDS lookup (w4_gemm_stream.cuh) costs one LDS access per 4-bit weight and the LDS
+// serves 32 addresses per clock -- at the HBM roofline a CU has to dequantise ~20 weights per clock, which leaves the LDS
+// 62 % busy with lookups alone (measured: 68 % LDS-busy, 61 % VALU-busy at 57 % of the HBM roofline).  A packed byte holds
+// TWO codes of one weight row, so a 256-entry table of code PAIRS per row turns two lookups and a merge into one lookup.
+// Such a table can only depend on the row (a per-(row, group) pair table would cost more to build than it saves), so the
+// per-group affine map moves behind the contraction:
+//
+//   y[a][row] = sum_g ( scale[g,row] * sum_{k in g} x[a][k] * lut[row][code[row][k]]  +  zero[g,row] * sum_{k in g} x[a][k] )
+//
+// with every product and every sum in f32: the MFMA contracts x with the RAW LUT values (16-bit x 16-bit products are exact
+// in f32), the accumulator of a group is scaled once, and sum_{k in g} x is computed once per workgroup.  Compared with the
+// reference (w = RNE16(fma(lut, scale, zero)) per element, MatrixLayoutB.cuh:1042-1046) this skips the rounding of every
+// dequantised weight to 16 bits: the result differs from the reference's by at most the reference's own per-weight rounding
+// (|dy| <= 2^-9 sum_k |x_k w_k| worst case, ~2^-9 sqrt(sum_k x_k^2 w_k^2) typically: below one output ulp for k <= 16K)
+// and is the closer of the two to the unrounded sum.  mx4 (scale = 2^e, zero = 0) loses nothing: its weights are exact.
+//
+//   workgroup  = 8 waves, 64 weight rows (two 32-row MFMA tiles), the whole k; wave w walks the k-slice w (split-K 8, the
+//                partial sums meet in LDS and are added in wave order: deterministic).
+//   MFMA       = v_mfma_f32_32x32x16: A operand = activations (act row a = lane & 31, k-slot h = lane >> 5),
+//                B operand = weights (weight row c = lane & 31, same k-slot), D[a][c]: lane (c, h) holds act rows
+//                (r & 3) + 8 (r >> 2) + 4 h of ITS weight row, so scale / zero are per-lane scalars.
+//   table      = LDS [256 byte values][64 columns] x 4 bytes at LDS address 0; column = weight row of the workgroup, entry =
+//                (lut[byte & 15], lut[byte >> 4]).  A 32-lane access group touches 32 distinct columns = 32 distinct banks:
+//                conflict-free data-dependent reads, the address is ONE v_perm_b32 (byte << 8 | column << 2).
+//   weights    = lane (c, h) reads the 4 I bytes (I words) of row c in k super-tile s that belong to lane-quads
+//                q = 2 h, 2 h + 1 of the reference layout: the 16 lanes of 8 rows x 2 h cover one whole 256-byte (I = 4)
+//                super-tile, so a wave-load touches 4 (8) fully used segments.  One word = 8 codes = one MFMA step.
+//   activations= staged once per workgroup into LDS in "byte order": byte j of a packed word of quad q holds the codes of
+//                k = {2q, 2q+16, 2q+1, 2q+17}[j] (low nibble) and that + 8 (high nibble) of a 32-k chunk
+//                (TinyGemmConvertB.cu:252-308), so the X fragment of (chunk, q) is the 8 values
+//                x[2q, 2q+8, 2q+16, 2q+24, 2q+1, 2q+9, 2q+17, 2q+25] as one 16-byte piece.
+//   persistent = a workgroup walks a contiguous range of work items (item = one 64-row block of one problem of the batch):
+//                the register ring of R super-tiles of packed words (+ scale|zero words) a wave keeps in flight from HBM
+//                runs across item boundaries, and the LUT rows of the next item are requested at the start of the current
+//                one, so the weight stream never drains while a table is rebuilt.  Two barriers per item.
+#pragma once
+
+struct PairParams {
+  const char* x;
+  const char* w;
+  const char* qinfo;
+  const char* lut;
+  char* y;
+  int32_t m, wrows, k;
+  int32_t ntiles;   // packed.size(0): 8-row groups
+  int32_t ksuper;   // packed.size(1)
+  int32_t gshift;   // log2(group)
+  int32_t ngroups;  // k / group
+  int32_t qtype;
+  int32_t spw;      // k super-tiles per wave (a multiple of the super-tiles per group)
+  int32_t nsg_shift; // log2(super-tiles per group), 0 when a group is at most one super-tile
+  int32_t gch_mask; // (32-k chunks per group) - 1
+  int32_t x_pitch;  // bytes per staged activation row
+  int32_t lds_x;    // LDS byte offsets: staged activations (m rows, then the 32-byte zero piece)
+  int32_t lds_xs;   //                   per-group activation sums, f32 [ngroups][xs_rows]
+  int32_t lds_red;  //                   split-K partial sums, f32 [8 waves][2 tiles][rused][red_lanes]
+  int32_t rused;    // accumulator registers that hold real activation rows (m < 4: m, else MREGS)
+  int32_t xs_rows;  // rows of the activation sums kept per group: 4 when m <= 4 (lane half 1 then holds no real row), else 2 * MREGS
+  int32_t red_lanes;  // lanes whose partial sums are exchanged: 32 when m <= 4, else 64
+  int32_t red_alias;  // 1: the partial sums reuse the table's LDS (m > 4: two more barriers per item), lds_red = 0
+  int32_t rblocks;  // 64-row blocks per problem
+  int32_t cblocks;  // activation-row passes per problem (ceil(m / (2 MREGS)))
+  int32_t items;    // rblocks * cblocks * batch
+  int64_t stride_x, stride_w, stride_qinfo, stride_lut, stride_y;
+  const char* bias;   // optional [wrows] 16-bit, added after the first rounding
+  int64_t stride_bias;
+  int32_t dry;        // host-side only: report the kernel family instead of launching (tg_gemm_w4_plan)
+};
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((address_space(3))) float* lds_fptr;
+
+template <typename DT>
+__device__ __forceinline__ f32x16 mfma32(u32x4 a, u32x4 b, f32x16 c) {
+  if constexpr (std::is_same<DT, BF16>::value)
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+template <typename DT>
+__device__ __forceinline__ float dot2_ones(uint32_t pair, float acc) {
+  if constexpr (std::is_same<DT, BF16>::value)
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, pair), __builtin_bit_cast(bf16x2, 0x3f803f80u), acc, false);
+  else
+    return __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, pair), __builtin_bit_cast(f16x2, 0x3c003c00u), acc, false);
+}
+
+// I     = innerKTiles of the Bint4 layout (2, 4, 8): k super-tile = 16 I, I words per lane and super-tile
+// GPS   = quantisation groups per super-tile (1 when group >= 16 I)
+// MREGS = accumulator registers that can hold real activation rows: 4 -> m <= 8, 8 -> m <= 16, 16 -> m <= 32
+// R     = super-tiles in flight per wave (register ring); the host guarantees every wave's k-slice has >= R super-tiles
+template <typename DT, int I, int GPS, int MREGS, bool QMX, int R, int ABL = 0, int SB = 1>
+__global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p) {
+  constexpr int WAVES = 8;
+  constexpr int TILES = 2;              // 32-row MFMA tiles per workgroup
+  constexpr int RW = 32 * TILES;
+  constexpr int CPS = I / 2;            // 32-k chunks per super-tile
+  constexpr int CPG = CPS / GPS;        // chunks per group inside a super-tile (GPS > 1 only)
+  constexpr int MA = 2 * MREGS;         // activation rows a pass can hold
+
+  // The pair table sits at LDS address 0 (a lookup address is just byte << 8 | column << 2): the kernel has no static LDS,
+  // which the host verifies once per kernel (hipFuncGetAttributes().sharedSizeBytes == 0) before the first launch.
+  constexpr uint32_t lds0 = 0u;
+  const uint32_t lds_x = lds0 + (uint32_t)p.lds_x;
+  const uint32_t lds_xs = lds0 + (uint32_t)p.lds_xs;
+  const uint32_t lds_red = lds0 + (uint32_t)p.lds_red;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 31;
+  const int h = lane >> 5;
+  const int tcol = tid & 63;  // table column = weight row of the item this thread builds
+
+  // ---- this workgroup's contiguous range of work items; item -> (problem b, activation pass ct, row block rb) ----
+  const int it_begin = (int)(((int64_t)blockIdx.x * p.items) / gridDim.x);
+  const int it_end = (int)(((int64_t)(blockIdx.x + 1) * p.items) / gridDim.x);
+  const int per_problem = p.rblocks * p.cblocks;
+
+  // ---- this wave's k-slice: super-tiles [s_begin, s_begin + nl) ----
+  const int s_begin = wave * p.spw;
+  const int nl = max(min(p.spw, p.ksuper - s_begin), 0);
+
+  struct Item {
+    int b, ct, rb;
+  };
+  auto decode = [&](int it) -> Item {
+    const int b = it / per_problem, r = it - b * per_problem;
+    const int ct = r / p.rblocks;
+    return Item{b, ct, r - ct * p.rblocks};
+  };
+
+  // ---- LUT rows: 16 values of this thread's table column as 8 packed 16-bit pairs, requested one item ahead ----
+  uint32_t lp[8];
+  auto lut_const = [&]() {
+#pragma unroll
+    for (int e = 0; e < 16; e += 2) {
+      float v0, v1;
+      if (p.qtype == TG_Q_INT4) {
+        v0 = (float)(e - 8);
+        v1 = (float)(e - 7);
+      } else {
+        const int e1 = e + 1;
+        v0 = (e & 8 ? -1.f : 1.f) * ((e & 7) < 5 ? 0.5f * (e & 7) : ((e & 7) == 5 ? 3.f : (e & 7) == 6 ? 4.f : 6.f));
+        v1 = (e1 & 8 ? -1.f : 1.f) * ((e1 & 7) < 5 ? 0.5f * (e1 & 7) : ((e1 & 7) == 5 ? 3.f : (e1 & 7) == 6 ? 4.f : 6.f));
+      }
+      lp[e >> 1] = DT::pack2(v0, v1);  // exact: small integers / fp4 values
+    }
+  };
+  const bool lut_loaded = p.qtype == TG_Q_ANY4_GLOBAL || p.qtype == TG_Q_ANY4_ROWWISE;
+  auto lut_request = [&](int it) {  // it is clamped by the caller to a valid item
+    const Item e = decode(it);
+    const int lrow = min(e.rb * RW + tcol, p.wrows - 1);
+    const char* lsrc = p.lut + (int64_t)e.b * p.stride_lut + (p.qtype == TG_Q_ANY4_ROWWISE ? (int64_t)lrow * 32 : 0);
+    const u32x4 l0 = reinterpret_cast<const u32x4*>(lsrc)[0];
+    const u32x4 l1 = reinterpret_cast<const u32x4*>(lsrc)[1];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { lp[j] = l0[j]; lp[4 + j] = l1[j]; }
+  };
+
+  // ---- ring of R super-tiles: packed words and scale|zero words (or mx4 exponent bytes) ----
+  struct Slot {
+    uint32_t w[TILES][I];
+    uint32_t q[TILES][GPS];
+  };
+  Slot ring[R];
+  // per-lane addressing of an item: byte offset of this lane's words in super-tile 0 of its rows (the host checks the matrix
+  // is < 4 GiB) and its rows
+  struct Rows {
+    uint32_t wbase[TILES];
+    uint32_t qrow[TILES];
+    const char* wb;
+    const char* qb;
+  };
+  auto rows_of = [&](int it) -> Rows {
+    const Item e = decode(it);
+    Rows r;
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) {
+      const int row = min(e.rb * RW + t * 32 + c, p.wrows - 1);
+      const int nt = min(row >> 3, p.ntiles - 1);
+      r.wbase[t] = ((uint32_t)nt * (uint32_t)p.ksuper * 32u + (uint32_t)(4 * (row & 7) + 2 * h)) * (uint32_t)(2 * I);
+      r.qrow[t] = (uint32_t)row;
+    }
+    r.wb = p.w + (int64_t)e.b * p.stride_w;
+    r.qb = p.qinfo + (int64_t)e.b * p.stride_qinfo;
+    return r;
+  };
+  // Requests super-tile s of the rows `rw`.  `valid` is wave-uniform.  A request past the last item is still ISSUED (so that
+  // the number of loads in flight is the same on every path and the compiler's vmcnt bookkeeping stays exact -- a conditional
+  // refill makes it wait for every outstanding load at the next use, draining the ring each round) but every lane reads the
+  // first bytes of the operand: one cached request, never consumed.
+  auto issue = [&](const Rows& rw, int s, Slot& sl, bool valid) {
+    const uint32_t vm = valid ? 0xffffffffu : 0u;
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) {
+      const char* src = rw.wb + ((rw.wbase[t] + (uint32_t)s * (uint32_t)(64 * I)) & vm);
+      if constexpr (ABL == 3) {
+#pragma unroll
+        for (int j = 0; j < I; ++j) sl.w[t][j] = (uint32_t)(s * 7 + j + t);
+      } else if constexpr (I == 2) {
+        const u32x2 v = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(src));
+        sl.w[t][0] = v[0]; sl.w[t][1] = v[1];
+      } else {
+#pragma unroll
+        for (int v4 = 0; v4 < I / 4; ++v4) {
+          const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src) + v4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) sl.w[t][4 * v4 + j] = v[j];
+        }
+      }
+#pragma unroll
+      for (int gg = 0; gg < GPS; ++gg) {
+        const uint32_t g = (uint32_t)(((s * CPS + gg * CPG) * 32) >> p.gshift);
+        if constexpr (QMX) sl.q[t][gg] = *reinterpret_cast<const uint8_t*>(rw.qb + ((rw.qrow[t] * (uint32_t)p.ngroups + g) & vm));
+        else sl.q[t][gg] = *reinterpret_cast<const uint32_t*>(rw.qb + (((g * (uint32_t)p.wrows + rw.qrow[t]) * 4u) & vm));
+      }
+    }
+  };
+
+  // ---- activation staging: chunk (row a, 32 k) -> LDS in byte order, and the per-group sums ----
+  const int nch = p.k >> 5;
+  auto x_load = [&](const char* xb, int xi, uint32_t (&d)[16]) {
+    const int a = xi / nch, ch = xi - a * nch;
+    const u32x4* src = reinterpret_cast<const u32x4*>(xb + ((int64_t)a * p.k + ch * 32) * 2);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const u32x4 v = src[j];
+      d[4 * j] = v[0]; d[4 * j + 1] = v[1]; d[4 * j + 2] = v[2]; d[4 * j + 3] = v[3];
+    }
+  };
+  auto x_store = [&](int xi, bool on, const uint32_t (&d)[16]) {  // d holds zeros when !on
+    const int a = on ? xi / nch : 0, ch = on ? xi - (xi / nch) * nch : 0;
+    if (on) {
+      const uint32_t dst = lds_x + (uint32_t)(a * p.x_pitch + ch * 64);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        u32x4 o;
+        o[0] = __builtin_amdgcn_perm(d[q + 4], d[q], 0x05040100u);       // x[2q]     x[2q+8]
+        o[1] = __builtin_amdgcn_perm(d[q + 12], d[q + 8], 0x05040100u);  // x[2q+16]  x[2q+24]
+        o[2] = __builtin_amdgcn_perm(d[q + 4], d[q], 0x07060302u);       // x[2q+1]   x[2q+9]
+        o[3] = __builtin_amdgcn_perm(d[q + 12], d[q + 8], 0x07060302u);  // x[2q+17]  x[2q+25]
+        *(lds_u32x4ptr)(dst + (uint32_t)(q * 16)) = o;
+      }
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) sum = dot2_ones<DT>(d[j], sum);
+    // chunks of one group sit in adjacent lanes (k / 32 is a multiple of the chunks per group): fixed-shape butterfly
+    for (int o = 1; o <= p.gch_mask; o <<= 1) sum += __shfl_xor(sum, o);
+    if (on && (ch & p.gch_mask) == 0) *(lds_fptr)(lds_xs + (uint32_t)(((ch >> (p.gshift - 5)) * p.xs_rows + a) * 4)) = sum;
+  };
+  // stages activation rows [a0, a0 + mrows) of problem b; `pre` = the first batch of chunks is already in xd
+  auto x_stage = [&](int b, int a0, int mrows, bool pre, uint32_t (&xd)[16]) {
+    const char* xb = p.x + (int64_t)b * p.stride_x + (int64_t)a0 * p.k * 2;
+    const int xtotal = mrows * nch;
+    for (int it0 = 0; it0 < xtotal; it0 += 512) {
+      const int xi = it0 + tid;
+      const bool on = xi < xtotal;
+      if (!(pre && it0 == 0)) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) xd[j] = 0u;
+        if (on) x_load(xb, xi, xd);
+      }
+      x_store(xi, on, xd);
+    }
+    // rows a >= mrows of the sums stay zero
+    for (int idx = tid; idx < p.ngroups * p.xs_rows; idx += 512)
+      if (idx % p.xs_rows >= mrows) *(lds_fptr)(lds_xs + (uint32_t)(idx * 4)) = 0.f;
+    if (tid < 2) *(lds_u32x4ptr)(lds_x + (uint32_t)(mrows * p.x_pitch + tid * 16)) = u32x4{0, 0, 0, 0};
+  };
+
+  // ---- requests before the first item, in the order the prologue consumes them (vector memory returns in order): its LUT
+  // rows, the first batch of its activation chunks, then its first R super-tiles (one by one: the scheduler must not reorder
+  // them, the ring is consumed in slot order) ----
+  if (it_begin >= it_end) return;
+  if (lut_loaded) lut_request(it_begin);
+  else lut_const();
+  const Item first = decode(it_begin);
+  int staged_b = first.b, staged_ct = first.ct;  // which activation block the LDS holds
+  uint32_t xd0[16];
+  {
+    const int mrows0 = min(p.m - first.ct * MA, MA);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) xd0[j] = 0u;
+    if (tid < mrows0 * nch) x_load(p.x + (int64_t)first.b * p.stride_x + (int64_t)first.ct * MA * p.k * 2, tid, xd0);
+  }
+  Rows rcur = rows_of(it_begin);
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+    __builtin_amdgcn_sched_barrier(0);
+    issue(rcur, s_begin + j, ring[j], j < nl);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  x_stage(first.b, first.ct * MA, min(p.m - first.ct * MA, MA), true, xd0);
+
+  uint32_t colreg[TILES];
+#pragma unroll
+  for (int t = 0; t < TILES; ++t) colreg[t] = (uint32_t)((t * 32 + c) * 4);
+
+  for (int it = it_begin; it < it_end; ++it) {
+    const Item cur = decode(it);
+    const int row0 = cur.rb * RW;
+    const int a0 = cur.ct * MA;
+    const int mrows = min(p.m - a0, MA);
+    const bool has_next = it + 1 < it_end;
+    const Rows rnext = rows_of(has_next ? it + 1 : it);
+
+    // ---- pair table of this item: thread = (column, high nibbles 2 wave and 2 wave + 1).  The previous item's lookups are
+    // all behind the barrier that ended it. ----
+    {
+      uint32_t hw = lp[0];
+#pragma unroll
+      for (int j = 1; j < 8; ++j) hw = (wave == j) ? lp[j] : hw;
+      const uint32_t base = lds0 + (uint32_t)(wave * 2 * 16 * 256 + tcol * 4);
+#pragma unroll
+      for (int a = 0; a < 16; ++a) {
+        const uint32_t e0 = __builtin_amdgcn_perm(hw, lp[a >> 1], (a & 1) ? 0x05040302u : 0x05040100u);
+        const uint32_t e1 = __builtin_amdgcn_perm(hw, lp[a >> 1], (a & 1) ? 0x07060302u : 0x07060100u);
+        *(lds_u32ptr)(base + (uint32_t)(a * 256)) = e0;
+        *(lds_u32ptr)(base + (uint32_t)((16 + a) * 256)) = e1;
+      }
+    }
+    // the next item's LUT rows travel while this item is computed (the last item re-reads its own)
+    if (lut_loaded) lut_request(has_next ? it + 1 : it);
+
+    // ---- activations: only when the activation block changes (the first item's block was staged above) ----
+    if (cur.b != staged_b || cur.ct != staged_ct) {
+      staged_b = cur.b;
+      staged_ct = cur.ct;
+      uint32_t xd[16];
+      x_stage(cur.b, a0, mrows, false, xd);
+    }
+    __syncthreads();  // table and activations visible (and every thread is done with the previous item's partial sums)
+
+    // ---- main loop of the item ----
+    const bool a_on = c < mrows;  // this lane's A-operand row is a real activation row; the others read the zero piece
+    const uint32_t xrow = a_on ? lds_x + (uint32_t)(c * p.x_pitch + 2 * h * 16) : lds_x + (uint32_t)(mrows * p.x_pitch);
+    const uint32_t xmask = a_on ? 0xffffffffu : 0u;  // lanes on the zero piece never move
+
+    f32x16 acc[TILES];
+    float yacc[TILES][MREGS];
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+#pragma unroll
+      for (int r = 0; r < MREGS; ++r) yacc[t][r] = 0.f;
+    }
+    float gs[TILES], gz[TILES];  // scale / zero of the current group
+    float xsv[MREGS];            // activation sums of the current group for this lane's accumulator rows
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) gs[t] = gz[t] = 0.f;
+#pragma unroll
+    for (int r = 0; r < MREGS; ++r) xsv[r] = 0.f;
+
+    auto unpack_q = [&](uint32_t q, float& s, float& z) {
+      if constexpr (QMX) {
+        s = u2f(q == 255u ? 0x7fc00000u : (q == 0u ? 0x00400000u : (q << 23)));  // Dequantization.cuh:331-339
+        z = 0.f;
+      } else {
+        s = DT::lo_f32(q);
+        z = DT::hi_f32(q);
+      }
+    };
+    // the group that just ended: y += scale * acc + zero * sum(x); acc restarts at zero
+    auto finalize = [&]() {
+#pragma unroll
+      for (int t = 0; t < TILES; ++t) {
+#pragma unroll
+        for (int r = 0; r < MREGS; ++r) {
+          yacc[t][r] = __builtin_fmaf(gs[t], acc[t][r], yacc[t][r]);
+          yacc[t][r] = __builtin_fmaf(gz[t], xsv[r], yacc[t][r]);
+        }
+        // rows >= m of the A operand are zero, so only the first MREGS registers ever hold anything
+#pragma unroll
+        for (int r = 0; r < MREGS; ++r) acc[t][r] = 0.f;
+      }
+    };
+    // one super-tile: 2 CPS MFMA steps, step = (chunk jc, quad pair qq) for both tiles: 8 table lookups + one X piece;
+    // SB steps are looked up together before their MFMAs (more LDS reads in flight per wait)
+    auto consume = [&](int s, const Slot& sl) {
+      if constexpr (ABL == 6) {  // ablation: stream only
+#pragma unroll
+        for (int t = 0; t < TILES; ++t)
+#pragma unroll
+          for (int j = 0; j < I; ++j) acc[t][0] += u2f(sl.w[t][j]);
+        acc[0][1] += u2f(sl.q[0][0] ^ sl.q[1][0]);
+        return;
+      }
+#pragma unroll
+      for (int u0 = 0; u0 < 2 * CPS; u0 += SB) {
+        u32x4 xf[SB];
+        u32x4 bf[SB][TILES];
+#pragma unroll
+        for (int v = 0; v < SB; ++v) {
+          const int u = u0 + v, jc = u >> 1, qq = u & 1;
+          const int chunk = s * CPS + jc;
+          if (qq == 0 && (chunk & p.gch_mask) == 0) {  // a group starts
+            const int gg = GPS == 1 ? 0 : jc / CPG;
+#pragma unroll
+            for (int t = 0; t < TILES; ++t) unpack_q(sl.q[t][gg], gs[t], gz[t]);
+            // lanes whose accumulator rows are all padding (lane half 1 when m <= 4) read the zero piece behind the staged rows
+            const uint32_t xsa = 4 * h < p.xs_rows ? lds_xs + (uint32_t)((((chunk * 32) >> p.gshift) * p.xs_rows + 4 * h) * 4)
+                                                   : lds_x + (uint32_t)(mrows * p.x_pitch);
+#pragma unroll
+            for (int r4 = 0; r4 < MREGS / 4; ++r4) {
+              const f32x4 vv = *(lds_cf32x4ptr)(xsa + (uint32_t)(4 * h < p.xs_rows ? r4 * 32 : 0));
+              xsv[4 * r4] = vv[0]; xsv[4 * r4 + 1] = vv[1]; xsv[4 * r4 + 2] = vv[2]; xsv[4 * r4 + 3] = vv[3];
+            }
+          }
+          if constexpr (ABL == 5) xf[v] = u32x4{xrow, (uint32_t)s, (uint32_t)jc, (uint32_t)qq};  // ablation: no X reads
+          else xf[v] = *(lds_cu32x4ptr)(xrow + ((uint32_t)(chunk * 64 + 16 * qq) & xmask));
+#pragma unroll
+          for (int t = 0; t < TILES; ++t) {
+            const uint32_t w = sl.w[t][qq * CPS + jc];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const uint32_t addr = __builtin_amdgcn_perm(w, colreg[t], 0x0c0c0400u + ((uint32_t)j << 8));
+              if constexpr (ABL == 1) bf[v][t][j] = addr;  // ablation: no lookups
+              else bf[v][t][j] = *(lds_cu32ptr)(addr);
+            }
+          }
+        }
+#pragma unroll
+        for (int v = 0; v < SB; ++v) {
+          const int u = u0 + v, jc = u >> 1, qq = u & 1;
+          const int chunk = s * CPS + jc;
+#pragma unroll
+          for (int t = 0; t < TILES; ++t) {
+            if constexpr (ABL == 4) acc[t][0] += u2f(bf[v][t][0] ^ bf[v][t][1] ^ bf[v][t][2] ^ bf[v][t][3] ^ xf[v][0] ^ xf[v][1] ^ xf[v][2] ^ xf[v][3]);  // ablation: no MFMA
+            else acc[t] = mfma32<DT>(xf[v], bf[v][t], acc[t]);
+          }
+          if (qq == 1 && (chunk & p.gch_mask) == p.gch_mask) finalize();
+        }
+      }
+    };
+
+    // Rounds of R slice positions; position l lives in ring[l % R].  All rounds but the last refill from this item; the
+    // last round (always executed, also by waves with an empty slice) refills slot j with position j of the NEXT item, so
+    // the weight stream never drains -- and the compiler knows that those R refills were issued after the LUT request
+    // above, so the next table build waits with vmcnt(loads of one round) instead of draining the ring.
+    const int rounds = max((nl + R - 1) / R, 1);
+    int l0 = 0;
+    for (int rd = 0; rd < rounds - 1; ++rd, l0 += R) {
+#pragma unroll
+      for (int j = 0; j < R; ++j) {
+        consume(s_begin + l0 + j, ring[j]);
+        issue(rcur, s_begin + l0 + j + R, ring[j], l0 + j + R < nl);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      if (l0 + j < nl) consume(s_begin + l0 + j, ring[j]);
+      issue(rnext, s_begin + j, ring[j], has_next && j < nl);
+    }
+
+    // ---- split-K tail: the partial sums of the 8 waves meet in LDS and are added in wave order ----
+    if (p.red_alias) __syncthreads();  // the partial sums overwrite the table: every wave must be done with its lookups
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) {
+#pragma unroll
+      for (int r = 0; r < MREGS; ++r)
+        if (r < p.rused && lane < p.red_lanes)
+          *(lds_fptr)(lds_red + (uint32_t)((((wave * TILES + t) * p.rused + r) * p.red_lanes + lane) * 4)) = yacc[t][r];
+    }
+    __syncthreads();  // partial sums visible; every wave is done with this item's table
+    {
+      char* yb = p.y + (int64_t)cur.b * p.stride_y;
+      for (int o = tid; o < TILES * p.rused * p.red_lanes; o += 512) {
+        const int l = o % p.red_lanes, r = (o / p.red_lanes) % p.rused, t = o / (p.red_lanes * p.rused);
+        const int a = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+        const int row = row0 + t * 32 + (l & 31);
+        if (a < mrows && row < p.wrows) {
+          float sum = 0.f;
+#pragma unroll
+          for (int w = 0; w < WAVES; ++w) sum += *(lds_fptr)(lds_red + (uint32_t)((((w * TILES + t) * p.rused + r) * p.red_lanes + l) * 4));
+          uint16_t o16 = DT::from_f32(sum);
+          if (p.bias)  // rounded sum + bias, rounded again: bit-identical to the reference module's separate `y + bias`
+            o16 = DT::from_f32(DT::lo_f32(o16) + DT::lo_f32(*reinterpret_cast<const uint16_t*>(p.bias + (int64_t)cur.b * p.stride_bias + (int64_t)row * 2)));
+          *reinterpret_cast<uint16_t*>(yb + ((int64_t)(a0 + a) * p.wrows + row) * 2) = o16;
+        }
+      }
+    }
+    if (p.red_alias) __syncthreads();  // ... and the next table must not overwrite partial sums that are still being read
+    rcur = rnext;
+  }
+}

@@ -28,7 +28,7 @@
 //                  workgroup ([quarters][act rows][k / 4], p.xslab_bytes = bytes per row) and stays resident
 //                  while the 16 waves walk p.tiles_per_wave tiles each: one barrier per workgroup instead of one per unit.
 //
-// LDS (dynamic, sized by the host, no static LDS so the base is 0):
+// LDS (dynamic, sized by the host; no static LDS, checked on the host, so the base is 0):
 //   [WAVES x 4 KiB lookup tables][X slabs][split-K partial tiles, only when splitk > 1].
 // Wave w's table starts at byte w * 4096.  With WAVES == 1 (the stacked m = 1 launches) the table sits at 0
 // and a lookup address is just (nibble << 8 | lane << 2); otherwise address bits 12..15 (the table
@@ -63,6 +63,9 @@ struct StreamParams {
   int32_t red_off;          // LDS byte offset of the split-K partial tiles (unused when splitk == 1)
   int32_t tiles_per_wave;   // resident-X launches: consecutive tile groups walked by one workgroup (else 1)
   int64_t stride_x, stride_w, stride_qinfo, stride_lut, stride_y;
+  const char* bias;   // optional [wrows] 16-bit, added after the first rounding (see store_rows4)
+  int64_t stride_bias;
+  int32_t dry;        // host-side only: report the kernel family instead of launching (tg_gemm_w4_plan)
 };
 
 // WPL = packed words per (k super-tile, lane-row) entry: Bint4: I/2, Aint4: I
@@ -77,8 +80,8 @@ __global__ void __launch_bounds__(WAVES * 64, MINW) w4_gemm_stream_kernel(const 
   constexpr int PPR = UNIT * 2 / 16;         // 16-byte pieces per staged X row
   constexpr int NSTAGE = PRIVX ? 64 : WAVES * 64;  // threads sharing one slab
 
-  extern __shared__ __attribute__((aligned(4096))) char smem[];
-  if ((uint32_t)reinterpret_cast<uintptr_t>(smem) != 0u) __builtin_trap();  // the layout below assumes LDS base 0
+  // LDS is addressed from offset 0: the kernel has no static LDS, which the host verifies before the first launch
+  // (prepare_lds_kernel: hipFuncGetAttributes().sharedSizeBytes == 0).
   constexpr uint32_t lds_x0 = WAVES * 4096u;
   const uint32_t lds_red = (uint32_t)p.red_off;  // split-K tiles live behind the X slabs (only allocated when splitk > 1)
 
@@ -371,8 +374,7 @@ __global__ void __launch_bounds__(WAVES * 64, MINW) w4_gemm_stream_kernel(const 
   const int col = ct * 16 + i;
   const int rowg = row0 + 4 * Q;
   if (rt_ok && col < p.m && rowg < p.wrows) {
-    u32x2 o = {DT::pack2(acc[0], acc[1]), DT::pack2(acc[2], acc[3])};
-    *reinterpret_cast<u32x2*>(yb + ((int64_t)col * p.wrows + rowg) * 2) = o;
+    store_rows4<DT>(yb, p.bias ? p.bias + b * p.stride_bias : nullptr, (int64_t)col * p.wrows + rowg, rowg, acc);
   }
   }  // tile loop
 }

@@ -139,7 +139,6 @@ __global__ void __launch_bounds__(WAVES * 64, 2) w8_gemm_kernel(const GemmParams
   const int col = ct * 16 + i;
   const int rowg = row0 + 4 * Q;
   if (rt_ok && col < p.m && rowg < p.wrows) {
-    u32x2 o = {DT::pack2(acc[0], acc[1]), DT::pack2(acc[2], acc[3])};
-    *reinterpret_cast<u32x2*>(yb + ((int64_t)col * p.wrows + rowg) * 2) = o;
+    store_rows4<DT>(yb, p.bias ? p.bias + b * p.stride_bias : nullptr, (int64_t)col * p.wrows + rowg, rowg, acc);
   }
 }

@@ -14,6 +14,7 @@ from __future__ import annotations
 import torch
 
 from . import functional as F
+from . import ops as _ops
 
 _T = torch.ops.tinygemm
 
@@ -56,9 +57,15 @@ class _PackedLinear(torch.nn.Module):
 
     def forward(self, input: torch.Tensor) -> torch.Tensor:
         lead = input.shape[:-1]
-        y = self._gemm(input.view(-1, input.shape[-1]))
-        if self.bias is not None:
-            y = y + self.bias
+        if self.bias is None:
+            y = self._gemm(input.view(-1, input.shape[-1]))
+        else:
+            # the row-major GEMM kernels add the bias in their output store (same bits as the reference's separate
+            # `y + bias`, modules.py:221-222, one launch fewer); layouts that cannot take it get the separate add
+            with _ops.fused_bias(self.bias) as fb:
+                y = self._gemm(input.view(-1, input.shape[-1]))
+            if not fb.consumed:
+                y = y + self.bias
         return y.view(*lead, y.shape[-1])
 
     def extra_repr(self) -> str:

@@ -10,7 +10,10 @@ and handed to the library, which never allocates.
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes
+import os
+import threading
 
 import torch
 
@@ -45,6 +48,95 @@ SCHEMAS = {
 }
 
 _F16_TYPES = (torch.bfloat16, torch.float16)
+
+# ---------------------------------------------------------------------------------------------
+# call-side state the reference's op schemas have no argument for: GEMM numerics and a fused bias
+# ---------------------------------------------------------------------------------------------
+_NUMERICS = {"fast": _lib.TG_NUM_FAST, "reference": _lib.TG_NUM_REFERENCE}
+_numerics = os.environ.get("ANY4_NUMERICS", "fast")
+if _numerics not in _NUMERICS:
+    raise ImportError(f"ANY4_NUMERICS must be one of {sorted(_NUMERICS)}, got {_numerics!r}")
+_tls = threading.local()
+
+
+def get_numerics() -> str:
+    """'fast' (default): the 4-bit GEMMs may apply scale / zero per quantisation group to the f32 accumulator instead of to
+    every weight (include/tinygemm_hip.h, TG_NUM_FAST: no per-weight rounding, results within the reference's own weight
+    rounding).  'reference': bit-identical dequantised weights (w = RNE16(fma(lut, scale, zero))), as the reference kernels."""
+    return getattr(_tls, "numerics", _numerics)
+
+
+def set_numerics(name: str) -> None:
+    """Process-wide default (ANY4_NUMERICS in the environment sets the initial value)."""
+    global _numerics
+    if name not in _NUMERICS:
+        raise ValueError(f"numerics must be one of {sorted(_NUMERICS)}")
+    _numerics = name
+
+
+@contextlib.contextmanager
+def numerics(name: str):
+    """Thread-local override: `with any4_amd.numerics("reference"): ...`"""
+    if name not in _NUMERICS:
+        raise ValueError(f"numerics must be one of {sorted(_NUMERICS)}")
+    prev = getattr(_tls, "numerics", None)
+    _tls.numerics = name
+    try:
+        yield
+    finally:
+        if prev is None:
+            del _tls.numerics
+        else:
+            _tls.numerics = prev
+
+
+_PLANS = {_lib.TG_PLAN_SPLITK: "splitk", _lib.TG_PLAN_STREAM: "stream", _lib.TG_PLAN_PAIR: "pair"}
+
+
+def gemm_w4_plan(m: int, wrows: int, k: int, group: int, qtype: int, weight_on_right: bool = True, inner_k_tiles: int = 4,
+                 dtype=torch.bfloat16, batch: int = 1, numerics: str | None = None) -> str:
+    """Which kernel family tg_gemm_w4 launches for this problem (tg_gemm_w4_plan; nothing is launched, no GPU needed):
+    'pair' = pair-table kernel, group-scaled numerics; 'stream' / 'splitk' = reference-numerics kernels."""
+    buf = ctypes.create_string_buffer(256)
+    p = (ctypes.addressof(buf) + 63) & ~63  # a non-NULL, aligned dummy: the planner never dereferences data pointers
+    args = W4Gemm(x=p, w=p, qinfo=p, lut=p, y=p, m=m, wrows=wrows, k=k, group=group, qtype=qtype,
+                  dtype=TG_BF16 if dtype == torch.bfloat16 else TG_F16, w_on_right=1 if weight_on_right else 0,
+                  inner_k_tiles=inner_k_tiles, batch=batch, stride_x=16, stride_w=16, stride_qinfo=16, stride_lut=16, stride_y=16,
+                  numerics=_NUMERICS[numerics or get_numerics()])
+    rc = _L.tg_gemm_w4_plan(ctypes.byref(args), 0)
+    _lib.check(rc if rc < 0 else 0, "tg_gemm_w4_plan")
+    return _PLANS[rc]
+
+
+class _FusedBias:
+    def __init__(self, bias):
+        self.bias = bias
+        self.consumed = False
+
+
+@contextlib.contextmanager
+def fused_bias(bias: torch.Tensor):
+    """Offer `bias` ([weight rows], 16-bit) to the next row-major 4-/8-bit GEMM op called on this thread: the kernel adds it
+    in its output store (bit-identical to the reference module's separate `y + bias`, modules.py:221-222).  The op takes
+    it only if it fits (same dtype / device, one value per tile-padded weight row); `.consumed` tells the caller."""
+    fb = _FusedBias(bias)
+    prev = getattr(_tls, "bias", None)
+    _tls.bias = fb
+    try:
+        yield fb
+    finally:
+        _tls.bias = prev
+
+
+def _take_bias(wrows: int, x: torch.Tensor):
+    fb = getattr(_tls, "bias", None)
+    if fb is None or fb.consumed:
+        return None
+    b = fb.bias
+    if b.dim() != 1 or b.numel() != wrows or b.dtype != x.dtype or b.device != x.device or not b.is_contiguous() or b.data_ptr() % 8:
+        return None
+    fb.consumed = True
+    return b
 
 
 def _check(cond: bool, msg: str) -> None:
@@ -212,10 +304,14 @@ def _w4_rm(A, B, q_group, qinfo, lut, qtype, weight_on_right, opname):
     y = torch.empty((m, wrows), dtype=x.dtype, device=x.device)
     if m == 0:
         return y
+    if lut is not None and lut.data_ptr() % 16:
+        lut = lut.clone()
+    bias = _take_bias(wrows, x)
     args = W4Gemm(
         x=x.data_ptr(), w=w.data_ptr(), qinfo=qinfo.data_ptr(), lut=(lut.data_ptr() if lut is not None else None),
         y=y.data_ptr(), m=m, wrows=wrows, k=k, group=q_group, qtype=qtype, dtype=_dt(x),
         w_on_right=1 if weight_on_right else 0, inner_k_tiles=inner, batch=1,
+        numerics=_NUMERICS[get_numerics()], bias=(bias.data_ptr() if bias is not None else None),
     )
     _lib.check(_L.tg_gemm_w4(ctypes.byref(args), _dev(x), _stream(x)), opname)
     return y
@@ -224,6 +320,11 @@ def _w4_rm(A, B, q_group, qinfo, lut, qtype, weight_on_right, opname):
 def _w4_tc(A, B, q_group, qinfo, lut, qtype, weight_on_right, opname):
     """Fragment-order activations / output (TinyGemm_int4.cu:28-292).  Implemented as
     un-layout -> row-major GEMM -> re-layout, all on the device."""
+    with fused_bias(torch.empty(0)):  # an offered bias is for a row-major result: hide it from the inner call
+        return _w4_tc_impl(A, B, q_group, qinfo, lut, qtype, weight_on_right, opname)
+
+
+def _w4_tc_impl(A, B, q_group, qinfo, lut, qtype, weight_on_right, opname):
     _check(A.dim() == 4 and A.is_contiguous() and A.size(2) == 32, "A must be a contiguous 4-D tensor-core layout tensor")
     _check(B.dim() == 4 and B.is_contiguous() and B.size(2) == 32, "B must be a contiguous 4-D tensor-core layout tensor")
     if weight_on_right:
@@ -379,9 +480,10 @@ def tinygemm_y_f16RM_x_f16RM_w_int8TC(A, B, qGroupSize, qScaleAndZeros, weightOn
     y = torch.empty((m, wrows), dtype=x.dtype, device=x.device)
     if m == 0:
         return y
+    bias = _take_bias(wrows, x)
     args = W4Gemm(x=x.data_ptr(), w=w.data_ptr(), qinfo=qinfo.data_ptr(), lut=None, y=y.data_ptr(), m=m, wrows=wrows, k=k,
                   group=qGroupSize, qtype=_lib.TG_Q_INT8, dtype=_dt(x), w_on_right=1 if weightOnRight else 0,
-                  inner_k_tiles=inner, batch=1)
+                  inner_k_tiles=inner, batch=1, bias=(bias.data_ptr() if bias is not None else None))
     _lib.check(_L.tg_gemm_w8(ctypes.byref(args), _dev(x), _stream(x)), opname)
     return y
 

@@ -6,7 +6,8 @@
  * function the reference registers with torch (tinygemm_lib/TinyGemm.cpp:17-200,
  * prototypes tinygemm_lib/TinyGemm.h:23-216).  The signatures carry plain device
  * pointers and sizes only: no torch types, no allocation inside the library (the caller
- * owns every buffer, outputs included), no global state, no host synchronisation.
+ * owns every buffer, outputs included), no mutable global state (the only statics are
+ * write-once per-kernel launch attributes), no environment variables, no host synchronisation.
  * All functions launch asynchronously on `stream` and are safe to call from several host
  * threads on distinct streams, and under hipGraph stream capture.
  *
@@ -33,7 +34,7 @@
 extern "C" {
 #endif
 
-#define TG_ABI_VERSION 1
+#define TG_ABI_VERSION 2
 
 #if defined(__GNUC__)
 #define TG_API __attribute__((visibility("default")))
@@ -55,6 +56,18 @@ enum {
   TG_Q_INT8 = 4          /* tg_gemm_w8 only: uniform int8, value = byte - 128              */
 };
 
+/* GEMM numerics (tg_w4_gemm.numerics).  Both contract bf16/fp16 products in f32 and round the result once.
+ *   TG_NUM_FAST       where a kernel for it exists (Bint4 weights, activation block small enough to stage on chip) the
+ *                     per-group affine map is applied to the f32 accumulator of the group instead of to every weight:
+ *                       y = sum_g ( scale_g * sum_{k in g} x_k * lut[code_k]  +  zero_g * sum_{k in g} x_k ).
+ *                     No per-weight rounding to 16 bits, so y differs from the reference's by at most the reference's own
+ *                     rounding of its dequantised weights (<= 2^-9 * sum_k |x_k w_k|, about one output ulp at k = 4096);
+ *                     mx4 weights are exact either way.  Other shapes run the TG_NUM_REFERENCE kernels.
+ *   TG_NUM_REFERENCE  w = RNE16(fma(lut[code], scale, zero)) per element exactly as the reference kernels compute it
+ *                     (MatrixLayoutB.cuh:1042-1046, MatrixLayoutA.cuh:747-754): bit-identical weights, e.g. the identity
+ *                     known-answer tests of the reference come out bit-equal.                                           */
+enum { TG_NUM_FAST = 0, TG_NUM_REFERENCE = 1 };
+
 /* precondition failures (wording of the matching TORCH_CHECK is in tg_error_string) */
 enum {
   TG_E_NULL = -1,      /* a required pointer is NULL                                       */
@@ -65,7 +78,9 @@ enum {
   TG_E_QTYPE = -6,     /* unknown quantisation variant                                     */
   TG_E_SHAPE = -7,     /* negative / zero / inconsistent sizes                             */
   TG_E_ALIGN = -8,     /* a buffer is not 16-byte aligned                                  */
-  TG_E_DEVICE = -9     /* hipSetDevice failed / no such device                             */
+  TG_E_DEVICE = -9,    /* hipSetDevice failed / no such device                             */
+  TG_E_SIZE = -10,     /* one problem's operand exceeds the kernels' 32-bit byte offsets   */
+  TG_E_INTERNAL = -11  /* build inconsistency (should not happen)                          */
 };
 
 TG_API int tg_abi_version(void);
@@ -132,9 +147,23 @@ typedef struct tg_w4_gemm {
    * operand b lives at base + b*stride (bytes).  batch <= 1 ignores the strides.             */
   int32_t batch;
   int64_t stride_x, stride_w, stride_qinfo, stride_lut, stride_y;
+  /* ---- ABI version 2 ---- */
+  int32_t numerics;   /* TG_NUM_FAST (0) or TG_NUM_REFERENCE                                      */
+  int32_t reserved;   /* must be 0                                                                */
+  const void* bias;   /* optional 16-bit [wrows]: y[a][row] = RNE16(RNE16(acc) + bias[row]), i.e. bit-identical to the
+                         reference module's separate `y + bias` (modules.py:221-222) without its extra launch; NULL = none */
+  int64_t stride_bias;
 } tg_w4_gemm;
 
 TG_API int tg_gemm_w4(const tg_w4_gemm* args, int device, tg_stream_t stream);
+
+/* Which kernel family tg_gemm_w4 would launch for these arguments (same validation, nothing is launched; the data
+ * pointers are only checked for NULL / alignment).  Negative: the TG_E_* code tg_gemm_w4 would return.
+ *   TG_PLAN_SPLITK  w4_gemm_kernel         one 16-wave split-K workgroup per 16-row tile (small launches), reference numerics
+ *   TG_PLAN_STREAM  w4_gemm_stream_kernel  per-(row, group) tables of final 16-bit weights, reference numerics
+ *   TG_PLAN_PAIR    w4_gemm_pair_kernel    per-row tables of LUT pairs, group-scaled numerics (TG_NUM_FAST only)  */
+enum { TG_PLAN_SPLITK = 1, TG_PLAN_STREAM = 2, TG_PLAN_PAIR = 3 };
+TG_API int tg_gemm_w4_plan(const tg_w4_gemm* args, int device);
 
 /*
  * int8 weights.

@@ -53,10 +53,11 @@ def lib() -> ctypes.CDLL:
         L.tgo_dequant.argtypes = [vp, i64, i64, i32, i32, i32, vp, vp, vp]
         L.tgo_gemm.argtypes = [vp, vp, i64, i64, i64, i32, i64, vp, vp]
         L.tgo_linear.argtypes = [vp, vp, i64, i64, i64, i32, i32, i32, vp, vp, i64, vp, vp]
+        L.tgo_linear_group_scaled.argtypes = [vp, vp, i64, i64, i64, i32, i32, i32, vp, vp, i64, vp, vp]
         L.tgo_dequant_int4_debug.argtypes = [vp, i64, vp]
         L.tgo_set_num_threads.argtypes = [i32]
         for f in ("tgo_pack_Bint4", "tgo_unpack_Bint4", "tgo_pack_Aint4", "tgo_unpack_Aint4", "tgo_to_A16",
-                  "tgo_from_A16", "tgo_to_B16", "tgo_from_B16", "tgo_dequant", "tgo_gemm", "tgo_linear",
+                  "tgo_from_A16", "tgo_to_B16", "tgo_from_B16", "tgo_dequant", "tgo_gemm", "tgo_linear", "tgo_linear_group_scaled",
                   "tgo_dequant_int4_debug", "tgo_num_threads"):
             getattr(L, f).restype = i32
         _lib = L
@@ -217,6 +218,22 @@ def linear(x, codes, group, qtype, qinfo, lut=None, dtype=BF16):
     y32 = np.empty((m, rows), np.float32)
     _check(lib().tgo_linear(_p(x), _p(codes), m, rows, k, group, qtype, dtype, _p(qinfo), _p(lut), rows,
                             _p(y16), _p(y32)), "linear")
+    return y16, y32
+
+
+def linear_group_scaled(x, codes, group, qtype, qinfo, lut=None, dtype=BF16):
+    """The same contraction with scale / zero applied per quantisation group to the exact group sums (the library's
+    TG_NUM_FAST numerics; derived, see tgo_linear_group_scaled).  Returns (y16, y32) like linear()."""
+    x = _c(x, np.uint16)
+    codes = _c(codes, np.int32)
+    m, k = x.shape
+    rows = codes.shape[0]
+    qinfo = _c(qinfo, np.uint8 if qtype == Q_MX4 else np.uint16)
+    lut = None if lut is None else _c(lut, np.uint16)
+    y16 = np.empty((m, rows), np.uint16)
+    y32 = np.empty((m, rows), np.float32)
+    _check(lib().tgo_linear_group_scaled(_p(x), _p(codes), m, rows, k, group, qtype, dtype, _p(qinfo), _p(lut), rows,
+                                         _p(y16), _p(y32)), "linear_group_scaled")
     return y16, y32
 
 

@@ -47,3 +47,14 @@ def bf16_ulp(x):
     x = np.abs(np.asarray(x, np.float32))
     e = np.floor(np.log2(np.maximum(x, 1e-38)))
     return np.exp2(e - 7).astype(np.float32)
+
+
+@pytest.fixture
+def reference_numerics():
+    """Run a test with bit-identical dequantised weights (TG_NUM_REFERENCE): the kernels whose results the tight
+    oracle tolerances of test_gpu_parity.py / test_gpu_decode.py were written for.  The default (fast, group-scaled)
+    numerics have their own tests in test_gpu_fast.py."""
+    import any4_amd
+
+    with any4_amd.numerics("reference"):
+        yield

@@ -10,7 +10,7 @@ import torch
 
 from tests.conftest import bits16, from_bits16
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("reference_numerics")]
 DEV = "cuda:0"
 CFG = dict(hidden=256, inter=512, layers=2, heads=4, kv_heads=2, head_dim=64, vocab=128, max_seq=32, group_size=64)
 

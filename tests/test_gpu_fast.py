@@ -1,0 +1,329 @@
+"""GPU suite (-m gpu): the library's DEFAULT numerics (TG_NUM_FAST, include/tinygemm_hip.h) -- the pair-table kernel of
+any4_amd/csrc/w4_gemm_pair.cuh, which applies scale / zero per quantisation group to the f32 accumulator -- plus what
+rides on the same ABI revision: the bias fused into the output store, re-entrancy across host threads, and parity of the
+exact launches bench.py times.
+
+Tolerances:
+  * against the oracle's group-scaled restatement (oracle.linear_group_scaled, same math in double):
+        |y - y64| <= 0.5 ulp16(y64) (1 + 2^-7) + 4e-6 S,   S = sum_k |x_k w_k|
+    i.e. the final rounding plus a bound on f32 accumulation error, the same budget as the reference-numerics tests.
+  * against the oracle's reference-faithful contraction (oracle.dequant + exact contraction): the fast result may differ
+    by the reference's own rounding of every dequantised weight to 16 bits, |dw_k| <= 2^-9 |w_k| (2^-12 for fp16):
+        |y - y64_ref| <= 0.5 ulp16 (1 + 2^-7) + 4e-6 S + eps16 S      (worst case; observed ~0.1 of it)
+  * north_star: max-abs <= 1e-2 against the reference's own CPU dequant-matmul on the captured fixture (max|y| = 2.2).
+"""
+import ctypes
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+from tests.conftest import bits16, from_bits16, load_golden
+from tests.test_gpu_parity import DEV, T, oracle_weights, rand_problem, run_rm, ulp16  # noqa: F401  (T is a fixture)
+
+pytestmark = pytest.mark.gpu
+
+QT = {"int4": 0, "any4_global": 1, "any4_rowwise": 2, "mx4": 3}
+
+
+def gs_reference(oracle, codes, x, qinfo, lut, g, qtype, dtype=torch.bfloat16):
+    q = {"int4": oracle.Q_INT4, "any4_global": oracle.Q_ANY4_GLOBAL, "any4_rowwise": oracle.Q_ANY4_ROWWISE, "mx4": oracle.Q_MX4}[qtype]
+    qi = qinfo.numpy() if qtype == "mx4" else bits16(qinfo)
+    dt = oracle.BF16 if dtype == torch.bfloat16 else oracle.F16
+    _, y32 = oracle.linear_group_scaled(bits16(x), codes.numpy(), g, q, qi, None if lut is None else bits16(lut), dt)
+    return y32.astype(np.float64)
+
+
+def assert_fast_close(oracle, y_hip, codes, x, qinfo, lut, g, qtype, dtype=torch.bfloat16, inner=4, batch=1, expect_pair=True):
+    """Both tolerances of the module docstring.  The tight comparison with the group-scaled oracle applies when the
+    library says (tg_gemm_w4_plan) that this problem runs the pair-table kernel, which `expect_pair` demands."""
+    from any4_amd import ops
+
+    plan = ops.gemm_w4_plan(x.shape[0], ((codes.shape[0] + 7) // 8) * 8, x.shape[1], g, QT[qtype], True, inner, dtype, batch, "fast")
+    assert (plan == "pair") == expect_pair, f"kernel plan {plan!r}, expected {'pair' if expect_pair else 'a reference kernel'}"
+    w = from_bits16(oracle_weights(oracle, codes, g, qtype, qinfo, lut, dtype), dtype).double()
+    x64 = x.double()
+    y_ref = (x64 @ w.t()).numpy()
+    S = (x64.abs() @ w.abs().t()).numpy()
+    y_gs = gs_reference(oracle, codes, x, qinfo, lut, g, qtype, dtype)
+    got = y_hip.detach().double().cpu().numpy()[:, :codes.shape[0]]
+    if plan == "pair":
+        tol = 0.5 * ulp16(y_gs, dtype) * (1 + 2.0 ** -7) + 4e-6 * S + 1e-37
+        bad = np.abs(got - y_gs) > tol
+        assert not bad.any(), f"vs group-scaled oracle: {bad.sum()} / {bad.size} outside tolerance; worst {np.abs(got - y_gs).max()}"
+    eps16 = 2.0 ** -9 if dtype == torch.bfloat16 else 2.0 ** -12
+    tol_ref = 0.5 * ulp16(y_ref, dtype) * (1 + 2.0 ** -7) + (4e-6 + eps16) * S + 1e-37
+    bad = np.abs(got - y_ref) > tol_ref
+    assert not bad.any(), f"vs reference-faithful oracle: {bad.sum()} / {bad.size} outside tolerance"
+
+
+def test_default_numerics_is_fast():
+    import any4_amd
+
+    assert any4_amd.get_numerics() == "fast"
+    with any4_amd.numerics("reference"):
+        assert any4_amd.get_numerics() == "reference"
+    assert any4_amd.get_numerics() == "fast"
+
+
+@pytest.mark.parametrize("qtype", ["any4_rowwise", "any4_global", "int4", "mx4"])
+@pytest.mark.parametrize("inner", [2, 4, 8])
+@pytest.mark.parametrize("g", [32, 64, 128, 256])
+def test_pair_kernel_vs_oracle(T, oracle, qtype, inner, g):
+    if qtype == "mx4":
+        g = 32
+    for (n, k, m) in [(64, 1024, 1), (40, 512, 3), (136, 2048, 1), (200, 4096, 1)]:
+        if k % (16 * inner) or k % g:
+            continue
+        codes, x, qinfo, lut = rand_problem(n, k, g, m, qtype, seed=n + k + inner)
+        y = run_rm(T, codes, x, qinfo, lut, g, qtype, True, inner)
+        assert y.shape == (m, n)
+        assert_fast_close(oracle, y, codes, x, qinfo, lut, g, qtype, inner=inner)
+
+
+@pytest.mark.parametrize("m", [1, 2, 3, 4, 5, 7, 8])
+def test_pair_kernel_m_sweep(T, oracle, m):
+    """m = 1..8 on one accumulator register set (rows 0-3 in lane half 0, 4-7 in half 1); k small enough for the
+    activation block to stay on chip at every m."""
+    n, k, g = 72, 256, 128
+    codes, x, qinfo, lut = rand_problem(n, k, g, m, "any4_rowwise", seed=m)
+    y = run_rm(T, codes, x, qinfo, lut, g, "any4_rowwise", True, 4)
+    assert_fast_close(oracle, y, codes, x, qinfo, lut, g, "any4_rowwise")
+
+
+@pytest.mark.parametrize("m", [9, 16, 17, 33])
+def test_pair_kernel_many_rows(T, oracle, m):
+    """m > 8: wider accumulator sets and several activation passes; whether the block still fits the on-chip stage is the
+    library's call (the plan decides which tolerance applies)."""
+    from any4_amd import ops
+
+    n, k, g = 64, 128, 64
+    codes, x, qinfo, lut = rand_problem(n, k, g, m, "any4_rowwise", seed=m)
+    y = run_rm(T, codes, x, qinfo, lut, g, "any4_rowwise", True, 4)
+    pair = ops.gemm_w4_plan(m, n, k, g, QT["any4_rowwise"]) == "pair"
+    assert_fast_close(oracle, y, codes, x, qinfo, lut, g, "any4_rowwise", expect_pair=pair)
+
+
+def test_pair_kernel_fp16(T, oracle):
+    for qtype in ("any4_rowwise", "int4"):
+        codes, x, qinfo, lut = rand_problem(96, 1024, 128, 2, qtype, dtype=torch.float16, seed=4)
+        y = run_rm(T, codes, x, qinfo, lut, 128, qtype, True, 4)
+        assert y.dtype == torch.float16
+        assert_fast_close(oracle, y, codes, x, qinfo, lut, 128, qtype, torch.float16)
+
+
+def test_fast_equals_reference_where_no_fast_kernel(T, oracle):
+    """Weights on the A side and activation blocks too large to stage have no group-scaled kernel yet: the fast setting
+    then runs the reference kernels, bit for bit."""
+    import any4_amd
+
+    for on_right, m, k in ((False, 2, 1024), (True, 16, 4096)):
+        codes, x, qinfo, lut = rand_problem(64, k, 128, m, "any4_rowwise", seed=3)
+        y_fast = run_rm(T, codes, x, qinfo, lut, 128, "any4_rowwise", on_right, 4)
+        with any4_amd.numerics("reference"):
+            y_ref = run_rm(T, codes, x, qinfo, lut, 128, "any4_rowwise", on_right, 4)
+        assert torch.equal(y_fast, y_ref)
+
+
+@pytest.mark.parametrize("g", [32, 128])
+def test_identity_fast_within_one_ulp(T, g):
+    """The reference's identity known-answer case (test_tinygemm_any4.py:14-37).  Bit-equal in reference numerics
+    (test_gpu_parity.test_identity_bit_exact); the group-scaled path multiplies x by 15 * bf16(1/15) without the
+    reference's rounding of that weight to 1.0, so y is x within one 16-bit ulp."""
+    import any4_amd.utils as U
+
+    k = 512
+    x = torch.randn(2, k, generator=torch.Generator().manual_seed(2)).bfloat16()
+    codes, sz = U.group_quantize_tensor(torch.eye(k, dtype=torch.bfloat16), 4, g)
+    lut = -(torch.arange(16, dtype=torch.bfloat16) - 8)
+    sz[:, :, 0] *= -1.0
+    y = run_rm(T, codes, x, sz, lut, g, "any4_global", True, 4).cpu()
+    err = (y.double() - x.double()).abs().numpy()
+    assert (err <= ulp16(x.double().numpy(), torch.bfloat16)).all()
+
+
+def test_identity_mx4_fast_is_exact(T):
+    """mx4 weights (fp4 * 2^e) are exact in 16 bits, so the fast numerics lose nothing: bit-equal (test_tinygemm_mx4.py:14-39)."""
+    import any4_amd.utils as U
+
+    k = 256
+    x = torch.randn(2, k, generator=torch.Generator().manual_seed(3)).bfloat16()
+    q, e = U.quantize_mx4(torch.eye(k), 32)
+    e = e + (torch.arange(k) % 4).to(torch.uint8).unsqueeze(1)
+    expect = (x.float() * (2.0 ** (torch.arange(k) % 4).float())).bfloat16()
+    y = run_rm(T, q, x, e, None, 32, "mx4", True, 4)
+    assert torch.equal(y.cpu(), expect)
+    e2 = e.clone()
+    e2[5, :] = 255  # NaN exponent: that weight row only (test_tinygemm_mx4.py:443-506)
+    y = run_rm(T, q, x, e2, None, 32, "mx4", True, 4).cpu()
+    assert torch.isnan(y[:, 5]).all() and not torch.isnan(y[:, :5]).any() and not torch.isnan(y[:, 6:]).any()
+
+
+def test_reference_fixture_fast(T):
+    """north_star: within 1e-2 max-abs of the reference's own CPU dequant-matmul on the captured any4 tensors."""
+    g = load_golden("any4_n1024_k1024_g128_seed1234.npz")
+    n, k, grp = int(g["n"]), int(g["k"]), int(g["g"])
+    nib = g["codes_nib"]
+    codes = np.empty((n, k), np.int32)
+    codes[:, 0::2] = nib & 15
+    codes[:, 1::2] = nib >> 4
+    x = from_bits16(g["x_bits"], torch.bfloat16)
+    lut = from_bits16(g["lut_m8_bits"], torch.bfloat16)
+    sz = from_bits16(g["sz_bits"], torch.bfloat16)
+    y = run_rm(T, torch.from_numpy(codes), x, sz, lut, grp, "any4_rowwise", True, 4)
+    y_ref = from_bits16(g["y_bits"], torch.bfloat16)
+    assert (y.float().cpu() - y_ref.float()).abs().max().item() <= 1e-2
+
+
+# ------------------------------------------------------------------------------------------------
+# the launches bench.py times, at their own shape: stacked tg_gemm_w4 over >= 16 layers of 4096 x 4096
+# ------------------------------------------------------------------------------------------------
+
+def _stacked_launch(layers, m, n, k, g, qtype, numerics, seed=0):
+    from any4_amd import _lib
+
+    L = _lib.load()
+    gen = torch.Generator(device=DEV).manual_seed(seed)
+    inner = 4
+    w = torch.randint(-2 ** 31, 2 ** 31 - 1, (layers, n // 8, k // (16 * inner), 32, inner // 2), dtype=torch.int64,
+                      device=DEV, generator=gen).to(torch.int32)
+    x = torch.randn(layers, m, k, device=DEV, generator=gen).to(torch.bfloat16)
+    if qtype == "mx4":
+        q = torch.randint(120, 131, (layers, n, k // g), dtype=torch.uint8, device=DEV, generator=gen)
+        qstride = q.stride(0)
+    else:
+        scales = torch.rand(layers, k // g, n, device=DEV, generator=gen) * 0.02 + 0.005
+        zeros = torch.randn(layers, k // g, n, device=DEV, generator=gen) * 0.01
+        q = torch.stack([scales, zeros], dim=3).to(torch.bfloat16).contiguous()
+        qstride = q.stride(0) * 2
+    lut = {"any4_rowwise": torch.randn(layers, n, 16, device=DEV, generator=gen).to(torch.bfloat16),
+           "any4_global": torch.randn(layers, 16, device=DEV, generator=gen).to(torch.bfloat16)}.get(qtype)
+    y = torch.full((layers, m, n), float("nan"), device=DEV, dtype=torch.bfloat16)
+    args = _lib.W4Gemm(x=x.data_ptr(), w=w.data_ptr(), qinfo=q.data_ptr(), lut=(lut.data_ptr() if lut is not None else None),
+                       y=y.data_ptr(), m=m, wrows=n, k=k, group=g, qtype=QT[qtype], dtype=_lib.TG_BF16, w_on_right=1,
+                       inner_k_tiles=inner, batch=layers, stride_x=x.stride(0) * 2, stride_w=w.stride(0) * 4,
+                       stride_qinfo=qstride, stride_lut=(lut.stride(0) * 2 if lut is not None else 0), stride_y=y.stride(0) * 2,
+                       numerics=numerics)
+    _lib.check(L.tg_gemm_w4(ctypes.byref(args), 0, torch.cuda.current_stream().cuda_stream), "stacked")
+    torch.cuda.synchronize()
+    return w, x, q, lut, y
+
+
+@pytest.mark.parametrize("qtype,g", [("any4_rowwise", 128), ("int4", 128), ("any4_global", 128), ("mx4", 32)])
+@pytest.mark.parametrize("m", [1, 8])
+@pytest.mark.parametrize("numerics", ["fast", "reference"])
+def test_benchmarked_launch_shape(T, oracle, qtype, g, m, numerics):
+    """BASELINE configs 2 and 4 exactly as bench.py launches them: ONE tg_gemm_w4 call over 16 independent layers of
+    n = k = 4096 (4096 16-row tiles: the streaming geometry with split-K 1), m = 1 and m = 8.  Three layers are checked in
+    full against the oracle; every output must have been written."""
+    from any4_amd import _lib
+
+    if numerics == "fast" and m == 8:
+        pytest.skip("m = 8 at k = 4096 does not fit the on-chip activation stage of the group-scaled kernel: same launch as 'reference'")
+    layers, n, k = 16, 4096, 4096
+    w, x, q, lut, y = _stacked_launch(layers, m, n, k, g, qtype, {"fast": _lib.TG_NUM_FAST, "reference": _lib.TG_NUM_REFERENCE}[numerics], seed=m)
+    assert not torch.isnan(y.float()).any()
+    for b in (0, 7, 15):
+        codes = torch.from_numpy(oracle.unpack_Bint4(w[b].cpu().numpy(), n, k))
+        xb, qb = x[b].cpu(), q[b].cpu()
+        lb = None if lut is None else lut[b].cpu()
+        if numerics == "fast":
+            assert_fast_close(oracle, y[b], codes, xb, qb, lb, g, qtype, batch=layers)
+        else:
+            from tests.test_gpu_parity import assert_gemm_close
+
+            assert_gemm_close(y[b], xb, oracle_weights(oracle, codes, g, qtype, qb, lb))
+
+
+# ------------------------------------------------------------------------------------------------
+# bias fused into the output store
+# ------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("numerics", ["fast", "reference"])
+@pytest.mark.parametrize("kernel,cls", [("linear_y_f16RM_x_f16RM_W_any4TC", "Any4Linear"), ("linear_y_f16RM_W_any4TC_x_f16RM", "Any4Linear"),
+                                        ("linear_y_f16RM_W_int4TC_x_f16RM", "Int4Linear"), ("linear_y_f16RM_x_f16RM_W_int8TC", "Int8Linear")])
+def test_module_bias_is_fused_and_bit_identical(T, kernel, cls, numerics):
+    """modules.py:221-222 computes y = gemm(x); y = y + bias as two 16-bit ops.  The fused store must give the same bits."""
+    import any4_amd
+    import modules
+    from any4_amd import ops
+
+    n, k, g, m = 64, 512, 128, 3
+    gen = torch.Generator().manual_seed(8)
+    mod = getattr(modules, cls)(k, n, bias=True, device=DEV, dtype=torch.bfloat16, group_size=g, kernel=kernel)
+    hi = 256 if cls == "Int8Linear" else 16
+    mod.weight.data = torch.randint(0, hi, (n, k), dtype=torch.int32, generator=gen).to(DEV)
+    mod.scales_and_zeros.data = (torch.rand(k // g, n, 2, generator=gen) * 0.02).bfloat16().to(DEV)
+    if cls == "Any4Linear":
+        mod.lut.data = torch.randn(n, 16, generator=gen).bfloat16().to(DEV)
+    mod.bias.data = torch.randn(n, generator=gen).bfloat16().to(DEV)
+    mod.reshape_weight()
+    x = torch.randn(2, m, k, generator=gen).bfloat16().to(DEV)
+    with any4_amd.numerics(numerics):
+        calls = []
+        orig = ops._take_bias
+        ops._take_bias = lambda wrows, xx: (calls.append(1), orig(wrows, xx))[1]
+        try:
+            y = mod(x)
+        finally:
+            ops._take_bias = orig
+        bias = mod.bias
+        mod.bias = None
+        y_plain = mod(x)
+        mod.bias = bias
+    assert calls, "the GEMM op never looked for a fused bias"
+    assert y.shape == (2, m, n)
+    assert torch.equal(y, y_plain + bias)
+
+
+def test_bias_not_fused_into_fragment_layouts(T):
+    """A TC-layout functional returns fragment-order output: an offered bias must not be consumed by its inner GEMM."""
+    from any4_amd import ops
+
+    codes, x, qinfo, lut = rand_problem(32, 256, 128, 4, "any4_rowwise", seed=1)
+    d = lambda t: t.to(DEV)
+    w2 = T.convert_matrix_to_m16n8k16_Bint4_layout(d(codes), 4)
+    x2 = T.convert_matrix_to_m16n8k16_A_layout(d(x), 1)
+    with ops.fused_bias(torch.ones(32, dtype=torch.bfloat16, device=DEV)) as fb:
+        T.tinygemm_y_f16TC_x_f16TC_w_any4TC(x2, w2, 128, d(qinfo), d(lut), True)
+    assert not fb.consumed
+
+
+# ------------------------------------------------------------------------------------------------
+# re-entrancy: two host threads, two streams (reference contract: TinyGemm_int4.cu:41-42, stateless)
+# ------------------------------------------------------------------------------------------------
+
+def test_two_host_threads_two_streams(T, oracle):
+    import any4_amd
+
+    probs = [rand_problem(128, 1024, 128, 1 + t, "any4_rowwise", seed=20 + t) for t in range(2)]
+    dev = [[None if v is None else v.to(DEV) for v in p] for p in probs]
+    packed = [T.convert_matrix_to_m16n8k16_Bint4_layout(d[0], 4) for d in dev]
+    expect = []
+    for t in range(2):
+        with any4_amd.numerics("reference" if t else "fast"):
+            expect.append(T.tinygemm_y_f16RM_x_f16RM_w_any4TC(dev[t][1], packed[t], 128, dev[t][2], dev[t][3], True).clone())
+    torch.cuda.synchronize()
+    results, errors = [None, None], []
+
+    def work(t):
+        try:
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s), any4_amd.numerics("reference" if t else "fast"):
+                out = []
+                for _ in range(200):
+                    out.append(T.tinygemm_y_f16RM_x_f16RM_w_any4TC(dev[t][1], packed[t], 128, dev[t][2], dev[t][3], True))
+                s.synchronize()
+            results[t] = out
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
+    for t in range(2):
+        assert all(torch.equal(o, expect[t]) for o in results[t])

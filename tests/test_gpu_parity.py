@@ -2,6 +2,9 @@
 oracle on identical seeded inputs, against the committed golden fixtures, and -- at BASELINE's full
 sizes -- through size-independent properties.
 
+Every test of this file runs in the library's REFERENCE numerics (conftest.reference_numerics): dequantised weights
+bit-identical to the reference kernels'.  The default fast (group-scaled) numerics are covered by test_gpu_fast.py.
+
 Tolerances (stated once, used everywhere):
   * packing / layout conversion / debug dequant: bit-exact.
   * GEMM: the dequantised bf16 weights are bit-identical by construction (f32 fma + RNE == the oracle),
@@ -19,7 +22,7 @@ import torch
 
 from tests.conftest import bf16_ulp, bits16, from_bits16, load_golden
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("reference_numerics")]
 
 DEV = "cuda:0"
 
@@ -123,6 +126,19 @@ def test_layout16_bit_exact_and_roundtrip(T, oracle, dtype, m, k):
         b = T.convert_matrix_to_m16n8k16_B_layout(x.to(DEV), inner)
         assert np.array_equal(bits16(b), oracle.to_B16(bits16(x), inner))
         assert torch.equal(T.convert_matrix_from_m16n8k16_B_layout(b, m, k).cpu(), x)
+
+
+@pytest.mark.parametrize("inner_b,inner_a", [(2, 1), (4, 2), (8, 4)])
+def test_pack_out_of_range_codes_bit_exact(T, oracle, inner_b, inner_a):
+    """The reference ORs the shifted UNMASKED 32-bit inputs (TinyGemmConvertB.cu:302-303, TinyGemmConvertA.cu:280-281):
+    codes outside 0..15 -- negative ones included -- must give the same words as that expression."""
+    gen = torch.Generator().manual_seed(5)
+    codes = torch.randint(-2**31, 2**31 - 1, (24, 256), dtype=torch.int64, generator=gen).to(torch.int32)
+    codes[::3] = torch.randint(0, 300, (8, 256), dtype=torch.int32, generator=gen)
+    got = T.convert_matrix_to_m16n8k16_Bint4_layout(codes.to(DEV), inner_b).cpu().numpy()
+    assert np.array_equal(got, oracle.pack_Bint4(codes.numpy(), inner_b))
+    got = T.convert_matrix_to_m16n8k16_Aint4_layout(codes.to(DEV), inner_a).cpu().numpy()
+    assert np.array_equal(got, oracle.pack_Aint4(codes.numpy(), inner_a))
 
 
 def test_dequant_int4_debug_bit_exact(T, oracle):
@@ -478,7 +494,8 @@ def test_batched_launch_matches_single(T, oracle):
     args = _lib.W4Gemm(x=xs.data_ptr(), w=packed.data_ptr(), qinfo=szs.data_ptr(), lut=luts.data_ptr(), y=ys.data_ptr(),
                        m=m, wrows=n, k=k, group=g, qtype=_lib.TG_Q_ANY4_ROWWISE, dtype=_lib.TG_BF16, w_on_right=1,
                        inner_k_tiles=4, batch=nb, stride_x=xs.stride(0) * 2, stride_w=packed.stride(0) * 4,
-                       stride_qinfo=szs.stride(0) * 2, stride_lut=luts.stride(0) * 2, stride_y=ys.stride(0) * 2)
+                       stride_qinfo=szs.stride(0) * 2, stride_lut=luts.stride(0) * 2, stride_y=ys.stride(0) * 2,
+                       numerics=_lib.TG_NUM_REFERENCE)
     _lib.check(L.tg_gemm_w4(ctypes.byref(args), 0, torch.cuda.current_stream().cuda_stream), "batched")
     for b in range(nb):
         y1 = T.tinygemm_y_f16RM_x_f16RM_w_any4TC(xs[b], packed[b], g, szs[b], luts[b], True)
@@ -516,7 +533,7 @@ def _stacked(T, probs, copies, g, qtype, on_right, inner, dtype=torch.bfloat16):
                        dtype=_lib.TG_BF16 if dtype == torch.bfloat16 else _lib.TG_F16, w_on_right=1 if on_right else 0,
                        inner_k_tiles=inner, batch=B, stride_x=xs.stride(0) * 2, stride_w=packed.stride(0) * 4,
                        stride_qinfo=qs.stride(0) * qs.element_size(), stride_lut=(luts.stride(0) * 2 if has_lut else 0),
-                       stride_y=ys.stride(0) * 2)
+                       stride_y=ys.stride(0) * 2, numerics=_lib.TG_NUM_REFERENCE)
     _lib.check(L.tg_gemm_w4(ctypes.byref(args), 0, torch.cuda.current_stream().cuda_stream), "stacked")
     return ys
 

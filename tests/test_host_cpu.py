@@ -30,7 +30,7 @@ def test_c_abi_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in include/*.h but not exported"
     assert set(syms) == set(_lib.SYMBOLS), "ctypes binding and header disagree"
-    assert _lib.load().tg_abi_version() == 1
+    assert _lib.load().tg_abi_version() == _lib.TG_ABI_VERSION == 2
 
 
 def test_c_abi_preconditions_fail_before_any_launch():
@@ -53,7 +53,13 @@ def test_c_abi_preconditions_fail_before_any_launch():
     assert L.tg_gemm_w4(ctypes.byref(a), 0, None) == -3                         # k % 32
     a.k, a.lut = 128, None
     assert L.tg_gemm_w4(ctypes.byref(a), 0, None) == -1                         # any4 without LUT
-    for code in range(-9, 1):
+    a.lut, a.numerics = p, 7
+    assert L.tg_gemm_w4(ctypes.byref(a), 0, None) == -7                         # unknown numerics
+    a.numerics, a.m, a.k = 0, 1 << 20, 4096
+    assert L.tg_gemm_w4(ctypes.byref(a), 0, None) == -10                        # TG_E_SIZE: activations of 8 GiB
+    a.m, a.k, a.wrows = 1, 1 << 17, 1 << 16
+    assert L.tg_gemm_w4(ctypes.byref(a), 0, None) == -10                        # TG_E_SIZE: packed weights of 4 GiB
+    for code in range(-11, 1):
         assert len(L.tg_error_string(code)) > 0
     with pytest.raises(RuntimeError, match="qGroupSize"):
         _lib.check(-4, "x")

@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--qtype", default="any4_rowwise")
     ap.add_argument("--g", type=int, default=128)
     ap.add_argument("--inner", type=int, default=4)
+    ap.add_argument("--numerics", default="fast", choices=["fast", "reference"])
     a = ap.parse_args()
     L_ = _lib.load()
     dev = "cuda:0"
@@ -69,7 +70,8 @@ def main():
                                lut=(lut[b].data_ptr() if a.qtype.startswith("any4") else None), y=y[b].data_ptr(),
                                m=m, wrows=n, k=k, group=g, qtype=qt, dtype=0, w_on_right=on_right, inner_k_tiles=inner,
                                batch=batch, stride_x=x.stride(0) * 2, stride_w=w.stride(0) * 4, stride_qinfo=qstride,
-                               stride_lut=lut.stride(0) * 2, stride_y=y.stride(0) * 2)
+                               stride_lut=lut.stride(0) * 2, stride_y=y.stride(0) * 2,
+                               numerics=(0 if a.numerics == "fast" else 1))
 
         singles = [mk(b, 1) for b in range(L)]
         stacked = mk(0, L)
