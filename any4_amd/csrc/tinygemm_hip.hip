@@ -640,25 +640,34 @@ enum { TG_PAIR_NA = -100 };
 #ifndef TG_PAIR_ABL
 #define TG_PAIR_ABL 0
 #endif
-#ifndef TG_PAIR_SB
-#define TG_PAIR_SB 1
+#ifndef TG_PAIR_MR1
+#define TG_PAIR_MR1 1  // 1: m = 1 runs the one-register specialisation (measured +2-3 %), 4: the general m <= 8 kernel
+#endif
+#ifndef TG_PAIR_NSG2
+#define TG_PAIR_NSG2 1  // 0: group boundaries always tested at run time (developer A/B)
 #endif
 #ifndef TG_PAIR_WGS
 #define TG_PAIR_WGS 512  // persistent workgroups: two per CU
 #endif
-template <typename DT, int I, int GPS, int MREGS, bool QMX>
+template <typename DT, int I, int GPS, int MR, bool QMX, int NSG>
 int launch_pair_k(PairParams& pp, unsigned lds, hipStream_t st) {
 #ifdef TG_DEV_MIN  // developer builds: only the headline instantiation (fast A/B builds)
-  if constexpr (!(std::is_same<DT, BF16>::value && I == 4 && GPS == 1 && MREGS == 4 && !QMX)) return TG_PAIR_NA;
+  if constexpr (!(std::is_same<DT, BF16>::value && I == 4 && GPS == 1 && MR == TG_PAIR_MR1 && !QMX && NSG == TG_DEV_MIN)) return TG_PAIR_NA;
   else {
 #endif
-  constexpr auto kern = w4_gemm_pair_kernel<DT, I, GPS, MREGS, QMX, TG_PAIR_R, TG_PAIR_ABL, TG_PAIR_SB>;
+  if constexpr (QMX && !std::is_same<DT, BF16>::value) return TG_E_DTYPE;  // mx4 is bf16-only (TinyGemm_int4.cu:758)
+  else {
+  // several groups per super-tile (group 32 / 64 with wide super-tiles): more per-slot state, one slot in flight fits the
+  // 128-VGPR budget without spills (ring depth measured irrelevant between 2 and 4)
+  constexpr int RING = GPS > 1 ? 1 : TG_PAIR_R;
+  constexpr auto kern = w4_gemm_pair_kernel<DT, I, GPS, MR, QMX, RING, NSG, TG_PAIR_ABL>;
   if (pp.dry) return TG_PLAN_PAIR;
   const int prc = prepare_lds_kernel<kern>();
   if (prc != 0) return prc;
   const unsigned wgs = (unsigned)(pp.items < TG_PAIR_WGS ? pp.items : TG_PAIR_WGS);
   hipLaunchKernelGGL(kern, dim3(wgs), dim3(512), lds, st, pp);
   return launch_status();
+  }
 #ifdef TG_DEV_MIN
   }
 #endif
@@ -669,7 +678,7 @@ int launch_pair(const GemmParams& p, int64_t batch, hipStream_t st) {
   constexpr int RW = 64;
   const int g = 1 << p.gshift;
   const int gps = g >= 16 * I ? 1 : (16 * I) / g;
-  const int mregs = p.m <= 8 ? 4 : (p.m <= 16 ? 8 : 16);
+  const int mregs = p.m <= 8 ? 4 : 16;  // accumulator registers of a row set (8 or 32 activation rows per pass)
   const int ma = 2 * mregs;
   PairParams pp;
   pp.x = p.x; pp.w = p.w; pp.qinfo = p.qinfo; pp.lut = p.lut; pp.y = p.y;
@@ -687,7 +696,7 @@ int launch_pair(const GemmParams& p, int64_t batch, hipStream_t st) {
   pp.red_lanes = mrows <= 4 ? 32 : 64;
   pp.x_pitch = p.k * 2 + 16;
   pp.lds_x = 65536;
-  pp.lds_xs = (pp.lds_x + mrows * pp.x_pitch + 32 + 15) & ~15;
+  pp.lds_xs = (pp.lds_x + mrows * pp.x_pitch + 32 * I + 15) & ~15;  // staged rows + a zero piece of one super-tile
   pp.lds_red = (pp.lds_xs + p.ngroups * pp.xs_rows * 4 + 15) & ~15;
   pp.red_alias = mrows > 4;  // 16 KiB and more of partial sums: reuse the table's LDS instead
   unsigned lds = (unsigned)pp.lds_red + (unsigned)(8 * 2 * pp.rused * pp.red_lanes * 4);
@@ -700,20 +709,32 @@ int launch_pair(const GemmParams& p, int64_t batch, hipStream_t st) {
   pp.cblocks = (p.m + ma - 1) / ma;
   const int64_t items = (int64_t)pp.rblocks * pp.cblocks * batch;
   if (items > INT32_MAX) return TG_PAIR_NA;
+  // The kernel's unit of work is a 64-row block over the whole k (8 waves): a launch needs about one item per workgroup slot
+  // (2 per CU) to fill the chip.  Smaller launches (one 4096-row layer = 64 items) are latency-bound and stay on the
+  // split-K kernels, which spread one 16-row tile over up to 16 waves.
+  if (items < 384) return TG_PAIR_NA;
   pp.items = (int32_t)items;
   pp.stride_x = p.stride_x; pp.stride_w = p.stride_w; pp.stride_qinfo = p.stride_qinfo;
   pp.stride_lut = p.stride_lut; pp.stride_y = p.stride_y;
   pp.bias = p.bias; pp.stride_bias = p.stride_bias; pp.dry = p.dry;
-#define TG_PAIR_M(GPS_)                                                        \
-  (mregs == 4 ? launch_pair_k<DT, I, GPS_, 4, QMX>(pp, lds, st)               \
-              : mregs == 8 ? launch_pair_k<DT, I, GPS_, 8, QMX>(pp, lds, st)  \
-                           : launch_pair_k<DT, I, GPS_, 16, QMX>(pp, lds, st))
-  if (gps == 1) return TG_PAIR_M(1);
+#define TG_PAIR_M(GPS_, NSG_)                                                          \
+  (p.m == 1 && TG_PAIR_MR1 == 1 ? launch_pair_k<DT, I, GPS_, 1, QMX, NSG_>(pp, lds, st) \
+            : mregs == 4 ? launch_pair_k<DT, I, GPS_, 4, QMX, NSG_>(pp, lds, st)       \
+                         : launch_pair_k<DT, I, GPS_, 16, QMX, NSG_>(pp, lds, st))
+  if (gps == 1) {
+    // group boundaries at fixed places of the unrolled round when a group is one super-tile or one whole round
+    // (not for the m = 1 specialisation: with fixed boundaries the compiler scatters its accumulator chain over several
+    //  register tuples and spills; it keeps the run-time test, which measured faster than the general kernel with fixed ones)
+    const bool fixed = TG_PAIR_NSG2 && !(p.m == 1 && TG_PAIR_MR1 == 1);
+    if (fixed && nsg == 1) return TG_PAIR_M(1, 1);
+    if (fixed && nsg == TG_PAIR_R) return TG_PAIR_M(1, TG_PAIR_R);
+    return TG_PAIR_M(1, 0);
+  }
   if constexpr (I >= 4) {
-    if (gps == 2) return TG_PAIR_M(2);
+    if (gps == 2) return TG_PAIR_M(2, 0);
   }
   if constexpr (I >= 8) {
-    if (gps == 4) return TG_PAIR_M(4);
+    if (gps == 4) return TG_PAIR_M(4, 0);
   }
 #undef TG_PAIR_M
   return TG_PAIR_NA;

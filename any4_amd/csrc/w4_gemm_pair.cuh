@@ -57,7 +57,7 @@ struct PairParams {
   int32_t nsg_shift; // log2(super-tiles per group), 0 when a group is at most one super-tile
   int32_t gch_mask; // (32-k chunks per group) - 1
   int32_t x_pitch;  // bytes per staged activation row
-  int32_t lds_x;    // LDS byte offsets: staged activations (m rows, then the 32-byte zero piece)
+  int32_t lds_x;    // LDS byte offsets: staged activations (m rows, then a zero piece of one super-tile = 32 I bytes)
   int32_t lds_xs;   //                   per-group activation sums, f32 [ngroups][xs_rows]
   int32_t lds_red;  //                   split-K partial sums, f32 [8 waves][2 tiles][rused][red_lanes]
   int32_t rused;    // accumulator registers that hold real activation rows (m < 4: m, else MREGS)
@@ -94,15 +94,20 @@ __device__ __forceinline__ float dot2_ones(uint32_t pair, float acc) {
 
 // I     = innerKTiles of the Bint4 layout (2, 4, 8): k super-tile = 16 I, I words per lane and super-tile
 // GPS   = quantisation groups per super-tile (1 when group >= 16 I)
-// MREGS = accumulator registers that can hold real activation rows: 4 -> m <= 8, 8 -> m <= 16, 16 -> m <= 32
-// R     = super-tiles in flight per wave (register ring); the host guarantees every wave's k-slice has >= R super-tiles
-template <typename DT, int I, int GPS, int MREGS, bool QMX, int R, int ABL = 0, int SB = 1>
+// MR    = 1: m = 1 (one accumulator register per tile is finalised and exchanged); else the accumulator registers that can
+//         hold real activation rows: 4 -> m <= 8, 8 -> m <= 16, 16 -> m <= 32
+// R     = super-tiles in flight per wave (register ring)
+// NSG   = super-tiles per quantisation group when that is 1 or R (group boundaries then sit at fixed places of the unrolled
+//         round: no per-step tests, scale | zero words are only requested for the first super-tile of a group); 0 = any, tested at run time
+template <typename DT, int I, int GPS, int MR, bool QMX, int R, int NSG = 0, int ABL = 0>
 __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p) {
   constexpr int WAVES = 8;
   constexpr int TILES = 2;              // 32-row MFMA tiles per workgroup
   constexpr int RW = 32 * TILES;
   constexpr int CPS = I / 2;            // 32-k chunks per super-tile
   constexpr int CPG = CPS / GPS;        // chunks per group inside a super-tile (GPS > 1 only)
+  constexpr int MREGS = MR == 1 ? 4 : MR;  // accumulator registers of a row set
+  constexpr int RF = MR;                   // registers that are finalised per group and exchanged at the end
   constexpr int MA = 2 * MREGS;         // activation rows a pass can hold
 
   // The pair table sits at LDS address 0 (a lookup address is just byte << 8 | column << 2): the kernel has no static LDS,
@@ -197,7 +202,7 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
   // the number of loads in flight is the same on every path and the compiler's vmcnt bookkeeping stays exact -- a conditional
   // refill makes it wait for every outstanding load at the next use, draining the ring each round) but every lane reads the
   // first bytes of the operand: one cached request, never consumed.
-  auto issue = [&](const Rows& rw, int s, Slot& sl, bool valid) {
+  auto issue = [&](const Rows& rw, int s, Slot& sl, bool valid, bool needq) {
     const uint32_t vm = valid ? 0xffffffffu : 0u;
 #pragma unroll
     for (int t = 0; t < TILES; ++t) {
@@ -211,15 +216,21 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
       } else {
 #pragma unroll
         for (int v4 = 0; v4 < I / 4; ++v4) {
+#ifdef TG_PAIR_NO_NT
+          const u32x4 v = reinterpret_cast<const u32x4*>(src)[v4];
+#else
           const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src) + v4);
+#endif
 #pragma unroll
           for (int j = 0; j < 4; ++j) sl.w[t][4 * v4 + j] = v[j];
         }
       }
 #pragma unroll
       for (int gg = 0; gg < GPS; ++gg) {
+        if (!needq) continue;  // (compile-time per call site) not the first super-tile of its group
         const uint32_t g = (uint32_t)(((s * CPS + gg * CPG) * 32) >> p.gshift);
-        if constexpr (QMX) sl.q[t][gg] = *reinterpret_cast<const uint8_t*>(rw.qb + ((rw.qrow[t] * (uint32_t)p.ngroups + g) & vm));
+        if constexpr (ABL == 8) sl.q[t][gg] = 0x3c003c00u + (uint32_t)s;  // ablation: no scale | zero loads
+        else if constexpr (QMX) sl.q[t][gg] = *reinterpret_cast<const uint8_t*>(rw.qb + ((rw.qrow[t] * (uint32_t)p.ngroups + g) & vm));
         else sl.q[t][gg] = *reinterpret_cast<const uint32_t*>(rw.qb + (((g * (uint32_t)p.wrows + rw.qrow[t]) * 4u) & vm));
       }
     }
@@ -274,7 +285,9 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
     // rows a >= mrows of the sums stay zero
     for (int idx = tid; idx < p.ngroups * p.xs_rows; idx += 512)
       if (idx % p.xs_rows >= mrows) *(lds_fptr)(lds_xs + (uint32_t)(idx * 4)) = 0.f;
-    if (tid < 2) *(lds_u32x4ptr)(lds_x + (uint32_t)(mrows * p.x_pitch + tid * 16)) = u32x4{0, 0, 0, 0};
+    // the zero piece behind the staged rows is one super-tile long: lanes whose A-operand row is padding read it with the same
+    // immediate offsets as the real rows
+    if (tid < CPS * 4) *(lds_u32x4ptr)(lds_x + (uint32_t)(mrows * p.x_pitch + tid * 16)) = u32x4{0, 0, 0, 0};
   };
 
   // ---- requests before the first item, in the order the prologue consumes them (vector memory returns in order): its LUT
@@ -296,7 +309,7 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
 #pragma unroll
   for (int j = 0; j < R; ++j) {
     __builtin_amdgcn_sched_barrier(0);
-    issue(rcur, s_begin + j, ring[j], j < nl);
+    issue(rcur, s_begin + j, ring[j], j < nl, NSG == 0 || j % NSG == 0);
   }
   __builtin_amdgcn_sched_barrier(0);
   x_stage(first.b, first.ct * MA, min(p.m - first.ct * MA, MA), true, xd0);
@@ -313,6 +326,9 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
     const bool has_next = it + 1 < it_end;
     const Rows rnext = rows_of(has_next ? it + 1 : it);
 
+#ifdef TG_PAIR_NOLP  // experiment: no LUT prefetch across the main loop (8 VGPRs less, LUT latency exposed)
+    if (lut_loaded && it != it_begin) lut_request(it);
+#endif
     // ---- pair table of this item: thread = (column, high nibbles 2 wave and 2 wave + 1).  The previous item's lookups are
     // all behind the barrier that ended it. ----
     {
@@ -329,7 +345,9 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
       }
     }
     // the next item's LUT rows travel while this item is computed (the last item re-reads its own)
+#ifndef TG_PAIR_NOLP
     if (lut_loaded) lut_request(has_next ? it + 1 : it);
+#endif
 
     // ---- activations: only when the activation block changes (the first item's block was staged above) ----
     if (cur.b != staged_b || cur.ct != staged_ct) {
@@ -346,20 +364,20 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
     const uint32_t xmask = a_on ? 0xffffffffu : 0u;  // lanes on the zero piece never move
 
     f32x16 acc[TILES];
-    float yacc[TILES][MREGS];
+    float yacc[TILES][RF];
 #pragma unroll
     for (int t = 0; t < TILES; ++t) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 #pragma unroll
-      for (int r = 0; r < MREGS; ++r) yacc[t][r] = 0.f;
+      for (int r = 0; r < RF; ++r) yacc[t][r] = 0.f;
     }
     float gs[TILES], gz[TILES];  // scale / zero of the current group
-    float xsv[MREGS];            // activation sums of the current group for this lane's accumulator rows
+    float xsv[RF];               // activation sums of the current group for this lane's accumulator rows
 #pragma unroll
     for (int t = 0; t < TILES; ++t) gs[t] = gz[t] = 0.f;
 #pragma unroll
-    for (int r = 0; r < MREGS; ++r) xsv[r] = 0.f;
+    for (int r = 0; r < RF; ++r) xsv[r] = 0.f;
 
     auto unpack_q = [&](uint32_t q, float& s, float& z) {
       if constexpr (QMX) {
@@ -370,23 +388,42 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
         z = DT::hi_f32(q);
       }
     };
-    // the group that just ended: y += scale * acc + zero * sum(x); acc restarts at zero
+    // m = 1: the accumulator tuples run through the whole slice (cleared per item) and a group's sum is taken as a difference;
+    // otherwise a group's first MFMA takes a zero C operand
+    constexpr bool DIFF = MR == 1;
+    float prev[TILES][RF];
+#pragma unroll
+    for (int t = 0; t < TILES; ++t)
+#pragma unroll
+      for (int r = 0; r < RF; ++r) prev[t][r] = 0.f;
+    // a finished group: y += scale * acc + zero * sum(x).  The accumulator tuple is only ever written by MFMAs -- a group's
+    // first MFMA takes a zero C operand instead of the tuple being cleared element-wise (partial writes of the 16-register
+    // tuple made the compiler copy it around).  The finalize of a group runs BEHIND the lookups of the next step (`pending`),
+    // so the MFMA results are ready when it reads them.
     auto finalize = [&]() {
 #pragma unroll
       for (int t = 0; t < TILES; ++t) {
 #pragma unroll
-        for (int r = 0; r < MREGS; ++r) {
-          yacc[t][r] = __builtin_fmaf(gs[t], acc[t][r], yacc[t][r]);
-          yacc[t][r] = __builtin_fmaf(gz[t], xsv[r], yacc[t][r]);
+        for (int r = 0; r < RF; ++r) {
+          float d = acc[t][r];
+          if constexpr (DIFF) {  // running accumulator: this group's sum is what was added since the last group ended
+            d -= prev[t][r];
+            prev[t][r] = acc[t][r];
+          }
+          yacc[t][r] = __builtin_fmaf(gs[t], d, yacc[t][r]);
+          if constexpr (!QMX) yacc[t][r] = __builtin_fmaf(gz[t], xsv[r], yacc[t][r]);  // mx4 has no zero point
         }
-        // rows >= m of the A operand are zero, so only the first MREGS registers ever hold anything
-#pragma unroll
-        for (int r = 0; r < MREGS; ++r) acc[t][r] = 0.f;
+        // keep the accumulator one opaque 16-register value: when only element 0 is read (m = 1) the compiler's
+        // sub-register liveness otherwise scatters the MFMA chain over several overlapping tuples and spills
+        asm volatile("" : "+v"(acc[t]));
+        if constexpr (RF == 1) asm volatile("" ::"v"(acc[t][1]), "v"(acc[t][2]), "v"(acc[t][3]));  // same purpose: as live as with m > 1
       }
     };
-    // one super-tile: 2 CPS MFMA steps, step = (chunk jc, quad pair qq) for both tiles: 8 table lookups + one X piece;
-    // SB steps are looked up together before their MFMAs (more LDS reads in flight per wait)
-    auto consume = [&](int s, const Slot& sl) {
+    bool pending = false;  // wave-uniform
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // one super-tile: 2 CPS MFMA steps, step = (chunk jc, quad pair qq) for both tiles: 8 table lookups + one X piece
+    auto consume = [&](int s, const Slot& sl, int j_slot) {
+      const uint32_t xst = xrow + ((uint32_t)(s * CPS * 64) & xmask);  // this lane's X pieces of the super-tile
       if constexpr (ABL == 6) {  // ablation: stream only
 #pragma unroll
         for (int t = 0; t < TILES; ++t)
@@ -396,50 +433,73 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
         return;
       }
 #pragma unroll
-      for (int u0 = 0; u0 < 2 * CPS; u0 += SB) {
-        u32x4 xf[SB];
-        u32x4 bf[SB][TILES];
+      for (int u = 0; u < 2 * CPS; ++u) {
+        const int jc = u >> 1, qq = u & 1;
+        const int chunk = s * CPS + jc;
+        // group boundaries: static when a super-tile holds several groups, else a wave-uniform runtime test
+        constexpr bool STATIC_G = GPS > 1 || NSG > 0;
+        const int gpos = NSG > 0 ? j_slot % NSG : 0;  // (compile-time) position of this super-tile in its group
+        const bool gfirst = qq == 0 && (GPS > 1 ? jc % CPG == 0 : NSG > 0 ? (gpos == 0 && jc == 0) : (chunk & p.gch_mask) == 0);
+        const bool glast = qq == 1 && (GPS > 1 ? jc % CPG == CPG - 1 : NSG > 0 ? (gpos == NSG - 1 && jc == CPS - 1) : (chunk & p.gch_mask) == p.gch_mask);
+        u32x4 xf;
+        u32x4 bf[TILES];
+        if constexpr (ABL == 5) xf = u32x4{xrow, (uint32_t)s, (uint32_t)jc, (uint32_t)qq};  // ablation: no X reads
+        else xf = *(lds_cu32x4ptr)(xst + (uint32_t)(jc * 64 + 16 * qq));
 #pragma unroll
-        for (int v = 0; v < SB; ++v) {
-          const int u = u0 + v, jc = u >> 1, qq = u & 1;
-          const int chunk = s * CPS + jc;
-          if (qq == 0 && (chunk & p.gch_mask) == 0) {  // a group starts
-            const int gg = GPS == 1 ? 0 : jc / CPG;
+        for (int t = 0; t < TILES; ++t) {
+          const uint32_t w = sl.w[t][qq * CPS + jc];
 #pragma unroll
-            for (int t = 0; t < TILES; ++t) unpack_q(sl.q[t][gg], gs[t], gz[t]);
+          for (int j = 0; j < 4; ++j) {
+            const uint32_t addr = __builtin_amdgcn_perm(w, colreg[t], 0x0c0c0400u + ((uint32_t)j << 8));
+            if constexpr (ABL == 1) bf[t][j] = addr;  // ablation: no lookups
+            else bf[t][j] = *(lds_cu32ptr)(addr);
+          }
+        }
+        // the previous step ended a group: its finalize runs here, behind this step's lookups (MFMA results ready, no stall)
+        if constexpr (STATIC_G) {
+          // fixed boundaries: the step that starts a group finalises the previous one (before the first group of an item
+          // the accumulators and scales are zero: it adds nothing)
+          if (gfirst) finalize();
+        } else if (qq == 0 && pending) {
+          finalize();
+          pending = false;
+        }
+        // the finished group's accumulators must be dead before the next group's first MFMA: if the scheduler sinks the
+        // finalize below it, the two groups need two accumulator tuples (32 VGPRs more)
+        __builtin_amdgcn_sched_barrier(0);
+        if (ABL != 7 && gfirst) {  // a group starts: its scale | zero and (not mx4) its activation sums
+          const int gg = GPS == 1 ? 0 : jc / CPG;
+#pragma unroll
+          for (int t = 0; t < TILES; ++t) unpack_q(sl.q[t][gg], gs[t], gz[t]);
+          if constexpr (!QMX) {
             // lanes whose accumulator rows are all padding (lane half 1 when m <= 4) read the zero piece behind the staged rows
             const uint32_t xsa = 4 * h < p.xs_rows ? lds_xs + (uint32_t)((((chunk * 32) >> p.gshift) * p.xs_rows + 4 * h) * 4)
                                                    : lds_x + (uint32_t)(mrows * p.x_pitch);
+            if constexpr (RF == 1) {
+              xsv[0] = *(const __attribute__((address_space(3))) float*)(xsa);
+            } else {
 #pragma unroll
-            for (int r4 = 0; r4 < MREGS / 4; ++r4) {
-              const f32x4 vv = *(lds_cf32x4ptr)(xsa + (uint32_t)(4 * h < p.xs_rows ? r4 * 32 : 0));
-              xsv[4 * r4] = vv[0]; xsv[4 * r4 + 1] = vv[1]; xsv[4 * r4 + 2] = vv[2]; xsv[4 * r4 + 3] = vv[3];
-            }
-          }
-          if constexpr (ABL == 5) xf[v] = u32x4{xrow, (uint32_t)s, (uint32_t)jc, (uint32_t)qq};  // ablation: no X reads
-          else xf[v] = *(lds_cu32x4ptr)(xrow + ((uint32_t)(chunk * 64 + 16 * qq) & xmask));
-#pragma unroll
-          for (int t = 0; t < TILES; ++t) {
-            const uint32_t w = sl.w[t][qq * CPS + jc];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const uint32_t addr = __builtin_amdgcn_perm(w, colreg[t], 0x0c0c0400u + ((uint32_t)j << 8));
-              if constexpr (ABL == 1) bf[v][t][j] = addr;  // ablation: no lookups
-              else bf[v][t][j] = *(lds_cu32ptr)(addr);
+              for (int r4 = 0; r4 < MREGS / 4; ++r4) {
+                const f32x4 vv = *(lds_cf32x4ptr)(xsa + (uint32_t)(4 * h < p.xs_rows ? r4 * 32 : 0));
+                xsv[4 * r4] = vv[0]; xsv[4 * r4 + 1] = vv[1]; xsv[4 * r4 + 2] = vv[2]; xsv[4 * r4 + 3] = vv[3];
+              }
             }
           }
         }
 #pragma unroll
-        for (int v = 0; v < SB; ++v) {
-          const int u = u0 + v, jc = u >> 1, qq = u & 1;
-          const int chunk = s * CPS + jc;
-#pragma unroll
-          for (int t = 0; t < TILES; ++t) {
-            if constexpr (ABL == 4) acc[t][0] += u2f(bf[v][t][0] ^ bf[v][t][1] ^ bf[v][t][2] ^ bf[v][t][3] ^ xf[v][0] ^ xf[v][1] ^ xf[v][2] ^ xf[v][3]);  // ablation: no MFMA
-            else acc[t] = mfma32<DT>(xf[v], bf[v][t], acc[t]);
-          }
-          if (qq == 1 && (chunk & p.gch_mask) == p.gch_mask) finalize();
+        for (int t = 0; t < TILES; ++t) {
+          if constexpr (ABL == 4) acc[t][0] += u2f(bf[t][0] ^ bf[t][1] ^ bf[t][2] ^ bf[t][3] ^ xf[0] ^ xf[1] ^ xf[2] ^ xf[3]);  // ablation: no MFMA
+          else if (ABL != 7 && !DIFF && gfirst) acc[t] = mfma32<DT>(xf, bf[t], zero16);
+          else acc[t] = mfma32<DT>(xf, bf[t], acc[t]);
         }
+        if constexpr (STATIC_G) {
+#pragma unroll
+          for (int t = 0; t < TILES; ++t) asm volatile("" : "+v"(acc[t]));  // see finalize()
+        }
+        if (ABL != 7 && !STATIC_G && glast) pending = true;
+        // keep the scheduler from hoisting the lookups of later steps above this point: it would trade the 4-waves-per-SIMD
+        // register budget for instruction-level parallelism the other waves already provide
+        __builtin_amdgcn_sched_barrier(0);
       }
     };
 
@@ -452,22 +512,25 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
     for (int rd = 0; rd < rounds - 1; ++rd, l0 += R) {
 #pragma unroll
       for (int j = 0; j < R; ++j) {
-        consume(s_begin + l0 + j, ring[j]);
-        issue(rcur, s_begin + l0 + j + R, ring[j], l0 + j + R < nl);
+        consume(s_begin + l0 + j, ring[j], j);
+        issue(rcur, s_begin + l0 + j + R, ring[j], l0 + j + R < nl, NSG == 0 || j % NSG == 0);
       }
     }
 #pragma unroll
     for (int j = 0; j < R; ++j) {
-      if (l0 + j < nl) consume(s_begin + l0 + j, ring[j]);
-      issue(rnext, s_begin + j, ring[j], has_next && j < nl);
+      if (l0 + j < nl) consume(s_begin + l0 + j, ring[j], j);
+      issue(rnext, s_begin + j, ring[j], has_next && j < nl, NSG == 0 || j % NSG == 0);
     }
+    if (pending || GPS > 1 || NSG > 0) finalize();  // the last group of the slice
+    if constexpr (ABL == 6) yacc[0][0] += acc[0][0] + acc[0][1] + acc[1][0];
+    if constexpr (ABL == 7) { yacc[0][0] = acc[0][0]; yacc[1][0] = acc[1][0]; }
 
     // ---- split-K tail: the partial sums of the 8 waves meet in LDS and are added in wave order ----
     if (p.red_alias) __syncthreads();  // the partial sums overwrite the table: every wave must be done with its lookups
 #pragma unroll
     for (int t = 0; t < TILES; ++t) {
 #pragma unroll
-      for (int r = 0; r < MREGS; ++r)
+      for (int r = 0; r < RF; ++r)
         if (r < p.rused && lane < p.red_lanes)
           *(lds_fptr)(lds_red + (uint32_t)((((wave * TILES + t) * p.rused + r) * p.red_lanes + lane) * 4)) = yacc[t][r];
     }

@@ -7,17 +7,21 @@ Contract (one JSON line on rank 0):
 
 Workload (BASELINE.json configs[1]): any4 (per-row 16-entry bf16 LUT, g = 128) W4A16 GEMV, m = 1,
 n = k = 4096, weights packed on the B side with innerKTiles = 4 -- exactly what Any4Linear's default
-kernel `linear_y_f16RM_x_f16RM_W_any4TC` runs.  One STEP is one pass over a batch of L = 512
-independent such layers (distinct weights, activations and outputs: 4.6 GB, far beyond L2 + Infinity
-Cache, so every step streams its weights from HBM; about the 4-bit weight volume of a Llama-3-8B
+kernel `linear_y_f16RM_x_f16RM_W_any4TC` runs, in the library's default numerics.  One STEP is one pass over a
+batch of L = 512 independent such layers (distinct weights, activations and outputs: 4.6 GB, far beyond L2 +
+Infinity Cache, so every step streams its weights from HBM; about the 4-bit weight volume of a Llama-3-8B
 decode step) issued as ONE stacked launch of the C-ABI entry point tg_gemm_w4 (batch = L).  Inputs are
-resident in HBM before the timed region.  A step is ~1 ms on purpose: the power controller needs ~30 ms
-of load to settle (it overshoots, throttles to ~75 % and recovers), so the warm-up steps must
-last that long for the timed steps to see the steady clock; if the requested warm-up is shorter than 60 ms of wall
-time, further UNTIMED steps follow it (`settle_steps` in the JSON line) before the K timed steps start.
+resident in HBM before the timed region.  Before the timed steps the GPU is kept under the same load for
+~1 s of untimed steps (`settle_steps`): the power controller needs tens of ms to reach its steady clock
+(DESIGN.md 5), and the run leaves a GPU footprint an external sampler can see.
 
 `value` = algorithmic bytes of all ranks per step / max-over-ranks step time.
 Algorithmic bytes per layer: n*k/2 + (k/g)*n*4 + 32*n + m*k*2 + m*n*2 = 9 060 352 B.
+
+After the timed region rank 0 (a) checks three layers of the timed launch's output against the CPU oracle,
+(b) times the other BASELINE configs as extra keys (m = 8; config 3 = m = 8, 8192^2, weights on the A side;
+config 4 = int4 / nf4-style global LUT / mx4 at m = 1), (c) times single-layer launches (what one
+Any4Linear.forward issues), (d) times the reference's CPU path on the host cores.
 
 N > 1: the projection is row-sharded (rank r owns rows [r*n, (r+1)*n) of an [N*n, k] weight; the
 activation is replicated); every step ends with the RCCL all-gather of the partial outputs, inside
@@ -33,38 +37,148 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# the cpu_baseline leg runs the OpenMP oracle: without thread binding libgomp's workers pile onto a few cores
-# (measured: 93 ms vs 7 ms per layer on 8 cores); must be set before anything loads libgomp
+# the cpu_baseline legs use OpenMP / torch threads: without thread binding libgomp's workers pile onto a few cores
 _SCHEDULABLE_CPUS = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)  # before binding
 os.environ.setdefault("OMP_PROC_BIND", "true")
 
 import torch  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 measured float4 copy
+QT = {"int4": 0, "any4_global": 1, "any4_rowwise": 2, "mx4": 3}
 
 
-def alg_bytes(m, n, k, g, lut_bytes):
-    return n * k // 2 + (k // g) * n * 4 + lut_bytes + m * k * 2 + m * n * 2
+def alg_bytes(m, n, k, g, qtype="any4_rowwise"):
+    """packed weights + quantisation info + LUT + activations + outputs."""
+    lut = {"any4_rowwise": 32 * n, "any4_global": 32, "int4": 0, "mx4": 0}[qtype]
+    q = n * k // g if qtype == "mx4" else (k // g) * n * 4
+    return n * k // 2 + q + lut + m * k * 2 + m * n * 2
 
 
-def make_batch(L, m, n, k, g, inner, device, seed):
+def physical_cores():
+    """(physical cores, logical CPUs) of the host from /proc/cpuinfo; (None, n) if it cannot be read."""
+    try:
+        seen, phys, core = set(), None, None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":")[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    seen.add((phys, core))
+                phys = core = None
+        return (len(seen) or None), (os.cpu_count() or 1)
+    except OSError:
+        return None, (os.cpu_count() or 1)
+
+
+def make_batch(L, m, n, k, g, inner, device, seed, qtype="any4_rowwise", on_right=True):
     """Synthetic tensors of the SURVEY 8d recipe, generated on the device (packed words are uniformly
     random nibbles, which is what packing uniformly random codes gives)."""
     gen = torch.Generator(device=device).manual_seed(seed)
-    w = torch.randint(-2 ** 31, 2 ** 31 - 1, (L, n // 8, k // (16 * inner), 32, inner // 2), dtype=torch.int64,
-                      device=device, generator=gen).to(torch.int32)
+    shape = (L, n // 8, k // (16 * inner), 32, inner // 2) if on_right else (L, n // 16, k // (16 * inner), 32, inner)
+    w = torch.randint(-2 ** 31, 2 ** 31 - 1, shape, dtype=torch.int64, device=device, generator=gen).to(torch.int32)
     x = torch.randn(L, m, k, device=device, generator=gen).to(torch.bfloat16)
-    scales = torch.rand(L, k // g, n, device=device, generator=gen) * 0.02 + 0.005
-    zeros = torch.randn(L, k // g, n, device=device, generator=gen) * 0.01
-    sz = torch.stack([scales, zeros], dim=3).to(torch.bfloat16).contiguous()
-    lut = torch.randn(L, n, 16, device=device, generator=gen).to(torch.bfloat16)
+    if qtype == "mx4":
+        q = torch.randint(120, 131, (L, n, k // g), dtype=torch.uint8, device=device, generator=gen)
+    else:
+        scales = torch.rand(L, k // g, n, device=device, generator=gen) * 0.02 + 0.005
+        zeros = torch.randn(L, k // g, n, device=device, generator=gen) * 0.01
+        q = torch.stack([scales, zeros], dim=3).to(torch.bfloat16).contiguous()
+    lut = {"any4_rowwise": lambda: torch.randn(L, n, 16, device=device, generator=gen).to(torch.bfloat16),
+           "any4_global": lambda: torch.randn(L, 16, device=device, generator=gen).to(torch.bfloat16)}.get(qtype, lambda: None)()
     y = torch.empty(L, m, n, device=device, dtype=torch.bfloat16)
-    return w, x, sz, lut, y
+    return w, x, q, lut, y
 
 
-def cpu_baseline(m, n, k, g, budget_s=12.0):
-    """The oracle (a C port of the reference's dequant + matmul, oracle/tinygemm_oracle.c) timed on the
-    host cores on a bounded sample of the same workload: whole layers until ~budget_s have elapsed."""
+def make_args(_lib, w, x, q, lut, y, m, n, k, g, qtype, on_right, inner, batch):
+    return _lib.W4Gemm(
+        x=x.data_ptr(), w=w.data_ptr(), qinfo=q.data_ptr(), lut=(lut.data_ptr() if lut is not None else None), y=y.data_ptr(),
+        m=m, wrows=n, k=k, group=g, qtype=QT[qtype], dtype=_lib.TG_BF16, w_on_right=1 if on_right else 0,
+        inner_k_tiles=inner, batch=batch, stride_x=x.stride(0) * 2, stride_w=w.stride(0) * 4,
+        stride_qinfo=q.stride(0) * q.element_size(), stride_lut=(lut.stride(0) * 2 if lut is not None else 0),
+        stride_y=y.stride(0) * 2, numerics=_lib.TG_NUM_FAST)
+
+
+def check_layers(w, x, q, lut, y, g, qtype, on_right, inner, plan, layers=(0, 1, -1), rows=256):
+    """Untimed: `rows` weight rows of a few layers of the launch's output against the CPU oracle (the group-scaled
+    restatement when the pair-table kernel ran, else the reference-faithful contraction)."""
+    import numpy as np
+
+    from oracle import oracle as orc
+
+    def bits(t):
+        return t.detach().cpu().contiguous().view(torch.int16).numpy().view(np.uint16)
+
+    n, k = y.shape[2], x.shape[2]
+    oq = {"int4": orc.Q_INT4, "any4_global": orc.Q_ANY4_GLOBAL, "any4_rowwise": orc.Q_ANY4_ROWWISE, "mx4": orc.Q_MX4}[qtype]
+    worst = 0.0
+    for b in layers:
+        codes = (orc.unpack_Bint4 if on_right else orc.unpack_Aint4)(w[b].cpu().numpy(), n, k)[:rows]
+        qi = q[b].cpu().numpy()[:rows] if qtype == "mx4" else bits(q[b][:, :rows].contiguous())
+        lb = None if lut is None else (bits(lut[b][:rows]) if qtype == "any4_rowwise" else bits(lut[b]))
+        xb = bits(x[b])
+        fn = orc.linear_group_scaled if plan == "pair" else orc.linear
+        _, y32 = fn(xb, codes, g, oq, qi, lb)
+        wq = orc.bf16_to_f32(orc.dequant(codes, g, oq, qi, lb)).astype(np.float64)
+        S = np.abs(x[b].double().cpu().numpy()) @ np.abs(wq).T
+        got = y[b][:, :rows].double().cpu().numpy()
+        ulp = np.exp2(np.floor(np.log2(np.maximum(np.abs(y32), 1e-30))) - 7)
+        err = np.abs(got - y32)
+        if not (err <= 0.5 * ulp * (1 + 2.0 ** -7) + 4e-6 * S).all():
+            raise SystemExit(f"bench.py: output of layer {b} ({qtype}) does not match the oracle: max err {err.max()}")
+        worst = max(worst, float(err.max()))
+    return worst
+
+
+def cpu_baseline_torch(m, n, k, g, budget_s=10.0):
+    """The reference's CPU path (quantize.py:612-637 anyq_dequantize_tensor -> degroup_q 160-174, then x @ W^T), restated
+    with torch ops on bf16 CPU tensors: gather the per-row LUT, (w - 8) * scale + zero op by op in bf16, matmul.
+    (the reference's LUT lives in the [0, 15] domain and the module stores lut - 8.)"""
+    gen = torch.Generator().manual_seed(0)
+    codes = torch.randint(0, 16, (n, k), dtype=torch.int64, generator=gen)
+    lut = (torch.rand(n, 16, generator=gen) * 15).to(torch.bfloat16)
+    scales = (torch.rand(k // g, n, generator=gen) * 0.02 + 0.005).to(torch.bfloat16)
+    zeros = (torch.randn(k // g, n, generator=gen) * 0.01).to(torch.bfloat16)
+    x = torch.randn(m, k, generator=gen).to(torch.bfloat16)
+
+    def layer():
+        w = torch.gather(lut, 1, codes)                                   # [n][k] bf16, values in [0, 15]
+        w = w.view(n, k // g, g)
+        w = (w - 8) * scales.t().unsqueeze(2) + zeros.t().unsqueeze(2)    # degroup_q: op by op in bf16
+        return x @ w.view(n, k).t()
+
+    # thread count: SURVEY 8d asks for os.cpu_count(), but torch's bf16 CPU element-wise ops collapse when oversubscribed
+    # (measured: 1.7 s per layer with 256 threads on a 128-core host), so probe and keep the fastest; all counts are reported
+    phys, logical = physical_cores()
+    cands = sorted({c for c in (8, 16, 32, 64, phys or 0, _SCHEDULABLE_CPUS) if 0 < c <= _SCHEDULABLE_CPUS})
+    probe = {}
+    for c in cands:
+        torch.set_num_threads(c)
+        layer()
+        t0 = time.perf_counter()
+        layer()
+        probe[c] = time.perf_counter() - t0
+        if probe[c] > 2.0 and len(probe) > 1:
+            break
+    threads = min(probe, key=probe.get)
+    torch.set_num_threads(threads)
+    layer()
+    layers, t0 = 0, time.perf_counter()
+    while True:
+        layer()
+        layers += 1
+        dt = time.perf_counter() - t0
+        if (dt >= budget_s and layers >= 3) or layers >= 2000:
+            break
+    return {"value": round(layers * alg_bytes(m, n, k, g) / dt / 1e9, 4), "unit": "GB/s", "cores": threads, "kind": "port",
+            "sample": f"{layers} layers of the bench workload (m={m}, n=k={n}, g={g}) in {dt:.1f} s = {dt / layers * 1e3:.1f} ms per layer; "
+                      f"torch {torch.__version__} CPU bf16: gather LUT -> (w-8)*scale+zero -> matmul (the reference's quantize.py:612-637, 160-174), "
+                      f"torch.set_num_threads({threads}) = fastest of {sorted(probe)} (os.cpu_count() = {logical}); host has {phys} physical cores / {logical} logical CPUs, {_SCHEDULABLE_CPUS} schedulable"}
+
+
+def cpu_baseline_oracle(m, n, k, g, budget_s=8.0):
+    """The C oracle (oracle/tinygemm_oracle.c: the reference KERNEL's arithmetic, OpenMP over weight rows) on the same workload."""
     import numpy as np
 
     from oracle import oracle as orc
@@ -75,9 +189,7 @@ def cpu_baseline(m, n, k, g, budget_s=12.0):
     lut = orc.bf16_bits(rng.standard_normal((n, 16)).astype(np.float32))
     sz = orc.bf16_bits((rng.random((k // g, n, 2)) * 0.02).astype(np.float32))
     x = orc.bf16_bits(rng.standard_normal((m, k)).astype(np.float32))
-    # thread count: the box may expose more logical CPUs than its cgroup lets run (256 threads on a quota of a
-    # few cores is ~10x slower than 8), so probe powers of two up to the affinity mask and keep the fastest
-    avail = _SCHEDULABLE_CPUS  # taken at import: OMP_PROC_BIND pins the main thread, which shrinks the mask seen later
+    avail = _SCHEDULABLE_CPUS
     cands = sorted({min(avail, 1 << i) for i in range(0, 10)} | {avail})
     best, best_t = 1, float("inf")
     for t in cands:
@@ -89,7 +201,7 @@ def cpu_baseline(m, n, k, g, budget_s=12.0):
         if dt < best_t:
             best, best_t = t, dt
     orc.set_num_threads(best)
-    orc.linear(x, codes, g, orc.Q_ANY4_ROWWISE, sz, lut)  # warm-up
+    orc.linear(x, codes, g, orc.Q_ANY4_ROWWISE, sz, lut)
     layers, t0 = 0, time.perf_counter()
     while True:
         orc.linear(x, codes, g, orc.Q_ANY4_ROWWISE, sz, lut)
@@ -97,26 +209,24 @@ def cpu_baseline(m, n, k, g, budget_s=12.0):
         dt = time.perf_counter() - t0
         if dt >= budget_s or layers >= 2000:
             break
-    gbps = layers * alg_bytes(m, n, k, g, 32 * n) / dt / 1e9
-    return {"value": round(gbps, 4), "unit": "GB/s", "cores": orc.num_threads(), "kind": "port",
-            "sample": f"{layers} layers of the bench workload (m={m}, n=k={n}, g={g}) in {dt:.1f} s, "
-                      f"OpenMP over weight rows, {dt / layers * 1e3:.1f} ms per layer; fastest of thread counts "
-                      f"{cands} on {avail} schedulable CPUs"}
+    return {"value": round(layers * alg_bytes(m, n, k, g) / dt / 1e9, 4), "unit": "GB/s", "cores": orc.num_threads(), "kind": "port",
+            "sample": f"{layers} layers in {dt:.1f} s, OpenMP over weight rows, {dt / layers * 1e3:.1f} ms per layer; fastest of thread counts {cands}"}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--layers", type=int, default=512, help="independent layers per step (stacked launch)")
     ap.add_argument("--m", type=int, default=1)
     ap.add_argument("--n", type=int, default=4096)
     ap.add_argument("--k", type=int, default=4096)
     ap.add_argument("--group", type=int, default=128)
+    ap.add_argument("--settle-s", type=float, default=1.0, help="seconds of untimed steps before the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--roofline-only", action="store_true",
-                    help="skip the informational legs (marginal, m8, single-layer, cpu): every launch of the stacked "
+                    help="skip the informational legs (other configs, single-layer, cpu): every launch of the stacked "
                          "kernel is then a timed-shape launch, which is what the rocprofv3 --stats pass wants")
     a = ap.parse_args()
 
@@ -135,7 +245,7 @@ def main():
     if world > 1:
         dist.init_process_group(backend="nccl")  # RCCL on ROCm
 
-    from any4_amd import _lib
+    from any4_amd import _lib, ops
 
     lib = _lib.load()
     L, m, n, k, g, inner = a.layers, a.m, a.n, a.k, a.group, 4
@@ -145,15 +255,15 @@ def main():
         dist.broadcast(x, src=0)
         y_all = torch.empty(world, L, m, n, device=device, dtype=torch.bfloat16)
 
-    args = _lib.W4Gemm(
-        x=x.data_ptr(), w=w.data_ptr(), qinfo=sz.data_ptr(), lut=lut.data_ptr(), y=y.data_ptr(),
-        m=m, wrows=n, k=k, group=g, qtype=_lib.TG_Q_ANY4_ROWWISE, dtype=_lib.TG_BF16, w_on_right=1,
-        inner_k_tiles=inner, batch=L, stride_x=x.stride(0) * 2, stride_w=w.stride(0) * 4,
-        stride_qinfo=sz.stride(0) * 2, stride_lut=lut.stride(0) * 2, stride_y=y.stride(0) * 2)
+    args = make_args(_lib, w, x, sz, lut, y, m, n, k, g, "any4_rowwise", True, inner, L)
+    plan = ops.gemm_w4_plan(m, n, k, g, QT["any4_rowwise"], True, inner, torch.bfloat16, L, "fast")
     stream = torch.cuda.current_stream()
 
+    def launch(aa):
+        _lib.check(lib.tg_gemm_w4(ctypes.byref(aa), local_rank, stream.cuda_stream), "tg_gemm_w4")
+
     def step():
-        _lib.check(lib.tg_gemm_w4(ctypes.byref(args), local_rank, stream.cuda_stream), "tg_gemm_w4")
+        launch(args)
         if world > 1:
             dist.all_gather_into_tensor(y_all, y)
 
@@ -169,14 +279,13 @@ def main():
     for _ in range(a.warmup - 1):
         step()
     fence()
-    # untimed settling: the power controller needs ~30-50 ms of continuous load ("Power transient").  When
-    # the requested warm-up is shorter than that, keep stepping (still untimed, reported as `settle_steps`).
+    # untimed settling under the timed load; every rank derives the SAME number of steps
     tw = torch.tensor([time.perf_counter() - t_w], device=device, dtype=torch.float64)
     if world > 1:
-        dist.all_reduce(tw, op=dist.ReduceOp.MAX)  # every rank derives the SAME number of settling steps
+        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
     t_warm = float(tw[0])
-    per_step = t_warm / (a.warmup - 1) if a.warmup > 1 else 1.2e-3
-    settle = 0 if t_warm >= 0.06 else min(1000, int((0.06 - t_warm) / max(per_step, 1e-5)) + 1)
+    per_step = t_warm / (a.warmup - 1) if a.warmup > 1 else 1.0e-3
+    settle = 0 if t_warm >= a.settle_s else min(5000, int((a.settle_s - t_warm) / max(per_step, 1e-5)) + 1)
     for _ in range(settle):
         step()
     fence()
@@ -185,7 +294,7 @@ def main():
     t0 = time.perf_counter()
     for s in range(a.steps):
         ev[s][0].record(stream)
-        _lib.check(lib.tg_gemm_w4(ctypes.byref(args), local_rank, stream.cuda_stream), "tg_gemm_w4")
+        launch(args)
         ev[s][1].record(stream)
         if world > 1:
             dist.all_gather_into_tensor(y_all, y)
@@ -198,7 +307,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed, kern_ms = float(t[0]), float(t[1])
 
-    bytes_layer = alg_bytes(m, n, k, g, 32 * n)
+    bytes_layer = alg_bytes(m, n, k, g)
     bytes_step_rank = L * bytes_layer
     ms_per_step = elapsed / a.steps * 1e3
     value = world * bytes_step_rank / (elapsed / a.steps) / 1e9
@@ -206,61 +315,75 @@ def main():
 
     if rank == 0 and a.roofline_only:
         print(json.dumps({"roofline_only": True, "launch_us": round(kern_ms * 1e3, 3), "GBps": round(achieved, 2),
-                          "steps": a.steps, "warmup": a.warmup, "layers": L}), flush=True)
+                          "steps": a.steps, "warmup": a.warmup, "settle_steps": settle, "layers": L, "kernel_plan": plan}), flush=True)
     elif rank == 0:
-        # single-layer launches (what one Any4Linear.forward issues), informational
-        single = _lib.W4Gemm.from_buffer_copy(args)
-        single.batch = 1
-        per = []
+        def timed(aa, reps):
+            for _ in range(3):
+                launch(aa)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            for _ in range(reps):
+                launch(aa)
+            e1.record(stream)
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) * 1e3 / reps  # us per launch
+
+        # marginal rate: slope of launch time over the number of stacked layers -- measured first, while the
+        # clock is still in the steady state of the timed region
+        half = make_args(_lib, w, x, sz, lut, y, m, n, k, g, "any4_rowwise", True, inner, L // 2)
+        t_half, t_full = timed(half, 40), timed(args, 40)
+        slope_us = (t_full - t_half) / (L - L // 2)
+        # (a) the timed launch's own output against the oracle
+        max_err = check_layers(w, x, sz, lut, y, g, "any4_rowwise", True, inner, plan)
+
+        def leg(qtype, mm, nn, kk, gg, on_right, layers, note):
+            """One more BASELINE config as a stacked launch of `layers` layers (same protocol: steady clock, HIP events)."""
+            ww, xx, qq, ll, yy = make_batch(layers, mm, nn, kk, gg, inner, device, 77, qtype, on_right)
+            aa = make_args(_lib, ww, xx, qq, ll, yy, mm, nn, kk, gg, qtype, on_right, inner, layers)
+            pl = ops.gemm_w4_plan(mm, nn, kk, gg, QT[qtype], on_right, inner, torch.bfloat16, layers, "fast")
+            bl = alg_bytes(mm, nn, kk, gg, qtype)
+            reps = max(10, int(0.25e6 / (layers * bl / 5e6)))  # ~0.25 s of launches
+            us = timed(aa, reps) / layers
+            err = check_layers(ww, xx, qq, ll, yy, gg, qtype, on_right, inner, pl, layers=(0, -1), rows=128)
+            return {"us_per_layer": round(us, 4), "GBps": round(bl / us / 1e3, 2), "frac": round(bl / us / 1e3 / HBM_PEAK_GBPS, 4),
+                    "algorithmic_bytes_per_layer": bl, "layers_per_launch": layers, "kernel_plan": pl,
+                    "max_abs_err_vs_oracle": err, "note": note}
+
+        legs = {
+            "m8": leg("any4_rowwise", 8, n, k, g, True, L, f"the metric's second point: m=8, n=k={n}, g={g}, Bint4"),
+            "config3": leg("any4_rowwise", 8, 8192, 8192, 128, False, 128, "BASELINE config 3: m=8, n=k=8192, g=128, weights on the A side (Aint4 innerKTiles=4)"),
+            "int4": leg("int4", 1, n, k, g, True, L, "BASELINE config 4: uniform int4, m=1"),
+            "nf4": leg("any4_global", 1, n, k, g, True, L, "BASELINE config 4: one global 16-entry LUT (the reference's NF4 path), m=1"),
+            "mx4": leg("mx4", 1, n, k, 32, True, L, "BASELINE config 4: mx4 (fp4-e2m1 codes, e8m0 exponent per 32), m=1"),
+        }
+
+        # (c) single-layer launches: what one Any4Linear.forward issues (the reference's microbenchmark shape)
+        singles = []
         for b in range(L):
-            sa = _lib.W4Gemm.from_buffer_copy(single)
-            sa.x, sa.w, sa.qinfo = x[b].data_ptr(), w[b].data_ptr(), sz[b].data_ptr()
-            sa.lut, sa.y = lut[b].data_ptr(), y[b].data_ptr()
-            per.append(sa)
-        for sa in per:
-            lib.tg_gemm_w4(ctypes.byref(sa), local_rank, stream.cuda_stream)
+            sa = make_args(_lib, w[b:b + 1], x[b:b + 1], sz[b:b + 1], lut[b:b + 1], y[b:b + 1], m, n, k, g, "any4_rowwise", True, inner, 1)
+            singles.append(sa)
+        for sa in singles:
+            launch(sa)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(stream)
-        for sa in per:
-            lib.tg_gemm_w4(ctypes.byref(sa), local_rank, stream.cuda_stream)
+        for sa in singles:
+            launch(sa)
         e1.record(stream)
         torch.cuda.synchronize()
         single_us = e0.elapsed_time(e1) * 1e3 / L
-
-        def stacked_us(mm, layers, reps=10):
-            """Event time of `reps` stacked launches over `layers` layers at batch rows mm (same weights)."""
-            xx = x if mm == m else torch.randn(L, mm, k, device=device).to(torch.bfloat16)
-            yy = y if mm == m else torch.empty(L, mm, n, device=device, dtype=torch.bfloat16)
-            aa = _lib.W4Gemm.from_buffer_copy(args)
-            aa.x, aa.y, aa.m, aa.batch = xx.data_ptr(), yy.data_ptr(), mm, layers
-            aa.stride_x, aa.stride_y = xx.stride(0) * 2, yy.stride(0) * 2
-            for _ in range(3):
-                _lib.check(lib.tg_gemm_w4(ctypes.byref(aa), local_rank, stream.cuda_stream), "tg_gemm_w4")
-            a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a0.record(stream)
-            for _ in range(reps):
-                _lib.check(lib.tg_gemm_w4(ctypes.byref(aa), local_rank, stream.cuda_stream), "tg_gemm_w4")
-            a1.record(stream)
+        # cold single launch: one launch between two events, a different (cold) layer every time
+        cold = []
+        for b in range(0, L, 8):
+            c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             torch.cuda.synchronize()
-            return a0.elapsed_time(a1) * 1e3 / reps
-
-        # marginal rate (SURVEY 8d): slope of launch time over the number of stacked layers
-        t_half, t_full = stacked_us(m, L // 2), stacked_us(m, L)
-        slope_us = (t_full - t_half) / (L - L // 2)
-        # the metric's second point: m = 8 at the same n, k (same stacked launch, 8 activation rows)
-        m8_us = stacked_us(8, L) / L
-        m8_bytes = alg_bytes(8, n, k, g, 32 * n)
-
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(pmc):
-            try:
-                # PMC passes are separate rocprofv3 runs of this same command (tools/gpu_round.sh); the committed
-                # summary holds HBM bytes per layer of the stacked launch, scaled here to this launch's layers
-                traffic = int(json.load(open(pmc))["hbm_bytes_per_layer"] * L)
-            except Exception:
-                traffic = None
+            c0.record(stream)
+            launch(singles[b])
+            c1.record(stream)
+            torch.cuda.synchronize()
+            cold.append(c0.elapsed_time(c1) * 1e3)
+        cold_us = sorted(cold)[len(cold) // 2]
+        single_plan = ops.gemm_w4_plan(m, n, k, g, QT["any4_rowwise"], True, inner, torch.bfloat16, 1, "fast")
 
         out = {
             "metric": "any4 W4A16 GEMM achieved GB/s (m=1, n=k=4096, g=128)",
@@ -277,20 +400,23 @@ def main():
             "dtype": "bf16",
             "data": "synthetic",
             "config": {
-                "workload": f"any4 W4A16 GEMV m={m} n={n} k={k} g={g} per-row LUT, Bint4 innerKTiles=4; "
+                "workload": f"any4 W4A16 GEMV m={m} n={n} k={k} g={g} per-row LUT, Bint4 innerKTiles=4, default (group-scaled) numerics; "
                             f"one step = {L} independent layers (distinct cold weights) in one stacked launch"
                             + (f"; rows sharded over {world} ranks + RCCL all-gather of y" if world > 1 else ""),
                 "layers_per_step": L, "m": m, "n": n, "k": k, "group": g,
                 "algorithmic_bytes_per_layer": bytes_layer,
+                "output_checked": f"3 layers x 256 rows of the timed launch's y against the CPU oracle: max abs err {max_err:.3e}",
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "w4_gemm_stream_kernel<BF16, Bint4 innerK=4> (stacked launch, one 16-row tile per wave)",
+                "kernel": {"pair": "w4_gemm_pair_kernel<BF16, I=4> (persistent, 64-row work items, pair-table lookups, group-scaled accumulators)",
+                           "stream": "w4_gemm_stream_kernel<BF16, Bint4 innerK=4>", "splitk": "w4_gemm_kernel<BF16>"}[plan],
                 "achieved": round(achieved, 2),
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                "traffic": traffic,
+                "traffic": None,
+                "traffic_note": "PMC HBM bytes are collected in separate rocprofv3 --pmc passes of this command (tools/gpu_round.sh) and committed under profiles/ (r02_pmc_traffic.json); not measured inside this run",
                 "launch_us": round(kern_ms * 1e3, 3),
                 "bytes_per_launch": bytes_step_rank,
             },
@@ -300,21 +426,21 @@ def main():
                 "frac": round(bytes_layer / slope_us / 1e3 / HBM_PEAK_GBPS, 4),
                 "note": f"dT/dL between stacked launches of {L // 2} and {L} layers (launch overhead cancels)",
             },
-            "m8": {
-                "us_per_layer": round(m8_us, 4),
-                "GBps": round(m8_bytes / m8_us / 1e3, 2),
-                "frac": round(m8_bytes / m8_us / 1e3 / HBM_PEAK_GBPS, 4),
-                "algorithmic_bytes_per_layer": m8_bytes,
-                "note": f"m=8, n=k={n}, g={g}: the metric's second point, same stacked launch of {L} layers",
-            },
+            **legs,
             "single_layer_launch": {
-                "us_per_launch": round(single_us, 3),
-                "GBps": round(bytes_layer / single_us / 1e3, 2),
-                "note": "back-to-back one-layer launches on one stream (streaming kernel, split-K 8, private X slabs), event time / launches",
+                "us_per_launch_back_to_back": round(single_us, 3),
+                "GBps_back_to_back": round(bytes_layer / single_us / 1e3, 2),
+                "frac_back_to_back": round(bytes_layer / single_us / 1e3 / HBM_PEAK_GBPS, 4),
+                "us_cold_event_pair": round(cold_us, 3),
+                "frac_cold": round(bytes_layer / cold_us / 1e3 / HBM_PEAK_GBPS, 4),
+                "kernel_plan": single_plan,
+                "note": "one 4096x4096 any4 GEMV per launch (what Any4Linear.forward issues): back-to-back launches of distinct cold layers on one "
+                        "stream (event time / launches), and the median HIP-event time of an isolated launch (event pair floor on this stack: ~4.3 us)",
             },
         }
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(m, n, k, g)
+            out["cpu_baseline"] = cpu_baseline_torch(m, n, k, g)
+            out["cpu_baseline_c_oracle"] = cpu_baseline_oracle(m, n, k, g)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

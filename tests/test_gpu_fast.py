@@ -58,6 +58,37 @@ def assert_fast_close(oracle, y_hip, codes, x, qinfo, lut, g, qtype, dtype=torch
     assert not bad.any(), f"vs reference-faithful oracle: {bad.sum()} / {bad.size} outside tolerance"
 
 
+def run_fast(T, codes, x, qinfo, lut, g, qtype, inner, bias=None, min_items=384):
+    """The pair-table kernel is dispatched when a launch has >= 384 work items (64-row blocks x problems; smaller launches are
+    latency-bound and stay on the split-K kernels): run `copies` identical problems in ONE tg_gemm_w4 call (the C ABI's
+    stacked launch), check that every copy gives the same bits, return (y of copy 0, copies)."""
+    from any4_amd import _lib
+
+    L = _lib.load()
+    n, k = codes.shape
+    m = x.shape[0]
+    dt = x.dtype
+    packed1 = T.convert_matrix_to_m16n8k16_Bint4_layout(codes.to(DEV), inner)
+    wrows = packed1.shape[0] * 8
+    copies = -(-min_items // (-(-wrows // 64) * -(-m // (8 if m <= 8 else 16 if m <= 16 else 32))))
+    rep = lambda t: None if t is None else t.to(DEV).unsqueeze(0).repeat(copies, *([1] * t.dim())).contiguous()
+    packed, xs, qs, luts = rep(packed1.cpu()), rep(x), rep(qinfo), rep(lut)
+    bs = rep(bias)
+    ys = torch.full((copies, m, wrows), float("nan"), dtype=dt, device=DEV)
+    args = _lib.W4Gemm(x=xs.data_ptr(), w=packed.data_ptr(), qinfo=qs.data_ptr(), lut=(luts.data_ptr() if luts is not None else None),
+                       y=ys.data_ptr(), m=m, wrows=wrows, k=k, group=g, qtype=QT[qtype],
+                       dtype=_lib.TG_BF16 if dt == torch.bfloat16 else _lib.TG_F16, w_on_right=1, inner_k_tiles=inner, batch=copies,
+                       stride_x=xs.stride(0) * 2, stride_w=packed.stride(0) * 4, stride_qinfo=qs.stride(0) * qs.element_size(),
+                       stride_lut=(luts.stride(0) * 2 if luts is not None else 0), stride_y=ys.stride(0) * 2,
+                       numerics=_lib.TG_NUM_FAST, bias=(bs.data_ptr() if bs is not None else None),
+                       stride_bias=(bs.stride(0) * 2 if bs is not None else 0))
+    _lib.check(L.tg_gemm_w4(ctypes.byref(args), 0, torch.cuda.current_stream().cuda_stream), "stacked fast launch")
+    torch.cuda.synchronize()
+    assert not torch.isnan(ys.float()).any() or qtype == "mx4"
+    assert torch.equal(ys[0].view(torch.int16), ys[-1].view(torch.int16)) and torch.equal(ys[0].view(torch.int16), ys[copies // 2].view(torch.int16))
+    return ys[0], copies
+
+
 def test_default_numerics_is_fast():
     import any4_amd
 
@@ -77,9 +108,8 @@ def test_pair_kernel_vs_oracle(T, oracle, qtype, inner, g):
         if k % (16 * inner) or k % g:
             continue
         codes, x, qinfo, lut = rand_problem(n, k, g, m, qtype, seed=n + k + inner)
-        y = run_rm(T, codes, x, qinfo, lut, g, qtype, True, inner)
-        assert y.shape == (m, n)
-        assert_fast_close(oracle, y, codes, x, qinfo, lut, g, qtype, inner=inner)
+        y, copies = run_fast(T, codes, x, qinfo, lut, g, qtype, inner)
+        assert_fast_close(oracle, y, codes, x, qinfo, lut, g, qtype, inner=inner, batch=copies)
 
 
 @pytest.mark.parametrize("m", [1, 2, 3, 4, 5, 7, 8])
@@ -88,8 +118,8 @@ def test_pair_kernel_m_sweep(T, oracle, m):
     activation block to stay on chip at every m."""
     n, k, g = 72, 256, 128
     codes, x, qinfo, lut = rand_problem(n, k, g, m, "any4_rowwise", seed=m)
-    y = run_rm(T, codes, x, qinfo, lut, g, "any4_rowwise", True, 4)
-    assert_fast_close(oracle, y, codes, x, qinfo, lut, g, "any4_rowwise")
+    y, copies = run_fast(T, codes, x, qinfo, lut, g, "any4_rowwise", 4)
+    assert_fast_close(oracle, y, codes, x, qinfo, lut, g, "any4_rowwise", batch=copies)
 
 
 @pytest.mark.parametrize("m", [9, 16, 17, 33])
@@ -100,25 +130,25 @@ def test_pair_kernel_many_rows(T, oracle, m):
 
     n, k, g = 64, 128, 64
     codes, x, qinfo, lut = rand_problem(n, k, g, m, "any4_rowwise", seed=m)
-    y = run_rm(T, codes, x, qinfo, lut, g, "any4_rowwise", True, 4)
-    pair = ops.gemm_w4_plan(m, n, k, g, QT["any4_rowwise"]) == "pair"
-    assert_fast_close(oracle, y, codes, x, qinfo, lut, g, "any4_rowwise", expect_pair=pair)
+    y, copies = run_fast(T, codes, x, qinfo, lut, g, "any4_rowwise", 4)
+    pair = ops.gemm_w4_plan(m, n, k, g, QT["any4_rowwise"], batch=copies) == "pair"
+    assert_fast_close(oracle, y, codes, x, qinfo, lut, g, "any4_rowwise", batch=copies, expect_pair=pair)
 
 
 def test_pair_kernel_fp16(T, oracle):
     for qtype in ("any4_rowwise", "int4"):
         codes, x, qinfo, lut = rand_problem(96, 1024, 128, 2, qtype, dtype=torch.float16, seed=4)
-        y = run_rm(T, codes, x, qinfo, lut, 128, qtype, True, 4)
+        y, copies = run_fast(T, codes, x, qinfo, lut, 128, qtype, 4)
         assert y.dtype == torch.float16
-        assert_fast_close(oracle, y, codes, x, qinfo, lut, 128, qtype, torch.float16)
+        assert_fast_close(oracle, y, codes, x, qinfo, lut, 128, qtype, torch.float16, batch=copies)
 
 
 def test_fast_equals_reference_where_no_fast_kernel(T, oracle):
-    """Weights on the A side and activation blocks too large to stage have no group-scaled kernel yet: the fast setting
-    then runs the reference kernels, bit for bit."""
+    """Weights on the A side, activation blocks too large to stage and small (latency-bound) launches have no group-scaled
+    kernel: the fast setting then runs the reference kernels, bit for bit."""
     import any4_amd
 
-    for on_right, m, k in ((False, 2, 1024), (True, 16, 4096)):
+    for on_right, m, k in ((False, 2, 1024), (True, 16, 4096), (True, 1, 1024)):
         codes, x, qinfo, lut = rand_problem(64, k, 128, m, "any4_rowwise", seed=3)
         y_fast = run_rm(T, codes, x, qinfo, lut, 128, "any4_rowwise", on_right, 4)
         with any4_amd.numerics("reference"):
@@ -138,7 +168,8 @@ def test_identity_fast_within_one_ulp(T, g):
     codes, sz = U.group_quantize_tensor(torch.eye(k, dtype=torch.bfloat16), 4, g)
     lut = -(torch.arange(16, dtype=torch.bfloat16) - 8)
     sz[:, :, 0] *= -1.0
-    y = run_rm(T, codes, x, sz, lut, g, "any4_global", True, 4).cpu()
+    y, _ = run_fast(T, codes, x, sz, lut, g, "any4_global", 4)
+    y = y.cpu()
     err = (y.double() - x.double()).abs().numpy()
     assert (err <= ulp16(x.double().numpy(), torch.bfloat16)).all()
 
@@ -152,11 +183,12 @@ def test_identity_mx4_fast_is_exact(T):
     q, e = U.quantize_mx4(torch.eye(k), 32)
     e = e + (torch.arange(k) % 4).to(torch.uint8).unsqueeze(1)
     expect = (x.float() * (2.0 ** (torch.arange(k) % 4).float())).bfloat16()
-    y = run_rm(T, q, x, e, None, 32, "mx4", True, 4)
+    y, _ = run_fast(T, q, x, e, None, 32, "mx4", 4)
     assert torch.equal(y.cpu(), expect)
     e2 = e.clone()
     e2[5, :] = 255  # NaN exponent: that weight row only (test_tinygemm_mx4.py:443-506)
-    y = run_rm(T, q, x, e2, None, 32, "mx4", True, 4).cpu()
+    y, _ = run_fast(T, q, x, e2, None, 32, "mx4", 4)
+    y = y.cpu()
     assert torch.isnan(y[:, 5]).all() and not torch.isnan(y[:, :5]).any() and not torch.isnan(y[:, 6:]).any()
 
 
@@ -171,7 +203,10 @@ def test_reference_fixture_fast(T):
     x = from_bits16(g["x_bits"], torch.bfloat16)
     lut = from_bits16(g["lut_m8_bits"], torch.bfloat16)
     sz = from_bits16(g["sz_bits"], torch.bfloat16)
-    y = run_rm(T, torch.from_numpy(codes), x, sz, lut, grp, "any4_rowwise", True, 4)
+    from any4_amd import ops
+
+    y, copies = run_fast(T, torch.from_numpy(codes), x, sz, lut, grp, "any4_rowwise", 4)
+    assert ops.gemm_w4_plan(1, n, k, grp, QT["any4_rowwise"], batch=copies) == "pair"
     y_ref = from_bits16(g["y_bits"], torch.bfloat16)
     assert (y.float().cpu() - y_ref.float()).abs().max().item() <= 1e-2
 
@@ -275,6 +310,15 @@ def test_module_bias_is_fused_and_bit_identical(T, kernel, cls, numerics):
     assert calls, "the GEMM op never looked for a fused bias"
     assert y.shape == (2, m, n)
     assert torch.equal(y, y_plain + bias)
+
+
+def test_pair_kernel_fused_bias(T, oracle):
+    """The same store-side bias in the pair-table kernel (reached through the stacked C-ABI launch)."""
+    codes, x, qinfo, lut = rand_problem(128, 1024, 128, 2, "any4_rowwise", seed=12)
+    bias = torch.randn(128, generator=torch.Generator().manual_seed(1)).bfloat16()
+    y0, _ = run_fast(T, codes, x, qinfo, lut, 128, "any4_rowwise", 4)
+    y1, _ = run_fast(T, codes, x, qinfo, lut, 128, "any4_rowwise", 4, bias=bias)
+    assert torch.equal(y1, y0 + bias.to(DEV))
 
 
 def test_bias_not_fused_into_fragment_layouts(T):

@@ -241,8 +241,15 @@ def test_bench_cpu_baseline_leg_and_byte_formula():
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
     # config 2 = 9 060 352 B, m = 8 -> 9 175 040 B
-    assert bench.alg_bytes(1, 4096, 4096, 128, 32 * 4096) == 9060352
-    assert bench.alg_bytes(8, 4096, 4096, 128, 32 * 4096) == 9175040
-    cb = bench.cpu_baseline(1, 512, 512, 128, budget_s=0.2)
-    assert cb["kind"] == "port" and cb["unit"] == "GB/s" and cb["value"] > 0 and cb["cores"] >= 1
-    assert "layers of the bench workload" in cb["sample"]
+    # SURVEY.md 8d figures
+    assert bench.alg_bytes(1, 4096, 4096, 128) == 9060352
+    assert bench.alg_bytes(8, 4096, 4096, 128) == 9175040
+    assert bench.alg_bytes(8, 8192, 8192, 128) == 36175872
+    assert bench.alg_bytes(1, 4096, 4096, 128, "int4") == 8929280
+    assert bench.alg_bytes(1, 4096, 4096, 128, "any4_global") == 8929312
+    assert bench.alg_bytes(1, 4096, 4096, 32, "mx4") == 8929280
+    cb = bench.cpu_baseline_torch(1, 512, 512, 128, budget_s=0.2)
+    assert cb["unit"] == "GB/s" and cb["value"] > 0 and cb["kind"] == "port" and cb["cores"] >= 1
+    assert "layers of the bench workload" in cb["sample"] and "physical cores" in cb["sample"]
+    co = bench.cpu_baseline_oracle(1, 512, 512, 128, budget_s=0.2)
+    assert co["value"] > 0 and co["cores"] >= 1

@@ -3,5 +3,5 @@
 set -e
 name=$1; shift
 cd "$(dirname "$0")/../.."
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -fvisibility=hidden -Wno-comment -Wno-int-to-pointer-cast -DTG_DEV_MIN "$@" any4_amd/csrc/tinygemm_hip.hip -o variants/$name.so
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -fvisibility=hidden -Wno-comment -Wno-int-to-pointer-cast -DTG_DEV_MIN=0 "$@" any4_amd/csrc/tinygemm_hip.hip -o variants/$name.so
 echo built variants/$name.so

@@ -1,6 +1,9 @@
-# Scratch pad for one-off GPU experiments (run as: gpurun -- 'bash tools/exp.sh').
 set -u
-mkdir -p gpurun_out
-python __graft_entry__.py smoke 2>&1 | tail -3
-timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -15
-timeout 300 python tools/quick_bench.py --configs "1,4096,4096,1" --L 256 --iters 5 2>&1 | grep -E "^m=|steady|eager"
+cp any4_amd/lib/libtinygemm_hip.so /tmp/orig.so
+for round in 1 2; do
+for v in mr4n0 mr4n2 mr1n0; do
+  cp variants/$v.so any4_amd/lib/libtinygemm_hip.so
+  echo "=== $v $(timeout 300 python tools/quick_bench.py --configs "1,4096,4096,1" --L 256 --iters 5 2>&1 | grep -E "steady|==eager")"
+done
+done
+cp /tmp/orig.so any4_amd/lib/libtinygemm_hip.so
