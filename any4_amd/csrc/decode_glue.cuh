@@ -141,6 +141,7 @@ __global__ void rope_kv_kernel(const uint16_t* __restrict__ qkv, const float* __
                                uint16_t* __restrict__ v_cache, int hl, int kvl, int d, int64_t max_seq) {
   const int b = blockIdx.x, head = blockIdx.y, j = threadIdx.x, d2 = d >> 1;
   const int64_t pos = *pos_p;
+  if (pos < 0 || pos >= max_seq) return;  // the position lives on the device (graph replays bypass the host check): never index the cache outside [0, max_seq)
   const uint16_t* src = qkv + ((int64_t)b * (hl + 2 * kvl) + head) * d;
   if (head >= hl + kvl) {  // v: plain copy into the cache
     uint16_t* dst = v_cache + (((int64_t)b * kvl + (head - hl - kvl)) * max_seq + pos) * d;
@@ -170,6 +171,7 @@ __global__ void __launch_bounds__(256) decode_attn_kernel(const uint16_t* __rest
   float* scratch = sm + 256;
   float* sc = sm + 260;
   const int b = blockIdx.x / hl, h = blockIdx.x % hl, kv = h / (hl / kvl), t = threadIdx.x;
+  if (*pos_p < 0 || *pos_p >= max_seq) return;  // see rope_kv_kernel
   const int S = (int)(*pos_p) + 1, d8 = d >> 3;
   if (t < d) qf[t] = DT::to_f32(q[((int64_t)b * hl + h) * d + t]);
   __syncthreads();
@@ -224,6 +226,7 @@ __global__ void __launch_bounds__(256) rope_attn_kernel(const uint16_t* __restri
   float* sc = sm + 772;
   const int b = blockIdx.x / hl, h = blockIdx.x % hl, kv = h / (hl / kvl), t = threadIdx.x;
   const int64_t pos = *pos_p;
+  if (pos < 0 || pos >= max_seq) return;  // the position lives on the device (graph replays bypass the host check): never index the cache outside [0, max_seq)
   const int S = (int)pos + 1, d8 = d >> 3, d2 = d >> 1;
   const uint16_t* row = qkv + (int64_t)b * (hl + 2 * kvl) * d;
   uint16_t* kdst = k_cache + (((int64_t)b * kvl + kv) * max_seq + pos) * d;
@@ -345,6 +348,7 @@ __global__ void __launch_bounds__(256) rope_attn_split_kernel(const uint16_t* __
   const int bh = blockIdx.x, c = blockIdx.y, NS = gridDim.y;
   const int b = bh / hl, h = bh % hl, kv = h / (hl / kvl), t = threadIdx.x;
   const int64_t pos = *pos_p;
+  if (pos < 0 || pos >= max_seq) return;  // the position lives on the device (graph replays bypass the host check): never index the cache outside [0, max_seq)
   const int S = (int)pos + 1, d8 = d >> 3, d2 = d >> 1;
   const int CS = (S + NS - 1) / NS;
   const int c0 = c * CS, c1 = min(S, c0 + CS);  // may be empty

@@ -328,6 +328,8 @@ class DecodeStack(torch.nn.Module):
     @torch.no_grad()
     def decode(self, tokens: torch.Tensor, position: int) -> torch.Tensor:
         """Feed `tokens` [bs] at sequence position `position`; graph replay if captured, else eager."""
+        if not 0 <= int(position) < self.cfg.max_seq:
+            raise ValueError(f"position {position} outside the KV cache [0, {self.cfg.max_seq})")
         self.tokens.copy_(tokens)
         self.pos.fill_(position)
         if self._graph is not None:

@@ -196,6 +196,10 @@ def kmeans_rows(x: torch.Tensor, n_clusters: int = 16, sample_weight: Optional[t
     lo = xs[:, :1]
     span = (xs[:, -1:] - lo).clamp_min(1e-12)
     best = None
+    # the reference forwards `init` to scikit-learn (None / "k-means++" / "random", quantize.py:413): those have no meaning
+    # for this batched Lloyd -> its default deterministic seedings
+    if init is None or (isinstance(init, str) and init in ("k-means++", "random")):
+        init = _SEEDINGS
     for kind in ((init,) if isinstance(init, str) else tuple(init)):
         a, c, sse = _lloyd(x, wts, xw, _init_centers(kind, x, xs, lo, span, n_clusters), span, max_iter, tol)
         if best is None:
@@ -211,6 +215,9 @@ def kmeans_rows(x: torch.Tensor, n_clusters: int = 16, sample_weight: Optional[t
 # --------------------------------------------------------------------------------------------------
 # any4 (quantize.py:523-637, 810-825)
 # --------------------------------------------------------------------------------------------------
+
+_SEEDINGS = ("uniform", "density", "quantile")
+
 
 @torch.no_grad()
 def anyq_quantize_tensor(W: torch.Tensor, n_bit: int = 4, q_group_size: int = 128, per_row: bool = True,
@@ -310,13 +317,25 @@ def intq_layer(module: torch.nn.Module, name: str = "", n_bit: int = 4, group_si
                **kwargs) -> torch.nn.Module:
     """nn.Linear -> Int4Linear (uniform int4 on tinygemm's grid) or, pseudo=True, reconstructed weights in place."""
     if pseudo is None:
-        pseudo = n_bit != 4
+        pseudo = n_bit not in (4, 8)
     w = module.weight
     if pseudo:
         module.weight.data = intq_reconstruct_tensor(w, n_bit=n_bit, q_group_size=group_size, **kwargs).to(device=w.device, dtype=w.dtype)
         return module
+    if n_bit == 8:  # quantize.py:337-360 builds Int8Linear from group_quantize_tensor(n_bit=8)
+        from .modules import Int8Linear
+        from .utils import group_quantize_tensor
+
+        codes, sz = group_quantize_tensor(w, n_bit=8, q_group_size=group_size)
+        q = Int8Linear(module.in_features, module.out_features, bias=module.bias is not None, device=w.device, dtype=w.dtype,
+                       group_size=group_size)
+        q.weight.data = codes.to(w.device)
+        q.scales_and_zeros.data = sz.to(w.device)
+        q.bias = module.bias
+        q.reshape_weight()
+        return q
     if n_bit != 4:
-        raise ValueError(f"No int quantized module built for n_bit={n_bit} (int8 is out of scope); use pseudo=True")
+        raise ValueError(f"No int quantized module built for n_bit={n_bit}; use pseudo=True")
     from .modules import Int4Linear
 
     codes, _, sz = intq_quantize_tensor(w, n_bit=n_bit, q_group_size=group_size, new_grouping="tinygemm")

@@ -86,6 +86,12 @@ def test_decode_matches_a_full_sequence_reference():
     assert torch.allclose(step, full, atol=1e-4), (step - full).abs().max()
     # replaying the same tokens on a fresh stack gives the same logits (no stale cache state)
     assert torch.equal(_run(cfg, 0, 1, toks), _run(cfg, 0, 1, toks))
+    # a position outside the KV cache is refused on the host (the fused kernels read it from device memory)
+    import pytest
+
+    for bad in (-1, cfg.max_seq, cfg.max_seq + 5):
+        with pytest.raises(ValueError, match="outside the KV cache"):
+            stack.decode(toks[0], bad)
 
 
 def _tp_worker(rank, world, port, results):

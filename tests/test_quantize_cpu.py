@@ -71,6 +71,7 @@ def test_kmeans_rows_properties():
     torch.manual_seed(0)
     x = torch.randn(6, 300)
     a, c = Q.kmeans_rows(x, 16)
+    a0, c0 = a, c
     assert a.shape == x.shape and c.shape == (6, 16) and bool((c[:, 1:] >= c[:, :-1]).all())
     # every point sits in its nearest cluster; every centre is the mean of its cluster (Lloyd fixed point)
     assert torch.equal(a.long(), (x[:, :, None] - c[:, None, :]).abs().argmin(-1))
@@ -89,6 +90,10 @@ def test_kmeans_rows_properties():
     assert abs(c1.item() - 0.1) < 1e-6
     with pytest.raises(ValueError):
         Q.kmeans_rows(x, 16, init="nope")
+    # the reference's defaults (init=None -> scikit-learn's "k-means++", quantize.py:413) select the built-in seedings
+    for init in (None, "k-means++", "random"):
+        a2, c2 = Q.kmeans_rows(x, 16, init=init)
+        assert torch.equal(a2, a0) and torch.equal(c2, c0)
 
 
 def test_intq_matches_tinygemm_grid():
