@@ -281,3 +281,42 @@ def test_fp16_conversions(oracle):
         exp = torch.tensor(v, dtype=torch.float32).half()
         assert h == int(exp.view(torch.int16).item()) & 0xFFFF, v
         assert L.tgo_f16_to_f32(h) == exp.float().item() or (exp.float().item() != exp.float().item())
+
+
+# ---------------------------------------------------------------- the group-scaled restatement (TG_NUM_FAST numerics)
+
+def test_group_scaled_restatement_is_pinned_to_the_reference_contraction(oracle):
+    """oracle.linear_group_scaled is a DERIVED formula (the reference's sum without its per-weight rounding to 16 bits): it must
+    stay within the analytic bound 2^-9 * sum|x w| (2^-12 for fp16) of oracle.linear on every quantisation type, and reproduce
+    the reference's captured CPU output of the any4 fixture as closely as the reference-faithful contraction does."""
+    rng = np.random.default_rng(5)
+    n, k, m = 48, 512, 3
+    for dtype, eps in ((oracle.BF16, 2.0 ** -9), (oracle.F16, 2.0 ** -12)):
+        to16 = oracle.bf16_bits if dtype == oracle.BF16 else (lambda a: a.astype(np.float16).view(np.uint16))
+        to32 = oracle.bf16_to_f32 if dtype == oracle.BF16 else (lambda b: b.view(np.float16).astype(np.float32))
+        x = to16(rng.standard_normal((m, k)).astype(np.float32))
+        codes = rng.integers(0, 16, (n, k), dtype=np.int32)
+        for g in (32, 128):
+            sz = to16((rng.random((k // g, n, 2)) * 0.02 + 0.005).astype(np.float32))
+            lut = to16(rng.standard_normal((n, 16)).astype(np.float32))
+            ex = rng.integers(120, 131, (n, k // g), dtype=np.uint8)
+            cases = [(oracle.Q_INT4, sz, None), (oracle.Q_ANY4_GLOBAL, sz, lut[0]), (oracle.Q_ANY4_ROWWISE, sz, lut)]
+            if dtype == oracle.BF16:
+                cases.append((oracle.Q_MX4, ex, None))
+            for q, qi, lt in cases:
+                _, y_ref = oracle.linear(x, codes, g, q, qi, lt, dtype)
+                _, y_gs = oracle.linear_group_scaled(x, codes, g, q, qi, lt, dtype)
+                w = to32(oracle.dequant(codes, g, q, qi, lt, dtype)).astype(np.float64)
+                S = np.abs(to32(x).astype(np.float64)) @ np.abs(w).T
+                bound = eps * S + 1e-6 * S + 1e-30
+                assert (np.abs(y_ref.astype(np.float64) - y_gs) <= bound).all(), (q, g, dtype)
+                if q == oracle.Q_MX4:  # exact weights: the two formulas agree to float32 rounding
+                    assert np.allclose(y_ref, y_gs, rtol=1e-6, atol=1e-30)
+    f = load_golden("any4_n1024_k1024_g128_seed1234.npz")
+    nib = f["codes_nib"]
+    codes = np.empty((int(f["n"]), int(f["k"])), np.int32)
+    codes[:, 0::2] = nib & 15
+    codes[:, 1::2] = nib >> 4
+    y16, _ = oracle.linear_group_scaled(f["x_bits"], codes, int(f["g"]), oracle.Q_ANY4_ROWWISE, f["sz_bits"], f["lut_m8_bits"])
+    err = np.abs(oracle.bf16_to_f32(y16) - oracle.bf16_to_f32(f["y_bits"])).max()
+    assert err <= 1e-2, err  # north_star tolerance against the reference's own CPU dequant-matmul
