@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libtinygemm_hip.so")
 TG_BF16, TG_F16 = 0, 1
 TG_Q_INT4, TG_Q_ANY4_GLOBAL, TG_Q_ANY4_ROWWISE, TG_Q_MX4, TG_Q_INT8 = 0, 1, 2, 3, 4
 TG_NUM_FAST, TG_NUM_REFERENCE = 0, 1
-TG_ABI_VERSION = 2
+TG_ABI_VERSION = 3
 TG_PLAN_SPLITK, TG_PLAN_STREAM, TG_PLAN_PAIR = 1, 2, 3
 
 _i32, _i64, _vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p
@@ -27,6 +27,7 @@ class W4Gemm(ctypes.Structure):
         ("batch", _i32),
         ("stride_x", _i64), ("stride_w", _i64), ("stride_qinfo", _i64), ("stride_lut", _i64), ("stride_y", _i64),
         ("numerics", _i32), ("reserved", _i32), ("bias", _vp), ("stride_bias", _i64),
+        ("workspace", _vp), ("workspace_bytes", _i64),
     ]
 
 
@@ -43,6 +44,7 @@ SYMBOLS = {
     "tg_dequant_int4": [_vp, _i64, _vp, ctypes.c_int, _vp],
     "tg_gemm_w4": [ctypes.POINTER(W4Gemm), ctypes.c_int, _vp],
     "tg_gemm_w4_plan": [ctypes.POINTER(W4Gemm), ctypes.c_int],
+    "tg_gemm_w4_workspace_bytes": [ctypes.POINTER(W4Gemm)],
     "tg_gemm_f16": [_vp, _vp, _vp, _i64, _i64, _i64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp],
     "tg_convert_to_Bint8": [_vp, _i64, _i64, ctypes.c_int, _vp, ctypes.c_int, _vp],
     "tg_convert_to_Aint8": [_vp, _i64, _i64, ctypes.c_int, _vp, ctypes.c_int, _vp],
@@ -82,7 +84,7 @@ def load() -> ctypes.CDLL:
             raise ImportError(f"{LIB_PATH} does not export {name}; rebuild with `python -m any4_amd.build`") from e
         fn.argtypes = argtypes
         fn.restype = (ctypes.c_char_p if name == "tg_error_string" else
-                      ctypes.c_int64 if name == "dg_rope_attn_split_scratch_bytes" else ctypes.c_int)
+                      ctypes.c_int64 if name in ("dg_rope_attn_split_scratch_bytes", "tg_gemm_w4_workspace_bytes") else ctypes.c_int)
     if lib.tg_abi_version() != TG_ABI_VERSION:
         raise ImportError(f"{LIB_PATH}: ABI version {lib.tg_abi_version()} != {TG_ABI_VERSION}; rebuild")
     _lib = lib

@@ -649,7 +649,7 @@ enum { TG_PAIR_NA = -100 };
 #ifndef TG_PAIR_WGS
 #define TG_PAIR_WGS 512  // persistent workgroups: two per CU
 #endif
-template <typename DT, int I, int GPS, int MR, bool QMX, int NSG>
+template <typename DT, int I, int GPS, int MR, bool QMX, int NSG, bool XG = false>
 int launch_pair_k(PairParams& pp, unsigned lds, hipStream_t st) {
 #ifdef TG_DEV_MIN  // developer builds: only the headline instantiation (fast A/B builds)
   if constexpr (!(std::is_same<DT, BF16>::value && I == 4 && GPS == 1 && MR == TG_PAIR_MR1 && !QMX && NSG == TG_DEV_MIN)) return TG_PAIR_NA;
@@ -660,7 +660,7 @@ int launch_pair_k(PairParams& pp, unsigned lds, hipStream_t st) {
   // several groups per super-tile (group 32 / 64 with wide super-tiles): more per-slot state, one slot in flight fits the
   // 128-VGPR budget without spills (ring depth measured irrelevant between 2 and 4)
   constexpr int RING = GPS > 1 ? 1 : TG_PAIR_R;
-  constexpr auto kern = w4_gemm_pair_kernel<DT, I, GPS, MR, QMX, RING, NSG, TG_PAIR_ABL>;
+  constexpr auto kern = w4_gemm_pair_kernel<DT, I, GPS, MR, QMX, RING, NSG, TG_PAIR_ABL, XG>;
   if (pp.dry) return TG_PLAN_PAIR;
   const int prc = prepare_lds_kernel<kern>();
   if (prc != 0) return prc;
@@ -673,8 +673,23 @@ int launch_pair_k(PairParams& pp, unsigned lds, hipStream_t st) {
 #endif
 }
 
+// The activation block of one pass does not fit next to the table (m = 8 at k = 4096, m = 1 at k >= 8192): the XG variant
+// takes the activations pre-arranged from a caller-provided workspace (w4_xprep_kernel, one small launch in front).
+// Workspace = [batch][m k 2 bytes] arranged activations, then [batch][passes][groups][xs_rows] f32 sums.
+template <typename DT>
+int launch_xprep(const PairParams& pp, int I, int ma, int64_t batch, hipStream_t st) {
+  XPrepParams xq;
+  xq.x = pp.x; xq.xp = const_cast<char*>(pp.xp); xq.xsum = const_cast<char*>(pp.xsum);
+  xq.m = pp.m; xq.k = pp.k; xq.ma = ma; xq.cps = I / 2; xq.gshift = pp.gshift; xq.gch_mask = pp.gch_mask;
+  xq.ngroups = pp.ngroups; xq.xs_rows = pp.xs_rows;
+  xq.stride_x = pp.stride_x; xq.stride_xp = pp.stride_xp; xq.stride_xsum = pp.stride_xsum;
+  const int64_t chunks = (int64_t)pp.m * (pp.k / 32);
+  hipLaunchKernelGGL(w4_xprep_kernel<DT>, dim3((unsigned)cdiv(chunks, 256), (unsigned)batch), dim3(256), 0, st, xq);
+  return launch_status();
+}
+
 template <typename DT, int I, bool QMX>
-int launch_pair(const GemmParams& p, int64_t batch, hipStream_t st) {
+int launch_pair(GemmParams& p, int64_t batch, hipStream_t st) {
   constexpr int RW = 64;
   const int g = 1 << p.gshift;
   const int gps = g >= 16 * I ? 1 : (16 * I) / g;
@@ -704,7 +719,33 @@ int launch_pair(const GemmParams& p, int64_t batch, hipStream_t st) {
     lds = (unsigned)pp.lds_red;
     pp.lds_red = 0;
   }
-  if (lds > 80u * 1024u) return TG_PAIR_NA;  // two workgroups per CU
+  bool xg = false;
+#ifdef TG_PAIR_FORCE_XG  // developer A/B: the workspace variant also where the staged plan fits
+  if (mregs == 4 && p.m <= ma) lds = 1u << 30;
+#endif
+  if (lds > 80u * 1024u) {  // two workgroups per CU
+    // XG: every wave keeps one super-tile of the pass's activations (<= 8 rows) in a private buffer
+    if (mregs != 4 || p.m > ma) return TG_PAIR_NA;
+    pp.xw_pitch = 32 * I + 16;
+    pp.xw_bytes = (I == 2 ? 16 : 8) * pp.xw_pitch;  // a row for every 2 I lanes of the wave's (unmasked) store
+    pp.lds_xs = (pp.lds_x + 8 * pp.xw_bytes + 32 * I + 15) & ~15;  // 8 buffers + the zero piece
+    pp.lds_red = (pp.lds_xs + p.ngroups * pp.xs_rows * 4 + 15) & ~15;
+    lds = (unsigned)pp.lds_red + (unsigned)(8 * 2 * pp.rused * pp.red_lanes * 4);
+    if (lds > 80u * 1024u) pp.red_alias = 1;
+    if (pp.red_alias) {
+      lds = (unsigned)pp.lds_red;
+      pp.lds_red = 0;
+    }
+    if (lds > 80u * 1024u) return TG_PAIR_NA;
+    pp.stride_xp = (int64_t)p.m * p.k * 2;
+    pp.stride_xsum = ((int64_t)p.ngroups * pp.xs_rows * 4 + 15) & ~(int64_t)15;
+    const int64_t need = batch * (pp.stride_xp + pp.stride_xsum);
+    p.ws_need = need;
+    if (!p.ws_query && (p.ws == nullptr || p.ws_bytes < need)) return TG_PAIR_NA;
+    pp.xp = p.ws;
+    pp.xsum = p.ws + batch * pp.stride_xp;
+    xg = true;
+  }
   pp.rblocks = (p.wrows + RW - 1) / RW;
   pp.cblocks = (p.m + ma - 1) / ma;
   const int64_t items = (int64_t)pp.rblocks * pp.cblocks * batch;
@@ -712,15 +753,21 @@ int launch_pair(const GemmParams& p, int64_t batch, hipStream_t st) {
   // The kernel's unit of work is a 64-row block over the whole k (8 waves): a launch needs about one item per workgroup slot
   // (2 per CU) to fill the chip.  Smaller launches (one 4096-row layer = 64 items) are latency-bound and stay on the
   // split-K kernels, which spread one 16-row tile over up to 16 waves.
-  if (items < 384) return TG_PAIR_NA;
+  if (items < 384) { p.ws_need = 0; return TG_PAIR_NA; }
   pp.items = (int32_t)items;
   pp.stride_x = p.stride_x; pp.stride_w = p.stride_w; pp.stride_qinfo = p.stride_qinfo;
   pp.stride_lut = p.stride_lut; pp.stride_y = p.stride_y;
   pp.bias = p.bias; pp.stride_bias = p.stride_bias; pp.dry = p.dry;
-#define TG_PAIR_M(GPS_, NSG_)                                                          \
-  (p.m == 1 && TG_PAIR_MR1 == 1 ? launch_pair_k<DT, I, GPS_, 1, QMX, NSG_>(pp, lds, st) \
-            : mregs == 4 ? launch_pair_k<DT, I, GPS_, 4, QMX, NSG_>(pp, lds, st)       \
-                         : launch_pair_k<DT, I, GPS_, 16, QMX, NSG_>(pp, lds, st))
+  if (xg && !p.dry) {
+    const int rc = launch_xprep<DT>(pp, I, ma, batch, st);
+    if (rc != 0) return rc;
+  }
+#define TG_PAIR_M(GPS_, NSG_)                                                                      \
+  (xg ? (p.m == 1 && TG_PAIR_MR1 == 1 ? launch_pair_k<DT, I, GPS_, 1, QMX, NSG_, true>(pp, lds, st)  \
+                                      : launch_pair_k<DT, I, GPS_, 4, QMX, NSG_, true>(pp, lds, st)) \
+   : p.m == 1 && TG_PAIR_MR1 == 1 ? launch_pair_k<DT, I, GPS_, 1, QMX, NSG_>(pp, lds, st)            \
+   : mregs == 4                   ? launch_pair_k<DT, I, GPS_, 4, QMX, NSG_>(pp, lds, st)            \
+                                  : launch_pair_k<DT, I, GPS_, 16, QMX, NSG_>(pp, lds, st))
   if (gps == 1) {
     // group boundaries at fixed places of the unrolled round when a group is one super-tile or one whole round
     // (not for the m = 1 specialisation: with fixed boundaries the compiler scatters its accumulator chain over several
@@ -910,7 +957,8 @@ int tg_dequant_int4(const int32_t* in, int64_t count, void* out_bf16, int device
   return launch_status();
 }
 
-static int gemm_w4_impl(const tg_w4_gemm* a, int device, tg_stream_t stream, int dry) {
+// dry: 0 launch, 1 report the kernel family (tg_gemm_w4_plan), 2 report the workspace the fastest kernel wants
+static int gemm_w4_impl(const tg_w4_gemm* a, int device, tg_stream_t stream, int dry, int64_t* ws_need = nullptr) {
   if (!a || !a->x || !a->w || !a->qinfo || !a->y) return TG_E_NULL;
   if (a->qtype < TG_Q_INT4 || a->qtype > TG_Q_MX4) return TG_E_QTYPE;
   if ((a->qtype == TG_Q_ANY4_GLOBAL || a->qtype == TG_Q_ANY4_ROWWISE) && !a->lut) return TG_E_NULL;
@@ -930,6 +978,7 @@ static int gemm_w4_impl(const tg_w4_gemm* a, int device, tg_stream_t stream, int
   if (a->lut && !aligned16(a->lut)) return TG_E_ALIGN;          // LUT rows are read as two 16-byte vectors
   if (a->bias && (reinterpret_cast<uintptr_t>(a->bias) & 7u)) return TG_E_ALIGN;
   if (!(a->numerics == TG_NUM_FAST || a->numerics == TG_NUM_REFERENCE) || a->reserved != 0) return TG_E_SHAPE;
+  if (a->workspace && (!aligned16(a->workspace) || a->workspace_bytes < 0)) return TG_E_ALIGN;
   const int batch = a->batch > 1 ? a->batch : 1;
   if (batch > 1 && ((a->stride_x | a->stride_w | a->stride_lut) & 15)) return TG_E_ALIGN;
   if (batch > 1 && a->bias && (a->stride_bias & 7)) return TG_E_ALIGN;
@@ -953,8 +1002,12 @@ static int gemm_w4_impl(const tg_w4_gemm* a, int device, tg_stream_t stream, int
   p.ngroups = (int32_t)(a->k / g);
   p.qtype = a->qtype;
   p.dbg = 0;
-  p.dry = dry;
+  p.dry = dry != 0;
   p.numerics = a->numerics;
+  p.ws = (char*)a->workspace;
+  p.ws_bytes = a->workspace ? a->workspace_bytes : 0;
+  p.ws_query = dry == 2;
+  p.ws_need = 0;
 #ifdef TG_DEV
   {
     static const int env_dbg = getenv("TG_DBG") ? atoi(getenv("TG_DBG")) : 0;
@@ -979,15 +1032,22 @@ static int gemm_w4_impl(const tg_w4_gemm* a, int device, tg_stream_t stream, int
   // packed words per lane-quad in the layout decide the in-register transpose
   const int canon = on_right ? (I == 2 ? CANON_NONE : I == 4 ? CANON_PAIR : CANON_QUAD)
                              : (I == 1 ? CANON_NONE : I == 2 ? CANON_PAIR : CANON_QUAD);
-  if (a->dtype == TG_BF16) {
-    return on_right ? launch_w4_c<BF16, false>(p, canon, coltiles, batch, st) : launch_w4_c<BF16, true>(p, canon, coltiles, batch, st);
-  }
-  return on_right ? launch_w4_c<F16, false>(p, canon, coltiles, batch, st) : launch_w4_c<F16, true>(p, canon, coltiles, batch, st);
+  int rc;
+  if (a->dtype == TG_BF16) rc = on_right ? launch_w4_c<BF16, false>(p, canon, coltiles, batch, st) : launch_w4_c<BF16, true>(p, canon, coltiles, batch, st);
+  else rc = on_right ? launch_w4_c<F16, false>(p, canon, coltiles, batch, st) : launch_w4_c<F16, true>(p, canon, coltiles, batch, st);
+  if (ws_need) *ws_need = rc == TG_PLAN_PAIR ? p.ws_need : 0;
+  return rc;
 }
 
 int tg_gemm_w4(const tg_w4_gemm* a, int device, tg_stream_t stream) { return gemm_w4_impl(a, device, stream, 0); }
 
 int tg_gemm_w4_plan(const tg_w4_gemm* a, int device) { return gemm_w4_impl(a, device, nullptr, 1); }
+
+int64_t tg_gemm_w4_workspace_bytes(const tg_w4_gemm* a) {
+  int64_t need = 0;
+  const int rc = gemm_w4_impl(a, -1, nullptr, 2, &need);
+  return rc < 0 ? rc : need;
+}
 
 int tg_convert_to_Bint8(const int32_t* in, int64_t n, int64_t k, int I, int32_t* out, int device, tg_stream_t stream) {
   if (!in || !out) return TG_E_NULL;

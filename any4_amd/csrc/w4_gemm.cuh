@@ -41,6 +41,10 @@ struct GemmParams {
   int64_t stride_x, stride_w, stride_qinfo, stride_lut, stride_y;
   const char* bias;   // optional [wrows] 16-bit, added after the first rounding (see store_rows4)
   int64_t stride_bias;
+  // host-side only: the caller's workspace (pair kernel, XG variant) and the planner's answer to "how much would help"
+  char* ws;
+  int64_t ws_bytes, ws_need;
+  int32_t ws_query;
 };
 
 enum { CANON_NONE = 0, CANON_PAIR = 1, CANON_QUAD = 2 };

@@ -40,6 +40,9 @@
 //                runs across item boundaries, and the LUT rows of the next item are requested at the start of the current
 //                one, so the weight stream never drains while a table is rebuilt.  Two barriers per item.
 #pragma once
+#ifndef TG_PAIR_PIN
+#define TG_PAIR_PIN 0  // 1: also pin the accumulator tuples in finalize() when a group's first MFMA takes a zero C operand
+#endif
 
 struct PairParams {
   const char* x;
@@ -71,6 +74,12 @@ struct PairParams {
   const char* bias;   // optional [wrows] 16-bit, added after the first rounding
   int64_t stride_bias;
   int32_t dry;        // host-side only: report the kernel family instead of launching (tg_gemm_w4_plan)
+  // XG variant (activation block too large to stage whole): activations pre-arranged by w4_xprep_kernel in the caller's workspace
+  const char* xp;     // [problem][pass][k super-tile][row of the pass][32 I bytes in byte order]
+  const char* xsum;   // f32 [problem][pass][group][xs_rows]
+  int64_t stride_xp, stride_xsum;  // bytes per problem
+  int32_t xw_pitch;   // bytes per activation row in a wave's LDS buffer (32 I + 16: rotates rows over the banks)
+  int32_t xw_bytes;   // bytes of one wave's buffer
 };
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -97,9 +106,12 @@ __device__ __forceinline__ float dot2_ones(uint32_t pair, float acc) {
 // MR    = 1: m = 1 (one accumulator register per tile is finalised and exchanged); else the accumulator registers that can
 //         hold real activation rows: 4 -> m <= 8, 8 -> m <= 16, 16 -> m <= 32
 // R     = super-tiles in flight per wave (register ring)
+// XG    = activations come pre-arranged from the workspace (w4_xprep_kernel) and each wave stages its own k-slice of them, one
+//         super-tile per ring slot, through a private LDS buffer (m <= 8 rows x 32 I bytes <= 1 KiB); else the workgroup stages
+//         the whole activation block itself
 // NSG   = super-tiles per quantisation group when that is 1 or R (group boundaries then sit at fixed places of the unrolled
 //         round: no per-step tests, scale | zero words are only requested for the first super-tile of a group); 0 = any, tested at run time
-template <typename DT, int I, int GPS, int MR, bool QMX, int R, int NSG = 0, int ABL = 0>
+template <typename DT, int I, int GPS, int MR, bool QMX, int R, int NSG = 0, int ABL = 0, bool XG = false>
 __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p) {
   constexpr int WAVES = 8;
   constexpr int TILES = 2;              // 32-row MFMA tiles per workgroup
@@ -109,6 +121,8 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
   constexpr int MREGS = MR == 1 ? 4 : MR;  // accumulator registers of a row set
   constexpr int RF = MR;                   // registers that are finalised per group and exchanged at the end
   constexpr int MA = 2 * MREGS;         // activation rows a pass can hold
+  constexpr int NXW = XG ? (MA * 2 * I + 63) / 64 : 1;  // XG: 16-byte pieces per lane of one super-tile's activation block
+  static_assert(!XG || MR <= 4, "XG: one pass is at most 8 activation rows");
 
   // The pair table sits at LDS address 0 (a lookup address is just byte << 8 | column << 2): the kernel has no static LDS,
   // which the host verifies once per kernel (hipFuncGetAttributes().sharedSizeBytes == 0) before the first launch.
@@ -124,9 +138,14 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
   const int h = lane >> 5;
   const int tcol = tid & 63;  // table column = weight row of the item this thread builds
 
-  // ---- this workgroup's contiguous range of work items; item -> (problem b, activation pass ct, row block rb) ----
-  const int it_begin = (int)(((int64_t)blockIdx.x * p.items) / gridDim.x);
-  const int it_end = (int)(((int64_t)(blockIdx.x + 1) * p.items) / gridDim.x);
+  // ---- this workgroup's work items; item -> (problem b, activation pass ct, row block rb) ----
+  // staged activations: a contiguous range (the block in LDS is re-staged only when the problem changes).
+  // XG: items dealt round-robin, so that the workgroups running at one time read the activations of a few problems only
+  // (with contiguous ranges every workgroup streams a different problem's block again and again: at m = 8, k = 4096 that is
+  // 64 KiB x 64 workgroups per XCD = the whole L2, behind the weight stream -- measured as +50 % time)
+  const int it_stride = XG ? (int)gridDim.x : 1;
+  const int it_begin = XG ? (int)blockIdx.x : (int)(((int64_t)blockIdx.x * p.items) / gridDim.x);
+  const int it_end = XG ? p.items : (int)(((int64_t)(blockIdx.x + 1) * p.items) / gridDim.x);
   const int per_problem = p.rblocks * p.cblocks;
 
   // ---- this wave's k-slice: super-tiles [s_begin, s_begin + nl) ----
@@ -174,6 +193,7 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
   struct Slot {
     uint32_t w[TILES][I];
     uint32_t q[TILES][GPS];
+    u32x4 xw[NXW];  // XG: this lane's 16-byte pieces of the super-tile's activation block
   };
   Slot ring[R];
   // per-lane addressing of an item: byte offset of this lane's words in super-tile 0 of its rows (the host checks the matrix
@@ -183,6 +203,8 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
     uint32_t qrow[TILES];
     const char* wb;
     const char* qb;
+    const char* xpb;  // XG: the pass's pre-arranged activations
+    uint32_t xblk;    // XG: bytes of one super-tile's block (rows of the pass x 32 I)
   };
   auto rows_of = [&](int it) -> Rows {
     const Item e = decode(it);
@@ -196,6 +218,14 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
     }
     r.wb = p.w + (int64_t)e.b * p.stride_w;
     r.qb = p.qinfo + (int64_t)e.b * p.stride_qinfo;
+    if constexpr (XG) {
+      const int rows = min(p.m - e.ct * MA, MA);
+      r.xpb = p.xp + (int64_t)e.b * p.stride_xp + (int64_t)e.ct * MA * p.k * 2;
+      r.xblk = (uint32_t)(rows * 32 * I);
+    } else {
+      r.xpb = nullptr;
+      r.xblk = 0;
+    }
     return r;
   };
   // Requests super-tile s of the rows `rw`.  `valid` is wave-uniform.  A request past the last item is still ISSUED (so that
@@ -204,6 +234,15 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
   // first bytes of the operand: one cached request, never consumed.
   auto issue = [&](const Rows& rw, int s, Slot& sl, bool valid, bool needq) {
     const uint32_t vm = valid ? 0xffffffffu : 0u;
+    if constexpr (XG) {
+      // lanes beyond the block re-read its first piece (never stored): the load stays unconditional
+#pragma unroll
+      for (int i = 0; i < NXW; ++i) {
+        const uint32_t pc = (uint32_t)(lane + 64 * i) * 16u;
+        if constexpr (ABL == 9) sl.xw[i] = u32x4{pc, (uint32_t)s, 0x3f803f80u, 0x3f803f80u};  // ablation: no activation loads
+        else sl.xw[i] = *reinterpret_cast<const u32x4*>(rw.xpb + (((uint32_t)s * rw.xblk + (pc < rw.xblk ? pc : 0u)) & vm));
+      }
+    }
 #pragma unroll
     for (int t = 0; t < TILES; ++t) {
       const char* src = rw.wb + ((rw.wbase[t] + (uint32_t)s * (uint32_t)(64 * I)) & vm);
@@ -290,6 +329,14 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
     if (tid < CPS * 4) *(lds_u32x4ptr)(lds_x + (uint32_t)(mrows * p.x_pitch + tid * 16)) = u32x4{0, 0, 0, 0};
   };
 
+  // XG: the pass's per-group sums (computed by w4_xprep_kernel) -> LDS, rows >= mrows zero, and the zero piece
+  auto xs_stage = [&](int b, int ct, int mrows) {
+    const float* src = reinterpret_cast<const float*>(p.xsum + (int64_t)b * p.stride_xsum) + (int64_t)ct * p.ngroups * p.xs_rows;
+    for (int idx = tid; idx < p.ngroups * p.xs_rows; idx += 512)
+      *(lds_fptr)(lds_xs + (uint32_t)(idx * 4)) = idx % p.xs_rows < mrows ? src[idx] : 0.f;
+    if (tid < CPS * 4) *(lds_u32x4ptr)(lds_x + (uint32_t)(WAVES * p.xw_bytes + tid * 16)) = u32x4{0, 0, 0, 0};
+  };
+
   // ---- requests before the first item, in the order the prologue consumes them (vector memory returns in order): its LUT
   // rows, the first batch of its activation chunks, then its first R super-tiles (one by one: the scheduler must not reorder
   // them, the ring is consumed in slot order) ----
@@ -299,7 +346,7 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
   const Item first = decode(it_begin);
   int staged_b = first.b, staged_ct = first.ct;  // which activation block the LDS holds
   uint32_t xd0[16];
-  {
+  if constexpr (!XG) {
     const int mrows0 = min(p.m - first.ct * MA, MA);
 #pragma unroll
     for (int j = 0; j < 16; ++j) xd0[j] = 0u;
@@ -312,19 +359,20 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
     issue(rcur, s_begin + j, ring[j], j < nl, NSG == 0 || j % NSG == 0);
   }
   __builtin_amdgcn_sched_barrier(0);
-  x_stage(first.b, first.ct * MA, min(p.m - first.ct * MA, MA), true, xd0);
+  if constexpr (XG) xs_stage(first.b, first.ct, min(p.m - first.ct * MA, MA));
+  else x_stage(first.b, first.ct * MA, min(p.m - first.ct * MA, MA), true, xd0);
 
   uint32_t colreg[TILES];
 #pragma unroll
   for (int t = 0; t < TILES; ++t) colreg[t] = (uint32_t)((t * 32 + c) * 4);
 
-  for (int it = it_begin; it < it_end; ++it) {
+  for (int it = it_begin; it < it_end; it += it_stride) {
     const Item cur = decode(it);
     const int row0 = cur.rb * RW;
     const int a0 = cur.ct * MA;
     const int mrows = min(p.m - a0, MA);
-    const bool has_next = it + 1 < it_end;
-    const Rows rnext = rows_of(has_next ? it + 1 : it);
+    const bool has_next = it + it_stride < it_end;
+    const Rows rnext = rows_of(has_next ? it + it_stride : it);
 
 #ifdef TG_PAIR_NOLP  // experiment: no LUT prefetch across the main loop (8 VGPRs less, LUT latency exposed)
     if (lut_loaded && it != it_begin) lut_request(it);
@@ -346,22 +394,30 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
     }
     // the next item's LUT rows travel while this item is computed (the last item re-reads its own)
 #ifndef TG_PAIR_NOLP
-    if (lut_loaded) lut_request(has_next ? it + 1 : it);
+    if (lut_loaded) lut_request(has_next ? it + it_stride : it);
 #endif
 
     // ---- activations: only when the activation block changes (the first item's block was staged above) ----
     if (cur.b != staged_b || cur.ct != staged_ct) {
       staged_b = cur.b;
       staged_ct = cur.ct;
-      uint32_t xd[16];
-      x_stage(cur.b, a0, mrows, false, xd);
+      if constexpr (XG) {
+        if (ABL != 11) xs_stage(cur.b, cur.ct, mrows);
+      } else {
+        uint32_t xd[16];
+        x_stage(cur.b, a0, mrows, false, xd);
+      }
     }
     __syncthreads();  // table and activations visible (and every thread is done with the previous item's partial sums)
 
     // ---- main loop of the item ----
     const bool a_on = c < mrows;  // this lane's A-operand row is a real activation row; the others read the zero piece
-    const uint32_t xrow = a_on ? lds_x + (uint32_t)(c * p.x_pitch + 2 * h * 16) : lds_x + (uint32_t)(mrows * p.x_pitch);
-    const uint32_t xmask = a_on ? 0xffffffffu : 0u;  // lanes on the zero piece never move
+    const uint32_t xzero = XG ? lds_x + (uint32_t)(WAVES * p.xw_bytes) : lds_x + (uint32_t)(mrows * p.x_pitch);
+    const uint32_t xwbuf = lds_x + (uint32_t)(wave * p.xw_bytes);  // XG: this wave's activation buffer (one super-tile)
+    const uint32_t xrow = !a_on ? xzero : XG ? xwbuf + (uint32_t)(c * p.xw_pitch + 2 * h * 16) : lds_x + (uint32_t)(c * p.x_pitch + 2 * h * 16);
+    const uint32_t xmask = a_on && !XG ? 0xffffffffu : 0u;  // lanes on the zero piece (and XG lanes: one buffer) never move
+    // XG: where this lane's 16 bytes of a super-tile's block go (piece = lane; 2 I pieces per activation row)
+    const uint32_t xw_dst = xwbuf + (uint32_t)((lane / (2 * I)) * p.xw_pitch + (lane % (2 * I)) * 16);
 
     f32x16 acc[TILES];
     float yacc[TILES][RF];
@@ -414,8 +470,9 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
           if constexpr (!QMX) yacc[t][r] = __builtin_fmaf(gz[t], xsv[r], yacc[t][r]);  // mx4 has no zero point
         }
         // keep the accumulator one opaque 16-register value: when only element 0 is read (m = 1) the compiler's
-        // sub-register liveness otherwise scatters the MFMA chain over several overlapping tuples and spills
-        asm volatile("" : "+v"(acc[t]));
+        // sub-register liveness otherwise scatters the MFMA chain over several overlapping tuples and spills.  (Not with
+        // zero-C group starts: there the pin made the compiler copy the finished tuple, 16 v_mov_b64 per group.)
+        if constexpr (DIFF || TG_PAIR_PIN) asm volatile("" : "+v"(acc[t]));
         if constexpr (RF == 1) asm volatile("" ::"v"(acc[t][1]), "v"(acc[t][2]), "v"(acc[t][3]));  // same purpose: as live as with m > 1
       }
     };
@@ -424,6 +481,15 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
     // one super-tile: 2 CPS MFMA steps, step = (chunk jc, quad pair qq) for both tiles: 8 table lookups + one X piece
     auto consume = [&](int s, const Slot& sl, int j_slot) {
       const uint32_t xst = xrow + ((uint32_t)(s * CPS * 64) & xmask);  // this lane's X pieces of the super-tile
+      if constexpr (XG) {
+        // the wave's own DS operations execute in order: the reads of the previous super-tile are behind us, the reads below
+        // follow this store; no barrier
+        // every lane stores (the buffer has a row for each: rows past the pass's are never read): a store under a lane mask
+        // is control flow, and around it the compiler copied the accumulator tuples
+#pragma unroll
+        for (int i = 0; i < NXW; ++i)
+          if constexpr (ABL != 10) *(lds_u32x4ptr)(xw_dst + (uint32_t)(i * (64 / (2 * I)) * p.xw_pitch)) = sl.xw[i];
+      }
       if constexpr (ABL == 6) {  // ablation: stream only
 #pragma unroll
         for (int t = 0; t < TILES; ++t)
@@ -474,7 +540,7 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
           if constexpr (!QMX) {
             // lanes whose accumulator rows are all padding (lane half 1 when m <= 4) read the zero piece behind the staged rows
             const uint32_t xsa = 4 * h < p.xs_rows ? lds_xs + (uint32_t)((((chunk * 32) >> p.gshift) * p.xs_rows + 4 * h) * 4)
-                                                   : lds_x + (uint32_t)(mrows * p.x_pitch);
+                                                   : xzero;
             if constexpr (RF == 1) {
               xsv[0] = *(const __attribute__((address_space(3))) float*)(xsa);
             } else {
@@ -555,4 +621,58 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
     if (p.red_alias) __syncthreads();  // ... and the next table must not overwrite partial sums that are still being read
     rcur = rnext;
   }
+}
+
+// ---- XG pre-pass: activations -> workspace in the order the pair kernel's waves consume them, plus the per-group sums ----
+// xp   [problem][pass][k super-tile][row of the pass][32 I bytes]: the 64 bytes of a 32-k chunk in "byte order" (see above)
+// xsum f32 [problem][pass][group][xs_rows]
+// thread = one (activation row, 32-k chunk); the sums are formed exactly as the staging path of the kernel forms them
+// (16 two-element dot products in k order, then a butterfly over the chunks of the group).
+struct XPrepParams {
+  const char* x;
+  char* xp;
+  char* xsum;
+  int32_t m, k, ma, cps, gshift, gch_mask, ngroups, xs_rows;
+  int64_t stride_x, stride_xp, stride_xsum;
+};
+
+template <typename DT>
+__global__ void __launch_bounds__(256) w4_xprep_kernel(const XPrepParams p) {
+  const int nch = p.k >> 5;
+  const int xi = blockIdx.x * 256 + threadIdx.x;
+  const bool on = xi < p.m * nch;
+  const int a = on ? xi / nch : 0, ch = on ? xi - a * nch : 0;
+  const int b = blockIdx.y;
+  uint32_t d[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) d[j] = 0u;
+  if (on) {
+    const u32x4* src = reinterpret_cast<const u32x4*>(p.x + (int64_t)b * p.stride_x + ((int64_t)a * p.k + ch * 32) * 2);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const u32x4 v = src[j];
+      d[4 * j] = v[0]; d[4 * j + 1] = v[1]; d[4 * j + 2] = v[2]; d[4 * j + 3] = v[3];
+    }
+  }
+  const int ct = a / p.ma, ar = a - ct * p.ma;
+  const int rows = min(p.m - ct * p.ma, p.ma);
+  if (on) {
+    const int s = ch / p.cps, jc = ch - s * p.cps;
+    char* dst = p.xp + (int64_t)b * p.stride_xp + (int64_t)ct * p.ma * p.k * 2 + ((int64_t)(s * rows + ar) * p.cps + jc) * 64;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      u32x4 o;
+      o[0] = __builtin_amdgcn_perm(d[q + 4], d[q], 0x05040100u);
+      o[1] = __builtin_amdgcn_perm(d[q + 12], d[q + 8], 0x05040100u);
+      o[2] = __builtin_amdgcn_perm(d[q + 4], d[q], 0x07060302u);
+      o[3] = __builtin_amdgcn_perm(d[q + 12], d[q + 8], 0x07060302u);
+      reinterpret_cast<u32x4*>(dst)[q] = o;
+    }
+  }
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) sum = dot2_ones<DT>(d[j], sum);
+  for (int o = 1; o <= p.gch_mask; o <<= 1) sum += __shfl_xor(sum, o);
+  if (on && (ch & p.gch_mask) == 0)
+    reinterpret_cast<float*>(p.xsum + (int64_t)b * p.stride_xsum)[((int64_t)ct * p.ngroups + (ch >> (p.gshift - 5))) * p.xs_rows + ar] = sum;
 }

@@ -94,15 +94,21 @@ _PLANS = {_lib.TG_PLAN_SPLITK: "splitk", _lib.TG_PLAN_STREAM: "stream", _lib.TG_
 
 
 def gemm_w4_plan(m: int, wrows: int, k: int, group: int, qtype: int, weight_on_right: bool = True, inner_k_tiles: int = 4,
-                 dtype=torch.bfloat16, batch: int = 1, numerics: str | None = None) -> str:
+                 dtype=torch.bfloat16, batch: int = 1, numerics: str | None = None, workspace: bool = True) -> str:
     """Which kernel family tg_gemm_w4 launches for this problem (tg_gemm_w4_plan; nothing is launched, no GPU needed):
-    'pair' = pair-table kernel, group-scaled numerics; 'stream' / 'splitk' = reference-numerics kernels."""
+    'pair' = pair-table kernel, group-scaled numerics; 'stream' / 'splitk' = reference-numerics kernels.
+    `workspace`: the caller provides the scratch tg_gemm_w4_workspace_bytes asks for (the ops of this module do)."""
     buf = ctypes.create_string_buffer(256)
     p = (ctypes.addressof(buf) + 63) & ~63  # a non-NULL, aligned dummy: the planner never dereferences data pointers
     args = W4Gemm(x=p, w=p, qinfo=p, lut=p, y=p, m=m, wrows=wrows, k=k, group=group, qtype=qtype,
                   dtype=TG_BF16 if dtype == torch.bfloat16 else TG_F16, w_on_right=1 if weight_on_right else 0,
                   inner_k_tiles=inner_k_tiles, batch=batch, stride_x=16, stride_w=16, stride_qinfo=16, stride_lut=16, stride_y=16,
                   numerics=_NUMERICS[numerics or get_numerics()])
+    if workspace:
+        need = _L.tg_gemm_w4_workspace_bytes(ctypes.byref(args))
+        _lib.check(need if need < 0 else 0, "tg_gemm_w4_workspace_bytes")
+        if need > 0:
+            args.workspace, args.workspace_bytes = p, need
     rc = _L.tg_gemm_w4_plan(ctypes.byref(args), 0)
     _lib.check(rc if rc < 0 else 0, "tg_gemm_w4_plan")
     return _PLANS[rc]
@@ -313,6 +319,10 @@ def _w4_rm(A, B, q_group, qinfo, lut, qtype, weight_on_right, opname):
         w_on_right=1 if weight_on_right else 0, inner_k_tiles=inner, batch=1,
         numerics=_NUMERICS[get_numerics()], bias=(bias.data_ptr() if bias is not None else None),
     )
+    ws_bytes = _L.tg_gemm_w4_workspace_bytes(ctypes.byref(args))
+    if ws_bytes > 0:  # scratch from torch's caching allocator: stream-ordered like every other temporary of the op
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
+        args.workspace, args.workspace_bytes = ws.data_ptr(), ws_bytes
     _lib.check(_L.tg_gemm_w4(ctypes.byref(args), _dev(x), _stream(x)), opname)
     return y
 

@@ -100,6 +100,19 @@ def make_args(_lib, w, x, q, lut, y, m, n, k, g, qtype, on_right, inner, batch):
         stride_y=y.stride(0) * 2, numerics=_lib.TG_NUM_FAST)
 
 
+def attach_workspace(lib, aa, device):
+    """The scratch tg_gemm_w4_workspace_bytes asks for (m > 1 at k = 4096: the activations are re-arranged once per launch
+    for the pair-table kernel).  Allocated once, outside every timed region; the returned tensor keeps it alive."""
+    need = lib.tg_gemm_w4_workspace_bytes(ctypes.byref(aa))
+    if need < 0:
+        raise SystemExit(f"bench.py: tg_gemm_w4_workspace_bytes failed with {need}")
+    if need == 0:
+        return None
+    ws = torch.empty(need, dtype=torch.uint8, device=device)
+    aa.workspace, aa.workspace_bytes = ws.data_ptr(), need
+    return ws
+
+
 def check_layers(w, x, q, lut, y, g, qtype, on_right, inner, plan, layers=(0, 1, -1), rows=256):
     """Untimed: `rows` weight rows of a few layers of the launch's output against the CPU oracle (the group-scaled
     restatement when the pair-table kernel ran, else the reference-faithful contraction)."""
@@ -256,6 +269,7 @@ def main():
         y_all = torch.empty(world, L, m, n, device=device, dtype=torch.bfloat16)
 
     args = make_args(_lib, w, x, sz, lut, y, m, n, k, g, "any4_rowwise", True, inner, L)
+    args_ws = attach_workspace(lib, args, device)  # noqa: F841  (kept alive)
     plan = ops.gemm_w4_plan(m, n, k, g, QT["any4_rowwise"], True, inner, torch.bfloat16, L, "fast")
     stream = torch.cuda.current_stream()
 
@@ -340,6 +354,7 @@ def main():
             """One more BASELINE config as a stacked launch of `layers` layers (same protocol: steady clock, HIP events)."""
             ww, xx, qq, ll, yy = make_batch(layers, mm, nn, kk, gg, inner, device, 77, qtype, on_right)
             aa = make_args(_lib, ww, xx, qq, ll, yy, mm, nn, kk, gg, qtype, on_right, inner, layers)
+            ws = attach_workspace(lib, aa, device)  # noqa: F841
             pl = ops.gemm_w4_plan(mm, nn, kk, gg, QT[qtype], on_right, inner, torch.bfloat16, layers, "fast")
             bl = alg_bytes(mm, nn, kk, gg, qtype)
             reps = max(10, int(0.25e6 / (layers * bl / 5e6)))  # ~0.25 s of launches

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define TG_ABI_VERSION 2
+#define TG_ABI_VERSION 3
 
 #if defined(__GNUC__)
 #define TG_API __attribute__((visibility("default")))
@@ -153,6 +153,11 @@ typedef struct tg_w4_gemm {
   const void* bias;   /* optional 16-bit [wrows]: y[a][row] = RNE16(RNE16(acc) + bias[row]), i.e. bit-identical to the
                          reference module's separate `y + bias` (modules.py:221-222) without its extra launch; NULL = none */
   int64_t stride_bias;
+  /* ---- ABI version 3 ---- */
+  void* workspace;         /* optional device scratch (16-byte aligned), written by the call on `stream`; NULL = none.       */
+  int64_t workspace_bytes; /* tg_gemm_w4_workspace_bytes() says how much lets the fastest kernel run; with less (or none) the  */
+                           /* call still succeeds on a kernel that needs no scratch.  Do not share one workspace between       */
+                           /* calls that may overlap (different streams).                                                      */
 } tg_w4_gemm;
 
 TG_API int tg_gemm_w4(const tg_w4_gemm* args, int device, tg_stream_t stream);
@@ -164,6 +169,12 @@ TG_API int tg_gemm_w4(const tg_w4_gemm* args, int device, tg_stream_t stream);
  *   TG_PLAN_PAIR    w4_gemm_pair_kernel    per-row tables of LUT pairs, group-scaled numerics (TG_NUM_FAST only)  */
 enum { TG_PLAN_SPLITK = 1, TG_PLAN_STREAM = 2, TG_PLAN_PAIR = 3 };
 TG_API int tg_gemm_w4_plan(const tg_w4_gemm* args, int device);
+
+/* Bytes of `workspace` with which tg_gemm_w4 takes its fastest kernel for these arguments (0: none needed; negative: the
+ * TG_E_* code tg_gemm_w4 would return).  Today: TG_NUM_FAST, Bint4 weights, stacked launches whose activation block of one
+ * pass does not fit next to the pair table in LDS (m > 4 at k = 4096, any m at k >= 8192): the activations are re-arranged
+ * once per call (w4_xprep_kernel) so that the waves can stream them like the weights.  Needs no GPU. */
+TG_API int64_t tg_gemm_w4_workspace_bytes(const tg_w4_gemm* args);
 
 /*
  * int8 weights.

@@ -58,7 +58,7 @@ def assert_fast_close(oracle, y_hip, codes, x, qinfo, lut, g, qtype, dtype=torch
     assert not bad.any(), f"vs reference-faithful oracle: {bad.sum()} / {bad.size} outside tolerance"
 
 
-def run_fast(T, codes, x, qinfo, lut, g, qtype, inner, bias=None, min_items=384):
+def run_fast(T, codes, x, qinfo, lut, g, qtype, inner, bias=None, min_items=384, workspace=True):
     """The pair-table kernel is dispatched when a launch has >= 384 work items (64-row blocks x problems; smaller launches are
     latency-bound and stay on the split-K kernels): run `copies` identical problems in ONE tg_gemm_w4 call (the C ABI's
     stacked launch), check that every copy gives the same bits, return (y of copy 0, copies)."""
@@ -82,6 +82,13 @@ def run_fast(T, codes, x, qinfo, lut, g, qtype, inner, bias=None, min_items=384)
                        stride_lut=(luts.stride(0) * 2 if luts is not None else 0), stride_y=ys.stride(0) * 2,
                        numerics=_lib.TG_NUM_FAST, bias=(bs.data_ptr() if bs is not None else None),
                        stride_bias=(bs.stride(0) * 2 if bs is not None else 0))
+    if workspace:
+        need = L.tg_gemm_w4_workspace_bytes(ctypes.byref(args))
+        assert need >= 0
+        if need:
+            ws = torch.empty(need + 64, dtype=torch.uint8, device=DEV)
+            ws.fill_(0xff)  # NaN bit patterns: nothing may be read that the call did not write first
+            args.workspace, args.workspace_bytes = ws.data_ptr(), need
     _lib.check(L.tg_gemm_w4(ctypes.byref(args), 0, torch.cuda.current_stream().cuda_stream), "stacked fast launch")
     torch.cuda.synchronize()
     assert not torch.isnan(ys.float()).any() or qtype == "mx4"
@@ -133,6 +140,30 @@ def test_pair_kernel_many_rows(T, oracle, m):
     y, copies = run_fast(T, codes, x, qinfo, lut, g, "any4_rowwise", 4)
     pair = ops.gemm_w4_plan(m, n, k, g, QT["any4_rowwise"], batch=copies) == "pair"
     assert_fast_close(oracle, y, codes, x, qinfo, lut, g, "any4_rowwise", batch=copies, expect_pair=pair)
+
+
+@pytest.mark.parametrize("case", [
+    # (n, k, m, g, inner, qtype): activation blocks that do not fit next to the table -> workspace variant
+    (64, 4096, 8, 64, 4, "any4_rowwise"), (72, 4096, 5, 128, 4, "any4_rowwise"), (64, 4096, 7, 256, 4, "int4"),
+    (64, 8192, 1, 128, 4, "any4_rowwise"), (40, 8192, 3, 64, 4, "any4_global"), (64, 14336, 1, 128, 4, "any4_rowwise"),
+    (64, 4096, 8, 32, 4, "mx4"), (48, 4096, 8, 32, 2, "int4"), (64, 8192, 2, 128, 2, "int4"), (64, 4096, 6, 256, 4, "any4_rowwise"),
+    (64, 2048, 8, 128, 2, "any4_rowwise"),
+])
+def test_pair_kernel_workspace_variant(T, oracle, case):
+    """tg_gemm_w4_workspace_bytes > 0: the activations are re-arranged into the caller's scratch and streamed by the waves.
+    Without the scratch the same call succeeds on a reference-numerics kernel."""
+    from any4_amd import ops
+
+    n, k, m, g, inner, qtype = case
+    codes, x, qinfo, lut = rand_problem(n, k, g, m, qtype, seed=n + k + m)
+    y, copies = run_fast(T, codes, x, qinfo, lut, g, qtype, inner)
+    assert ops.gemm_w4_plan(m, n, k, g, QT[qtype], True, inner, batch=copies, workspace=False) != "pair"
+    assert_fast_close(oracle, y, codes, x, qinfo, lut, g, qtype, inner=inner, batch=copies)
+    y0, _ = run_fast(T, codes, x, qinfo, lut, g, qtype, inner, workspace=False)
+    w = from_bits16(oracle_weights(oracle, codes, g, qtype, qinfo, lut, torch.bfloat16), torch.bfloat16).double()
+    S = (x.double().abs() @ w.abs().t()).numpy()
+    d = np.abs(y0.double().cpu().numpy()[:, :n] - y.double().cpu().numpy()[:, :n])
+    assert (d <= ulp16(y.double().cpu().numpy()[:, :n], torch.bfloat16) + 2.0 ** -8 * S + 1e-37).all()
 
 
 def test_pair_kernel_fp16(T, oracle):

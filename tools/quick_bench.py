@@ -75,6 +75,14 @@ def main():
 
         singles = [mk(b, 1) for b in range(L)]
         stacked = mk(0, L)
+        ws = None
+        if a.qtype != "int8" and not os.environ.get("QB_NO_WS"):
+            need = L_.tg_gemm_w4_workspace_bytes(ctypes.byref(stacked))
+            assert need >= 0, need
+            if need:
+                ws = torch.empty(need, dtype=torch.uint8, device=dev)
+                stacked.workspace, stacked.workspace_bytes = ws.data_ptr(), need
+        plan = L_.tg_gemm_w4_plan(ctypes.byref(stacked), 0) if a.qtype != "int8" else 0
 
         def run_eager():
             for s in singles:
@@ -115,7 +123,7 @@ def main():
             torch.cuda.synchronize()
         t_steady = timeit(run_stacked, max(a.iters, 20)) / L
         B = alg_bytes(m, n, k, g, a.qtype)
-        print(f"m={m} n={n} k={k} on_right={on_right} {a.qtype} g={g} I={inner} L={L} bytes={B} stacked==eager:{same}")
+        print(f"m={m} n={n} k={k} on_right={on_right} {a.qtype} g={g} I={inner} L={L} bytes={B} stacked==eager:{same} plan={plan} ws={0 if ws is None else ws.numel()}")
         for name, t in (("eager", t_eager), ("graph", t_graph), ("stacked", t_stack), ("steady", t_steady)):
             print(f"   {name:8s} {t:8.2f} us/matrix  {B / t / 1e6:8.3f} TB/s  {B / t / 1e6 / 8.0 * 100:5.1f}% of 8 TB/s")
 
