@@ -646,13 +646,25 @@ enum { TG_PAIR_NA = -100 };
 #ifndef TG_PAIR_NSG2
 #define TG_PAIR_NSG2 1  // 0: group boundaries always tested at run time (developer A/B)
 #endif
+#ifndef TG_PAIR_MR1_GPS
+#define TG_PAIR_MR1_GPS 1  // the m = 1 specialisation is used up to this many groups per super-tile
+#endif
 #ifndef TG_PAIR_WGS
 #define TG_PAIR_WGS 512  // persistent workgroups: two per CU
 #endif
 template <typename DT, int I, int GPS, int MR, bool QMX, int NSG, bool XG = false>
 int launch_pair_k(PairParams& pp, unsigned lds, hipStream_t st) {
 #ifdef TG_DEV_MIN  // developer builds: only the headline instantiation (fast A/B builds)
-  if constexpr (!(std::is_same<DT, BF16>::value && I == 4 && GPS == 1 && MR == TG_PAIR_MR1 && !QMX && NSG == TG_DEV_MIN)) return TG_PAIR_NA;
+#ifndef TG_DEV_GPS
+#define TG_DEV_GPS 1
+#endif
+#ifndef TG_DEV_QMX
+#define TG_DEV_QMX false
+#endif
+#ifndef TG_DEV_MR
+#define TG_DEV_MR TG_PAIR_MR1
+#endif
+  if constexpr (!(std::is_same<DT, BF16>::value && I == 4 && GPS == TG_DEV_GPS && MR == TG_DEV_MR && QMX == TG_DEV_QMX && NSG == TG_DEV_MIN)) return TG_PAIR_NA;
   else {
 #endif
   if constexpr (QMX && !std::is_same<DT, BF16>::value) return TG_E_DTYPE;  // mx4 is bf16-only (TinyGemm_int4.cu:758)
@@ -719,6 +731,9 @@ int launch_pair(GemmParams& p, int64_t batch, hipStream_t st) {
     lds = (unsigned)pp.lds_red;
     pp.lds_red = 0;
   }
+  // mx4: exponent blocks of 16 bytes per row, read at 4-byte alignment (w4_gemm_pair.cuh, e_request)
+  // (a slice that starts off a 4-byte boundary loses up to 3 bytes of its one block)
+  if (QMX && (p.ngroups < 16 || p.ngroups % 4 != 0 || ((pp.spw * gps) % 4 != 0 && pp.spw * gps > 12))) return TG_PAIR_NA;
   bool xg = false;
 #ifdef TG_PAIR_FORCE_XG  // developer A/B: the workspace variant also where the staged plan fits
   if (mregs == 4 && p.m <= ma) lds = 1u << 30;
@@ -762,10 +777,12 @@ int launch_pair(GemmParams& p, int64_t batch, hipStream_t st) {
     const int rc = launch_xprep<DT>(pp, I, ma, batch, st);
     if (rc != 0) return rc;
   }
+  // m = 1 has its own specialisation (one accumulator register finalised per group, taken as a running difference) --
+  // except with several groups per super-tile, where the general kernel's zero-C group starts compile without spills
 #define TG_PAIR_M(GPS_, NSG_)                                                                      \
-  (xg ? (p.m == 1 && TG_PAIR_MR1 == 1 ? launch_pair_k<DT, I, GPS_, 1, QMX, NSG_, true>(pp, lds, st)  \
+  (xg ? (p.m == 1 && TG_PAIR_MR1 == 1 && GPS_ <= TG_PAIR_MR1_GPS ? launch_pair_k<DT, I, GPS_, 1, QMX, NSG_, true>(pp, lds, st)  \
                                       : launch_pair_k<DT, I, GPS_, 4, QMX, NSG_, true>(pp, lds, st)) \
-   : p.m == 1 && TG_PAIR_MR1 == 1 ? launch_pair_k<DT, I, GPS_, 1, QMX, NSG_>(pp, lds, st)            \
+   : p.m == 1 && TG_PAIR_MR1 == 1 && GPS_ <= TG_PAIR_MR1_GPS ? launch_pair_k<DT, I, GPS_, 1, QMX, NSG_>(pp, lds, st)            \
    : mregs == 4                   ? launch_pair_k<DT, I, GPS_, 4, QMX, NSG_>(pp, lds, st)            \
                                   : launch_pair_k<DT, I, GPS_, 16, QMX, NSG_>(pp, lds, st))
   if (gps == 1) {

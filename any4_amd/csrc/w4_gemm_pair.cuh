@@ -269,10 +269,38 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
         if (!needq) continue;  // (compile-time per call site) not the first super-tile of its group
         const uint32_t g = (uint32_t)(((s * CPS + gg * CPG) * 32) >> p.gshift);
         if constexpr (ABL == 8) sl.q[t][gg] = 0x3c003c00u + (uint32_t)s;  // ablation: no scale | zero loads
-        else if constexpr (QMX) sl.q[t][gg] = *reinterpret_cast<const uint8_t*>(rw.qb + ((rw.qrow[t] * (uint32_t)p.ngroups + g) & vm));
+        else if constexpr (QMX) sl.q[t][gg] = 0u;  // mx4: the exponents come in 16-byte blocks per row, see e_request
         else sl.q[t][gg] = *reinterpret_cast<const uint32_t*>(rw.qb + (((g * (uint32_t)p.wrows + rw.qrow[t]) * 4u) & vm));
       }
     }
+  };
+
+  // ---- mx4: e8m0 exponents [row][k / 32].  A lane owns a weight row, so a per-group byte load touches 32 different cache
+  // lines per wave-instruction (measured: the kernel's bound at 41 % of the HBM roofline).  Instead every lane fetches the 16
+  // exponent bytes of its row for the next 16 groups of the wave's k-slice in one load, one block ahead. ----
+  constexpr int EBS = QMX ? 16 / GPS : 1;  // super-tiles per exponent block
+  u32x4 ecur[TILES], enext[TILES];
+  int eoff_next = 0;
+  auto e_request = [&](const Rows& rw, int blk, bool valid) {
+    const uint32_t vm = valid ? 0xffffffffu : 0u;
+    const int start = s_begin * GPS + blk * 16;          // first group of the block
+    const int st = max(min(start & ~3, p.ngroups - 16), 0);  // 4-byte aligned; the last block of a row is moved back inside the row
+    eoff_next = start - st;
+#pragma unroll
+    for (int t = 0; t < TILES; ++t)
+      enext[t] = *reinterpret_cast<const u32x4*>(rw.qb + ((rw.qrow[t] * (uint32_t)p.ngroups + (uint32_t)st) & vm));
+  };
+  int ebase = 0;  // byte of ecur that holds group 0 of the wave's slice (block start and the shift above folded in)
+  // the dword of ecur[t] that holds the exponents of slice group gi (wave-uniform); the GPS groups of one super-tile share it
+  auto e_dword = [&](int t, int gi) -> uint32_t {
+    const int dw = (gi + ebase) >> 2;
+    return dw == 0 ? ecur[t][0] : dw == 1 ? ecur[t][1] : dw == 2 ? ecur[t][2] : ecur[t][3];
+  };
+  // 2^(e - 127) as f32 bits-wise: e << 23, e = 0 -> 2^-127 (a denormal), e = 255 -> NaN (Dequantization.cuh:331-339)
+  auto e_scale = [&](uint32_t d, int gi) -> float {
+    const uint32_t e23 = __builtin_amdgcn_ubfe(d, (uint32_t)(((gi + ebase) & 3) * 8), 8u) << 23;
+    const float sc = u2f(e23 > 0x00400000u ? e23 : 0x00400000u);
+    return __builtin_fmaf(sc, 0.f, sc);  // inf (e = 255) -> NaN, everything else unchanged
   };
 
   // ---- activation staging: chunk (row a, 32 k) -> LDS in byte order, and the per-group sums ----
@@ -353,6 +381,7 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
     if (tid < mrows0 * nch) x_load(p.x + (int64_t)first.b * p.stride_x + (int64_t)first.ct * MA * p.k * 2, tid, xd0);
   }
   Rows rcur = rows_of(it_begin);
+  if constexpr (QMX) e_request(rcur, 0, nl > 0);
 #pragma unroll
   for (int j = 0; j < R; ++j) {
     __builtin_amdgcn_sched_barrier(0);
@@ -479,6 +508,7 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
     bool pending = false;  // wave-uniform
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     // one super-tile: 2 CPS MFMA steps, step = (chunk jc, quad pair qq) for both tiles: 8 table lookups + one X piece
+    uint32_t edw[TILES] = {0u, 0u};  // mx4: the exponent dword of the current super-tile
     auto consume = [&](int s, const Slot& sl, int j_slot) {
       const uint32_t xst = xrow + ((uint32_t)(s * CPS * 64) & xmask);  // this lane's X pieces of the super-tile
       if constexpr (XG) {
@@ -536,7 +566,15 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
         if (ABL != 7 && gfirst) {  // a group starts: its scale | zero and (not mx4) its activation sums
           const int gg = GPS == 1 ? 0 : jc / CPG;
 #pragma unroll
-          for (int t = 0; t < TILES; ++t) unpack_q(sl.q[t][gg], gs[t], gz[t]);
+          for (int t = 0; t < TILES; ++t) {
+            if constexpr (QMX) {
+              const int gi = (s - s_begin) * GPS + gg;
+              if (gg == 0) edw[t] = e_dword(t, gi);
+              gs[t] = e_scale(edw[t], gi);
+            } else {
+              unpack_q(sl.q[t][gg], gs[t], gz[t]);
+            }
+          }
           if constexpr (!QMX) {
             // lanes whose accumulator rows are all padding (lane half 1 when m <= 4) read the zero piece behind the staged rows
             const uint32_t xsa = 4 * h < p.xs_rows ? lds_xs + (uint32_t)((((chunk * 32) >> p.gshift) * p.xs_rows + 4 * h) * 4)
@@ -575,11 +613,24 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
     // above, so the next table build waits with vmcnt(loads of one round) instead of draining the ring.
     const int rounds = max((nl + R - 1) / R, 1);
     int l0 = 0;
-    for (int rd = 0; rd < rounds - 1; ++rd, l0 += R) {
+    // mx4: the slice is walked in blocks of EBS super-tiles (16 exponent bytes per row); at the start of a block the next
+    // block's exponents are requested -- for the last block, the first block of the next item
+    const int nblk = QMX ? max((nl + EBS - 1) / EBS, 1) : 1;
+    for (int blk = 0; blk < nblk; ++blk) {
+      const bool lastb = blk + 1 == nblk;
+      if constexpr (QMX) {
 #pragma unroll
-      for (int j = 0; j < R; ++j) {
-        consume(s_begin + l0 + j, ring[j], j);
-        issue(rcur, s_begin + l0 + j + R, ring[j], l0 + j + R < nl, NSG == 0 || j % NSG == 0);
+        for (int t = 0; t < TILES; ++t) ecur[t] = enext[t];
+        ebase = eoff_next - blk * 16;
+        e_request(lastb ? rnext : rcur, lastb ? 0 : blk + 1, lastb ? has_next && nl > 0 : true);
+      }
+      const int rend = lastb ? rounds - 1 : (blk + 1) * (EBS / R);  // rounds before the peeled one / of this block
+      for (int rd = l0 / R; rd < rend; ++rd, l0 += R) {
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+          consume(s_begin + l0 + j, ring[j], j);
+          issue(rcur, s_begin + l0 + j + R, ring[j], l0 + j + R < nl, NSG == 0 || j % NSG == 0);
+        }
       }
     }
 #pragma unroll
