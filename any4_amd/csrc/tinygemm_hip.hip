@@ -652,7 +652,7 @@ enum { TG_PAIR_NA = -100 };
 #ifndef TG_PAIR_WGS
 #define TG_PAIR_WGS 512  // persistent workgroups: two per CU
 #endif
-template <typename DT, int I, int GPS, int MR, bool QMX, int NSG, bool XG = false>
+template <typename DT, int I, int GPS, int MR, bool QMX, int NSG, bool XG = false, bool LA = false>
 int launch_pair_k(PairParams& pp, unsigned lds, hipStream_t st) {
 #ifdef TG_DEV_MIN  // developer builds: only the headline instantiation (fast A/B builds)
 #ifndef TG_DEV_GPS
@@ -664,7 +664,10 @@ int launch_pair_k(PairParams& pp, unsigned lds, hipStream_t st) {
 #ifndef TG_DEV_MR
 #define TG_DEV_MR TG_PAIR_MR1
 #endif
-  if constexpr (!(std::is_same<DT, BF16>::value && I == 4 && GPS == TG_DEV_GPS && MR == TG_DEV_MR && QMX == TG_DEV_QMX && NSG == TG_DEV_MIN)) return TG_PAIR_NA;
+#ifndef TG_DEV_LA
+#define TG_DEV_LA false
+#endif
+  if constexpr (!(std::is_same<DT, BF16>::value && I == 4 && GPS == TG_DEV_GPS && MR == TG_DEV_MR && QMX == TG_DEV_QMX && NSG == TG_DEV_MIN && LA == TG_DEV_LA)) return TG_PAIR_NA;
   else {
 #endif
   if constexpr (QMX && !std::is_same<DT, BF16>::value) return TG_E_DTYPE;  // mx4 is bf16-only (TinyGemm_int4.cu:758)
@@ -672,7 +675,7 @@ int launch_pair_k(PairParams& pp, unsigned lds, hipStream_t st) {
   // several groups per super-tile (group 32 / 64 with wide super-tiles): more per-slot state, one slot in flight fits the
   // 128-VGPR budget without spills (ring depth measured irrelevant between 2 and 4)
   constexpr int RING = GPS > 1 ? 1 : TG_PAIR_R;
-  constexpr auto kern = w4_gemm_pair_kernel<DT, I, GPS, MR, QMX, RING, NSG, TG_PAIR_ABL, XG>;
+  constexpr auto kern = w4_gemm_pair_kernel<DT, I, GPS, MR, QMX, RING, NSG, TG_PAIR_ABL, XG, LA>;
   if (pp.dry) return TG_PLAN_PAIR;
   const int prc = prepare_lds_kernel<kern>();
   if (prc != 0) return prc;
@@ -724,7 +727,7 @@ int launch_pair(GemmParams& p, int64_t batch, hipStream_t st) {
   pp.x_pitch = p.k * 2 + 16;
   pp.lds_x = 65536;
   pp.lds_xs = (pp.lds_x + mrows * pp.x_pitch + 32 * I + 15) & ~15;  // staged rows + a zero piece of one super-tile
-  pp.lds_red = (pp.lds_xs + p.ngroups * pp.xs_rows * 4 + 15) & ~15;
+  pp.lds_red = (pp.lds_xs + (QMX ? 0 : p.ngroups * pp.xs_rows * 4) + 15) & ~15;  // mx4: no zero point, no activation sums
   pp.red_alias = mrows > 4;  // 16 KiB and more of partial sums: reuse the table's LDS instead
   unsigned lds = (unsigned)pp.lds_red + (unsigned)(8 * 2 * pp.rused * pp.red_lanes * 4);
   if (pp.red_alias) {
@@ -744,7 +747,7 @@ int launch_pair(GemmParams& p, int64_t batch, hipStream_t st) {
     pp.xw_pitch = 32 * I + 16;
     pp.xw_bytes = (I == 2 ? 16 : 8) * pp.xw_pitch;  // a row for every 2 I lanes of the wave's (unmasked) store
     pp.lds_xs = (pp.lds_x + 8 * pp.xw_bytes + 32 * I + 15) & ~15;  // 8 buffers + the zero piece
-    pp.lds_red = (pp.lds_xs + p.ngroups * pp.xs_rows * 4 + 15) & ~15;
+    pp.lds_red = (pp.lds_xs + (QMX ? 0 : p.ngroups * pp.xs_rows * 4) + 15) & ~15;  // mx4: no zero point, no activation sums
     lds = (unsigned)pp.lds_red + (unsigned)(8 * 2 * pp.rused * pp.red_lanes * 4);
     if (lds > 80u * 1024u) pp.red_alias = 1;
     if (pp.red_alias) {
@@ -804,6 +807,74 @@ int launch_pair(GemmParams& p, int64_t batch, hipStream_t st) {
   return TG_PAIR_NA;
 }
 
+// Aint4 weights (weightOnRight = false) on the pair-table kernel: 32 weight rows per work item, v_mfma_f32_16x16x32,
+// activations always through the workspace (one pass of at most 8 rows).
+template <typename DT, int I, bool QMX>
+int launch_pair_a(GemmParams& p, int64_t batch, hipStream_t st) {
+  if constexpr (I < 2) return TG_PAIR_NA;  // one 16-k tile per word set: no word pair for a 32-k MFMA step
+  else {
+  if (p.m > 8) return TG_PAIR_NA;
+  const int g = 1 << p.gshift;
+  const int gps = g >= 16 * I ? 1 : (16 * I) / g;
+  PairParams pp;
+  pp.x = p.x; pp.w = p.w; pp.qinfo = p.qinfo; pp.lut = p.lut; pp.y = p.y;
+  pp.m = p.m; pp.wrows = p.wrows; pp.k = p.k; pp.ntiles = p.ntiles; pp.ksuper = p.ksuper;
+  pp.gshift = p.gshift; pp.ngroups = p.ngroups; pp.qtype = p.qtype;
+  const int nsg = g >= 16 * I ? g / (16 * I) : 1;
+  const int units = p.ksuper / nsg;
+  pp.spw = ((units + 7) / 8) * nsg;
+  pp.nsg_shift = 0;
+  while ((1 << pp.nsg_shift) < nsg) ++pp.nsg_shift;
+  pp.gch_mask = g / 32 - 1;
+  if (QMX && (p.ngroups < 16 || p.ngroups % 4 != 0 || ((pp.spw * gps) % 4 != 0 && pp.spw * gps > 12))) return TG_PAIR_NA;
+  const int mrows = p.m;
+  pp.rused = mrows < 4 ? mrows : 4;
+  pp.xs_rows = mrows <= 4 ? 4 : 8;
+  pp.red_lanes = 32;  // lanes 0..31 hold activation rows 0..7
+  pp.x_pitch = 0;
+  pp.lds_x = 65536;
+  pp.xw_pitch = 32 * I + 16;
+  pp.xw_bytes = (I == 2 ? 16 : 8) * pp.xw_pitch;
+  pp.lds_xs = (pp.lds_x + 8 * pp.xw_bytes + 32 * I + 15) & ~15;
+  pp.lds_red = (pp.lds_xs + (QMX ? 0 : p.ngroups * pp.xs_rows * 4) + 15) & ~15;  // mx4: no zero point, no activation sums
+  unsigned lds = (unsigned)pp.lds_red + (unsigned)(8 * 2 * pp.rused * pp.red_lanes * 4);
+  pp.red_alias = lds > 80u * 1024u;
+  if (pp.red_alias) {
+    lds = (unsigned)pp.lds_red;
+    pp.lds_red = 0;
+  }
+  if (lds > 80u * 1024u) return TG_PAIR_NA;
+  pp.stride_xp = (int64_t)p.m * p.k * 2;
+  pp.stride_xsum = ((int64_t)p.ngroups * pp.xs_rows * 4 + 15) & ~(int64_t)15;
+  const int64_t need = batch * (pp.stride_xp + pp.stride_xsum);
+  pp.rblocks = (p.wrows + 31) / 32;
+  pp.cblocks = 1;
+  const int64_t items = (int64_t)pp.rblocks * batch;
+  if (items > INT32_MAX || items < 384) return TG_PAIR_NA;
+  p.ws_need = need;
+  if (!p.ws_query && (p.ws == nullptr || p.ws_bytes < need)) return TG_PAIR_NA;
+  pp.xp = p.ws;
+  pp.xsum = p.ws + batch * pp.stride_xp;
+  pp.items = (int32_t)items;
+  pp.stride_x = p.stride_x; pp.stride_w = p.stride_w; pp.stride_qinfo = p.stride_qinfo;
+  pp.stride_lut = p.stride_lut; pp.stride_y = p.stride_y;
+  pp.bias = p.bias; pp.stride_bias = p.stride_bias; pp.dry = p.dry;
+  if (!p.dry) {
+    const int rc = launch_xprep<DT>(pp, I, 8, batch, st);
+    if (rc != 0) return rc;
+  }
+  if (gps == 1) {
+    if (TG_PAIR_NSG2 && nsg == 1) return launch_pair_k<DT, I, 1, 4, QMX, 1, true, true>(pp, lds, st);
+    if (TG_PAIR_NSG2 && nsg == TG_PAIR_R) return launch_pair_k<DT, I, 1, 4, QMX, TG_PAIR_R, true, true>(pp, lds, st);
+    return launch_pair_k<DT, I, 1, 4, QMX, 0, true, true>(pp, lds, st);
+  }
+  if constexpr (I >= 4) {
+    if (gps == 2) return launch_pair_k<DT, I, 2, 4, QMX, 0, true, true>(pp, lds, st);
+  }
+  return TG_PAIR_NA;
+  }
+}
+
 template <typename DT, bool LAYOUT_A, int CANON, bool QMX>
 int launch_w4(GemmParams& p, int64_t coltiles, int64_t batch, hipStream_t st) {
   constexpr int KSTEP = LAYOUT_A ? 64 : 128;
@@ -821,11 +892,12 @@ int launch_w4(GemmParams& p, int64_t coltiles, int64_t batch, hipStream_t st) {
 #endif
   constexpr int WPL = CANON == CANON_NONE ? 1 : (CANON == CANON_PAIR ? 2 : 4);
   // TG_NUM_FAST, weights on the B side: the pair-table kernel (group-scaled numerics) whenever its LDS plan fits
-  if constexpr (!LAYOUT_A) {
-    if (p.numerics == TG_NUM_FAST) {
-      const int rc = launch_pair<DT, 2 * WPL, QMX>(p, batch, st);
-      if (rc != TG_PAIR_NA) return rc;
-    }
+  if (p.numerics == TG_NUM_FAST) {
+    int rc;
+    if constexpr (LAYOUT_A) rc = launch_pair_a<DT, WPL, QMX>(p, batch, st);
+    else rc = launch_pair<DT, 2 * WPL, QMX>(p, batch, st);
+    if (rc != TG_PAIR_NA) return rc;
+    p.ws_need = 0;
   }
   // m = 1 always streams: with private X slabs its split-K variants beat the latency kernel down to one matrix
   if (use_stream && (g.waves == 8 || p.m == 1 || use_stream == 2) && (1 << p.gshift) >= (LAYOUT_A ? 64 : 128)) {

@@ -93,6 +93,15 @@ __device__ __forceinline__ f32x16 mfma32(u32x4 a, u32x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+template <typename DT>
+__device__ __forceinline__ f32x4_t mfma16(u32x4 a, u32x4 b, f32x4_t c) {
+  if constexpr (std::is_same<DT, BF16>::value)
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
 template <typename DT>
 __device__ __forceinline__ float dot2_ones(uint32_t pair, float acc) {
   if constexpr (std::is_same<DT, BF16>::value)
@@ -111,11 +120,22 @@ __device__ __forceinline__ float dot2_ones(uint32_t pair, float acc) {
 //         the whole activation block itself
 // NSG   = super-tiles per quantisation group when that is 1 or R (group boundaries then sit at fixed places of the unrolled
 //         round: no per-step tests, scale | zero words are only requested for the first super-tile of a group); 0 = any, tested at run time
-template <typename DT, int I, int GPS, int MR, bool QMX, int R, int NSG = 0, int ABL = 0, bool XG = false>
+// LA    = weights in the Aint4 layout (weightOnRight = false; I = 2, 4; workspace activations, m <= 8).  A packed word holds
+//         4 codes of row r and 4 of row r + 8 of a 16-row tile at k = 2 kq + {0, 1, 8, 9} of one 16-k tile
+//         (TinyGemmConvertA.cu:172-255), lane t = 4 (r & 7) + kq.  Lane (n = lane & 15, kb = lane >> 4) of a wave takes
+//         row n & 7 of 16-row tile n >> 3 at kq = kb: its word pair (two k-tiles) is the B operand of
+//         v_mfma_f32_16x16x32 for the rows r (MFMA "tile" 0) and r + 8 (tile 1): 32 weight rows per workgroup.
+//         The pair bytes are (code k, code k + 8): v_bfi of the word with itself shifted by one nibble.  Two lanes of a
+//         32-lane LDS access group share a weight row, so the table holds every row twice (32 rows x 2 copies = the same
+//         64 columns), the copy chosen by kb & 1: conflict-free.
+template <typename DT, int I, int GPS, int MR, bool QMX, int R, int NSG = 0, int ABL = 0, bool XG = false, bool LA = false>
 __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p) {
   constexpr int WAVES = 8;
-  constexpr int TILES = 2;              // 32-row MFMA tiles per workgroup
-  constexpr int RW = 32 * TILES;
+  constexpr int TILES = 2;              // MFMA tiles per workgroup (B side: 32 rows each; A side: 16 rows each, sharing their words)
+  constexpr int WT = LA ? 1 : TILES;    // sets of packed words per ring slot
+  constexpr int RW = LA ? 32 : 32 * TILES;
+  static_assert(!LA || (XG && MR == 4 && (I == 2 || I == 4)), "A side: workspace activations, one 8-row pass");
+  using acc_t = typename std::conditional<LA, f32x4_t, f32x16>::type;
   constexpr int CPS = I / 2;            // 32-k chunks per super-tile
   constexpr int CPG = CPS / GPS;        // chunks per group inside a super-tile (GPS > 1 only)
   constexpr int MREGS = MR == 1 ? 4 : MR;  // accumulator registers of a row set
@@ -136,7 +156,14 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = lane & 31;
   const int h = lane >> 5;
-  const int tcol = tid & 63;  // table column = weight row of the item this thread builds
+  const int xa = LA ? lane & 15 : c;       // activation row this lane supplies to the MFMA (X operand)
+  const int xq = LA ? lane >> 4 : 2 * h;   // first 16-byte piece (k-quad) of a 32-k chunk this lane reads
+  const int hh = LA ? lane >> 4 : h;       // this lane's accumulator registers r < 4 are activation rows 4 hh + r
+  // weight row (inside the workgroup's block) of this lane in tile t
+  auto wrow_local = [&](int t) -> int { return LA ? 16 * ((lane & 15) >> 3) + (lane & 7) + 8 * t : t * 32 + c; };
+  const int tcol = tid & 63;  // table column this thread builds
+  // ... and the weight row it belongs to (A side: column = 32 tile + 16 copy + n)
+  const int tcol_row = LA ? 16 * ((tcol & 15) >> 3) + (tcol & 7) + 8 * (tcol >> 5) : tcol;
 
   // ---- this workgroup's work items; item -> (problem b, activation pass ct, row block rb) ----
   // staged activations: a contiguous range (the block in LDS is re-staged only when the problem changes).
@@ -181,7 +208,7 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
   const bool lut_loaded = p.qtype == TG_Q_ANY4_GLOBAL || p.qtype == TG_Q_ANY4_ROWWISE;
   auto lut_request = [&](int it) {  // it is clamped by the caller to a valid item
     const Item e = decode(it);
-    const int lrow = min(e.rb * RW + tcol, p.wrows - 1);
+    const int lrow = min(e.rb * RW + tcol_row, p.wrows - 1);
     const char* lsrc = p.lut + (int64_t)e.b * p.stride_lut + (p.qtype == TG_Q_ANY4_ROWWISE ? (int64_t)lrow * 32 : 0);
     const u32x4 l0 = reinterpret_cast<const u32x4*>(lsrc)[0];
     const u32x4 l1 = reinterpret_cast<const u32x4*>(lsrc)[1];
@@ -191,7 +218,7 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
 
   // ---- ring of R super-tiles: packed words and scale|zero words (or mx4 exponent bytes) ----
   struct Slot {
-    uint32_t w[TILES][I];
+    uint32_t w[WT][I];
     uint32_t q[TILES][GPS];
     u32x4 xw[NXW];  // XG: this lane's 16-byte pieces of the super-tile's activation block
   };
@@ -199,7 +226,7 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
   // per-lane addressing of an item: byte offset of this lane's words in super-tile 0 of its rows (the host checks the matrix
   // is < 4 GiB) and its rows
   struct Rows {
-    uint32_t wbase[TILES];
+    uint32_t wbase[WT];
     uint32_t qrow[TILES];
     const char* wb;
     const char* qb;
@@ -211,10 +238,16 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
     Rows r;
 #pragma unroll
     for (int t = 0; t < TILES; ++t) {
-      const int row = min(e.rb * RW + t * 32 + c, p.wrows - 1);
-      const int nt = min(row >> 3, p.ntiles - 1);
-      r.wbase[t] = ((uint32_t)nt * (uint32_t)p.ksuper * 32u + (uint32_t)(4 * (row & 7) + 2 * h)) * (uint32_t)(2 * I);
+      const int row = min(e.rb * RW + wrow_local(t), p.wrows - 1);
       r.qrow[t] = (uint32_t)row;
+      if constexpr (!LA) {
+        const int nt = min(row >> 3, p.ntiles - 1);
+        r.wbase[t] = ((uint32_t)nt * (uint32_t)p.ksuper * 32u + (uint32_t)(4 * (row & 7) + 2 * h)) * (uint32_t)(2 * I);
+      }
+    }
+    if constexpr (LA) {  // [16-row tile][k super-tile][32 lanes][I words]
+      const int mt = min(e.rb * 2 + ((lane & 15) >> 3), p.ntiles - 1);
+      r.wbase[0] = ((uint32_t)mt * (uint32_t)p.ksuper * 32u + (uint32_t)(4 * (lane & 7) + (lane >> 4))) * (uint32_t)(4 * I);
     }
     r.wb = p.w + (int64_t)e.b * p.stride_w;
     r.qb = p.qinfo + (int64_t)e.b * p.stride_qinfo;
@@ -245,23 +278,26 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
     }
 #pragma unroll
     for (int t = 0; t < TILES; ++t) {
-      const char* src = rw.wb + ((rw.wbase[t] + (uint32_t)s * (uint32_t)(64 * I)) & vm);
-      if constexpr (ABL == 3) {
+      if (t < WT) {  // (compile-time; the A side's two tiles share one set of words)
+        const int tw = t < WT ? t : 0;
+        const char* src = rw.wb + ((rw.wbase[tw] + (uint32_t)s * (uint32_t)((LA ? 128 : 64) * I)) & vm);
+        if constexpr (ABL == 3) {
 #pragma unroll
-        for (int j = 0; j < I; ++j) sl.w[t][j] = (uint32_t)(s * 7 + j + t);
-      } else if constexpr (I == 2) {
-        const u32x2 v = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(src));
-        sl.w[t][0] = v[0]; sl.w[t][1] = v[1];
-      } else {
+          for (int j = 0; j < I; ++j) sl.w[tw][j] = (uint32_t)(s * 7 + j + t);
+        } else if constexpr (I == 2) {
+          const u32x2 v = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(src));
+          sl.w[tw][0] = v[0]; sl.w[tw][1] = v[1];
+        } else {
 #pragma unroll
-        for (int v4 = 0; v4 < I / 4; ++v4) {
+          for (int v4 = 0; v4 < I / 4; ++v4) {
 #ifdef TG_PAIR_NO_NT
-          const u32x4 v = reinterpret_cast<const u32x4*>(src)[v4];
+            const u32x4 v = reinterpret_cast<const u32x4*>(src)[v4];
 #else
-          const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src) + v4);
+            const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src) + v4);
 #endif
 #pragma unroll
-          for (int j = 0; j < 4; ++j) sl.w[t][4 * v4 + j] = v[j];
+            for (int j = 0; j < 4; ++j) sl.w[tw][4 * v4 + j] = v[j];
+          }
         }
       }
 #pragma unroll
@@ -328,6 +364,7 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
         *(lds_u32x4ptr)(dst + (uint32_t)(q * 16)) = o;
       }
     }
+    if constexpr (QMX) return;  // mx4 has no zero point: no activation sums (the host plans no LDS for them)
     float sum = 0.f;
 #pragma unroll
     for (int j = 0; j < 16; ++j) sum = dot2_ones<DT>(d[j], sum);
@@ -350,8 +387,9 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
       x_store(xi, on, xd);
     }
     // rows a >= mrows of the sums stay zero
-    for (int idx = tid; idx < p.ngroups * p.xs_rows; idx += 512)
-      if (idx % p.xs_rows >= mrows) *(lds_fptr)(lds_xs + (uint32_t)(idx * 4)) = 0.f;
+    if constexpr (!QMX)
+      for (int idx = tid; idx < p.ngroups * p.xs_rows; idx += 512)
+        if (idx % p.xs_rows >= mrows) *(lds_fptr)(lds_xs + (uint32_t)(idx * 4)) = 0.f;
     // the zero piece behind the staged rows is one super-tile long: lanes whose A-operand row is padding read it with the same
     // immediate offsets as the real rows
     if (tid < CPS * 4) *(lds_u32x4ptr)(lds_x + (uint32_t)(mrows * p.x_pitch + tid * 16)) = u32x4{0, 0, 0, 0};
@@ -360,8 +398,9 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
   // XG: the pass's per-group sums (computed by w4_xprep_kernel) -> LDS, rows >= mrows zero, and the zero piece
   auto xs_stage = [&](int b, int ct, int mrows) {
     const float* src = reinterpret_cast<const float*>(p.xsum + (int64_t)b * p.stride_xsum) + (int64_t)ct * p.ngroups * p.xs_rows;
-    for (int idx = tid; idx < p.ngroups * p.xs_rows; idx += 512)
-      *(lds_fptr)(lds_xs + (uint32_t)(idx * 4)) = idx % p.xs_rows < mrows ? src[idx] : 0.f;
+    if constexpr (!QMX)
+      for (int idx = tid; idx < p.ngroups * p.xs_rows; idx += 512)
+        *(lds_fptr)(lds_xs + (uint32_t)(idx * 4)) = idx % p.xs_rows < mrows ? src[idx] : 0.f;
     if (tid < CPS * 4) *(lds_u32x4ptr)(lds_x + (uint32_t)(WAVES * p.xw_bytes + tid * 16)) = u32x4{0, 0, 0, 0};
   };
 
@@ -393,7 +432,7 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
 
   uint32_t colreg[TILES];
 #pragma unroll
-  for (int t = 0; t < TILES; ++t) colreg[t] = (uint32_t)((t * 32 + c) * 4);
+  for (int t = 0; t < TILES; ++t) colreg[t] = (uint32_t)((LA ? 32 * t + 16 * ((lane >> 4) & 1) + (lane & 15) : t * 32 + c) * 4);
 
   for (int it = it_begin; it < it_end; it += it_stride) {
     const Item cur = decode(it);
@@ -440,20 +479,20 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
     __syncthreads();  // table and activations visible (and every thread is done with the previous item's partial sums)
 
     // ---- main loop of the item ----
-    const bool a_on = c < mrows;  // this lane's A-operand row is a real activation row; the others read the zero piece
+    const bool a_on = xa < mrows;  // this lane's A-operand row is a real activation row; the others read the zero piece
     const uint32_t xzero = XG ? lds_x + (uint32_t)(WAVES * p.xw_bytes) : lds_x + (uint32_t)(mrows * p.x_pitch);
     const uint32_t xwbuf = lds_x + (uint32_t)(wave * p.xw_bytes);  // XG: this wave's activation buffer (one super-tile)
-    const uint32_t xrow = !a_on ? xzero : XG ? xwbuf + (uint32_t)(c * p.xw_pitch + 2 * h * 16) : lds_x + (uint32_t)(c * p.x_pitch + 2 * h * 16);
+    const uint32_t xrow = !a_on ? xzero : XG ? xwbuf + (uint32_t)(xa * p.xw_pitch + xq * 16) : lds_x + (uint32_t)(xa * p.x_pitch + xq * 16);
     const uint32_t xmask = a_on && !XG ? 0xffffffffu : 0u;  // lanes on the zero piece (and XG lanes: one buffer) never move
     // XG: where this lane's 16 bytes of a super-tile's block go (piece = lane; 2 I pieces per activation row)
     const uint32_t xw_dst = xwbuf + (uint32_t)((lane / (2 * I)) * p.xw_pitch + (lane % (2 * I)) * 16);
 
-    f32x16 acc[TILES];
+    acc_t acc[TILES];
     float yacc[TILES][RF];
 #pragma unroll
     for (int t = 0; t < TILES; ++t) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+      for (int r = 0; r < (LA ? 4 : 16); ++r) acc[t][r] = 0.f;
 #pragma unroll
       for (int r = 0; r < RF; ++r) yacc[t][r] = 0.f;
     }
@@ -506,7 +545,9 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
       }
     };
     bool pending = false;  // wave-uniform
-    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    acc_t zero16;
+#pragma unroll
+    for (int r = 0; r < (LA ? 4 : 16); ++r) zero16[r] = 0.f;
     // one super-tile: 2 CPS MFMA steps, step = (chunk jc, quad pair qq) for both tiles: 8 table lookups + one X piece
     uint32_t edw[TILES] = {0u, 0u};  // mx4: the exponent dword of the current super-tile
     auto consume = [&](int s, const Slot& sl, int j_slot) {
@@ -522,33 +563,53 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
       }
       if constexpr (ABL == 6) {  // ablation: stream only
 #pragma unroll
-        for (int t = 0; t < TILES; ++t)
+        for (int t = 0; t < WT; ++t)
 #pragma unroll
           for (int j = 0; j < I; ++j) acc[t][0] += u2f(sl.w[t][j]);
         acc[0][1] += u2f(sl.q[0][0] ^ sl.q[1][0]);
         return;
       }
 #pragma unroll
-      for (int u = 0; u < 2 * CPS; ++u) {
-        const int jc = u >> 1, qq = u & 1;
+      // B side: a step = half a 32-k chunk (quads 2 h + qq); A side: a whole chunk (one word pair = two 16-k tiles)
+      for (int u = 0; u < (LA ? CPS : 2 * CPS); ++u) {
+        const int jc = LA ? u : u >> 1, qq = LA ? 0 : u & 1;
+        const bool qfirst = LA || qq == 0, qlast = LA || qq == 1;
         const int chunk = s * CPS + jc;
         // group boundaries: static when a super-tile holds several groups, else a wave-uniform runtime test
         constexpr bool STATIC_G = GPS > 1 || NSG > 0;
         const int gpos = NSG > 0 ? j_slot % NSG : 0;  // (compile-time) position of this super-tile in its group
-        const bool gfirst = qq == 0 && (GPS > 1 ? jc % CPG == 0 : NSG > 0 ? (gpos == 0 && jc == 0) : (chunk & p.gch_mask) == 0);
-        const bool glast = qq == 1 && (GPS > 1 ? jc % CPG == CPG - 1 : NSG > 0 ? (gpos == NSG - 1 && jc == CPS - 1) : (chunk & p.gch_mask) == p.gch_mask);
+        const bool gfirst = qfirst && (GPS > 1 ? jc % CPG == 0 : NSG > 0 ? (gpos == 0 && jc == 0) : (chunk & p.gch_mask) == 0);
+        const bool glast = qlast && (GPS > 1 ? jc % CPG == CPG - 1 : NSG > 0 ? (gpos == NSG - 1 && jc == CPS - 1) : (chunk & p.gch_mask) == p.gch_mask);
         u32x4 xf;
         u32x4 bf[TILES];
         if constexpr (ABL == 5) xf = u32x4{xrow, (uint32_t)s, (uint32_t)jc, (uint32_t)qq};  // ablation: no X reads
         else xf = *(lds_cu32x4ptr)(xst + (uint32_t)(jc * 64 + 16 * qq));
 #pragma unroll
         for (int t = 0; t < TILES; ++t) {
-          const uint32_t w = sl.w[t][qq * CPS + jc];
+          if constexpr (LA) {
+            // tile 0 = the low nibbles (rows r), tile 1 = the high nibbles (rows r + 8) of the chunk's two words; pair byte =
+            // (code k, code k + 8): bytes 0 / 2 of the low-nibble word, 1 / 3 of the high-nibble word; operand order
+            // (k, k+8) (k+16, k+24) (k+1, k+9) (k+17, k+25) = the activation pieces' order
+            uint32_t uw[2];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const uint32_t addr = __builtin_amdgcn_perm(w, colreg[t], 0x0c0c0400u + ((uint32_t)j << 8));
-            if constexpr (ABL == 1) bf[t][j] = addr;  // ablation: no lookups
-            else bf[t][j] = *(lds_cu32ptr)(addr);
+            for (int e = 0; e < 2; ++e) {
+              const uint32_t w = sl.w[0][2 * jc + e];
+              uw[e] = t == 0 ? ((w & 0x0f0f0f0fu) | ((w >> 4) & 0xf0f0f0f0u)) : ((w & 0xf0f0f0f0u) | ((w << 4) & 0x0f0f0f0fu));
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const uint32_t addr = __builtin_amdgcn_perm(uw[j & 1], colreg[t], 0x0c0c0400u + ((uint32_t)(t + 2 * (j >> 1)) << 8));
+              if constexpr (ABL == 1) bf[t][j] = addr;
+              else bf[t][j] = *(lds_cu32ptr)(addr);
+            }
+          } else {
+            const uint32_t w = sl.w[t < WT ? t : 0][qq * CPS + jc];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const uint32_t addr = __builtin_amdgcn_perm(w, colreg[t], 0x0c0c0400u + ((uint32_t)j << 8));
+              if constexpr (ABL == 1) bf[t][j] = addr;  // ablation: no lookups
+              else bf[t][j] = *(lds_cu32ptr)(addr);
+            }
           }
         }
         // the previous step ended a group: its finalize runs here, behind this step's lookups (MFMA results ready, no stall)
@@ -556,7 +617,7 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
           // fixed boundaries: the step that starts a group finalises the previous one (before the first group of an item
           // the accumulators and scales are zero: it adds nothing)
           if (gfirst) finalize();
-        } else if (qq == 0 && pending) {
+        } else if (qfirst && pending) {
           finalize();
           pending = false;
         }
@@ -577,14 +638,14 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
           }
           if constexpr (!QMX) {
             // lanes whose accumulator rows are all padding (lane half 1 when m <= 4) read the zero piece behind the staged rows
-            const uint32_t xsa = 4 * h < p.xs_rows ? lds_xs + (uint32_t)((((chunk * 32) >> p.gshift) * p.xs_rows + 4 * h) * 4)
+            const uint32_t xsa = 4 * hh < p.xs_rows ? lds_xs + (uint32_t)((((chunk * 32) >> p.gshift) * p.xs_rows + 4 * hh) * 4)
                                                    : xzero;
             if constexpr (RF == 1) {
               xsv[0] = *(const __attribute__((address_space(3))) float*)(xsa);
             } else {
 #pragma unroll
               for (int r4 = 0; r4 < MREGS / 4; ++r4) {
-                const f32x4 vv = *(lds_cf32x4ptr)(xsa + (uint32_t)(4 * h < p.xs_rows ? r4 * 32 : 0));
+                const f32x4 vv = *(lds_cf32x4ptr)(xsa + (uint32_t)(4 * hh < p.xs_rows ? r4 * 32 : 0));
                 xsv[4 * r4] = vv[0]; xsv[4 * r4 + 1] = vv[1]; xsv[4 * r4 + 2] = vv[2]; xsv[4 * r4 + 3] = vv[3];
               }
             }
@@ -593,6 +654,7 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
 #pragma unroll
         for (int t = 0; t < TILES; ++t) {
           if constexpr (ABL == 4) acc[t][0] += u2f(bf[t][0] ^ bf[t][1] ^ bf[t][2] ^ bf[t][3] ^ xf[0] ^ xf[1] ^ xf[2] ^ xf[3]);  // ablation: no MFMA
+          else if constexpr (LA) acc[t] = mfma16<DT>(xf, bf[t], (ABL != 7 && gfirst) ? zero16 : acc[t]);
           else if (ABL != 7 && !DIFF && gfirst) acc[t] = mfma32<DT>(xf, bf[t], zero16);
           else acc[t] = mfma32<DT>(xf, bf[t], acc[t]);
         }
@@ -656,8 +718,8 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
       char* yb = p.y + (int64_t)cur.b * p.stride_y;
       for (int o = tid; o < TILES * p.rused * p.red_lanes; o += 512) {
         const int l = o % p.red_lanes, r = (o / p.red_lanes) % p.rused, t = o / (p.red_lanes * p.rused);
-        const int a = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
-        const int row = row0 + t * 32 + (l & 31);
+        const int a = LA ? r + 4 * (l >> 4) : (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+        const int row = row0 + (LA ? 16 * ((l & 15) >> 3) + (l & 7) + 8 * t : t * 32 + (l & 31));
         if (a < mrows && row < p.wrows) {
           float sum = 0.f;
 #pragma unroll

@@ -35,12 +35,14 @@ def gs_reference(oracle, codes, x, qinfo, lut, g, qtype, dtype=torch.bfloat16):
     return y32.astype(np.float64)
 
 
-def assert_fast_close(oracle, y_hip, codes, x, qinfo, lut, g, qtype, dtype=torch.bfloat16, inner=4, batch=1, expect_pair=True):
+def assert_fast_close(oracle, y_hip, codes, x, qinfo, lut, g, qtype, dtype=torch.bfloat16, inner=4, batch=1, expect_pair=True,
+                      on_right=True):
     """Both tolerances of the module docstring.  The tight comparison with the group-scaled oracle applies when the
     library says (tg_gemm_w4_plan) that this problem runs the pair-table kernel, which `expect_pair` demands."""
     from any4_amd import ops
 
-    plan = ops.gemm_w4_plan(x.shape[0], ((codes.shape[0] + 7) // 8) * 8, x.shape[1], g, QT[qtype], True, inner, dtype, batch, "fast")
+    pad = 8 if on_right else 16
+    plan = ops.gemm_w4_plan(x.shape[0], -(-codes.shape[0] // pad) * pad, x.shape[1], g, QT[qtype], on_right, inner, dtype, batch, "fast")
     assert (plan == "pair") == expect_pair, f"kernel plan {plan!r}, expected {'pair' if expect_pair else 'a reference kernel'}"
     w = from_bits16(oracle_weights(oracle, codes, g, qtype, qinfo, lut, dtype), dtype).double()
     x64 = x.double()
@@ -58,7 +60,7 @@ def assert_fast_close(oracle, y_hip, codes, x, qinfo, lut, g, qtype, dtype=torch
     assert not bad.any(), f"vs reference-faithful oracle: {bad.sum()} / {bad.size} outside tolerance"
 
 
-def run_fast(T, codes, x, qinfo, lut, g, qtype, inner, bias=None, min_items=384, workspace=True):
+def run_fast(T, codes, x, qinfo, lut, g, qtype, inner, bias=None, min_items=384, workspace=True, on_right=True):
     """The pair-table kernel is dispatched when a launch has >= 384 work items (64-row blocks x problems; smaller launches are
     latency-bound and stay on the split-K kernels): run `copies` identical problems in ONE tg_gemm_w4 call (the C ABI's
     stacked launch), check that every copy gives the same bits, return (y of copy 0, copies)."""
@@ -68,16 +70,27 @@ def run_fast(T, codes, x, qinfo, lut, g, qtype, inner, bias=None, min_items=384,
     n, k = codes.shape
     m = x.shape[0]
     dt = x.dtype
-    packed1 = T.convert_matrix_to_m16n8k16_Bint4_layout(codes.to(DEV), inner)
-    wrows = packed1.shape[0] * 8
-    copies = -(-min_items // (-(-wrows // 64) * -(-m // (8 if m <= 8 else 16 if m <= 16 else 32))))
+    if on_right:
+        packed1 = T.convert_matrix_to_m16n8k16_Bint4_layout(codes.to(DEV), inner)
+        wrows = packed1.shape[0] * 8
+        copies = -(-min_items // (-(-wrows // 64) * -(-m // (8 if m <= 8 else 16 if m <= 16 else 32))))
+    else:  # Aint4: 32-row work items, one pass of up to 8 activation rows
+        packed1 = T.convert_matrix_to_m16n8k16_Aint4_layout(codes.to(DEV), inner)
+        wrows = packed1.shape[0] * 16
+        copies = -(-min_items // -(-wrows // 32))
+    if qtype == "mx4" and qinfo.shape[0] < wrows:  # exponent rows cover the tile padding
+        qinfo = torch.cat([qinfo, torch.full((wrows - qinfo.shape[0], qinfo.shape[1]), 127, dtype=qinfo.dtype)])
+    elif qtype != "mx4" and qinfo.shape[1] < wrows:
+        qinfo = torch.cat([qinfo, torch.zeros(qinfo.shape[0], wrows - qinfo.shape[1], 2, dtype=qinfo.dtype)], dim=1)
+    if lut is not None and lut.dim() == 2 and lut.shape[0] < wrows:
+        lut = torch.cat([lut, torch.zeros(wrows - lut.shape[0], 16, dtype=lut.dtype)])
     rep = lambda t: None if t is None else t.to(DEV).unsqueeze(0).repeat(copies, *([1] * t.dim())).contiguous()
     packed, xs, qs, luts = rep(packed1.cpu()), rep(x), rep(qinfo), rep(lut)
     bs = rep(bias)
     ys = torch.full((copies, m, wrows), float("nan"), dtype=dt, device=DEV)
     args = _lib.W4Gemm(x=xs.data_ptr(), w=packed.data_ptr(), qinfo=qs.data_ptr(), lut=(luts.data_ptr() if luts is not None else None),
                        y=ys.data_ptr(), m=m, wrows=wrows, k=k, group=g, qtype=QT[qtype],
-                       dtype=_lib.TG_BF16 if dt == torch.bfloat16 else _lib.TG_F16, w_on_right=1, inner_k_tiles=inner, batch=copies,
+                       dtype=_lib.TG_BF16 if dt == torch.bfloat16 else _lib.TG_F16, w_on_right=1 if on_right else 0, inner_k_tiles=inner, batch=copies,
                        stride_x=xs.stride(0) * 2, stride_w=packed.stride(0) * 4, stride_qinfo=qs.stride(0) * qs.element_size(),
                        stride_lut=(luts.stride(0) * 2 if luts is not None else 0), stride_y=ys.stride(0) * 2,
                        numerics=_lib.TG_NUM_FAST, bias=(bs.data_ptr() if bs is not None else None),
@@ -164,6 +177,31 @@ def test_pair_kernel_workspace_variant(T, oracle, case):
     S = (x.double().abs() @ w.abs().t()).numpy()
     d = np.abs(y0.double().cpu().numpy()[:, :n] - y.double().cpu().numpy()[:, :n])
     assert (d <= ulp16(y.double().cpu().numpy()[:, :n], torch.bfloat16) + 2.0 ** -8 * S + 1e-37).all()
+
+
+@pytest.mark.parametrize("qtype", ["any4_rowwise", "any4_global", "int4", "mx4"])
+@pytest.mark.parametrize("inner", [2, 4])
+@pytest.mark.parametrize("g", [32, 64, 128, 256])
+def test_pair_kernel_a_side(T, oracle, qtype, inner, g):
+    """Aint4 weights (weightOnRight = false) on the pair-table kernel: 16x16x32 MFMA tiles, duplicated table, m <= 8."""
+    from any4_amd import ops
+
+    if qtype == "mx4":
+        g = 32
+    for (n, k, m) in [(64, 1024, 1), (40, 512, 3), (136, 2048, 8), (80, 8192, 8), (48, 4096, 5)]:
+        if k % (16 * inner) or k % g:
+            continue
+        codes, x, qinfo, lut = rand_problem(n, k, g, m, qtype, seed=n + k + inner + 1)
+        y, copies = run_fast(T, codes, x, qinfo, lut, g, qtype, inner, on_right=False)
+        pair = ops.gemm_w4_plan(m, -(-n // 16) * 16, k, g, QT[qtype], False, inner, batch=copies) == "pair"
+        assert pair or (g == 32 and k >= 8192), (n, k, m)  # (8 KiB of activation sums do not fit next to the table)
+        assert_fast_close(oracle, y, codes, x, qinfo, lut, g, qtype, inner=inner, batch=copies, expect_pair=pair, on_right=False)
+
+
+def test_pair_kernel_a_side_fp16_bias(T, oracle):
+    codes, x, qinfo, lut = rand_problem(96, 1024, 128, 6, "any4_rowwise", dtype=torch.float16, seed=14)
+    y, copies = run_fast(T, codes, x, qinfo, lut, 128, "any4_rowwise", 4, on_right=False)
+    assert_fast_close(oracle, y, codes, x, qinfo, lut, 128, "any4_rowwise", dtype=torch.float16, batch=copies, on_right=False)
 
 
 def test_pair_kernel_fp16(T, oracle):
