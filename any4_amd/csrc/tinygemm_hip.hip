@@ -649,6 +649,12 @@ enum { TG_PAIR_NA = -100 };
 #ifndef TG_PAIR_MR1_GPS
 #define TG_PAIR_MR1_GPS 1  // the m = 1 specialisation is used up to this many groups per super-tile
 #endif
+#ifndef TG_PAIR_RA
+#define TG_PAIR_RA 2   // ring depth of the A-side kernels (few accumulator registers: room for more)
+#endif
+#ifndef TG_PAIR_RA1
+#define TG_PAIR_RA1 1  // ... with several groups per super-tile
+#endif
 #ifndef TG_PAIR_WGS
 #define TG_PAIR_WGS 512  // persistent workgroups: two per CU
 #endif
@@ -674,7 +680,7 @@ int launch_pair_k(PairParams& pp, unsigned lds, hipStream_t st) {
   else {
   // several groups per super-tile (group 32 / 64 with wide super-tiles): more per-slot state, one slot in flight fits the
   // 128-VGPR budget without spills (ring depth measured irrelevant between 2 and 4)
-  constexpr int RING = GPS > 1 ? 1 : TG_PAIR_R;
+  constexpr int RING = GPS > 1 ? (LA ? TG_PAIR_RA1 : 1) : LA ? TG_PAIR_RA : TG_PAIR_R;
   constexpr auto kern = w4_gemm_pair_kernel<DT, I, GPS, MR, QMX, RING, NSG, TG_PAIR_ABL, XG, LA>;
   if (pp.dry) return TG_PLAN_PAIR;
   const int prc = prepare_lds_kernel<kern>();
@@ -692,8 +698,9 @@ int launch_pair_k(PairParams& pp, unsigned lds, hipStream_t st) {
 // takes the activations pre-arranged from a caller-provided workspace (w4_xprep_kernel, one small launch in front).
 // Workspace = [batch][m k 2 bytes] arranged activations, then [batch][passes][groups][xs_rows] f32 sums.
 template <typename DT>
-int launch_xprep(const PairParams& pp, int I, int ma, int64_t batch, hipStream_t st) {
+int launch_xprep(const PairParams& pp, int I, int ma, int64_t batch, hipStream_t st, int la = 0) {
   XPrepParams xq;
+  xq.la = la;
   xq.x = pp.x; xq.xp = const_cast<char*>(pp.xp); xq.xsum = const_cast<char*>(pp.xsum);
   xq.m = pp.m; xq.k = pp.k; xq.ma = ma; xq.cps = I / 2; xq.gshift = pp.gshift; xq.gch_mask = pp.gch_mask;
   xq.ngroups = pp.ngroups; xq.xs_rows = pp.xs_rows;
@@ -813,7 +820,7 @@ template <typename DT, int I, bool QMX>
 int launch_pair_a(GemmParams& p, int64_t batch, hipStream_t st) {
   if constexpr (I < 2) return TG_PAIR_NA;  // one 16-k tile per word set: no word pair for a 32-k MFMA step
   else {
-  if (p.m > 8) return TG_PAIR_NA;
+  if (p.m > 16) return TG_PAIR_NA;
   const int g = 1 << p.gshift;
   const int gps = g >= 16 * I ? 1 : (16 * I) / g;
   PairParams pp;
@@ -829,13 +836,13 @@ int launch_pair_a(GemmParams& p, int64_t batch, hipStream_t st) {
   if (QMX && (p.ngroups < 16 || p.ngroups % 4 != 0 || ((pp.spw * gps) % 4 != 0 && pp.spw * gps > 12))) return TG_PAIR_NA;
   const int mrows = p.m;
   pp.rused = mrows < 4 ? mrows : 4;
-  pp.xs_rows = mrows <= 4 ? 4 : 8;
-  pp.red_lanes = 32;  // lanes 0..31 hold activation rows 0..7
+  pp.xs_rows = mrows <= 4 ? 4 : mrows <= 8 ? 8 : 16;
+  pp.red_lanes = mrows <= 8 ? 32 : 64;  // lanes 0..31 hold activation rows 0..7
   pp.x_pitch = 0;
   pp.lds_x = 65536;
-  pp.xw_pitch = 32 * I + 16;
-  pp.xw_bytes = (I == 2 ? 16 : 8) * pp.xw_pitch;
-  pp.lds_xs = (pp.lds_x + 8 * pp.xw_bytes + 32 * I + 15) & ~15;
+  pp.xw_pitch = 0;  // the lanes' MFMA operands come straight from the workspace: LDS only holds a zero piece here
+  pp.xw_bytes = 0;
+  pp.lds_xs = (pp.lds_x + 32 * I + 15) & ~15;
   pp.lds_red = (pp.lds_xs + (QMX ? 0 : p.ngroups * pp.xs_rows * 4) + 15) & ~15;  // mx4: no zero point, no activation sums
   unsigned lds = (unsigned)pp.lds_red + (unsigned)(8 * 2 * pp.rused * pp.red_lanes * 4);
   pp.red_alias = lds > 80u * 1024u;
@@ -844,7 +851,7 @@ int launch_pair_a(GemmParams& p, int64_t batch, hipStream_t st) {
     pp.lds_red = 0;
   }
   if (lds > 80u * 1024u) return TG_PAIR_NA;
-  pp.stride_xp = (int64_t)p.m * p.k * 2;
+  pp.stride_xp = (int64_t)(p.m + 1) * p.k * 2;  // + a zero row
   pp.stride_xsum = ((int64_t)p.ngroups * pp.xs_rows * 4 + 15) & ~(int64_t)15;
   const int64_t need = batch * (pp.stride_xp + pp.stride_xsum);
   pp.rblocks = (p.wrows + 31) / 32;
@@ -860,7 +867,7 @@ int launch_pair_a(GemmParams& p, int64_t batch, hipStream_t st) {
   pp.stride_lut = p.stride_lut; pp.stride_y = p.stride_y;
   pp.bias = p.bias; pp.stride_bias = p.stride_bias; pp.dry = p.dry;
   if (!p.dry) {
-    const int rc = launch_xprep<DT>(pp, I, 8, batch, st);
+    const int rc = launch_xprep<DT>(pp, I, 16, batch, st, 1);
     if (rc != 0) return rc;
   }
   if (gps == 1) {

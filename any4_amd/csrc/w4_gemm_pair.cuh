@@ -102,6 +102,12 @@ __device__ __forceinline__ f32x4_t mfma16(u32x4 a, u32x4 b, f32x4_t c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 
+__device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) {  // (mask & a) | (~mask & b)
+  uint32_t d;
+  asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(d) : "s"(mask), "v"(a), "v"(b));
+  return d;
+}
+
 template <typename DT>
 __device__ __forceinline__ float dot2_ones(uint32_t pair, float acc) {
   if constexpr (std::is_same<DT, BF16>::value)
@@ -140,8 +146,11 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
   constexpr int CPG = CPS / GPS;        // chunks per group inside a super-tile (GPS > 1 only)
   constexpr int MREGS = MR == 1 ? 4 : MR;  // accumulator registers of a row set
   constexpr int RF = MR;                   // registers that are finalised per group and exchanged at the end
-  constexpr int MA = 2 * MREGS;         // activation rows a pass can hold
-  constexpr int NXW = XG ? (MA * 2 * I + 63) / 64 : 1;  // XG: 16-byte pieces per lane of one super-tile's activation block
+  constexpr int MA = LA ? 16 : 2 * MREGS;  // activation rows a pass can hold
+  // XG: 16-byte pieces per lane of one super-tile's activation block.  A side: the lane's own MFMA operand of every 32-k chunk,
+  // straight from the workspace into registers (lane (row i, k-quad kb) of v_mfma_f32_16x16x32 needs exactly one piece per
+  // chunk): no LDS round trip for the activations at all
+  constexpr int NXW = LA ? I / 2 : XG ? (MA * 2 * I + 63) / 64 : 1;
   static_assert(!XG || MR <= 4, "XG: one pass is at most 8 activation rows");
 
   // The pair table sits at LDS address 0 (a lookup address is just byte << 8 | column << 2): the kernel has no static LDS,
@@ -228,10 +237,13 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
   struct Rows {
     uint32_t wbase[WT];
     uint32_t qrow[TILES];
+    uint32_t qrow4[TILES];  // byte offset of the row in a group's scale | zero words
     const char* wb;
     const char* qb;
     const char* xpb;  // XG: the pass's pre-arranged activations
     uint32_t xblk;    // XG: bytes of one super-tile's block (rows of the pass x 32 I)
+    uint32_t xoff[NXW];  // XG: this lane's piece(s) inside a super-tile's block (A side: inside a chunk's block; lanes whose
+                         // row is padding point at the block's zero row)
   };
   auto rows_of = [&](int it) -> Rows {
     const Item e = decode(it);
@@ -240,6 +252,7 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
     for (int t = 0; t < TILES; ++t) {
       const int row = min(e.rb * RW + wrow_local(t), p.wrows - 1);
       r.qrow[t] = (uint32_t)row;
+      r.qrow4[t] = (uint32_t)row * 4u;
       if constexpr (!LA) {
         const int nt = min(row >> 3, p.ntiles - 1);
         r.wbase[t] = ((uint32_t)nt * (uint32_t)p.ksuper * 32u + (uint32_t)(4 * (row & 7) + 2 * h)) * (uint32_t)(2 * I);
@@ -255,9 +268,18 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
       const int rows = min(p.m - e.ct * MA, MA);
       r.xpb = p.xp + (int64_t)e.b * p.stride_xp + (int64_t)e.ct * MA * p.k * 2;
       r.xblk = (uint32_t)(rows * 32 * I);
+      if constexpr (LA) {  // workspace [32-k chunk][k-quad][rows + 1][16 bytes]: row `rows` of every block is zero
+        r.xblk = (uint32_t)((rows + 1) * 64);  // bytes of one chunk's block
+        r.xoff[0] = (uint32_t)(((lane >> 4) * (rows + 1) + min(lane & 15, rows)) * 16);
+      } else {
+#pragma unroll
+        for (int i = 0; i < NXW; ++i) r.xoff[i] = (uint32_t)(lane + 64 * i) * 16u < r.xblk ? (uint32_t)(lane + 64 * i) * 16u : 0u;
+      }
     } else {
       r.xpb = nullptr;
       r.xblk = 0;
+#pragma unroll
+      for (int i = 0; i < NXW; ++i) r.xoff[i] = 0;
     }
     return r;
   };
@@ -265,22 +287,34 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
   // the number of loads in flight is the same on every path and the compiler's vmcnt bookkeeping stays exact -- a conditional
   // refill makes it wait for every outstanding load at the next use, draining the ring each round) but every lane reads the
   // first bytes of the operand: one cached request, never consumed.
-  auto issue = [&](const Rows& rw, int s, Slot& sl, bool valid, bool needq) {
-    const uint32_t vm = valid ? 0xffffffffu : 0u;
+  // Every address below is (wave-uniform base that moves with s) + (per-lane offset fixed for the item): the base lives in
+  // SGPRs, the loads take the saddr + VGPR-offset form and a request costs no vector ALU work.  An invalid request uses the
+  // item's super-tile 0.
+  // `pin` makes a per-lane offset opaque at its use: its zero-extension then stays next to the load (saddr form, 32-bit VGPR
+  // offset) instead of being hoisted out of the loop as a 64-bit register pair that every load adds to its base.
+  auto pin = [](uint32_t& v) -> uint32_t { asm volatile("" : "+v"(v)); return v; };
+  auto issue = [&](Rows& rw, int s, Slot& sl, bool valid, bool needq) {
+    // (readfirstlane keeps the moving part a scalar: otherwise loop strength reduction turns every address into a per-lane
+    //  64-bit induction variable -- two vector adds and two more VGPRs per load)
+    auto uni = [](uint32_t v) -> uint32_t { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
+    const uint32_t sv = valid ? (uint32_t)s : 0u;
     if constexpr (XG) {
       // lanes beyond the block re-read its first piece (never stored): the load stays unconditional
 #pragma unroll
       for (int i = 0; i < NXW; ++i) {
-        const uint32_t pc = (uint32_t)(lane + 64 * i) * 16u;
-        if constexpr (ABL == 9) sl.xw[i] = u32x4{pc, (uint32_t)s, 0x3f803f80u, 0x3f803f80u};  // ablation: no activation loads
-        else sl.xw[i] = *reinterpret_cast<const u32x4*>(rw.xpb + (((uint32_t)s * rw.xblk + (pc < rw.xblk ? pc : 0u)) & vm));
+        if constexpr (LA) {  // chunk s CPS + i: a block of 4 k-quads x (rows + the zero row) pieces
+          sl.xw[i] = *reinterpret_cast<const u32x4*>(rw.xpb + uni((sv * CPS + (uint32_t)i) * rw.xblk) + pin(rw.xoff[0]));
+          continue;
+        }
+        if constexpr (ABL == 9) sl.xw[i] = u32x4{rw.xoff[i], (uint32_t)s, 0x3f803f80u, 0x3f803f80u};  // ablation: no activation loads
+        else sl.xw[i] = *reinterpret_cast<const u32x4*>(rw.xpb + uni(sv * rw.xblk) + pin(rw.xoff[i]));
       }
     }
 #pragma unroll
     for (int t = 0; t < TILES; ++t) {
       if (t < WT) {  // (compile-time; the A side's two tiles share one set of words)
         const int tw = t < WT ? t : 0;
-        const char* src = rw.wb + ((rw.wbase[tw] + (uint32_t)s * (uint32_t)((LA ? 128 : 64) * I)) & vm);
+        const char* src = rw.wb + uni(sv * (uint32_t)((LA ? 128 : 64) * I)) + pin(rw.wbase[tw]);
         if constexpr (ABL == 3) {
 #pragma unroll
           for (int j = 0; j < I; ++j) sl.w[tw][j] = (uint32_t)(s * 7 + j + t);
@@ -303,10 +337,10 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
 #pragma unroll
       for (int gg = 0; gg < GPS; ++gg) {
         if (!needq) continue;  // (compile-time per call site) not the first super-tile of its group
-        const uint32_t g = (uint32_t)(((s * CPS + gg * CPG) * 32) >> p.gshift);
+        const uint32_t g = (uint32_t)(((sv * CPS + gg * CPG) * 32) >> p.gshift);
         if constexpr (ABL == 8) sl.q[t][gg] = 0x3c003c00u + (uint32_t)s;  // ablation: no scale | zero loads
         else if constexpr (QMX) sl.q[t][gg] = 0u;  // mx4: the exponents come in 16-byte blocks per row, see e_request
-        else sl.q[t][gg] = *reinterpret_cast<const uint32_t*>(rw.qb + (((g * (uint32_t)p.wrows + rw.qrow[t]) * 4u) & vm));
+        else sl.q[t][gg] = *reinterpret_cast<const uint32_t*>(rw.qb + uni(g * (uint32_t)p.wrows * 4u) + pin(rw.qrow4[t]));
       }
     }
   };
@@ -317,14 +351,13 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
   constexpr int EBS = QMX ? 16 / GPS : 1;  // super-tiles per exponent block
   u32x4 ecur[TILES], enext[TILES];
   int eoff_next = 0;
-  auto e_request = [&](const Rows& rw, int blk, bool valid) {
-    const uint32_t vm = valid ? 0xffffffffu : 0u;
+  auto e_request = [&](Rows& rw, int blk, bool valid) {
     const int start = s_begin * GPS + blk * 16;          // first group of the block
     const int st = max(min(start & ~3, p.ngroups - 16), 0);  // 4-byte aligned; the last block of a row is moved back inside the row
     eoff_next = start - st;
 #pragma unroll
     for (int t = 0; t < TILES; ++t)
-      enext[t] = *reinterpret_cast<const u32x4*>(rw.qb + ((rw.qrow[t] * (uint32_t)p.ngroups + (uint32_t)st) & vm));
+      enext[t] = *reinterpret_cast<const u32x4*>(rw.qb + (uint32_t)__builtin_amdgcn_readfirstlane(valid ? st : 0) + rw.qrow[t] * (uint32_t)p.ngroups);
   };
   int ebase = 0;  // byte of ecur that holds group 0 of the wave's slice (block start and the shift above folded in)
   // the dword of ecur[t] that holds the exponents of slice group gi (wave-uniform); the GPS groups of one super-tile share it
@@ -440,7 +473,7 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
     const int a0 = cur.ct * MA;
     const int mrows = min(p.m - a0, MA);
     const bool has_next = it + it_stride < it_end;
-    const Rows rnext = rows_of(has_next ? it + it_stride : it);
+    Rows rnext = rows_of(has_next ? it + it_stride : it);
 
 #ifdef TG_PAIR_NOLP  // experiment: no LUT prefetch across the main loop (8 VGPRs less, LUT latency exposed)
     if (lut_loaded && it != it_begin) lut_request(it);
@@ -481,6 +514,8 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
     // ---- main loop of the item ----
     const bool a_on = xa < mrows;  // this lane's A-operand row is a real activation row; the others read the zero piece
     const uint32_t xzero = XG ? lds_x + (uint32_t)(WAVES * p.xw_bytes) : lds_x + (uint32_t)(mrows * p.x_pitch);
+    const uint32_t xs_mask = 4 * hh < p.xs_rows ? 0xffffffffu : 0u;
+    const uint32_t xs_lane = 4 * hh < p.xs_rows ? lds_xs + (uint32_t)(4 * hh * 4) : xzero;
     const uint32_t xwbuf = lds_x + (uint32_t)(wave * p.xw_bytes);  // XG: this wave's activation buffer (one super-tile)
     const uint32_t xrow = !a_on ? xzero : XG ? xwbuf + (uint32_t)(xa * p.xw_pitch + xq * 16) : lds_x + (uint32_t)(xa * p.x_pitch + xq * 16);
     const uint32_t xmask = a_on && !XG ? 0xffffffffu : 0u;  // lanes on the zero piece (and XG lanes: one buffer) never move
@@ -552,7 +587,7 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
     uint32_t edw[TILES] = {0u, 0u};  // mx4: the exponent dword of the current super-tile
     auto consume = [&](int s, const Slot& sl, int j_slot) {
       const uint32_t xst = xrow + ((uint32_t)(s * CPS * 64) & xmask);  // this lane's X pieces of the super-tile
-      if constexpr (XG) {
+      if constexpr (XG && !LA) {
         // the wave's own DS operations execute in order: the reads of the previous super-tile are behind us, the reads below
         // follow this store; no barrier
         // every lane stores (the buffer has a row for each: rows past the pass's are never read): a store under a lane mask
@@ -583,6 +618,7 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
         u32x4 xf;
         u32x4 bf[TILES];
         if constexpr (ABL == 5) xf = u32x4{xrow, (uint32_t)s, (uint32_t)jc, (uint32_t)qq};  // ablation: no X reads
+        else if constexpr (LA) xf = sl.xw[jc];
         else xf = *(lds_cu32x4ptr)(xst + (uint32_t)(jc * 64 + 16 * qq));
 #pragma unroll
         for (int t = 0; t < TILES; ++t) {
@@ -594,7 +630,8 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
               const uint32_t w = sl.w[0][2 * jc + e];
-              uw[e] = t == 0 ? ((w & 0x0f0f0f0fu) | ((w >> 4) & 0xf0f0f0f0u)) : ((w & 0xf0f0f0f0u) | ((w << 4) & 0x0f0f0f0fu));
+              // (mask & w) | (~mask & shifted w): one v_bfi_b32 (the compiler's own choice for the C expression is three ops)
+              uw[e] = t == 0 ? bfi(0x0f0f0f0fu, w, w >> 4) : bfi(0xf0f0f0f0u, w, w << 4);
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -638,14 +675,14 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
           }
           if constexpr (!QMX) {
             // lanes whose accumulator rows are all padding (lane half 1 when m <= 4) read the zero piece behind the staged rows
-            const uint32_t xsa = 4 * hh < p.xs_rows ? lds_xs + (uint32_t)((((chunk * 32) >> p.gshift) * p.xs_rows + 4 * hh) * 4)
-                                                   : xzero;
+            // (branch-free: a data-dependent branch in this loop makes the compiler copy accumulators around it)
+            const uint32_t xsa = xs_lane + ((uint32_t)((((chunk * 32) >> p.gshift) * p.xs_rows) * 4) & xs_mask);
             if constexpr (RF == 1) {
               xsv[0] = *(const __attribute__((address_space(3))) float*)(xsa);
             } else {
 #pragma unroll
               for (int r4 = 0; r4 < MREGS / 4; ++r4) {
-                const f32x4 vv = *(lds_cf32x4ptr)(xsa + (uint32_t)(4 * hh < p.xs_rows ? r4 * 32 : 0));
+                const f32x4 vv = *(lds_cf32x4ptr)(xsa + ((uint32_t)(r4 * 32) & xs_mask));
                 xsv[4 * r4] = vv[0]; xsv[4 * r4 + 1] = vv[1]; xsv[4 * r4 + 2] = vv[2]; xsv[4 * r4 + 3] = vv[3];
               }
             }
@@ -746,6 +783,7 @@ struct XPrepParams {
   char* xp;
   char* xsum;
   int32_t m, k, ma, cps, gshift, gch_mask, ngroups, xs_rows;
+  int32_t la;  // 1: A-side order [32-k chunk][k-quad][rows + 1]: the last row of every block is zero
   int64_t stride_x, stride_xp, stride_xsum;
 };
 
@@ -771,7 +809,9 @@ __global__ void __launch_bounds__(256) w4_xprep_kernel(const XPrepParams p) {
   const int rows = min(p.m - ct * p.ma, p.ma);
   if (on) {
     const int s = ch / p.cps, jc = ch - s * p.cps;
-    char* dst = p.xp + (int64_t)b * p.stride_xp + (int64_t)ct * p.ma * p.k * 2 + ((int64_t)(s * rows + ar) * p.cps + jc) * 64;
+    char* dst = p.xp + (int64_t)b * p.stride_xp + (int64_t)ct * p.ma * p.k * 2 +
+                (p.la ? ((int64_t)ch * 4 * (rows + 1) + ar) * 16 : ((int64_t)(s * rows + ar) * p.cps + jc) * 64);
+    const int qstride = p.la ? rows + 1 : 1;  // in 16-byte pieces
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       u32x4 o;
@@ -779,8 +819,11 @@ __global__ void __launch_bounds__(256) w4_xprep_kernel(const XPrepParams p) {
       o[1] = __builtin_amdgcn_perm(d[q + 12], d[q + 8], 0x05040100u);
       o[2] = __builtin_amdgcn_perm(d[q + 4], d[q], 0x07060302u);
       o[3] = __builtin_amdgcn_perm(d[q + 12], d[q + 8], 0x07060302u);
-      reinterpret_cast<u32x4*>(dst)[q] = o;
+      reinterpret_cast<u32x4*>(dst)[q * qstride] = o;
     }
+    if (p.la && ar == 0)  // the zero row of this chunk's blocks
+#pragma unroll
+      for (int q = 0; q < 4; ++q) reinterpret_cast<u32x4*>(dst)[q * qstride + rows] = u32x4{0, 0, 0, 0};
   }
   float sum = 0.f;
 #pragma unroll

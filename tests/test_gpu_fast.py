@@ -183,12 +183,12 @@ def test_pair_kernel_workspace_variant(T, oracle, case):
 @pytest.mark.parametrize("inner", [2, 4])
 @pytest.mark.parametrize("g", [32, 64, 128, 256])
 def test_pair_kernel_a_side(T, oracle, qtype, inner, g):
-    """Aint4 weights (weightOnRight = false) on the pair-table kernel: 16x16x32 MFMA tiles, duplicated table, m <= 8."""
+    """Aint4 weights (weightOnRight = false) on the pair-table kernel: 16x16x32 MFMA tiles, duplicated table, m <= 16."""
     from any4_amd import ops
 
     if qtype == "mx4":
         g = 32
-    for (n, k, m) in [(64, 1024, 1), (40, 512, 3), (136, 2048, 8), (80, 8192, 8), (48, 4096, 5)]:
+    for (n, k, m) in [(64, 1024, 1), (40, 512, 3), (136, 2048, 8), (80, 8192, 8), (48, 4096, 5), (64, 2048, 12), (48, 1024, 16)]:
         if k % (16 * inner) or k % g:
             continue
         codes, x, qinfo, lut = rand_problem(n, k, g, m, qtype, seed=n + k + inner + 1)
