@@ -97,6 +97,7 @@ __device__ __forceinline__ void store_rows4(char* yb, const char* bias, int64_t 
 #include "w4_gemm.cuh"
 #include "w4_gemm_stream.cuh"
 #include "w4_gemm_pair.cuh"
+#include "w4_gemm_pair16.cuh"
 #include "w8_gemm.cuh"
 
 #ifndef STREAM_MINW
@@ -814,6 +815,54 @@ int launch_pair(GemmParams& p, int64_t batch, hipStream_t st) {
   return TG_PAIR_NA;
 }
 
+// Small launches of Bint4 weights (one layer per call): w4_gemm_pair16_kernel, 16 weight rows per workgroup, the whole k-slice
+// of a wave requested up front.  Taken when the launch is too small for the persistent kernel (or its LDS plan does not fit)
+// and the activations (m <= 16 rows) fit in LDS next to the table.
+template <typename DT, int I, bool QMX>
+int launch_pair16(const GemmParams& p, int64_t batch, hipStream_t st) {
+  if constexpr (QMX && !std::is_same<DT, BF16>::value) return TG_E_DTYPE;  // mx4 is bf16-only (TinyGemm_int4.cu:758)
+  else {
+#ifdef TG_DEV_MIN
+  if constexpr (!(std::is_same<DT, BF16>::value && I == 4 && !QMX)) return TG_PAIR_NA;
+#endif
+  if (p.m > 16 || batch > 65535) return TG_PAIR_NA;
+  const int g = 1 << p.gshift;
+  const int nsg = g >= 16 * I ? g / (16 * I) : 1;
+  Pair16Params pp;
+  pp.x = p.x; pp.w = p.w; pp.qinfo = p.qinfo; pp.lut = p.lut; pp.y = p.y;
+  pp.m = p.m; pp.wrows = p.wrows; pp.k = p.k; pp.ntiles = p.ntiles; pp.ksuper = p.ksuper;
+  pp.gshift = p.gshift; pp.ngroups = p.ngroups; pp.qtype = p.qtype;
+  pp.spw = ((p.ksuper / nsg + 15) / 16) * nsg;
+  pp.gch_mask = g / 32 - 1;
+  pp.x_pitch = p.k * 2 + 16;
+  pp.lds_x = 65536;
+  pp.lds_xs = (pp.lds_x + p.m * pp.x_pitch + 16 + 15) & ~15;
+  const unsigned lds = (unsigned)pp.lds_xs + (QMX ? 0u : (unsigned)p.ngroups * 64u);
+  const int64_t wgs = (int64_t)((p.wrows + 15) / 16) * batch;
+  // one workgroup per CU may take the whole LDS; a launch of more than two rounds of workgroups should fit two per CU
+  if (lds > (wgs <= 512 ? 160u : 80u) * 1024u) return TG_PAIR_NA;
+  pp.stride_x = p.stride_x; pp.stride_w = p.stride_w; pp.stride_qinfo = p.stride_qinfo;
+  pp.stride_lut = p.stride_lut; pp.stride_y = p.stride_y;
+  pp.bias = p.bias; pp.stride_bias = p.stride_bias;
+  if (p.dry) return TG_PLAN_PAIR;
+  const dim3 grid((unsigned)((p.wrows + 15) / 16), (unsigned)batch);
+#define TG_P16(CPG_)                                                        \
+  do {                                                                      \
+    constexpr auto kern = w4_gemm_pair16_kernel<DT, I, QMX, CPG_>;          \
+    const int prc = prepare_lds_kernel<kern>();                             \
+    if (prc != 0) return prc;                                               \
+    hipLaunchKernelGGL(kern, grid, dim3(1024), lds, st, pp);                \
+  } while (0)
+  if constexpr (QMX) TG_P16(1);  // mx4: group = 32
+  else if (g == 32) TG_P16(1);
+  else if (g == 64) TG_P16(2);
+  else if (g == 128) TG_P16(4);
+  else TG_P16(8);
+#undef TG_P16
+  return launch_status();
+  }
+}
+
 // Aint4 weights (weightOnRight = false) on the pair-table kernel: 32 weight rows per work item, v_mfma_f32_16x16x32,
 // activations always through the workspace (one pass of at most 8 rows).
 template <typename DT, int I, bool QMX>
@@ -905,6 +954,10 @@ int launch_w4(GemmParams& p, int64_t coltiles, int64_t batch, hipStream_t st) {
     else rc = launch_pair<DT, 2 * WPL, QMX>(p, batch, st);
     if (rc != TG_PAIR_NA) return rc;
     p.ws_need = 0;
+    if constexpr (!LAYOUT_A) {
+      rc = launch_pair16<DT, 2 * WPL, QMX>(p, batch, st);
+      if (rc != TG_PAIR_NA) return rc;
+    }
   }
   // m = 1 always streams: with private X slabs its split-K variants beat the latency kernel down to one matrix
   if (use_stream && (g.waves == 8 || p.m == 1 || use_stream == 2) && (1 << p.gshift) >= (LAYOUT_A ? 64 : 128)) {

@@ -1,0 +1,318 @@
+// w4_gemm_pair16.cuh -- the pair-table W4A16 kernel for SMALL launches (one Any4Linear.forward: a single 4096 x 4096 layer is
+// 64 work items of w4_gemm_pair_kernel -- a quarter of the chip, each wave walking 16 KiB through a two-deep ring).
+//
+// Same contract and numerics as w4_gemm_pair.cuh (TG_NUM_FAST, group-scaled), Bint4 weights (reference TinyGemmImpl.cuh:23-345
+// with BLayout_TC_int4, MatrixLayoutB.cuh:686-1101, Dequantization.cuh:55-178, 331-351), other decomposition:
+//
+//   workgroup  = 16 weight rows (two 8-row tiles of the layout) x the whole k, 16 waves, split-K 16: a 4096-row layer is 256
+//                workgroups, one per CU; nothing persistent, no ring: a wave requests its WHOLE k-slice (k = 4096: 4 super-tiles
+//                = 8 packed words per lane) before it does anything else, so the launch costs one memory round trip, and the
+//                dependent chain of a wave (lookup -> MFMA, 8 steps) is short.
+//   MFMA       = v_mfma_f32_16x16x32: lane (n = lane & 15, q = lane >> 4) holds, in ONE packed word of the reference layout, the 8
+//                codes of weight row n at k = 2 q + {0, 16, 1, 17, 8, 24, 9, 25} of a 32-k chunk (TinyGemmConvertB.cu:252-308) --
+//                exactly one B operand.  A operand = activations, lane (row i = lane & 15, k-quad q): the 16-byte piece (chunk, q)
+//                of the byte-order staging of w4_gemm_pair.cuh.  D[i][n]: lane (n, q) holds activation rows 4 q + r of ITS row.
+//   table      = [256 byte values][64 columns] x 4 bytes at LDS address 0 as in the large kernel (address = byte << 8 | column
+//                << 2, one v_perm_b32); only columns 16 (q & 1) + n are used: the two lanes of a 32-lane LDS access group that
+//                share a weight row read different copies, a group touches 32 distinct banks.
+//   activations= m <= 16 rows staged whole in LDS (byte order) with their per-group sums.
+#pragma once
+#ifndef P16_ABL
+#define P16_ABL 0  // developer ablations (0 in the product)
+#endif
+
+struct Pair16Params {
+  const char* x;
+  const char* w;
+  const char* qinfo;
+  const char* lut;
+  char* y;
+  int32_t m, wrows, k;
+  int32_t ntiles;    // packed.size(0): 8-row tiles
+  int32_t ksuper;    // packed.size(1)
+  int32_t gshift, ngroups, qtype;
+  int32_t spw;       // k super-tiles per wave (whole groups)
+  int32_t gch_mask;  // 32-k chunks per group - 1
+  int32_t x_pitch;   // bytes per staged activation row
+  int32_t lds_x, lds_xs;  // LDS byte offsets: staged activations (m rows + a 16-byte zero piece), sums f32 [ngroups][16]
+  int64_t stride_x, stride_w, stride_qinfo, stride_lut, stride_y;
+  const char* bias;
+  int64_t stride_bias;
+};
+
+// I   = innerKTiles of the Bint4 layout (2, 4, 8): I / 2 words per lane and super-tile (one per 32-k chunk)
+// CPG = 32-k chunks per quantisation group (1, 2, 4, 8): a full block of CH super-tiles then has its group boundaries at fixed
+//       places of the unrolled code (no branches between the steps)
+template <typename DT, int I, bool QMX, int CPG>
+__global__ void __launch_bounds__(1024) w4_gemm_pair16_kernel(const Pair16Params p) {
+  constexpr int WAVES = 16;
+  constexpr int NT = WAVES * 64;
+  constexpr int CPS = I / 2;  // 32-k chunks (= words per lane) of a super-tile
+  constexpr int CH = 4;       // super-tiles requested at once (k = 4096, I = 4: the whole slice)
+  constexpr bool STATIC_G = (CH * CPS) % CPG == 0;
+  const uint32_t lds_x = (uint32_t)p.lds_x, lds_xs = (uint32_t)p.lds_xs;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = lane & 15, q = lane >> 4;
+  const int b = blockIdx.y;
+  const int row0 = blockIdx.x * 16;
+
+  const int s_begin = wave * p.spw;
+  const int nl = max(min(p.spw, p.ksuper - s_begin), 0);
+
+  // ---- requests, in the order they are consumed: LUT row of this thread's table column, activations, weights ----
+  const int tcol = tid & 31;                     // table column = 16 copy + row
+  const int trow = min(row0 + (tcol & 15), p.wrows - 1);
+  uint32_t lp[8];
+  if (p.qtype == TG_Q_ANY4_GLOBAL || p.qtype == TG_Q_ANY4_ROWWISE) {
+    const char* lsrc = p.lut + (int64_t)b * p.stride_lut + (p.qtype == TG_Q_ANY4_ROWWISE ? (int64_t)trow * 32 : 0);
+    const u32x4 l0 = reinterpret_cast<const u32x4*>(lsrc)[0];
+    const u32x4 l1 = reinterpret_cast<const u32x4*>(lsrc)[1];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { lp[j] = l0[j]; lp[4 + j] = l1[j]; }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 16; e += 2) {
+      float v0, v1;
+      if (p.qtype == TG_Q_INT4) {
+        v0 = (float)(e - 8);
+        v1 = (float)(e - 7);
+      } else {  // fp4 e2m1 (mx4)
+        const int e1 = e + 1;
+        v0 = (e & 8 ? -1.f : 1.f) * ((e & 7) < 5 ? 0.5f * (e & 7) : ((e & 7) == 5 ? 3.f : (e & 7) == 6 ? 4.f : 6.f));
+        v1 = (e1 & 8 ? -1.f : 1.f) * ((e1 & 7) < 5 ? 0.5f * (e1 & 7) : ((e1 & 7) == 5 ? 3.f : (e1 & 7) == 6 ? 4.f : 6.f));
+      }
+      lp[e >> 1] = DT::pack2(v0, v1);
+    }
+  }
+
+  // activations: chunk (row a, 32 k) per thread, 64 bytes
+  const int nch = p.k >> 5;
+  const int xtotal = p.m * nch;
+  const char* xb = p.x + (int64_t)b * p.stride_x;
+  uint32_t xd[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) xd[j] = 0u;
+  auto x_load = [&](int xi) {
+    const int a = xi / nch, ch = xi - a * nch;
+    const u32x4* src = reinterpret_cast<const u32x4*>(xb + ((int64_t)a * p.k + ch * 32) * 2);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const u32x4 v = src[j];
+      xd[4 * j] = v[0]; xd[4 * j + 1] = v[1]; xd[4 * j + 2] = v[2]; xd[4 * j + 3] = v[3];
+    }
+  };
+  if (tid < xtotal) x_load(tid);
+
+  // weights of this lane: row n of the workgroup's 16, quad q
+  const int wrow = min(row0 + n, p.wrows - 1);
+  const int nt = min(wrow >> 3, p.ntiles - 1);
+  const char* wl = p.w + (int64_t)b * p.stride_w + ((int64_t)nt * p.ksuper * 32 + (4 * (wrow & 7) + q)) * (2 * I);
+  const char* qb = p.qinfo + (int64_t)b * p.stride_qinfo;
+  uint32_t wreg[CH][CPS];
+  uint32_t qreg[CH][CPS];  // scale | zero word (or mx4 exponent byte) of the group of every chunk
+  auto w_request = [&](int l0) {
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      const int l = l0 + j;
+      const int s = nl > 0 ? s_begin + (l < nl ? l : 0) : 0;  // past the slice: re-read its first super-tile (never consumed)
+      const char* src = wl + (int64_t)s * (64 * I);
+      if constexpr (I == 2) {
+        wreg[j][0] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(src));
+      } else if constexpr (I == 4) {
+        const u32x2 v = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(src));
+        wreg[j][0] = v[0]; wreg[j][1] = v[1];
+      } else {
+        const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src));
+        wreg[j][0] = v[0]; wreg[j][1] = v[1]; wreg[j][2] = v[2]; wreg[j][3] = v[3];
+      }
+#pragma unroll
+      for (int jc = 0; jc < CPS; ++jc) {
+        const int g = ((s * CPS + jc) * 32) >> p.gshift;
+        if constexpr (QMX) qreg[j][jc] = *reinterpret_cast<const uint8_t*>(qb + (int64_t)wrow * p.ngroups + g);
+        else qreg[j][jc] = *reinterpret_cast<const uint32_t*>(qb + ((int64_t)g * p.wrows + wrow) * 4);
+      }
+    }
+  };
+  if (P16_ABL != 1) w_request(0);
+  else {
+#pragma unroll
+    for (int j = 0; j < CH; ++j)
+#pragma unroll
+      for (int jc = 0; jc < CPS; ++jc) { wreg[j][jc] = (uint32_t)(tid * 977 + j * 13 + jc); qreg[j][jc] = 0x3c003c00u; }
+  }
+
+  // ---- stage the activations (byte order) and their group sums; build the table ----
+  auto x_store = [&](int xi, bool on) {
+    const int a = on ? xi / nch : 0, ch = on ? xi - (xi / nch) * nch : 0;
+    if (on) {
+      const uint32_t dst = lds_x + (uint32_t)(a * p.x_pitch + ch * 64);
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) {
+        u32x4 o;
+        o[0] = __builtin_amdgcn_perm(xd[qq + 4], xd[qq], 0x05040100u);       // x[2q]     x[2q+8]
+        o[1] = __builtin_amdgcn_perm(xd[qq + 12], xd[qq + 8], 0x05040100u);  // x[2q+16]  x[2q+24]
+        o[2] = __builtin_amdgcn_perm(xd[qq + 4], xd[qq], 0x07060302u);       // x[2q+1]   x[2q+9]
+        o[3] = __builtin_amdgcn_perm(xd[qq + 12], xd[qq + 8], 0x07060302u);  // x[2q+17]  x[2q+25]
+        *(lds_u32x4ptr)(dst + (uint32_t)(qq * 16)) = o;
+      }
+    }
+    if constexpr (!QMX) {
+      float sum = 0.f;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) sum = dot2_ones<DT>(xd[j], sum);
+      for (int o = 1; o <= p.gch_mask; o <<= 1) sum += __shfl_xor(sum, o);
+      if (on && (ch & p.gch_mask) == 0) *(lds_fptr)(lds_xs + (uint32_t)(((ch >> (p.gshift - 5)) * 16 + a) * 4)) = sum;
+    }
+  };
+  for (int it0 = 0; it0 < (P16_ABL == 3 ? 0 : xtotal); it0 += NT) {
+    const int xi = it0 + tid;
+    const bool on = xi < xtotal;
+    if (it0 > 0) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) xd[j] = 0u;
+      if (on) x_load(xi);
+    }
+    x_store(xi, on);
+  }
+  if constexpr (!QMX)
+    for (int idx = tid; idx < p.ngroups * 16; idx += NT)
+      if ((idx & 15) >= p.m) *(lds_fptr)(lds_xs + (uint32_t)(idx * 4)) = 0.f;
+  if (tid == 0) *(lds_u32x4ptr)(lds_x + (uint32_t)(p.m * p.x_pitch)) = u32x4{0, 0, 0, 0};  // zero piece for padding rows
+  {
+    // thread = (column tcol, high nibble (tid >> 5) & 15, half tid >> 9 of the low nibbles): entries (lut[lo], lut[hi])
+    const int hi = (tid >> 5) & 15, half = tid >> 9;
+    uint32_t hw = lp[0];
+#pragma unroll
+    for (int j = 1; j < 8; ++j) hw = ((hi >> 1) == j) ? lp[j] : hw;
+    const uint32_t hsel = (hi & 1) ? 0x07060000u : 0x05040000u;  // the high half of the entry: value `hi` of the pair hw
+    const uint32_t base = (uint32_t)((hi * 16 + half * 8) * 256 + tcol * 4);
+    // (masks, not `half ? lp[4 + j] : lp[j]`: a select between two array elements becomes a dynamically indexed private array,
+    //  which the compiler then moves to static LDS -- and this kernel's table must start at LDS address 0)
+    const uint32_t hm = half ? 0xffffffffu : 0u;
+    uint32_t lq[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) lq[j] = (lp[4 + j] & hm) | (lp[j] & ~hm);
+#pragma unroll
+    for (int a = 0; a < (P16_ABL == 4 ? 1 : 8); ++a) {
+      const uint32_t e = __builtin_amdgcn_perm(hw, lq[a >> 1], hsel | ((a & 1) ? 0x0302u : 0x0100u));
+      *(lds_u32ptr)(base + (uint32_t)(a * 256)) = e;
+    }
+  }
+  __syncthreads();
+
+  // ---- main loop ----
+  const bool a_on = n < p.m;  // (as the A operand's row index: lane (i = n, q))
+  const uint32_t xzero = lds_x + (uint32_t)(p.m * p.x_pitch);
+  const uint32_t xrow = a_on ? lds_x + (uint32_t)(n * p.x_pitch + q * 16) : xzero;
+  const uint32_t xmask = a_on ? 0xffffffffu : 0u;
+  const uint32_t colreg = (uint32_t)((16 * (q & 1) + n) * 4);
+  // this lane's accumulator rows are activation rows 4 q + r
+  const uint32_t xs_lane = lds_xs + (uint32_t)(4 * q * 4);
+
+  f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+  float yacc[4] = {0.f, 0.f, 0.f, 0.f};
+  float gs = 0.f, gz = 0.f;
+  f32x4 xsv = {0.f, 0.f, 0.f, 0.f};
+  const f32x4_t zero4 = {0.f, 0.f, 0.f, 0.f};
+
+  if (P16_ABL == 2) {  // loads consumed, nothing computed
+#pragma unroll
+    for (int j = 0; j < CH; ++j)
+#pragma unroll
+      for (int jc = 0; jc < CPS; ++jc) yacc[0] += u2f(wreg[j][jc] ^ qreg[j][jc]);
+  }
+  for (int l0 = 0; l0 < (P16_ABL == 2 ? 0 : nl); l0 += CH) {
+    if (l0 > 0) w_request(l0);
+    if (STATIC_G && l0 + CH <= nl) {
+      // a whole block: the slice starts on a group boundary and CH CPS is a multiple of CPG, so step u starts a group iff
+      // u % CPG == 0 -- straight-line code
+      const int chunk0 = (s_begin + l0) * CPS;
+#pragma unroll
+      for (int u = 0; u < CH * CPS; ++u) {
+        const int j = u / CPS, jc = u % CPS;
+        const u32x4 xf = *(lds_cu32x4ptr)(xrow + ((uint32_t)((chunk0 + u) * 64) & xmask));
+        u32x4 bf;
+        const uint32_t w = wreg[j][jc];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bf[e] = *(lds_cu32ptr)(__builtin_amdgcn_perm(w, colreg, 0x0c0c0400u + ((uint32_t)e << 8)));
+        if (u % CPG == 0) {
+          const uint32_t qv = qreg[j][jc];
+          if constexpr (QMX) {
+            gs = u2f(qv == 255u ? 0x7fc00000u : (qv == 0u ? 0x00400000u : (qv << 23)));
+          } else {
+            gs = DT::lo_f32(qv);
+            gz = DT::hi_f32(qv);
+            xsv = *(lds_cf32x4ptr)(xs_lane + (uint32_t)(((((chunk0 + u) * 32) >> p.gshift) * 16) * 4));
+          }
+          acc = mfma16<DT>(xf, bf, zero4);
+        } else {
+          acc = mfma16<DT>(xf, bf, acc);
+        }
+        if (u % CPG == CPG - 1) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            yacc[r] = __builtin_fmaf(gs, acc[r], yacc[r]);
+            if constexpr (!QMX) yacc[r] = __builtin_fmaf(gz, xsv[r], yacc[r]);
+          }
+        }
+      }
+      continue;
+    }
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      if (l0 + j < nl) {
+        const int s = s_begin + l0 + j;
+#pragma unroll
+        for (int jc = 0; jc < CPS; ++jc) {
+          const int chunk = s * CPS + jc;
+          const bool gfirst = (chunk & p.gch_mask) == 0, glast = (chunk & p.gch_mask) == p.gch_mask;
+          const u32x4 xf = *(lds_cu32x4ptr)(xrow + ((uint32_t)(chunk * 64) & xmask));
+          u32x4 bf;
+          const uint32_t w = wreg[j][jc];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) bf[e] = *(lds_cu32ptr)(__builtin_amdgcn_perm(w, colreg, 0x0c0c0400u + ((uint32_t)e << 8)));
+          if (gfirst) {
+            const uint32_t qv = qreg[j][jc];
+            if constexpr (QMX) {
+              gs = u2f(qv == 255u ? 0x7fc00000u : (qv == 0u ? 0x00400000u : (qv << 23)));  // Dequantization.cuh:331-339
+            } else {
+              gs = DT::lo_f32(qv);
+              gz = DT::hi_f32(qv);
+              xsv = *(lds_cf32x4ptr)(xs_lane + (uint32_t)((((chunk * 32) >> p.gshift) * 16) * 4));
+            }
+          }
+          acc = mfma16<DT>(xf, bf, gfirst ? zero4 : acc);
+          if (glast) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              yacc[r] = __builtin_fmaf(gs, acc[r], yacc[r]);
+              if constexpr (!QMX) yacc[r] = __builtin_fmaf(gz, xsv[r], yacc[r]);
+            }
+          }
+        }
+      }
+    }
+  }
+
+  // ---- split-K tail: partial sums of the 8 waves meet in the (now unused) table's LDS, added in wave order ----
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 4; ++r) *(lds_fptr)((uint32_t)(((wave * 4 + r) * 64 + lane) * 4)) = yacc[r];
+  __syncthreads();
+  if (tid < 256) {
+    const int r = tid >> 6, l = tid & 63;
+    const int a = 4 * (l >> 4) + r, row = row0 + (l & 15);
+    if (a < p.m && row < p.wrows) {
+      float sum = 0.f;
+#pragma unroll
+      for (int w8 = 0; w8 < WAVES; ++w8) sum += *(lds_fptr)((uint32_t)(((w8 * 4 + r) * 64 + l) * 4));
+      uint16_t o16 = DT::from_f32(sum);
+      if (p.bias)  // rounded sum + bias, rounded again: the reference module's separate `y + bias` (modules.py:221-222)
+        o16 = DT::from_f32(DT::lo_f32(o16) + DT::lo_f32(*reinterpret_cast<const uint16_t*>(p.bias + (int64_t)b * p.stride_bias + (int64_t)row * 2)));
+      *reinterpret_cast<uint16_t*>(p.y + (int64_t)b * p.stride_y + ((int64_t)a * p.wrows + row) * 2) = o16;
+    }
+  }
+}

@@ -204,6 +204,33 @@ def test_pair_kernel_a_side_fp16_bias(T, oracle):
     assert_fast_close(oracle, y, codes, x, qinfo, lut, 128, "any4_rowwise", dtype=torch.float16, batch=copies, on_right=False)
 
 
+@pytest.mark.parametrize("qtype", ["any4_rowwise", "any4_global", "int4", "mx4"])
+@pytest.mark.parametrize("inner", [2, 4, 8])
+@pytest.mark.parametrize("g", [32, 64, 128, 256])
+def test_pair16_single_launch(T, oracle, qtype, inner, g):
+    """One problem per launch (what Any4Linear.forward issues): w4_gemm_pair16_kernel, 16 weight rows per workgroup, m <= 16."""
+    if qtype == "mx4":
+        g = 32
+    for (n, k, m) in [(64, 1024, 1), (40, 512, 3), (136, 2048, 8), (24, 4096, 1), (200, 4096, 2), (48, 1024, 16), (16, 14336, 1)]:
+        if k % (16 * inner) or k % g:
+            continue
+        codes, x, qinfo, lut = rand_problem(n, k, g, m, qtype, seed=n + k + inner + 7)
+        y, copies = run_fast(T, codes, x, qinfo, lut, g, qtype, inner, min_items=1)
+        assert copies == 1
+        assert_fast_close(oracle, y, codes, x, qinfo, lut, g, qtype, inner=inner, batch=1)
+
+
+def test_pair16_fp16_bias_and_batch(T, oracle):
+    codes, x, qinfo, lut = rand_problem(96, 1024, 128, 5, "any4_rowwise", dtype=torch.float16, seed=21)
+    bias = torch.randn(96).half()
+    y, copies = run_fast(T, codes, x, qinfo, lut, 128, "any4_rowwise", 4, bias=bias, min_items=6)  # 3 stacked problems
+    assert copies == 3
+    y0, _ = run_fast(T, codes, x, qinfo, lut, 128, "any4_rowwise", 4, min_items=1)
+    assert_fast_close(oracle, y0, codes, x, qinfo, lut, 128, "any4_rowwise", dtype=torch.float16, batch=1)
+    want = (y0.float().cpu() + bias.float()[None, :]).half()
+    assert torch.equal(want.view(torch.int16), y.cpu().view(torch.int16))
+
+
 def test_pair_kernel_fp16(T, oracle):
     for qtype in ("any4_rowwise", "int4"):
         codes, x, qinfo, lut = rand_problem(96, 1024, 128, 2, qtype, dtype=torch.float16, seed=4)
@@ -213,12 +240,14 @@ def test_pair_kernel_fp16(T, oracle):
 
 
 def test_fast_equals_reference_where_no_fast_kernel(T, oracle):
-    """Weights on the A side, activation blocks too large to stage and small (latency-bound) launches have no group-scaled
-    kernel: the fast setting then runs the reference kernels, bit for bit."""
+    """Shapes without a group-scaled kernel (small launches of A-side weights, more than 16 activation rows at k = 4096): the
+    fast setting then runs the reference kernels, bit for bit."""
     import any4_amd
+    from any4_amd import ops
 
-    for on_right, m, k in ((False, 2, 1024), (True, 16, 4096), (True, 1, 1024)):
+    for on_right, m, k in ((False, 2, 1024), (True, 17, 4096), (False, 1, 4096)):
         codes, x, qinfo, lut = rand_problem(64, k, 128, m, "any4_rowwise", seed=3)
+        assert ops.gemm_w4_plan(m, 64, k, 128, QT["any4_rowwise"], on_right, 4) != "pair"
         y_fast = run_rm(T, codes, x, qinfo, lut, 128, "any4_rowwise", on_right, 4)
         with any4_amd.numerics("reference"):
             y_ref = run_rm(T, codes, x, qinfo, lut, 128, "any4_rowwise", on_right, 4)
