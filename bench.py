@@ -399,6 +399,31 @@ def main():
             cold.append(c0.elapsed_time(c1) * 1e3)
         cold_us = sorted(cold)[len(cold) // 2]
         single_plan = ops.gemm_w4_plan(m, n, k, g, QT["any4_rowwise"], True, inner, torch.bfloat16, 1, "fast")
+        # the same launches replayed from one hipGraph (no per-launch host work: what the GPU needs per layer), and the host
+        # floor of this entry point: back-to-back launches of a 16 x 512 problem (5.9 KB) through the same C-ABI call
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            for sa in singles:
+                launch(sa)
+        gr.replay()
+        torch.cuda.synchronize()
+        e0.record(stream)
+        for _ in range(5):
+            gr.replay()
+        e1.record(stream)
+        torch.cuda.synchronize()
+        graph_us = e0.elapsed_time(e1) * 1e3 / (5 * L)
+        tw_, tx_, tq_, tl_, ty_ = make_batch(1, 1, 16, 512, g, inner, device, 5)
+        tiny = make_args(_lib, tw_, tx_, tq_, tl_, ty_, 1, 16, 512, g, "any4_rowwise", True, inner, 1)
+        for _ in range(20):
+            launch(tiny)
+        torch.cuda.synchronize()
+        e0.record(stream)
+        for _ in range(L):
+            launch(tiny)
+        e1.record(stream)
+        torch.cuda.synchronize()
+        floor_us = e0.elapsed_time(e1) * 1e3 / L
 
         out = {
             "metric": "any4 W4A16 GEMM achieved GB/s (m=1, n=k=4096, g=128)",
@@ -448,9 +473,14 @@ def main():
                 "frac_back_to_back": round(bytes_layer / single_us / 1e3 / HBM_PEAK_GBPS, 4),
                 "us_cold_event_pair": round(cold_us, 3),
                 "frac_cold": round(bytes_layer / cold_us / 1e3 / HBM_PEAK_GBPS, 4),
+                "us_per_launch_in_hipgraph": round(graph_us, 3),
+                "frac_in_hipgraph": round(bytes_layer / graph_us / 1e3 / HBM_PEAK_GBPS, 4),
+                "us_launch_floor_back_to_back": round(floor_us, 3),
                 "kernel_plan": single_plan,
                 "note": "one 4096x4096 any4 GEMV per launch (what Any4Linear.forward issues): back-to-back launches of distinct cold layers on one "
-                        "stream (event time / launches), and the median HIP-event time of an isolated launch (event pair floor on this stack: ~4.3 us)",
+                        "stream (event time / launches), and the median HIP-event time of an isolated launch (event pair floor on this stack: ~4.3 us); "
+                        "in_hipgraph = the same launches replayed from one captured graph; launch_floor = a 16 x 512 problem through the same "
+                        "entry point, back to back: the host/runtime cost per launch that the back-to-back figure cannot go below",
             },
         }
         if world == 1 and not a.no_cpu_baseline:

@@ -280,3 +280,33 @@ def test_nf4_and_mx4_modules():
     ref = (scaled[..., None] - torch.tensor(NF4_VALUES, device=DEV)).abs().argmin(-1).reshape(lin.weight.shape)
     assert (codes.long() != ref).float().mean() < 1e-4   # exact ties aside
     assert book.dtype == torch.bfloat16 and sz.shape == (512 // 64, 192, 2) and bool((sz[..., 1] == 0).all())
+
+
+def test_accuracy_loop_with_real_kernels():
+    """SURVEY 8f N4 on the GPU: calibration -> any4 quantization (Any4Linear on the HIP library, activation-aware) -> perplexity;
+    the quantized model's perplexity on the synthetic stream stays close to the 16-bit model's, and the hook profiler sees every
+    attention / MLP block."""
+    import math
+
+    from transformers import AutoModelForCausalLM, LlamaConfig
+
+    from any4_amd import accuracy as A
+    from any4_amd import quantize as Q
+
+    torch.manual_seed(0)
+    cfg = LlamaConfig(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2,
+                      vocab_size=512, max_position_embeddings=128)
+    model = AutoModelForCausalLM.from_config(cfg, dtype=torch.bfloat16).to(DEV).eval()
+    toks = A.synthetic_corpus(512, 64 * 24, seed=7)
+    ppl0 = A.perplexity(model, toks, seqlen=64)
+    sw = A.calibrate(model, A.windows(toks, 64, 4))
+    Q.quantize_model(model, layer_from=torch.nn.Linear, layer_to=Q.anyq_layer, skip_modules=["lm_head"], pseudo=False, group_size=64,
+                     sample_weight=sw)
+    assert sum(type(m).__name__ == "Any4Linear" for m in model.modules()) == 2 * 7
+    ppl1 = A.perplexity(model, toks, seqlen=64)
+    assert math.isfinite(ppl1) and abs(math.log(ppl1 / ppl0)) < 0.25, (ppl0, ppl1)
+    ids = torch.randint(0, 512, (1, 1), device=DEV)
+    prof = A.HookProfiler("cuda")
+    prof.run_profiling(model, lambda m: m(input_ids=ids, use_cache=False), warmup=1, iters=2)
+    s = prof.summarize()
+    assert len(prof.timings) == 4 and s["attention_time"] > 0 and s["mlp_time"] > 0

@@ -63,9 +63,20 @@ def main():
     mask = torch.ones_like(ids)
     f = lambda m: m(input_ids=ids, attention_mask=mask, use_cache=False)
 
+    from any4_amd.accuracy import HookProfiler
+
+    def split(m):  # attention / MLP time per forward (benchmark.py:37-111): host wall-clock and device events
+        out = {}
+        for mode in ("cpu", "cuda"):
+            prof = HookProfiler(mode)
+            prof.run_profiling(m, f, warmup=3, iters=max(3, a.iters // 5))
+            out[mode] = prof.summarize()
+        return out
+
     torch.cuda.reset_peak_memory_stats()
     t, tc = benchmark_in_ms(f, a.warmup, a.iters, model), benchmark_cuda_only_in_ms(f, a.warmup, a.iters, model)
     size0, peak0 = model_size_bytes(model), memory_allocated_mb()
+    split0 = split(model)
     ref = f(model).logits.float()
 
     t0 = time.perf_counter()
@@ -76,6 +87,7 @@ def main():
     torch.cuda.reset_peak_memory_stats()
     qt, qtc = benchmark_in_ms(f, a.warmup, a.iters, model), benchmark_cuda_only_in_ms(f, a.warmup, a.iters, model)
     out = f(model).logits.float()
+    split1 = split(model)
     n_q = sum(type(m).__name__ in ("Any4Linear", "Int4Linear") for m in model.modules())
 
     print(f"Model: {a.model_path or a.arch}  layers={model.config.num_hidden_layers}  bs={a.batch_size} seqlen={a.seqlen}")
@@ -86,6 +98,12 @@ def main():
     print(f"\tModel Size:\t{model_size_bytes(model) / 2**30:.2f} GB\tPeak: {memory_allocated_mb():.0f} MB")
     print(f"\tModel:\tTotal {qt:.3f} ms\tCUDA {qtc:.3f} ms")
     print(f"Speedup:\tTotal {t / qt:.2f}x\tCUDA {tc / qtc:.2f}x")
+    for kind in ("attention", "mlp"):
+        b_c, b_g = split0["cpu"][f"{kind}_time"], split0["cuda"][f"{kind}_time"]
+        q_c, q_g = split1["cpu"][f"{kind}_time"], split1["cuda"][f"{kind}_time"]
+        print(f"\t{kind:<10} baseline {b_c:.3f} / {b_g:.3f} ms ({b_c / t * 100:.0f} % / {b_g / tc * 100:.0f} % of the model)"
+              f"\tquantized {q_c:.3f} / {q_g:.3f} ms\tspeedup {b_c / q_c:.2f}x / {b_g / q_g:.2f}x   (total / CUDA)")
+    print(f"\tattention : MLP ratio\tbaseline {split0['cuda']['ratio']:.2f}\tquantized {split1['cuda']['ratio']:.2f}")
     print(f"logits: max |quantized - baseline| = {(out - ref).abs().max():.3f} at max |baseline| = {ref.abs().max():.3f}")
 
 
