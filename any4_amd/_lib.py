@@ -13,6 +13,8 @@ TG_Q_INT4, TG_Q_ANY4_GLOBAL, TG_Q_ANY4_ROWWISE, TG_Q_MX4, TG_Q_INT8 = 0, 1, 2, 3
 TG_NUM_FAST, TG_NUM_REFERENCE = 0, 1
 TG_ABI_VERSION = 3
 TG_PLAN_SPLITK, TG_PLAN_STREAM, TG_PLAN_PAIR = 1, 2, 3
+TG_LAYOUT_RM, TG_LAYOUT_TC_A = 0, 1
+TG_E_LAYOUT = -12
 
 _i32, _i64, _vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p
 
@@ -28,6 +30,7 @@ class W4Gemm(ctypes.Structure):
         ("stride_x", _i64), ("stride_w", _i64), ("stride_qinfo", _i64), ("stride_lut", _i64), ("stride_y", _i64),
         ("numerics", _i32), ("reserved", _i32), ("bias", _vp), ("stride_bias", _i64),
         ("workspace", _vp), ("workspace_bytes", _i64),
+        ("x_layout", _i32), ("y_layout", _i32),
     ]
 
 

@@ -703,6 +703,7 @@ int launch_xprep(const PairParams& pp, int I, int ma, int64_t batch, hipStream_t
   XPrepParams xq;
   xq.la = la;
   xq.x = pp.x; xq.xp = const_cast<char*>(pp.xp); xq.xsum = const_cast<char*>(pp.xsum);
+  xq.x_tc = pp.x_tc;
   xq.m = pp.m; xq.k = pp.k; xq.ma = ma; xq.cps = I / 2; xq.gshift = pp.gshift; xq.gch_mask = pp.gch_mask;
   xq.ngroups = pp.ngroups; xq.xs_rows = pp.xs_rows;
   xq.stride_x = pp.stride_x; xq.stride_xp = pp.stride_xp; xq.stride_xsum = pp.stride_xsum;
@@ -784,6 +785,7 @@ int launch_pair(GemmParams& p, int64_t batch, hipStream_t st) {
   pp.stride_x = p.stride_x; pp.stride_w = p.stride_w; pp.stride_qinfo = p.stride_qinfo;
   pp.stride_lut = p.stride_lut; pp.stride_y = p.stride_y;
   pp.bias = p.bias; pp.stride_bias = p.stride_bias; pp.dry = p.dry;
+  pp.x_tc = p.x_tc; pp.y_tc = p.y_tc; pp.y_tiles = (p.wrows + 15) / 16;
   if (xg && !p.dry) {
     const int rc = launch_xprep<DT>(pp, I, ma, batch, st);
     if (rc != 0) return rc;
@@ -832,18 +834,30 @@ int launch_pair16(const GemmParams& p, int64_t batch, hipStream_t st) {
   pp.x = p.x; pp.w = p.w; pp.qinfo = p.qinfo; pp.lut = p.lut; pp.y = p.y;
   pp.m = p.m; pp.wrows = p.wrows; pp.k = p.k; pp.ntiles = p.ntiles; pp.ksuper = p.ksuper;
   pp.gshift = p.gshift; pp.ngroups = p.ngroups; pp.qtype = p.qtype;
-  pp.spw = ((p.ksuper / nsg + 15) / 16) * nsg;
   pp.gch_mask = g / 32 - 1;
-  pp.x_pitch = p.k * 2 + 16;
   pp.lds_x = 65536;
-  pp.lds_xs = (pp.lds_x + p.m * pp.x_pitch + 16 + 15) & ~15;
-  const unsigned lds = (unsigned)pp.lds_xs + (QMX ? 0u : (unsigned)p.ngroups * 64u);
   const int64_t wgs = (int64_t)((p.wrows + 15) / 16) * batch;
   // one workgroup per CU may take the whole LDS; a launch of more than two rounds of workgroups should fit two per CU
-  if (lds > (wgs <= 512 ? 160u : 80u) * 1024u) return TG_PAIR_NA;
+  const unsigned lds_limit = (wgs <= 512 ? 160u : 80u) * 1024u;
+  // activation rows that do not fit next to the table are staged one part of k at a time (whole groups per part)
+  unsigned lds = 0;
+  int phases = 1;
+  for (; phases <= (wgs <= 512 ? 8 : 1); phases *= 2) {
+    if (p.ksuper % (phases * nsg) != 0 || p.ngroups % phases != 0) return TG_PAIR_NA;
+    const int kp = p.k / phases;
+    pp.x_pitch = kp * 2 + 16;
+    pp.lds_xs = (pp.lds_x + p.m * pp.x_pitch + 16 + 15) & ~15;
+    lds = (unsigned)pp.lds_xs + (QMX ? 0u : (unsigned)(p.ngroups / phases) * 64u);
+    if (lds <= lds_limit) break;
+  }
+  if (lds > lds_limit) return TG_PAIR_NA;
+  pp.phases = phases;
+  pp.ksuper_p = p.ksuper / phases;
+  pp.spw = ((pp.ksuper_p / nsg + 15) / 16) * nsg;
   pp.stride_x = p.stride_x; pp.stride_w = p.stride_w; pp.stride_qinfo = p.stride_qinfo;
   pp.stride_lut = p.stride_lut; pp.stride_y = p.stride_y;
   pp.bias = p.bias; pp.stride_bias = p.stride_bias;
+  pp.x_tc = p.x_tc; pp.y_tc = p.y_tc; pp.y_tiles = (p.wrows + 15) / 16;
   if (p.dry) return TG_PLAN_PAIR;
   const dim3 grid((unsigned)((p.wrows + 15) / 16), (unsigned)batch);
 #define TG_P16(CPG_)                                                        \
@@ -869,10 +883,11 @@ template <typename DT, int I, bool QMX>
 int launch_pair_a(GemmParams& p, int64_t batch, hipStream_t st) {
   if constexpr (I < 2) return TG_PAIR_NA;  // one 16-k tile per word set: no word pair for a 32-k MFMA step
   else {
-  if (p.m > 16) return TG_PAIR_NA;
+  if (p.m > 16 || p.x_tc || p.y_tc) return TG_PAIR_NA;
   const int g = 1 << p.gshift;
   const int gps = g >= 16 * I ? 1 : (16 * I) / g;
   PairParams pp;
+  pp.x_tc = pp.y_tc = 0; pp.y_tiles = 0;
   pp.x = p.x; pp.w = p.w; pp.qinfo = p.qinfo; pp.lut = p.lut; pp.y = p.y;
   pp.m = p.m; pp.wrows = p.wrows; pp.k = p.k; pp.ntiles = p.ntiles; pp.ksuper = p.ksuper;
   pp.gshift = p.gshift; pp.ngroups = p.ngroups; pp.qtype = p.qtype;
@@ -959,6 +974,7 @@ int launch_w4(GemmParams& p, int64_t coltiles, int64_t batch, hipStream_t st) {
       if (rc != TG_PAIR_NA) return rc;
     }
   }
+  if (p.x_tc || p.y_tc) return TG_E_LAYOUT;  // only the pair-table kernels read / write fragment order themselves
   // m = 1 always streams: with private X slabs its split-K variants beat the latency kernel down to one matrix
   if (use_stream && (g.waves == 8 || p.m == 1 || use_stream == 2) && (1 << p.gshift) >= (LAYOUT_A ? 64 : 128)) {
     return launch_stream<DT, LAYOUT_A, WPL, QMX>(p, coltiles, batch, st);
@@ -1007,6 +1023,7 @@ const char* tg_error_string(int code) {
     case TG_E_DEVICE: return "could not select the requested device";
     case TG_E_SIZE: return "an operand is too large for the kernels' 32-bit byte offsets (activations, packed weights or quantisation info of one problem must stay below 2 GiB; at most 65535 16-row activation tiles)";
     case TG_E_INTERNAL: return "internal error: a kernel that addresses LDS from offset 0 was built with static LDS";
+    case TG_E_LAYOUT: return "fragment-order activations / outputs (x_layout, y_layout) are not available for this problem: convert with tg_convert_{from,to}_A16 around a row-major call";
     default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown tinygemm error";
   }
 }
@@ -1128,6 +1145,8 @@ static int gemm_w4_impl(const tg_w4_gemm* a, int device, tg_stream_t stream, int
   if (a->bias && (reinterpret_cast<uintptr_t>(a->bias) & 7u)) return TG_E_ALIGN;
   if (!(a->numerics == TG_NUM_FAST || a->numerics == TG_NUM_REFERENCE) || a->reserved != 0) return TG_E_SHAPE;
   if (a->workspace && (!aligned16(a->workspace) || a->workspace_bytes < 0)) return TG_E_ALIGN;
+  if (!(a->x_layout == TG_LAYOUT_RM || a->x_layout == TG_LAYOUT_TC_A) || !(a->y_layout == TG_LAYOUT_RM || a->y_layout == TG_LAYOUT_TC_A)) return TG_E_LAYOUT;
+  if ((a->x_layout || a->y_layout) && (!a->w_on_right || a->m % 16 != 0 || a->bias)) return TG_E_LAYOUT;
   const int batch = a->batch > 1 ? a->batch : 1;
   if (batch > 1 && ((a->stride_x | a->stride_w | a->stride_lut) & 15)) return TG_E_ALIGN;
   if (batch > 1 && a->bias && (a->stride_bias & 7)) return TG_E_ALIGN;
@@ -1157,6 +1176,8 @@ static int gemm_w4_impl(const tg_w4_gemm* a, int device, tg_stream_t stream, int
   p.ws_bytes = a->workspace ? a->workspace_bytes : 0;
   p.ws_query = dry == 2;
   p.ws_need = 0;
+  p.x_tc = a->x_layout == TG_LAYOUT_TC_A;
+  p.y_tc = a->y_layout == TG_LAYOUT_TC_A;
 #ifdef TG_DEV
   {
     static const int env_dbg = getenv("TG_DBG") ? atoi(getenv("TG_DBG")) : 0;

@@ -45,6 +45,7 @@ struct GemmParams {
   char* ws;
   int64_t ws_bytes, ws_need;
   int32_t ws_query;
+  int32_t x_tc, y_tc;  // fragment-order activations / output (pair-table kernels only)
 };
 
 enum { CANON_NONE = 0, CANON_PAIR = 1, CANON_QUAD = 2 };

@@ -44,6 +44,20 @@
 #define TG_PAIR_PIN 0  // 1: also pin the accumulator tuples in finalize() when a group's first MFMA takes a zero C operand
 #endif
 
+// Element (r, c) of a matrix kept in the reference's m16n8k16 A-fragment order [ceil(rows/16)][ctiles = ceil(cols/16)][32][8]
+// (TinyGemmConvertA.cu:19-141: lane t = 4 (r & 7) + (c & 7) / 2 holds (r, c0) (r, c0+1) (r+8, c0) (r+8, c0+1) and the same at
+// c0 + 8): the "TC" activations / outputs of tinygemm_y_f16TC_x_f16TC_w_*TC with the weights on the right.
+__device__ __forceinline__ int64_t tc_a_index(int r, int c, int ctiles) {
+  const int t = (r & 7) * 4 + ((c & 7) >> 1);
+  const int j = (c & 1) + 2 * ((r >> 3) & 1) + 4 * ((c >> 3) & 1);
+  return (((int64_t)(r >> 4) * ctiles + (c >> 4)) * 32 + t) * 8 + j;
+}
+// the 32 k of chunk ch of row a (16 dwords in k order) from A-fragment-order activations
+__device__ __forceinline__ void tc_a_load_chunk(const char* xb, int a, int ch, int ktiles, uint32_t (&d)[16]) {
+#pragma unroll
+  for (int dw = 0; dw < 16; ++dw) d[dw] = *reinterpret_cast<const uint32_t*>(xb + tc_a_index(a, ch * 32 + 2 * dw, ktiles) * 2);
+}
+
 struct PairParams {
   const char* x;
   const char* w;
@@ -80,6 +94,8 @@ struct PairParams {
   int64_t stride_xp, stride_xsum;  // bytes per problem
   int32_t xw_pitch;   // bytes per activation row in a wave's LDS buffer (32 I + 16: rotates rows over the banks)
   int32_t xw_bytes;   // bytes of one wave's buffer
+  int32_t x_tc, y_tc; // 1: activations / output in A-fragment order (tc_a_index) instead of row-major; y_tiles = ceil(wrows/16)
+  int32_t y_tiles;
 };
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -179,9 +195,13 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
   // XG: items dealt round-robin, so that the workgroups running at one time read the activations of a few problems only
   // (with contiguous ranges every workgroup streams a different problem's block again and again: at m = 8, k = 4096 that is
   // 64 KiB x 64 workgroups per XCD = the whole L2, behind the weight stream -- measured as +50 % time)
-  const int it_stride = XG ? (int)gridDim.x : 1;
-  const int it_begin = XG ? (int)blockIdx.x : (int)(((int64_t)blockIdx.x * p.items) / gridDim.x);
-  const int it_end = XG ? p.items : (int)(((int64_t)(blockIdx.x + 1) * p.items) / gridDim.x);
+#ifndef TG_XG_ROUNDROBIN
+#define TG_XG_ROUNDROBIN 1
+#endif
+  constexpr bool RR = XG && TG_XG_ROUNDROBIN;
+  const int it_stride = RR ? (int)gridDim.x : 1;
+  const int it_begin = RR ? (int)blockIdx.x : (int)(((int64_t)blockIdx.x * p.items) / gridDim.x);
+  const int it_end = RR ? p.items : (int)(((int64_t)(blockIdx.x + 1) * p.items) / gridDim.x);
   const int per_problem = p.rblocks * p.cblocks;
 
   // ---- this wave's k-slice: super-tiles [s_begin, s_begin + nl) ----
@@ -374,9 +394,13 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
 
   // ---- activation staging: chunk (row a, 32 k) -> LDS in byte order, and the per-group sums ----
   const int nch = p.k >> 5;
-  auto x_load = [&](const char* xb, int xi, uint32_t (&d)[16]) {
+  auto x_load = [&](const char* xb, int a0, int xi, uint32_t (&d)[16]) {  // xb = the problem's activations, a0 = the pass's first row
     const int a = xi / nch, ch = xi - a * nch;
-    const u32x4* src = reinterpret_cast<const u32x4*>(xb + ((int64_t)a * p.k + ch * 32) * 2);
+    if (p.x_tc) {
+      tc_a_load_chunk(xb, a0 + a, ch, p.k >> 4, d);
+      return;
+    }
+    const u32x4* src = reinterpret_cast<const u32x4*>(xb + ((int64_t)(a0 + a) * p.k + ch * 32) * 2);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const u32x4 v = src[j];
@@ -407,7 +431,7 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
   };
   // stages activation rows [a0, a0 + mrows) of problem b; `pre` = the first batch of chunks is already in xd
   auto x_stage = [&](int b, int a0, int mrows, bool pre, uint32_t (&xd)[16]) {
-    const char* xb = p.x + (int64_t)b * p.stride_x + (int64_t)a0 * p.k * 2;
+    const char* xb = p.x + (int64_t)b * p.stride_x;
     const int xtotal = mrows * nch;
     for (int it0 = 0; it0 < xtotal; it0 += 512) {
       const int xi = it0 + tid;
@@ -415,7 +439,7 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
       if (!(pre && it0 == 0)) {
 #pragma unroll
         for (int j = 0; j < 16; ++j) xd[j] = 0u;
-        if (on) x_load(xb, xi, xd);
+        if (on) x_load(xb, a0, xi, xd);
       }
       x_store(xi, on, xd);
     }
@@ -450,7 +474,7 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
     const int mrows0 = min(p.m - first.ct * MA, MA);
 #pragma unroll
     for (int j = 0; j < 16; ++j) xd0[j] = 0u;
-    if (tid < mrows0 * nch) x_load(p.x + (int64_t)first.b * p.stride_x + (int64_t)first.ct * MA * p.k * 2, tid, xd0);
+    if (tid < mrows0 * nch) x_load(p.x + (int64_t)first.b * p.stride_x, first.ct * MA, tid, xd0);
   }
   Rows rcur = rows_of(it_begin);
   if constexpr (QMX) e_request(rcur, 0, nl > 0);
@@ -764,7 +788,7 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
           uint16_t o16 = DT::from_f32(sum);
           if (p.bias)  // rounded sum + bias, rounded again: bit-identical to the reference module's separate `y + bias`
             o16 = DT::from_f32(DT::lo_f32(o16) + DT::lo_f32(*reinterpret_cast<const uint16_t*>(p.bias + (int64_t)cur.b * p.stride_bias + (int64_t)row * 2)));
-          *reinterpret_cast<uint16_t*>(yb + ((int64_t)(a0 + a) * p.wrows + row) * 2) = o16;
+          *reinterpret_cast<uint16_t*>(yb + (p.y_tc ? tc_a_index(a0 + a, row, p.y_tiles) : (int64_t)(a0 + a) * p.wrows + row) * 2) = o16;
         }
       }
     }
@@ -784,6 +808,7 @@ struct XPrepParams {
   char* xsum;
   int32_t m, k, ma, cps, gshift, gch_mask, ngroups, xs_rows;
   int32_t la;  // 1: A-side order [32-k chunk][k-quad][rows + 1]: the last row of every block is zero
+  int32_t x_tc;  // 1: the activations come in A-fragment order (tc_a_index)
   int64_t stride_x, stride_xp, stride_xsum;
 };
 
@@ -797,7 +822,9 @@ __global__ void __launch_bounds__(256) w4_xprep_kernel(const XPrepParams p) {
   uint32_t d[16];
 #pragma unroll
   for (int j = 0; j < 16; ++j) d[j] = 0u;
-  if (on) {
+  if (on && p.x_tc) {
+    tc_a_load_chunk(p.x + (int64_t)b * p.stride_x, a, ch, p.k >> 4, d);
+  } else if (on) {
     const u32x4* src = reinterpret_cast<const u32x4*>(p.x + (int64_t)b * p.stride_x + ((int64_t)a * p.k + ch * 32) * 2);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {

@@ -31,13 +31,17 @@ struct Pair16Params {
   int32_t ntiles;    // packed.size(0): 8-row tiles
   int32_t ksuper;    // packed.size(1)
   int32_t gshift, ngroups, qtype;
-  int32_t spw;       // k super-tiles per wave (whole groups)
+  int32_t phases;    // the k range is walked in `phases` equal parts (activation rows of one part staged at a time; 1: whole k)
+  int32_t ksuper_p;  // super-tiles per phase
+  int32_t spw;       // k super-tiles per wave and phase (whole groups)
   int32_t gch_mask;  // 32-k chunks per group - 1
-  int32_t x_pitch;   // bytes per staged activation row
-  int32_t lds_x, lds_xs;  // LDS byte offsets: staged activations (m rows + a 16-byte zero piece), sums f32 [ngroups][16]
+  int32_t x_pitch;   // bytes per staged activation row (one phase of it)
+  int32_t lds_x, lds_xs;  // LDS byte offsets: staged activations (m rows + a 16-byte zero piece), sums f32 [groups of a phase][16]
   int64_t stride_x, stride_w, stride_qinfo, stride_lut, stride_y;
   const char* bias;
   int64_t stride_bias;
+  int32_t x_tc, y_tc;  // 1: activations / output in A-fragment order (tc_a_index, w4_gemm_pair.cuh)
+  int32_t y_tiles;     // ceil(wrows / 16)
 };
 
 // I   = innerKTiles of the Bint4 layout (2, 4, 8): I / 2 words per lane and super-tile (one per 32-k chunk)
@@ -59,8 +63,9 @@ __global__ void __launch_bounds__(1024) w4_gemm_pair16_kernel(const Pair16Params
   const int b = blockIdx.y;
   const int row0 = blockIdx.x * 16;
 
-  const int s_begin = wave * p.spw;
-  const int nl = max(min(p.spw, p.ksuper - s_begin), 0);
+  // this wave's slice of phase ph: super-tiles [ph ksuper_p + wave spw, + nl)
+  const int nl = max(min(p.spw, p.ksuper_p - wave * p.spw), 0);
+  int s_begin = wave * p.spw;
 
   // ---- requests, in the order they are consumed: LUT row of this thread's table column, activations, weights ----
   const int tcol = tid & 31;                     // table column = 16 copy + row
@@ -89,14 +94,18 @@ __global__ void __launch_bounds__(1024) w4_gemm_pair16_kernel(const Pair16Params
   }
 
   // activations: chunk (row a, 32 k) per thread, 64 bytes
-  const int nch = p.k >> 5;
+  const int nch = (p.ksuper_p * 16 * I) >> 5;  // chunks per row and phase
   const int xtotal = p.m * nch;
   const char* xb = p.x + (int64_t)b * p.stride_x;
   uint32_t xd[16];
 #pragma unroll
   for (int j = 0; j < 16; ++j) xd[j] = 0u;
-  auto x_load = [&](int xi) {
-    const int a = xi / nch, ch = xi - a * nch;
+  auto x_load = [&](int xi, int ph) {
+    const int a = xi / nch, ch = xi - a * nch + ph * nch;
+    if (p.x_tc) {
+      tc_a_load_chunk(xb, a, ch, p.k >> 4, xd);
+      return;
+    }
     const u32x4* src = reinterpret_cast<const u32x4*>(xb + ((int64_t)a * p.k + ch * 32) * 2);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -104,7 +113,7 @@ __global__ void __launch_bounds__(1024) w4_gemm_pair16_kernel(const Pair16Params
       xd[4 * j] = v[0]; xd[4 * j + 1] = v[1]; xd[4 * j + 2] = v[2]; xd[4 * j + 3] = v[3];
     }
   };
-  if (tid < xtotal) x_load(tid);
+  if (tid < xtotal) x_load(tid, 0);
 
   // weights of this lane: row n of the workgroup's 16, quad q
   const int wrow = min(row0 + n, p.wrows - 1);
@@ -167,20 +176,24 @@ __global__ void __launch_bounds__(1024) w4_gemm_pair16_kernel(const Pair16Params
       if (on && (ch & p.gch_mask) == 0) *(lds_fptr)(lds_xs + (uint32_t)(((ch >> (p.gshift - 5)) * 16 + a) * 4)) = sum;
     }
   };
-  for (int it0 = 0; it0 < (P16_ABL == 3 ? 0 : xtotal); it0 += NT) {
-    const int xi = it0 + tid;
-    const bool on = xi < xtotal;
-    if (it0 > 0) {
+  const int gpp = p.ngroups / p.phases;  // groups per phase
+  auto x_stage = [&](int ph, bool pre) {  // pre: the first batch of chunks is already in xd
+    for (int it0 = 0; it0 < (P16_ABL == 3 ? 0 : xtotal); it0 += NT) {
+      const int xi = it0 + tid;
+      const bool on = xi < xtotal;
+      if (it0 > 0 || !pre) {
 #pragma unroll
-      for (int j = 0; j < 16; ++j) xd[j] = 0u;
-      if (on) x_load(xi);
+        for (int j = 0; j < 16; ++j) xd[j] = 0u;
+        if (on) x_load(xi, ph);
+      }
+      x_store(xi, on);
     }
-    x_store(xi, on);
-  }
-  if constexpr (!QMX)
-    for (int idx = tid; idx < p.ngroups * 16; idx += NT)
-      if ((idx & 15) >= p.m) *(lds_fptr)(lds_xs + (uint32_t)(idx * 4)) = 0.f;
-  if (tid == 0) *(lds_u32x4ptr)(lds_x + (uint32_t)(p.m * p.x_pitch)) = u32x4{0, 0, 0, 0};  // zero piece for padding rows
+    if constexpr (!QMX)
+      for (int idx = tid; idx < gpp * 16; idx += NT)
+        if ((idx & 15) >= p.m) *(lds_fptr)(lds_xs + (uint32_t)(idx * 4)) = 0.f;
+    if (tid == 0) *(lds_u32x4ptr)(lds_x + (uint32_t)(p.m * p.x_pitch)) = u32x4{0, 0, 0, 0};  // zero piece for padding rows
+  };
+  x_stage(0, true);
   {
     // thread = (column tcol, high nibble (tid >> 5) & 15, half tid >> 9 of the low nibbles): entries (lut[lo], lut[hi])
     const int hi = (tid >> 5) & 15, half = tid >> 9;
@@ -224,6 +237,17 @@ __global__ void __launch_bounds__(1024) w4_gemm_pair16_kernel(const Pair16Params
 #pragma unroll
       for (int jc = 0; jc < CPS; ++jc) yacc[0] += u2f(wreg[j][jc] ^ qreg[j][jc]);
   }
+  for (int ph = 0; ph < p.phases; ++ph) {
+  if (ph > 0) {
+    // the next part of k: its first weights are requested before the activations are re-staged (two barriers: every wave is
+    // done with the previous part's activations / the new ones are visible)
+    s_begin = ph * p.ksuper_p + wave * p.spw;
+    w_request(0);
+    __syncthreads();
+    x_stage(ph, false);
+    __syncthreads();
+  }
+  const int chunk_ph = ph * p.ksuper_p * CPS;  // first chunk of the phase: LDS holds chunks / groups relative to it
   for (int l0 = 0; l0 < (P16_ABL == 2 ? 0 : nl); l0 += CH) {
     if (l0 > 0) w_request(l0);
     if (STATIC_G && l0 + CH <= nl) {
@@ -233,7 +257,7 @@ __global__ void __launch_bounds__(1024) w4_gemm_pair16_kernel(const Pair16Params
 #pragma unroll
       for (int u = 0; u < CH * CPS; ++u) {
         const int j = u / CPS, jc = u % CPS;
-        const u32x4 xf = *(lds_cu32x4ptr)(xrow + ((uint32_t)((chunk0 + u) * 64) & xmask));
+        const u32x4 xf = *(lds_cu32x4ptr)(xrow + ((uint32_t)((chunk0 + u - chunk_ph) * 64) & xmask));
         u32x4 bf;
         const uint32_t w = wreg[j][jc];
 #pragma unroll
@@ -245,7 +269,7 @@ __global__ void __launch_bounds__(1024) w4_gemm_pair16_kernel(const Pair16Params
           } else {
             gs = DT::lo_f32(qv);
             gz = DT::hi_f32(qv);
-            xsv = *(lds_cf32x4ptr)(xs_lane + (uint32_t)(((((chunk0 + u) * 32) >> p.gshift) * 16) * 4));
+            xsv = *(lds_cf32x4ptr)(xs_lane + (uint32_t)(((((chunk0 + u - chunk_ph) * 32) >> p.gshift) * 16) * 4));
           }
           acc = mfma16<DT>(xf, bf, zero4);
         } else {
@@ -269,7 +293,7 @@ __global__ void __launch_bounds__(1024) w4_gemm_pair16_kernel(const Pair16Params
         for (int jc = 0; jc < CPS; ++jc) {
           const int chunk = s * CPS + jc;
           const bool gfirst = (chunk & p.gch_mask) == 0, glast = (chunk & p.gch_mask) == p.gch_mask;
-          const u32x4 xf = *(lds_cu32x4ptr)(xrow + ((uint32_t)(chunk * 64) & xmask));
+          const u32x4 xf = *(lds_cu32x4ptr)(xrow + ((uint32_t)((chunk - chunk_ph) * 64) & xmask));
           u32x4 bf;
           const uint32_t w = wreg[j][jc];
 #pragma unroll
@@ -281,7 +305,7 @@ __global__ void __launch_bounds__(1024) w4_gemm_pair16_kernel(const Pair16Params
             } else {
               gs = DT::lo_f32(qv);
               gz = DT::hi_f32(qv);
-              xsv = *(lds_cf32x4ptr)(xs_lane + (uint32_t)((((chunk * 32) >> p.gshift) * 16) * 4));
+              xsv = *(lds_cf32x4ptr)(xs_lane + (uint32_t)(((((chunk - chunk_ph) * 32) >> p.gshift) * 16) * 4));
             }
           }
           acc = mfma16<DT>(xf, bf, gfirst ? zero4 : acc);
@@ -297,7 +321,9 @@ __global__ void __launch_bounds__(1024) w4_gemm_pair16_kernel(const Pair16Params
     }
   }
 
-  // ---- split-K tail: partial sums of the 8 waves meet in the (now unused) table's LDS, added in wave order ----
+  }  // phases
+
+  // ---- split-K tail: partial sums of the 16 waves meet in the (now unused) table's LDS, added in wave order ----
   __syncthreads();
 #pragma unroll
   for (int r = 0; r < 4; ++r) *(lds_fptr)((uint32_t)(((wave * 4 + r) * 64 + lane) * 4)) = yacc[r];
@@ -312,7 +338,7 @@ __global__ void __launch_bounds__(1024) w4_gemm_pair16_kernel(const Pair16Params
       uint16_t o16 = DT::from_f32(sum);
       if (p.bias)  // rounded sum + bias, rounded again: the reference module's separate `y + bias` (modules.py:221-222)
         o16 = DT::from_f32(DT::lo_f32(o16) + DT::lo_f32(*reinterpret_cast<const uint16_t*>(p.bias + (int64_t)b * p.stride_bias + (int64_t)row * 2)));
-      *reinterpret_cast<uint16_t*>(p.y + (int64_t)b * p.stride_y + ((int64_t)a * p.wrows + row) * 2) = o16;
+      *reinterpret_cast<uint16_t*>(p.y + (int64_t)b * p.stride_y + (p.y_tc ? tc_a_index(a, row, p.y_tiles) : (int64_t)a * p.wrows + row) * 2) = o16;
     }
   }
 }

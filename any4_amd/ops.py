@@ -254,9 +254,29 @@ def tinygemm_dequant_int4(t: torch.Tensor) -> torch.Tensor:
 # 4-bit weight GEMMs
 # ---------------------------------------------------------------------------------------------
 
-def _w4_rm(A, B, q_group, qinfo, lut, qtype, weight_on_right, opname):
+class _FragX:
+    """Activations in A-fragment order [m/16][k/16][32][8] standing in for the row-major [m][k] matrix of _w4_rm."""
+
+    def __init__(self, t):
+        self.t = t
+        self.shape = (t.size(0) * 16, t.size(1) * 16)
+        self.dtype, self.device = t.dtype, t.device
+
+    def dim(self):
+        return 2
+
+    def is_contiguous(self):
+        return self.t.is_contiguous()
+
+    def data_ptr(self):
+        return self.t.data_ptr()
+
+
+def _w4_rm(A, B, q_group, qinfo, lut, qtype, weight_on_right, opname, frag=False):
     """Row-major activations / output.  Mirrors tinygemm_y_FT16RM_x_FT16RM_w_int4TC
-    (TinyGemm_int4.cu:294-548)."""
+    (TinyGemm_int4.cu:294-548).  frag=True (weights on the right only): A is a _FragX, the output comes back in A-fragment
+    order [m/16][ceil(wrows/16)][32][8], or None when the library has no kernel that reads / writes fragment order itself
+    for this problem (TG_E_LAYOUT: the caller converts around a row-major call)."""
     _check(A.device == B.device, "A and B must be on the same device")
     if weight_on_right:
         x, w = A, B
@@ -305,21 +325,34 @@ def _w4_rm(A, B, q_group, qinfo, lut, qtype, weight_on_right, opname):
         lut = lut.contiguous()
     qinfo = qinfo.contiguous()
     _check(k % 32 == 0 and k_tiles % inner == 0, "k must be a multiple of 32 and of innerKTiles * 16")
-    if x.data_ptr() % 16:
-        x = x.clone()
-    y = torch.empty((m, wrows), dtype=x.dtype, device=x.device)
-    if m == 0:
-        return y
     if lut is not None and lut.data_ptr() % 16:
         lut = lut.clone()
-    bias = _take_bias(wrows, x)
+    if frag:
+        if m == 0 or get_numerics() != "fast":
+            return None
+        # zero-filled when the last 16-column tile is half used (wrows = 8 * odd): the kernel writes wrows columns
+        alloc = torch.zeros if wrows % 16 else torch.empty
+        y = alloc((m // 16, _cdiv(wrows, 16), 32, 8), dtype=x.dtype, device=x.device)
+        bias = None
+        layout = _lib.TG_LAYOUT_TC_A
+    else:
+        if x.data_ptr() % 16:
+            x = x.clone()
+        y = torch.empty((m, wrows), dtype=x.dtype, device=x.device)
+        if m == 0:
+            return y
+        bias = _take_bias(wrows, x)
+        layout = _lib.TG_LAYOUT_RM
     args = W4Gemm(
         x=x.data_ptr(), w=w.data_ptr(), qinfo=qinfo.data_ptr(), lut=(lut.data_ptr() if lut is not None else None),
         y=y.data_ptr(), m=m, wrows=wrows, k=k, group=q_group, qtype=qtype, dtype=_dt(x),
         w_on_right=1 if weight_on_right else 0, inner_k_tiles=inner, batch=1,
         numerics=_NUMERICS[get_numerics()], bias=(bias.data_ptr() if bias is not None else None),
+        x_layout=layout, y_layout=layout,
     )
     ws_bytes = _L.tg_gemm_w4_workspace_bytes(ctypes.byref(args))
+    if frag and ws_bytes == _lib.TG_E_LAYOUT:
+        return None
     if ws_bytes > 0:  # scratch from torch's caching allocator: stream-ordered like every other temporary of the op
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
         args.workspace, args.workspace_bytes = ws.data_ptr(), ws_bytes
@@ -343,6 +376,11 @@ def _w4_tc_impl(A, B, q_group, qinfo, lut, qtype, weight_on_right, opname):
         k_tiles_a, k_tiles_b = A.size(1), B.size(1) * B.size(3) * 2
         _check(k_tiles_a == k_tiles_b, "A and B disagree on k")
         m_pad, k = A.size(0) * 16, k_tiles_a * 16
+        # native: the pair-table kernels read the fragment-order activations and write the fragment-order output themselves
+        # (MatrixLayoutA.cuh:211-373 in the reference): one launch instead of convert -> GEMM -> convert
+        y = _w4_rm(_FragX(A), B, q_group, qinfo, lut, qtype, True, opname, frag=True)
+        if y is not None:
+            return y
         x = convert_matrix_from_m16n8k16_A_layout(A, m_pad, k)
         y = _w4_rm(x, B, q_group, qinfo, lut, qtype, True, opname)       # [m_pad][n_pad]
         return convert_matrix_to_m16n8k16_A_layout(y, 1)                 # [mTiles][ceil(nTiles/2)][32][8]

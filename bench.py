@@ -403,8 +403,9 @@ def main():
         # floor of this entry point: back-to-back launches of a 16 x 512 problem (5.9 KB) through the same C-ABI call
         gr = torch.cuda.CUDAGraph()
         with torch.cuda.graph(gr):
+            cs = torch.cuda.current_stream().cuda_stream  # the capture stream
             for sa in singles:
-                launch(sa)
+                _lib.check(lib.tg_gemm_w4(ctypes.byref(sa), local_rank, cs), "tg_gemm_w4 (graph capture)")
         gr.replay()
         torch.cuda.synchronize()
         e0.record(stream)

@@ -80,7 +80,8 @@ enum {
   TG_E_ALIGN = -8,     /* a buffer is not 16-byte aligned                                  */
   TG_E_DEVICE = -9,    /* hipSetDevice failed / no such device                             */
   TG_E_SIZE = -10,     /* one problem's operand exceeds the kernels' 32-bit byte offsets   */
-  TG_E_INTERNAL = -11  /* build inconsistency (should not happen)                          */
+  TG_E_INTERNAL = -11, /* build inconsistency (should not happen)                          */
+  TG_E_LAYOUT = -12    /* x_layout / y_layout not available for this problem               */
 };
 
 TG_API int tg_abi_version(void);
@@ -158,6 +159,12 @@ typedef struct tg_w4_gemm {
   int64_t workspace_bytes; /* tg_gemm_w4_workspace_bytes() says how much lets the fastest kernel run; with less (or none) the  */
                            /* call still succeeds on a kernel that needs no scratch.  Do not share one workspace between       */
                            /* calls that may overlap (different streams).                                                      */
+  int32_t x_layout;        /* TG_LAYOUT_RM (0) or TG_LAYOUT_TC_A: activations in the m16n8k16 A-fragment order                 */
+                           /*   [m/16][k/16][32][8] of tinygemm_y_f16TC_x_f16TC_w_*TC (weightOnRight; TinyGemm_int4.cu:28-292,  */
+                           /*   MatrixLayoutA.cuh:211-373): m % 16 == 0, w_on_right = 1, no bias.                              */
+  int32_t y_layout;        /* same for the output: [m/16][ceil(wrows/16)][32][8] (allocate zero-filled when wrows % 16 != 0)   */
+                           /* Only the TG_NUM_FAST kernels read / write fragment order themselves; otherwise TG_E_LAYOUT       */
+                           /* (tg_gemm_w4_plan reports it without launching): convert around a row-major call instead.         */
 } tg_w4_gemm;
 
 TG_API int tg_gemm_w4(const tg_w4_gemm* args, int device, tg_stream_t stream);
@@ -168,6 +175,7 @@ TG_API int tg_gemm_w4(const tg_w4_gemm* args, int device, tg_stream_t stream);
  *   TG_PLAN_STREAM  w4_gemm_stream_kernel  per-(row, group) tables of final 16-bit weights, reference numerics
  *   TG_PLAN_PAIR    w4_gemm_pair_kernel    per-row tables of LUT pairs, group-scaled numerics (TG_NUM_FAST only)  */
 enum { TG_PLAN_SPLITK = 1, TG_PLAN_STREAM = 2, TG_PLAN_PAIR = 3 };
+enum { TG_LAYOUT_RM = 0, TG_LAYOUT_TC_A = 1 };
 TG_API int tg_gemm_w4_plan(const tg_w4_gemm* args, int device);
 
 /* Bytes of `workspace` with which tg_gemm_w4 takes its fastest kernel for these arguments (0: none needed; negative: the

@@ -310,17 +310,59 @@ def test_reference_fixture_fast(T):
 
 
 # ------------------------------------------------------------------------------------------------
+# fragment-order ("TC") activations and outputs read / written by the GEMM kernel itself
+# ------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("qtype", ["any4_rowwise", "int4", "mx4"])
+@pytest.mark.parametrize("case", [(64, 1024, 16, 128, 4), (40, 512, 16, 64, 2), (136, 4096, 16, 128, 4), (24, 2048, 16, 32, 8)])
+def test_tc_ops_native_fragment_order(T, oracle, qtype, case, monkeypatch):
+    """tinygemm_y_f16TC_x_f16TC_w_*TC with the weights on the right (TinyGemm_int4.cu:28-292): the pair-table kernels take the
+    A-fragment-order activations and write the A-fragment-order output (no converter launches: they are made to fail here), and
+    the result is the row-major op's, re-laid out, bit for bit."""
+    from any4_amd import ops
+
+    n, k, m, g, inner = case
+    if qtype == "mx4":
+        g = 32
+    if k % (16 * inner) or k % g:
+        pytest.skip("shape does not divide")
+    codes, x, qinfo, lut = rand_problem(n, k, g, m, qtype, seed=n + m)
+    d = lambda t: None if t is None else t.to(DEV)
+    w2 = T.convert_matrix_to_m16n8k16_Bint4_layout(d(codes), inner)
+    wrows = w2.shape[0] * 8
+    if qtype == "mx4":
+        qi = torch.cat([qinfo, torch.full((wrows - n, qinfo.shape[1]), 127, dtype=qinfo.dtype)]) if wrows > n else qinfo
+    else:
+        qi = qinfo
+    xa = T.convert_matrix_to_m16n8k16_A_layout(d(x), 1)
+    y_rm = run_rm(T, codes, x, qi, lut, g, qtype, True, inner)                       # [m][wrows]
+    want = T.convert_matrix_to_m16n8k16_A_layout(y_rm, 1)
+    def boom(*a, **k):
+        raise AssertionError("converter launched: the fragment-order path is not native")
+    monkeypatch.setattr(ops, "convert_matrix_from_m16n8k16_A_layout", boom)
+    monkeypatch.setattr(ops, "convert_matrix_to_m16n8k16_A_layout", boom)
+    if qtype == "mx4":
+        got = T.tinygemm_y_f16TC_x_f16TC_w_mx4TC(xa, w2, g, d(qi), True)
+    elif qtype == "int4":
+        got = T.tinygemm_y_f16TC_x_f16TC_w_int4TC(xa, w2, g, d(qi), True)
+    else:
+        got = T.tinygemm_y_f16TC_x_f16TC_w_any4TC(xa, w2, g, d(qi), d(lut), True)
+    assert got.shape == want.shape
+    assert torch.equal(got.view(torch.int16), want.view(torch.int16))
+
+
+# ------------------------------------------------------------------------------------------------
 # the launches bench.py times, at their own shape: stacked tg_gemm_w4 over >= 16 layers of 4096 x 4096
 # ------------------------------------------------------------------------------------------------
 
-def _stacked_launch(layers, m, n, k, g, qtype, numerics, seed=0):
+def _stacked_launch(layers, m, n, k, g, qtype, numerics, seed=0, on_right=True):
     from any4_amd import _lib
 
     L = _lib.load()
     gen = torch.Generator(device=DEV).manual_seed(seed)
     inner = 4
-    w = torch.randint(-2 ** 31, 2 ** 31 - 1, (layers, n // 8, k // (16 * inner), 32, inner // 2), dtype=torch.int64,
-                      device=DEV, generator=gen).to(torch.int32)
+    wshape = (layers, n // 8, k // (16 * inner), 32, inner // 2) if on_right else (layers, n // 16, k // (16 * inner), 32, inner)
+    w = torch.randint(-2 ** 31, 2 ** 31 - 1, wshape, dtype=torch.int64, device=DEV, generator=gen).to(torch.int32)
     x = torch.randn(layers, m, k, device=DEV, generator=gen).to(torch.bfloat16)
     if qtype == "mx4":
         q = torch.randint(120, 131, (layers, n, k // g), dtype=torch.uint8, device=DEV, generator=gen)
@@ -334,10 +376,15 @@ def _stacked_launch(layers, m, n, k, g, qtype, numerics, seed=0):
            "any4_global": torch.randn(layers, 16, device=DEV, generator=gen).to(torch.bfloat16)}.get(qtype)
     y = torch.full((layers, m, n), float("nan"), device=DEV, dtype=torch.bfloat16)
     args = _lib.W4Gemm(x=x.data_ptr(), w=w.data_ptr(), qinfo=q.data_ptr(), lut=(lut.data_ptr() if lut is not None else None),
-                       y=y.data_ptr(), m=m, wrows=n, k=k, group=g, qtype=QT[qtype], dtype=_lib.TG_BF16, w_on_right=1,
+                       y=y.data_ptr(), m=m, wrows=n, k=k, group=g, qtype=QT[qtype], dtype=_lib.TG_BF16, w_on_right=1 if on_right else 0,
                        inner_k_tiles=inner, batch=layers, stride_x=x.stride(0) * 2, stride_w=w.stride(0) * 4,
                        stride_qinfo=qstride, stride_lut=(lut.stride(0) * 2 if lut is not None else 0), stride_y=y.stride(0) * 2,
                        numerics=numerics)
+    need = L.tg_gemm_w4_workspace_bytes(ctypes.byref(args))  # as bench.py does
+    assert need >= 0
+    if need:
+        ws = torch.empty(need, dtype=torch.uint8, device=DEV)
+        args.workspace, args.workspace_bytes = ws.data_ptr(), need
     _lib.check(L.tg_gemm_w4(ctypes.byref(args), 0, torch.cuda.current_stream().cuda_stream), "stacked")
     torch.cuda.synchronize()
     return w, x, q, lut, y
@@ -352,8 +399,6 @@ def test_benchmarked_launch_shape(T, oracle, qtype, g, m, numerics):
     full against the oracle; every output must have been written."""
     from any4_amd import _lib
 
-    if numerics == "fast" and m == 8:
-        pytest.skip("m = 8 at k = 4096 does not fit the on-chip activation stage of the group-scaled kernel: same launch as 'reference'")
     layers, n, k = 16, 4096, 4096
     w, x, q, lut, y = _stacked_launch(layers, m, n, k, g, qtype, {"fast": _lib.TG_NUM_FAST, "reference": _lib.TG_NUM_REFERENCE}[numerics], seed=m)
     assert not torch.isnan(y.float()).any()
@@ -367,6 +412,33 @@ def test_benchmarked_launch_shape(T, oracle, qtype, g, m, numerics):
             from tests.test_gpu_parity import assert_gemm_close
 
             assert_gemm_close(y[b], xb, oracle_weights(oracle, codes, g, qtype, qb, lb))
+
+
+@pytest.mark.parametrize("numerics", ["fast", "reference"])
+def test_benchmarked_launch_shape_config3(T, oracle, numerics):
+    """BASELINE config 3 as bench.py launches it: m = 8, n = k = 8192, g = 128, weights on the A side (Aint4, innerKTiles 4),
+    stacked over 4 layers (1024 32-row work items); 256 rows of two layers against the oracle."""
+    from any4_amd import _lib, ops
+    from tests.test_gpu_parity import assert_gemm_close
+
+    layers, m, n, k, g = 4, 8, 8192, 8192, 128
+    w, x, q, lut, y = _stacked_launch(layers, m, n, k, g, "any4_rowwise", {"fast": _lib.TG_NUM_FAST, "reference": _lib.TG_NUM_REFERENCE}[numerics],
+                                      seed=3, on_right=False)
+    assert not torch.isnan(y.float()).any()
+    if numerics == "fast":
+        assert ops.gemm_w4_plan(m, n, k, g, QT["any4_rowwise"], False, 4, batch=layers) == "pair"
+    rows = 256
+    for b in (0, 3):
+        codes = torch.from_numpy(oracle.unpack_Aint4(w[b].cpu().numpy(), n, k))[:rows]
+        xb, qb, lb = x[b].cpu(), q[b].cpu()[:, :rows].contiguous(), lut[b].cpu()[:rows]
+        wq = from_bits16(oracle_weights(oracle, codes, g, "any4_rowwise", qb, lb), torch.bfloat16).double()
+        if numerics == "fast":
+            y_gs = gs_reference(oracle, codes, xb, qb, lb, g, "any4_rowwise")
+            S = (xb.double().abs() @ wq.abs().t()).numpy()
+            got = y[b][:, :rows].double().cpu().numpy()
+            assert (np.abs(got - y_gs) <= 0.5 * ulp16(y_gs, torch.bfloat16) * (1 + 2.0 ** -7) + 4e-6 * S + 1e-37).all()
+        else:
+            assert_gemm_close(y[b][:, :rows], xb, oracle_weights(oracle, codes, g, "any4_rowwise", qb, lb))
 
 
 # ------------------------------------------------------------------------------------------------

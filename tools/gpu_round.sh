@@ -52,5 +52,5 @@ json.dump(sq, open(f"gpurun_out/{RN}_sq_counters_pair.json", "w"), indent=1)
 for k, v in sq.items():
     print(k, v)
 PY
-echo "== quick_bench default dispatch"; timeout 300 python tools/quick_bench.py --configs "1,4096,4096,1;8,4096,4096,1;16,4096,4096,1;1,4096,4096,0;8,8192,8192,0;1,8192,8192,1" --iters 3 2>&1 | grep -E "^m=|eager|stacked|steady" | tee gpurun_out/${RN}_quick_bench_default.txt
-for q in int4 any4_global mx4; do timeout 200 python tools/quick_bench.py --configs "1,4096,4096,1" --qtype $q --iters 3 2>&1 | grep -E "^m=|eager|stacked|steady"; done | tee gpurun_out/${RN}_quick_bench_variants.txt
+echo "== quick_bench default dispatch"; timeout 600 python tools/quick_bench.py --configs "1,4096,4096,1;2,4096,4096,1;4,4096,4096,1;8,4096,4096,1;16,4096,4096,1;1,8192,8192,1;8,8192,8192,1;1,14336,4096,1;1,4096,14336,1;8,4096,14336,1;1,4096,4096,0;8,4096,4096,0;1,8192,8192,0;8,8192,8192,0;16,8192,8192,0" --L 256 --iters 3 2>&1 | grep -E "^m=|eager|graph|stacked|steady" | tee gpurun_out/${RN}_quick_bench_default.txt
+for q in "int4" "any4_global" "mx4" "int4 --g 32" "any4_rowwise --g 64" "any4_rowwise --g 256"; do timeout 300 python tools/quick_bench.py --configs "1,4096,4096,1;8,4096,4096,1;8,8192,8192,0" --qtype $q --L 256 --iters 3 2>&1 | grep -E "^m=|stacked|steady"; done | tee gpurun_out/${RN}_quick_bench_variants.txt
