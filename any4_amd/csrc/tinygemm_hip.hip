@@ -656,6 +656,11 @@ enum { TG_PAIR_NA = -100 };
 #ifndef TG_PAIR_RA1
 #define TG_PAIR_RA1 1  // ... with several groups per super-tile
 #endif
+#ifndef TG_PAIR_MIN_ITEMS
+#define TG_PAIR_MIN_ITEMS 192  // fewer work items: the launch is latency-bound, w4_gemm_pair16_kernel / the reference kernels take
+                               // it (measured per hipGraph node, one layer, m = 1: 14336 x 4096 = 224 items 12.3 us here against
+                               // 18.3 us on pair16 and 13.8 us on the stream kernel; 6144 x 4096 = 96 items 10.7 against 9.9 / 8.2)
+#endif
 #ifndef TG_PAIR_WGS
 #define TG_PAIR_WGS 512  // persistent workgroups: two per CU
 #endif
@@ -780,7 +785,7 @@ int launch_pair(GemmParams& p, int64_t batch, hipStream_t st) {
   // The kernel's unit of work is a 64-row block over the whole k (8 waves): a launch needs about one item per workgroup slot
   // (2 per CU) to fill the chip.  Smaller launches (one 4096-row layer = 64 items) are latency-bound and stay on the
   // split-K kernels, which spread one 16-row tile over up to 16 waves.
-  if (items < 384) { p.ws_need = 0; return TG_PAIR_NA; }
+  if (items < TG_PAIR_MIN_ITEMS) { p.ws_need = 0; return TG_PAIR_NA; }
   pp.items = (int32_t)items;
   pp.stride_x = p.stride_x; pp.stride_w = p.stride_w; pp.stride_qinfo = p.stride_qinfo;
   pp.stride_lut = p.stride_lut; pp.stride_y = p.stride_y;
@@ -921,7 +926,7 @@ int launch_pair_a(GemmParams& p, int64_t batch, hipStream_t st) {
   pp.rblocks = (p.wrows + 31) / 32;
   pp.cblocks = 1;
   const int64_t items = (int64_t)pp.rblocks * batch;
-  if (items > INT32_MAX || items < 384) return TG_PAIR_NA;
+  if (items > INT32_MAX || items < TG_PAIR_MIN_ITEMS) return TG_PAIR_NA;
   p.ws_need = need;
   if (!p.ws_query && (p.ws == nullptr || p.ws_bytes < need)) return TG_PAIR_NA;
   pp.xp = p.ws;

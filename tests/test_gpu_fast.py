@@ -61,9 +61,9 @@ def assert_fast_close(oracle, y_hip, codes, x, qinfo, lut, g, qtype, dtype=torch
 
 
 def run_fast(T, codes, x, qinfo, lut, g, qtype, inner, bias=None, min_items=384, workspace=True, on_right=True):
-    """The pair-table kernel is dispatched when a launch has >= 384 work items (64-row blocks x problems; smaller launches are
-    latency-bound and stay on the split-K kernels): run `copies` identical problems in ONE tg_gemm_w4 call (the C ABI's
-    stacked launch), check that every copy gives the same bits, return (y of copy 0, copies)."""
+    """The persistent pair-table kernel is dispatched when a launch has >= 192 work items (64-row blocks x problems; tested here
+    with >= 384; smaller launches are latency-bound and go to w4_gemm_pair16_kernel): run `copies` identical problems in ONE
+    tg_gemm_w4 call (the C ABI's stacked launch), check that every copy gives the same bits, return (y of copy 0, copies)."""
     from any4_amd import _lib
 
     L = _lib.load()
