@@ -541,3 +541,26 @@ def test_two_host_threads_two_streams(T, oracle):
     assert not errors, errors
     for t in range(2):
         assert all(torch.equal(o, expect[t]) for o in results[t])
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE config 5 at its own size: one decoder layer of Llama-3-8B shapes through the decode harness
+# ------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("bs", [1, 8])
+def test_decode_layer_at_llama3_8b_shapes(oracle, bs):
+    """hidden 4096, 32 / 8 heads of 128, intermediate 14336, g = 128 (q/k/v 6144 x 4096, o 4096 x 4096, gate|up 28672 x 4096,
+    down 4096 x 14336: the launches of config 5), default numerics, against the same stack on nn.Linear with the oracle's
+    dequantised weights.  (The vocabulary is cut to 1024 to keep the LM head small.)"""
+    from any4_amd.decode import DecodeConfig, DecodeStack
+    from tests.test_gpu_decode import _PairedFactories
+
+    cfg = DecodeConfig(hidden=4096, inter=14336, layers=1, heads=32, kv_heads=8, head_dim=128, vocab=1024, max_seq=64, group_size=128)
+    fac = _PairedFactories(oracle, cfg, "linear_y_f16RM_x_f16RM_W_any4TC")
+    q = DecodeStack(cfg, fac.any4, DEV, torch.bfloat16, bs=bs, seed=5, fused=True)
+    d = DecodeStack(cfg, fac.dense, DEV, torch.bfloat16, bs=bs, seed=5, fused=False)
+    toks = torch.randint(0, cfg.vocab, (4, bs), generator=torch.Generator().manual_seed(1)).to(DEV)
+    for i, t in enumerate(toks):
+        a, b = q.decode(t, i).float(), d.decode(t, i).float()
+        assert torch.isfinite(a).all()
+        assert (a - b).abs().max() <= 0.03 * b.abs().max() + 1e-3, (i, (a - b).abs().max(), b.abs().max())
