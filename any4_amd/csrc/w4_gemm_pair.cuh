@@ -453,11 +453,37 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
   };
 
   // XG: the pass's per-group sums (computed by w4_xprep_kernel) -> LDS, rows >= mrows zero, and the zero piece
+  // Items are dealt round-robin, so every item stages another layer's sums: one L2 round trip at the item's start.  They are
+  // requested BEFORE the next item's LUT rows (vector memory returns in order: behind those cold HBM loads the sums would wait a
+  // DRAM latency per item; same-box A/B +0.5 % at 4096^2, +1.5 % at 8192^2).  On the A side (registers to spare) the first
+  // 2 x 512 sums are requested one item ahead into registers (xs_request), like the LUT rows: +0.5-1.7 %; on the B side that
+  // costs 7 more spilled registers and 5 %.
+#ifndef TG_XS_PREFETCH
+#define TG_XS_PREFETCH 1  // 0: developer A/B, no register prefetch on the A side either
+#endif
+  constexpr int NXS = (LA && TG_XS_PREFETCH) ? 2 : 0;
+  float xsn[2] = {0.f, 0.f};
+  auto xs_request = [&](int it) {  // `it` is a valid item
+    if constexpr (XG && !QMX) {
+      const Item e = decode(it);
+      const float* src = reinterpret_cast<const float*>(p.xsum + (int64_t)e.b * p.stride_xsum) + (int64_t)e.ct * p.ngroups * p.xs_rows;
+      const int total = p.ngroups * p.xs_rows;
+#pragma unroll
+      for (int j = 0; j < NXS; ++j) xsn[j] = src[min(tid + 512 * j, total - 1)];
+    }
+  };
   auto xs_stage = [&](int b, int ct, int mrows) {
     const float* src = reinterpret_cast<const float*>(p.xsum + (int64_t)b * p.stride_xsum) + (int64_t)ct * p.ngroups * p.xs_rows;
-    if constexpr (!QMX)
-      for (int idx = tid; idx < p.ngroups * p.xs_rows; idx += 512)
+    if constexpr (!QMX) {
+      const int total = p.ngroups * p.xs_rows;
+#pragma unroll
+      for (int j = 0; j < NXS; ++j) {
+        const int idx = tid + 512 * j;
+        if (idx < total) *(lds_fptr)(lds_xs + (uint32_t)(idx * 4)) = idx % p.xs_rows < mrows ? xsn[j] : 0.f;
+      }
+      for (int idx = tid + 512 * NXS; idx < total; idx += 512)
         *(lds_fptr)(lds_xs + (uint32_t)(idx * 4)) = idx % p.xs_rows < mrows ? src[idx] : 0.f;
+    }
     if (tid < CPS * 4) *(lds_u32x4ptr)(lds_x + (uint32_t)(WAVES * p.xw_bytes + tid * 16)) = u32x4{0, 0, 0, 0};
   };
 
@@ -467,8 +493,9 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
   if (it_begin >= it_end) return;
   if (lut_loaded) lut_request(it_begin);
   else lut_const();
+  xs_request(it_begin);
   const Item first = decode(it_begin);
-  int staged_b = first.b, staged_ct = first.ct;  // which activation block the LDS holds
+  int staged_b = XG ? -1 : first.b, staged_ct = first.ct;  // which activation block the LDS holds (XG: staged by the first item)
   uint32_t xd0[16];
   if constexpr (!XG) {
     const int mrows0 = min(p.m - first.ct * MA, MA);
@@ -484,8 +511,7 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
     issue(rcur, s_begin + j, ring[j], j < nl, NSG == 0 || j % NSG == 0);
   }
   __builtin_amdgcn_sched_barrier(0);
-  if constexpr (XG) xs_stage(first.b, first.ct, min(p.m - first.ct * MA, MA));
-  else x_stage(first.b, first.ct * MA, min(p.m - first.ct * MA, MA), true, xd0);
+  if constexpr (!XG) x_stage(first.b, first.ct * MA, min(p.m - first.ct * MA, MA), true, xd0);
 
   uint32_t colreg[TILES];
 #pragma unroll
@@ -517,12 +543,8 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
         *(lds_u32ptr)(base + (uint32_t)((16 + a) * 256)) = e1;
       }
     }
-    // the next item's LUT rows travel while this item is computed (the last item re-reads its own)
-#ifndef TG_PAIR_NOLP
-    if (lut_loaded) lut_request(has_next ? it + it_stride : it);
-#endif
-
-    // ---- activations: only when the activation block changes (the first item's block was staged above) ----
+    // ---- activations: only when the activation block changes (staged: the first item's block was staged above; XG: the sums
+    // of this item were requested one item ago) ----
     if (cur.b != staged_b || cur.ct != staged_ct) {
       staged_b = cur.b;
       staged_ct = cur.ct;
@@ -533,6 +555,11 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
         x_stage(cur.b, a0, mrows, false, xd);
       }
     }
+    // the next item's LUT rows (and activation sums) travel while this item is computed (the last item re-reads its own)
+#ifndef TG_PAIR_NOLP
+    if (lut_loaded) lut_request(has_next ? it + it_stride : it);
+#endif
+    xs_request(has_next ? it + it_stride : it);
     __syncthreads();  // table and activations visible (and every thread is done with the previous item's partial sums)
 
     // ---- main loop of the item ----
