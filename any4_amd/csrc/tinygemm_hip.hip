@@ -807,8 +807,9 @@ int launch_pair(GemmParams& p, int64_t batch, hipStream_t st) {
     // group boundaries at fixed places of the unrolled round when a group is one super-tile or one whole round
     // (not for the m = 1 specialisation: with fixed boundaries the compiler scatters its accumulator chain over several
     //  register tuples and spills; it keeps the run-time test, which measured faster than the general kernel with fixed ones)
+    // (a group of ONE super-tile, g = 64 at I = 4, also keeps the run-time test: its fixed-boundary build spills 27 registers,
+    //  m = 8 50 % against 59 %)
     const bool fixed = TG_PAIR_NSG2 && !(p.m == 1 && TG_PAIR_MR1 == 1);
-    if (fixed && nsg == 1) return TG_PAIR_M(1, 1);
     if (fixed && nsg == TG_PAIR_R) return TG_PAIR_M(1, TG_PAIR_R);
     return TG_PAIR_M(1, 0);
   }
