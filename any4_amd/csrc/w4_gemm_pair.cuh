@@ -1,8 +1,14 @@
-// w4_gemm_pair.cuh -- the "pair-table" W4A16 GEMM kernel for gfx950 (weights on the B side, Bint4 layout).
+// w4_gemm_pair.cuh -- the persistent "pair-table" W4A16 GEMM kernel for gfx950: Bint4 weights (described first) and, with
+// the template flag LA, Aint4 weights; plus its activation pre-pass w4_xprep_kernel.
 //
-// Same contract as w4_gemm.cuh / w4_gemm_stream.cuh (reference TinyGemmImpl.cuh:23-345 with BLayout_TC_int4,
-// MatrixLayoutB.cuh:686-1101, and the converters of Dequantization.cuh:55-178, 331-351), with the "group-scaled"
-// numerics described below.
+// Same contract as w4_gemm.cuh / w4_gemm_stream.cuh (reference TinyGemmImpl.cuh:23-345 with {A,B}Layout_TC_int4,
+// MatrixLayoutB.cuh:686-1101 / MatrixLayoutA.cuh, and the converters of Dequantization.cuh:55-178, 331-351), with the
+// "group-scaled" numerics described below.  Variants (template flags, all in this one kernel):
+//   XG   activations too large to stage whole: pre-arranged in a caller workspace, streamed per wave through a 1 KiB LDS buffer
+//   LA   Aint4 weights: v_mfma_f32_16x16x32, duplicated table, activations straight from the workspace into the MFMA operand
+//   QMX  mx4: e8m0 exponents fetched as 16-byte blocks per row
+//   MR   1 = the m = 1 specialisation (one accumulator register per tile, group sums as running differences), 4 / 16 = general
+//   x_tc / y_tc (run time): activations / output in the reference's A-fragment order instead of row-major
 //
 // Why another kernel: a per-element LDS lookup (w4_gemm_stream.cuh) costs one LDS access per 4-bit weight and the LDS
 // serves 32 addresses per clock -- at the HBM roofline a CU has to dequantise ~20 weights per clock, which leaves the LDS
