@@ -49,6 +49,9 @@
 #ifndef TG_PAIR_PIN
 #define TG_PAIR_PIN 0  // 1: also pin the accumulator tuples in finalize() when a group's first MFMA takes a zero C operand
 #endif
+#ifndef TG_PAIR_FIN_ASM
+#define TG_PAIR_FIN_ASM 1  // 0: developer A/B, the m = 1 group update as plain C++
+#endif
 
 // Element (r, c) of a matrix kept in the reference's m16n8k16 A-fragment order [ceil(rows/16)][ctiles = ceil(cols/16)][32][8]
 // (TinyGemmConvertA.cu:19-141: lane t = 4 (r & 7) + (c & 7) / 2 holds (r, c0) (r, c0+1) (r+8, c0) (r+8, c0+1) and the same at
@@ -619,6 +622,21 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
     auto finalize = [&]() {
 #pragma unroll
       for (int t = 0; t < TILES; ++t) {
+        if constexpr (DIFF && RF == 1 && !QMX && TG_PAIR_FIN_ASM) {
+          // m = 1: four single-register instructions per tile, spelled out.  Left to the compiler the two tiles' updates become
+          // v_pk_* on register PAIRS; at the 128-VGPR budget the only aligned pair it finds overlaps an accumulator tuple, which
+          // it then moves out of the way and back (17 v_mov_b64 per group and wave).
+          float a0 = acc[t][0];
+          asm volatile("" : "+v"(a0));  // a copy made by the compiler (it knows the MFMA -> VALU read hazard), not by the asm below
+          float d;
+          asm("v_sub_f32 %0, %1, %2" : "=v"(d) : "v"(a0), "v"(prev[t][0]));
+          prev[t][0] = a0;
+          asm("v_fmac_f32 %0, %1, %2" : "+v"(yacc[t][0]) : "v"(gs[t]), "v"(d));
+          asm("v_fmac_f32 %0, %1, %2" : "+v"(yacc[t][0]) : "v"(gz[t]), "v"(xsv[0]));
+          asm volatile("" : "+v"(acc[t]));
+          asm volatile("" ::"v"(acc[t][1]), "v"(acc[t][2]), "v"(acc[t][3]));
+          continue;
+        }
 #pragma unroll
         for (int r = 0; r < RF; ++r) {
           float d = acc[t][r];
@@ -735,7 +753,9 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
             // (branch-free: a data-dependent branch in this loop makes the compiler copy accumulators around it)
             const uint32_t xsa = xs_lane + ((uint32_t)((((chunk * 32) >> p.gshift) * p.xs_rows) * 4) & xs_mask);
             if constexpr (RF == 1) {
-              xsv[0] = *(const __attribute__((address_space(3))) float*)(xsa);
+              // m = 1: every lane reads row 0's sum (a wave-uniform address: one v_mov); the lanes of half 1 hold activation
+              // row 4 in this register, which is never stored
+              xsv[0] = *(const __attribute__((address_space(3))) float*)(lds_xs + (uint32_t)((((chunk * 32) >> p.gshift) * p.xs_rows) * 4));
             } else {
 #pragma unroll
               for (int r4 = 0; r4 < MREGS / 4; ++r4) {

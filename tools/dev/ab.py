@@ -1,0 +1,53 @@
+"""Developer A/B on one GPU box: for the installed any4_amd/lib/libtinygemm_hip.so, check a stacked launch against the CPU
+oracle and time it in the steady state.   python tools/dev/ab.py [m,n,k,on_right,qtype,g[,L]] ...   (one process per library)"""
+import ctypes
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+
+import bench
+from any4_amd import _lib, ops
+
+lib = _lib.load()
+dev = torch.device("cuda", 0)
+st = torch.cuda.current_stream()
+for cfg in sys.argv[1:] or ["1,4096,4096,1,any4_rowwise,128"]:
+    f = cfg.split(",")
+    m, n, k, on_right, qtype, g = int(f[0]), int(f[1]), int(f[2]), int(f[3]) == 1, f[4], int(f[5])
+    L = int(f[6]) if len(f) > 6 else (512 if n * k <= 4096 * 4096 else 128)
+    w, x, q, lut, y = bench.make_batch(L, m, n, k, g, 4, dev, 7, qtype, on_right)
+    aa = bench.make_args(_lib, w, x, q, lut, y, m, n, k, g, qtype, on_right, 4, L)
+    ws = bench.attach_workspace(lib, aa, dev)
+    plan = ops.gemm_w4_plan(m, n, k, g, bench.QT[qtype], on_right, 4, torch.bfloat16, L, "fast")
+
+    def launch():
+        _lib.check(lib.tg_gemm_w4(ctypes.byref(aa), 0, st.cuda_stream), "tg_gemm_w4")
+
+    y.fill_(float("nan"))
+    launch()
+    torch.cuda.synchronize()
+    try:
+        err = bench.check_layers(w, x, q, lut, y, g, qtype, on_right, 4, plan, layers=(0, L // 2, -1), rows=128)
+        ok = f"ok max|err| {err:.3e}"
+    except SystemExit as e:
+        ok = f"MISMATCH {e}"
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 0.7:
+        for _ in range(20):
+            launch()
+        torch.cuda.synchronize()
+    best = []
+    for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        for _ in range(40):
+            launch()
+        e1.record(st)
+        torch.cuda.synchronize()
+        best.append(e0.elapsed_time(e1) / 40 / L * 1e3)
+    us = sorted(best)[2]
+    by = bench.alg_bytes(m, n, k, g, qtype)
+    print(f"{cfg:40s} plan={plan} {ok}  {us:.3f} us/layer  {by / us / 1e3 / 8000 * 100:.1f}% (min {min(best):.3f} max {max(best):.3f})", flush=True)
