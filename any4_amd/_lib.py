@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libtinygemm_hip.so")
 TG_BF16, TG_F16 = 0, 1
 TG_Q_INT4, TG_Q_ANY4_GLOBAL, TG_Q_ANY4_ROWWISE, TG_Q_MX4, TG_Q_INT8 = 0, 1, 2, 3, 4
 TG_NUM_FAST, TG_NUM_REFERENCE = 0, 1
-TG_ABI_VERSION = 3
+TG_ABI_VERSION = 4
 TG_PLAN_SPLITK, TG_PLAN_STREAM, TG_PLAN_PAIR = 1, 2, 3
 TG_LAYOUT_RM, TG_LAYOUT_TC_A = 0, 1
 TG_E_LAYOUT = -12
@@ -34,6 +34,24 @@ class W4Gemm(ctypes.Structure):
     ]
 
 
+TG_PEER_MAX_WORLD = 16
+
+
+class PeerHandle(ctypes.Structure):
+    """struct tg_peer_handle (include/peer_gather_hip.h): a hipIpcMemHandle_t"""
+
+    _fields_ = [("bytes", ctypes.c_ubyte * 64)]
+
+
+class PeerGather(ctypes.Structure):
+    """struct tg_peer_gather (include/peer_gather_hip.h)"""
+
+    _fields_ = [
+        ("src", _vp), ("dst", _vp * TG_PEER_MAX_WORLD), ("flags", _vp * TG_PEER_MAX_WORLD), ("seq", _vp), ("status", _vp),
+        ("world", _i32), ("rank", _i32), ("m", _i64), ("cols_local", _i64), ("timeout_us", _i64),
+    ]
+
+
 # name -> argtypes, exactly the prototypes of include/tinygemm_hip.h
 SYMBOLS = {
     "tg_abi_version": [],
@@ -52,6 +70,13 @@ SYMBOLS = {
     "tg_convert_to_Bint8": [_vp, _i64, _i64, ctypes.c_int, _vp, ctypes.c_int, _vp],
     "tg_convert_to_Aint8": [_vp, _i64, _i64, ctypes.c_int, _vp, ctypes.c_int, _vp],
     "tg_gemm_w8": [ctypes.POINTER(W4Gemm), ctypes.c_int, _vp],
+    # include/peer_gather_hip.h (one-shot peer-write gather of row-sharded outputs)
+    "tg_peer_alloc": [ctypes.c_int, _i64, ctypes.POINTER(_vp)],
+    "tg_peer_free": [ctypes.c_int, _vp],
+    "tg_peer_export": [ctypes.c_int, _vp, ctypes.POINTER(PeerHandle)],
+    "tg_peer_open": [ctypes.c_int, ctypes.POINTER(PeerHandle), ctypes.POINTER(_vp)],
+    "tg_peer_close": [ctypes.c_int, _vp],
+    "tg_peer_gather_launch": [ctypes.POINTER(PeerGather), ctypes.c_int, _vp],
     # include/decode_glue_hip.h (non-GEMM kernels of the decode harness)
     "dg_add_rmsnorm": [_vp, _vp, _vp, _vp, _vp, _i64, _i64, ctypes.c_float, ctypes.c_int, ctypes.c_int, _vp],
     "dg_rope_kv": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, ctypes.c_int, ctypes.c_int, ctypes.c_int, _i64,

@@ -29,6 +29,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <string.h>
 #include <atomic>
 #include <type_traits>
 
@@ -1345,3 +1346,4 @@ int tg_gemm_f16(const void* x, const void* w, void* y, int64_t m, int64_t wrows,
 }  // extern "C"
 
 #include "decode_glue.cuh"
+#include "peer_gather.cuh"

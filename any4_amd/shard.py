@@ -9,6 +9,8 @@ RCCL on ROCm, over xGMI inside a node.  The payload is tiny (m*n/G*2 bytes), i.e
 """
 from __future__ import annotations
 
+import ctypes
+
 import torch
 import torch.distributed as dist
 
@@ -33,20 +35,148 @@ def shard_mx4_params(codes: torch.Tensor, exponents: torch.Tensor, rank: int, wo
     return codes[lo:hi].contiguous(), exponents[lo:hi].contiguous()
 
 
+class _DeviceBytes:
+    """__cuda_array_interface__ holder: lets torch view device memory owned by the C library (no copy, no ownership)."""
+
+    def __init__(self, ptr: int, nbytes: int):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+
+class PeerWriteGather:
+    """Host side of include/peer_gather_hip.h: the one-shot gather of the [m, n/G] output slices of a row-sharded Linear.
+
+    Every rank stores its slice straight into every peer's gathered buffer over xGMI and raises a flag there; one kernel
+    launch per rank and call, no host synchronisation.  The result has the layout the consumer wants ([m, n], rank-major
+    feature order), which RCCL's all_gather_into_tensor ([G, m, n/G]) only gives for m = 1.  One process per GPU; the
+    buffers are uncached device memory of the C library, shared as IPC handles through `group` (any backend) once, here.
+    Calls alternate between two gathered buffers (see the header for why two are enough); the tensor a call returns is
+    overwritten by the call after the next one.
+    """
+
+    def __init__(self, m_max: int, cols_local: int, group=None, device=None, dtype=torch.bfloat16, timeout_us: int = 2_000_000):
+        from . import _lib
+
+        if dtype not in (torch.bfloat16, torch.float16):
+            raise TypeError("PeerWriteGather moves 16-bit outputs")
+        if (cols_local * 2) % 16 != 0:
+            raise ValueError("cols_local * 2 bytes must be a multiple of 16")
+        self._L = _lib
+        self.lib = _lib.load()
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        if self.world > _lib.TG_PEER_MAX_WORLD:
+            raise ValueError(f"world size {self.world} > {_lib.TG_PEER_MAX_WORLD}")
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.dev_index = self.device.index
+        self.m_max, self.cols_local, self.dtype, self.timeout_us = m_max, cols_local, dtype, timeout_us
+        self.buf_bytes = (m_max * cols_local * self.world * 2 + 255) & ~255
+        # control block: flags uint32[16] | seq uint32[16] | status uint32
+        self.ctl_bytes = 256
+        self._own = []
+        self._data = self._alloc(2 * self.buf_bytes)
+        self._ctl = self._alloc(self.ctl_bytes)
+        handles = [None] * self.world
+        mine = (bytes(self._export(self._data).bytes), bytes(self._export(self._ctl).bytes))
+        dist.all_gather_object(handles, mine, group=group)
+        self._opened = []
+        self._peer_data, self._peer_ctl = [], []
+        for r, (hd, hc) in enumerate(handles):
+            if r == self.rank:
+                self._peer_data.append(self._data)
+                self._peer_ctl.append(self._ctl)
+            else:
+                self._peer_data.append(self._open(hd))
+                self._peer_ctl.append(self._open(hc))
+        self._calls = 0
+        self._args = []
+        for parity in range(2):
+            a = _lib.PeerGather()
+            for r in range(self.world):
+                a.dst[r] = self._peer_data[r] + parity * self.buf_bytes
+                a.flags[r] = self._peer_ctl[r]
+            a.seq = self._ctl + 64
+            a.status = self._ctl + 128
+            a.world, a.rank, a.cols_local, a.timeout_us = self.world, self.rank, cols_local, timeout_us
+            self._args.append(a)
+        self._views = [torch.as_tensor(_DeviceBytes(self._data + parity * self.buf_bytes, self.buf_bytes), device=self.device)
+                       for parity in range(2)]
+        self._status = torch.as_tensor(_DeviceBytes(self._ctl + 128, 4), device=self.device).view(torch.int32)
+        dist.barrier(group=group)  # every rank has mapped every buffer before the first store into one
+
+    def _alloc(self, nbytes: int) -> int:
+        p = ctypes.c_void_p()
+        self._L.check(self.lib.tg_peer_alloc(self.dev_index, nbytes, ctypes.byref(p)), "tg_peer_alloc")
+        self._own.append(p.value)
+        return p.value
+
+    def _export(self, ptr: int):
+        h = self._L.PeerHandle()
+        self._L.check(self.lib.tg_peer_export(self.dev_index, ptr, ctypes.byref(h)), "tg_peer_export")
+        return h
+
+    def _open(self, raw: bytes) -> int:
+        h = self._L.PeerHandle()
+        ctypes.memmove(h.bytes, raw, 64)
+        p = ctypes.c_void_p()
+        self._L.check(self.lib.tg_peer_open(self.dev_index, ctypes.byref(h), ctypes.byref(p)), "tg_peer_open")
+        self._opened.append(p.value)
+        return p.value
+
+    def gather(self, y_local: torch.Tensor) -> torch.Tensor:
+        """y_local [m, cols_local] (contiguous, on this device) -> [m, world * cols_local], on the current stream."""
+        if y_local.dim() != 2 or y_local.shape[1] != self.cols_local or y_local.shape[0] > self.m_max:
+            raise ValueError(f"expected [m <= {self.m_max}, {self.cols_local}], got {tuple(y_local.shape)}")
+        if y_local.dtype != self.dtype or not y_local.is_contiguous() or y_local.device != self.device:
+            raise ValueError("y_local must be a contiguous tensor of the gather's dtype on its device")
+        m = y_local.shape[0]
+        parity = self._calls & 1
+        self._calls += 1
+        a = self._args[parity]
+        a.src, a.m = y_local.data_ptr(), m
+        self._L.check(self.lib.tg_peer_gather_launch(ctypes.byref(a), self.dev_index, torch.cuda.current_stream(self.device).cuda_stream),
+                      "tg_peer_gather_launch")
+        return self._views[parity][: m * self.world * self.cols_local * 2].view(self.dtype).view(m, self.world * self.cols_local)
+
+    def check(self) -> None:
+        """Synchronises and raises if a peer's slice did not arrive within the timeout of some call."""
+        torch.cuda.synchronize(self.device)
+        if int(self._status.item()) != 0:
+            raise RuntimeError("PeerWriteGather: a peer's slice did not arrive within the timeout")
+
+    def close(self) -> None:
+        torch.cuda.synchronize(self.device)
+        if dist.is_initialized():
+            dist.barrier(group=self.group)  # no peer is still storing into this rank's buffers
+        for p in self._opened:
+            self.lib.tg_peer_close(self.dev_index, p)
+        for p in self._own:
+            self.lib.tg_peer_free(self.dev_index, p)
+        self._opened, self._own = [], []
+
+
 class RowShardedLinear(torch.nn.Module):
     """Wraps the rank-local quantized Linear (rows [lo, hi) only) and all-gathers its output.
 
     local        any module mapping [..., k] -> [..., n/G] (Any4Linear / Int4Linear built from the shard)
     out_features full n
     gather_output=False leaves the result sharded (for a following column-parallel consumer).
+    gather="rccl" (all_gather_into_tensor) or "peer" (PeerWriteGather: one-shot stores into the peers' buffers, for inputs of
+    at most peer_m_max rows; larger inputs take the RCCL collective).
     """
 
-    def __init__(self, local: torch.nn.Module, out_features: int, group=None, gather_output: bool = True):
+    def __init__(self, local: torch.nn.Module, out_features: int, group=None, gather_output: bool = True, gather: str = "rccl",
+                 peer_m_max: int = 16):
         super().__init__()
+        if gather not in ("rccl", "peer"):
+            raise ValueError("gather must be 'rccl' or 'peer'")
         self.local = local
         self.out_features = out_features
         self.group = group
         self.gather_output = gather_output
+        self.gather = gather
+        self.peer_m_max = peer_m_max
+        self._peer = None
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         y_local = self.local(x)
@@ -58,6 +188,12 @@ class RowShardedLinear(torch.nn.Module):
         y_local = y_local.contiguous()
         if y_local.shape[-1] * world != self.out_features:
             raise RuntimeError("local output width * world_size != out_features")
+        rows = y_local.numel() // y_local.shape[-1]
+        if self.gather == "peer" and y_local.is_cuda and rows <= self.peer_m_max:
+            if self._peer is None:
+                self._peer = PeerWriteGather(self.peer_m_max, y_local.shape[-1], group=self.group, device=y_local.device,
+                                             dtype=y_local.dtype)
+            return self._peer.gather(y_local.view(rows, -1)).view(*y_local.shape[:-1], self.out_features)
         parts = torch.empty((world,) + tuple(y_local.shape), dtype=y_local.dtype, device=y_local.device)
         if dist.get_backend(self.group) == "nccl":
             dist.all_gather_into_tensor(parts, y_local, group=self.group)

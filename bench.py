@@ -304,14 +304,23 @@ def main():
         step()
     fence()
     # kernel-only duration of the dominant kernel, measured live with HIP events on the launch stream
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    # (N = 1: ONE event pair around the K back-to-back launches -- an event pair per launch puts two marker packets between
+    #  consecutive kernels, 5-6 us per 820-us step that belong to the measurement, not to the path; N > 1: a pair per launch,
+    #  because the all-gather sits between the launches)
+    per_launch = world > 1
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps if per_launch else 1)]
     t0 = time.perf_counter()
+    if not per_launch:
+        ev[0][0].record(stream)
     for s in range(a.steps):
-        ev[s][0].record(stream)
+        if per_launch:
+            ev[s][0].record(stream)
         launch(args)
-        ev[s][1].record(stream)
-        if world > 1:
+        if per_launch:
+            ev[s][1].record(stream)
             dist.all_gather_into_tensor(y_all, y)
+    if not per_launch:
+        ev[0][1].record(stream)
     fence()
     elapsed = time.perf_counter() - t0
     kern_ms = sum(e0.elapsed_time(e1) for e0, e1 in ev) / a.steps

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define TG_ABI_VERSION 3
+#define TG_ABI_VERSION 4
 
 #if defined(__GNUC__)
 #define TG_API __attribute__((visibility("default")))

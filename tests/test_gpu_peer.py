@@ -1,0 +1,99 @@
+"""GPU suite: the one-shot peer-write gather (include/peer_gather_hip.h, any4_amd.shard.PeerWriteGather).
+
+SURVEY.md 8(e): rank r of G owns weight rows [r n/G, (r+1) n/G) and all ranks need y[m, n] after the GEMM.  The GPU boxes of this
+build have ONE GPU, so the test runs two processes (two ranks) on the same device: the buffers still cross a process boundary
+as IPC handles, every store is a peer store into memory the other process allocated, and the flags are polled by a kernel that
+is already running -- only the xGMI hop itself is missing.
+"""
+import os
+import socket
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _expected(rank, call, m, cols, dtype):
+    g = torch.Generator().manual_seed(1000 * call + rank)
+    return torch.randn(m, cols, generator=g).to(dtype)
+
+
+def _worker(rank, world, port, cols, m_max, calls, dtype_name):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    dtype = getattr(torch, dtype_name)
+    from any4_amd.shard import PeerWriteGather
+
+    pg = PeerWriteGather(m_max, cols, device="cuda:0", dtype=dtype, timeout_us=20_000_000)
+    try:
+        for call in range(calls):
+            m = 1 + call % m_max
+            y_local = _expected(rank, call, m, cols, dtype).cuda()
+            out = pg.gather(y_local)
+            want = torch.cat([_expected(r, call, m, cols, dtype) for r in range(world)], dim=1)
+            # the consumer runs on the same stream, behind the gather kernel
+            got = out.clone()
+            torch.cuda.synchronize()
+            assert got.shape == (m, world * cols)
+            assert torch.equal(got.cpu().view(torch.int16), want.view(torch.int16)), f"rank {rank} call {call}: gathered rows differ"
+        pg.check()
+    finally:
+        pg.close()
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("cols,m_max,dtype_name", [(2048, 8, "bfloat16"), (512, 16, "float16")])
+def test_peer_write_gather_two_processes(cols, m_max, dtype_name):
+    import torch.multiprocessing as mp
+
+    mp.spawn(_worker, args=(2, _free_port(), cols, m_max, 24, dtype_name), nprocs=2, join=True)
+
+
+def _linear_worker(rank, world, port):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    import tinygemm  # noqa: F401
+    from any4_amd.shard import build_row_sharded_any4
+
+    n, k, g = 256, 512, 128
+    gen = torch.Generator().manual_seed(5)
+    codes = torch.randint(0, 16, (n, k), dtype=torch.int32, generator=gen)
+    lut = torch.randn(n, 16, generator=gen).bfloat16()
+    sz = torch.stack([torch.rand(k // g, n, generator=gen) * 0.02 + 0.005, torch.randn(k // g, n, generator=gen) * 0.01], dim=2).bfloat16()
+    full = build_row_sharded_any4(codes, lut, sz, None, g, 0, 1, "cuda:0", torch.bfloat16)  # world 1: the unsharded layer
+    shard = build_row_sharded_any4(codes, lut, sz, None, g, rank, world, "cuda:0", torch.bfloat16)
+    shard.gather = "peer"
+    try:
+        for m in (1, 3, 8):
+            x = torch.randn(m, k, generator=gen).bfloat16().cuda()
+            y = shard(x).clone()
+            y_ref = full.local(x)
+            torch.cuda.synchronize()
+            assert torch.equal(y.view(torch.int16), y_ref.view(torch.int16)), f"rank {rank} m={m}"
+        shard._peer.check()
+    finally:
+        if shard._peer is not None:
+            shard._peer.close()
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_row_sharded_any4_linear_with_peer_gather():
+    """Two ranks, each with half the weight rows of an Any4Linear, gather through PeerWriteGather: bit-equal to the unsharded layer."""
+    import torch.multiprocessing as mp
+
+    mp.spawn(_linear_worker, args=(2, _free_port()), nprocs=2, join=True)

@@ -30,7 +30,29 @@ def test_c_abi_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in include/*.h but not exported"
     assert set(syms) == set(_lib.SYMBOLS), "ctypes binding and header disagree"
-    assert _lib.load().tg_abi_version() == _lib.TG_ABI_VERSION == 3
+    assert _lib.load().tg_abi_version() == _lib.TG_ABI_VERSION == 4
+
+
+def test_peer_gather_preconditions_fail_before_any_launch():
+    """include/peer_gather_hip.h: argument validation of the one-shot gather returns TG_E_* without touching HIP."""
+    from any4_amd import _lib
+
+    L = _lib.load()
+    a = _lib.PeerGather()
+    assert L.tg_peer_gather_launch(ctypes.byref(a), 0, None) == -1               # TG_E_NULL: no src / seq / status
+    a.src, a.seq, a.status = 4096, 8192, 8192 + 128
+    a.world, a.rank, a.m, a.cols_local = 2, 2, 1, 64
+    assert L.tg_peer_gather_launch(ctypes.byref(a), 0, None) == -7               # rank outside the world
+    a.rank, a.world = 0, _lib.TG_PEER_MAX_WORLD + 1
+    assert L.tg_peer_gather_launch(ctypes.byref(a), 0, None) == -7               # world too large
+    a.world, a.cols_local = 2, 60
+    assert L.tg_peer_gather_launch(ctypes.byref(a), 0, None) == -8               # row bytes not a multiple of 16
+    a.cols_local = 64
+    assert L.tg_peer_gather_launch(ctypes.byref(a), 0, None) == -1               # dst / flags of a rank missing
+    assert L.tg_peer_alloc(0, 0, ctypes.byref(ctypes.c_void_p())) == -7
+    assert L.tg_peer_export(0, None, ctypes.byref(_lib.PeerHandle())) == -1
+    assert L.tg_peer_open(0, None, ctypes.byref(ctypes.c_void_p())) == -1
+    assert L.tg_peer_close(0, None) == -1 and L.tg_peer_free(0, None) == -1
 
 
 def test_c_abi_preconditions_fail_before_any_launch():
