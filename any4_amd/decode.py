@@ -230,13 +230,19 @@ class DecodeStack(torch.nn.Module):
 
     def __init__(self, cfg: DecodeConfig, linear_factory: Callable, device, dtype=torch.bfloat16, bs: int = 1,
                  rank: int = 0, world: int = 1, group=None, seed: int = 0, lm_head: bool = True,
-                 fused: Optional[bool] = None, emulate_gather: bool = False):
+                 fused: Optional[bool] = None, emulate_gather: bool = False, gather: str = "rccl"):
         """fused: run the non-GEMM parts on the HIP glue kernels (default on a GPU) or as plain torch ops
         (the formulation the glue kernels are tested against; also what runs in the CPU plumbing tests).
         emulate_gather: TIMING ONLY -- build rank `rank` of `world` in a single process and replace every all-gather
         by a local copy of the rank's shard into all `world` slots (the values are meaningless): the per-GPU compute
-        of a TP=world decode step, without the interconnect."""
+        of a TP=world decode step, without the interconnect.
+        gather: "rccl" = all_gather_into_tensor per exchange; "peer" = the one-shot peer-write gather of
+        include/peer_gather_hip.h (any4_amd.shard.PeerWriteGather: one kernel per exchange, stores into the peers' buffers)."""
         super().__init__()
+        if gather not in ("rccl", "peer"):
+            raise ValueError("gather must be 'rccl' or 'peer'")
+        self.gather_mode = gather
+        self._peer = {}  # output width per rank -> PeerWriteGather
         self.cfg, self.bs, self.rank, self.world, self.group = cfg, bs, rank, world, group
         self.emulate_gather = emulate_gather
         self.fused = torch.device(device).type == "cuda" if fused is None else fused
@@ -280,6 +286,13 @@ class DecodeStack(torch.nn.Module):
         y = y.contiguous()
         if self.emulate_gather:
             return y.repeat(1, self.world)
+        if self.gather_mode == "peer":
+            from .shard import PeerWriteGather
+
+            pg = self._peer.get(y.shape[1])
+            if pg is None:
+                pg = self._peer[y.shape[1]] = PeerWriteGather(self.bs, y.shape[1], group=self.group, device=y.device, dtype=y.dtype)
+            return pg.gather(y)
         parts = torch.empty((self.world,) + tuple(y.shape), dtype=y.dtype, device=y.device)
         if dist.get_backend(self.group) == "nccl":
             dist.all_gather_into_tensor(parts, y, group=self.group)
@@ -293,6 +306,18 @@ class DecodeStack(torch.nn.Module):
     def step(self) -> torch.Tensor:
         """One decode step on the static inputs `self.tokens` [bs], `self.pos` [1]; returns logits (or the
         final hidden state when built without LM head)."""
+        if self._peer or (self.gather_mode == "peer" and self.world > 1 and not self.emulate_gather):
+            before = {w: pg._calls for w, pg in self._peer.items()}
+            out = self._step()
+            # a gather object alternates between two buffers per call: an odd number of calls per step would make the last
+            # call of one step and the first of the next share a buffer (and a captured graph replays the SAME buffers)
+            for w, pg in self._peer.items():
+                if (pg._calls - before.get(w, 0)) & 1:
+                    pg.gather(torch.zeros(1, w, dtype=pg.dtype, device=pg.device))
+            return out
+        return self._step()
+
+    def _step(self) -> torch.Tensor:
         pos = self.pos
         if self.fused:
             h, delta = self.embed(self.tokens), None

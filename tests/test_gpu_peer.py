@@ -97,3 +97,59 @@ def test_row_sharded_any4_linear_with_peer_gather():
     import torch.multiprocessing as mp
 
     mp.spawn(_linear_worker, args=(2, _free_port()), nprocs=2, join=True)
+
+
+def _decode_worker(rank, world, port, results):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from any4_amd.decode import DecodeConfig, DecodeStack, shard_rows
+
+    cfg = DecodeConfig(hidden=256, inter=512, layers=2, heads=4, kv_heads=2, head_dim=64, vocab=128, max_seq=32, group_size=128)
+
+    def factory(r, w):
+        def make(name, layer, in_features, rows):
+            full_rows = {n: o for n, o, _ in cfg.linear_shapes()}[name]
+            gen = torch.Generator().manual_seed(1000 * layer + sum(map(ord, name)))
+            wt = torch.randn(full_rows, in_features, generator=gen) / in_features ** 0.5
+            lin = torch.nn.Linear(in_features, rows, bias=False, device="cuda:0", dtype=torch.bfloat16)
+            lin.weight.data = wt[shard_rows(cfg, name, r, w)].contiguous().to("cuda:0", torch.bfloat16)
+            return lin
+        return make
+
+    toks = torch.randint(0, cfg.vocab, (5, 2), generator=torch.Generator().manual_seed(3)).cuda()
+    try:
+        full = DecodeStack(cfg, factory(0, 1), "cuda:0", torch.bfloat16, bs=2, seed=7)
+        tp = DecodeStack(cfg, factory(rank, world), "cuda:0", torch.bfloat16, bs=2, rank=rank, world=world, seed=7, gather="peer")
+        ref = torch.stack([full.decode(t, i).float().clone() for i, t in enumerate(toks)])
+        eager = torch.stack([tp.decode(t, i).float().clone() for i, t in enumerate(toks)])
+        # ... and the same steps replayed from one captured hipGraph (the gather kernels keep their sequence number on the device)
+        tp.capture()
+        graph = torch.stack([tp.decode(t, i).float().clone() for i, t in enumerate(toks)])
+        torch.cuda.synchronize()
+        for pg in tp._peer.values():
+            pg.check()
+        scale = float(ref.abs().max())
+        results[rank] = (float((eager - ref).abs().max()) / scale, float((graph - eager).abs().max()) / scale,
+                         sorted(pg._calls for pg in tp._peer.values()))
+    finally:
+        for pg in tp._peer.values():
+            pg.close()
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_tensor_parallel_decode_with_peer_gather():
+    """TP = 2 decode stack (heads / rows split, 4 exchanges per layer through PeerWriteGather, HIP glue kernels) against the
+    unsharded stack, eager and replayed from a hipGraph; both ranks live on the one GPU of the box."""
+    import torch.multiprocessing as mp
+
+    results = mp.Manager().dict()
+    mp.spawn(_decode_worker, args=(2, _free_port(), results), nprocs=2, join=True)
+    assert set(results.keys()) == {0, 1}
+    for rank, (err_eager, err_graph, calls) in results.items():
+        assert err_eager < 3e-2, (rank, err_eager)   # bf16 GEMMs of different shapes (row shards) and summation orders
+        assert err_graph < 3e-2, (rank, err_graph)
+        assert all(c % 2 == 0 for c in calls), calls  # every gather object ended on an even number of calls

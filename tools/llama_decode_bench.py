@@ -53,17 +53,28 @@ def main():
     ap.add_argument("--emulate-tp", type=int, default=0,
                     help="single process, timing only: build rank 0 of a TP=N model and replace the all-gathers by local "
                          "copies -> per-GPU compute time of a TP=N step without the interconnect")
+    ap.add_argument("--gather", default="rccl", choices=["rccl", "peer"],
+                    help="TP > 1: RCCL all_gather_into_tensor per exchange, or the one-shot peer-write gather (include/peer_gather_hip.h)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend; gloo needs --gather peer (no CUDA collectives: only the IPC handles travel through it)")
+    ap.add_argument("--same-device", action="store_true",
+                    help="functional check on a one-GPU box: every rank uses GPU 0 (needs --backend gloo --gather peer); the time "
+                         "it prints is two processes sharing one GPU, not a TP measurement")
     a = ap.parse_args()
+    if a.backend == "gloo" and a.gather != "peer":
+        raise SystemExit("--backend gloo moves no CUDA tensors: use it with --gather peer")
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("needs a GPU (the HIP path has no CPU fallback)")
+    if a.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group(backend="nccl")
+        dist.init_process_group(backend=a.backend)
 
     from any4_amd.decode import Any4Factory, DecodeConfig, DecodeStack, DenseFactory, memory_allocated_mb
 
@@ -81,7 +92,7 @@ def main():
         if a.emulate_tp > 1:
             stack = DecodeStack(cfg, fac, device, torch.bfloat16, bs=a.bs, rank=0, world=a.emulate_tp, emulate_gather=True)
         else:
-            stack = DecodeStack(cfg, fac, device, torch.bfloat16, bs=a.bs, rank=rank, world=world)
+            stack = DecodeStack(cfg, fac, device, torch.bfloat16, bs=a.bs, rank=rank, world=world, gather=a.gather)
         graph = False
         if not a.no_graph:
             try:
@@ -96,11 +107,15 @@ def main():
                "hipgraph": graph, "peak_mem_mib": round(memory_allocated_mb(device), 1)}
         if label == "any4":
             out["weight_stream_GBps_all_ranks"] = round(cfg.weight_bytes_4bit() / dt / 1e9, 1)
+        for pg in stack._peer.values():
+            pg.check()
+            pg.close()
         del stack, fac
         torch.cuda.empty_cache()
         return out
 
-    res = {"config": a.config, "layers": cfg.layers, "bs": a.bs, "tp": world, "emulated_tp_compute_only": a.emulate_tp or None, "max_seq": cfg.max_seq,
+    res = {"config": a.config, "layers": cfg.layers, "bs": a.bs, "tp": world, "gather": a.gather if world > 1 else None,
+           "ranks_share_one_gpu": bool(a.same_device), "emulated_tp_compute_only": a.emulate_tp or None, "max_seq": cfg.max_seq,
            "steps": a.steps, "warmup": a.warmup, "data": "synthetic (random weights, random tokens)",
            "algorithmic_4bit_bytes_per_token": cfg.weight_bytes_4bit()}
     res["any4"] = run(Any4Factory, "any4")
