@@ -835,6 +835,9 @@ int launch_pair16(const GemmParams& p, int64_t batch, hipStream_t st) {
   if constexpr (!(std::is_same<DT, BF16>::value && I == 4 && !QMX)) return TG_PAIR_NA;
 #endif
   if (p.m > 16 || batch > 65535) return TG_PAIR_NA;
+  // m = 1 and more than one round of workgroups (one per CU): the streaming kernel's split-K launches are faster there
+  // (per hipGraph node, 6144 x 4096: 8.6 us against 10.2 us; 14336 x 4096: 13.8 against 18.3)
+  if (p.m == 1 && !p.x_tc && !p.y_tc && (int64_t)((p.wrows + 15) / 16) * batch > 256 && (1 << p.gshift) >= 128) return TG_PAIR_NA;
   const int g = 1 << p.gshift;
   const int nsg = g >= 16 * I ? g / (16 * I) : 1;
   Pair16Params pp;

@@ -16,6 +16,11 @@
 //                << 2, one v_perm_b32); only columns 16 (q & 1) + n are used: the two lanes of a 32-lane LDS access group that
 //                share a weight row read different copies, a group touches 32 distinct banks.
 //   activations= m <= 16 rows staged whole in LDS (byte order) with their per-group sums.
+//   TPW        = 16-row MFMA tiles per workgroup.  Only 1 is instantiated: 2 (table columns 32 t + 16 (q & 1) + n, one X fragment
+//                read per step for both tiles; would keep 6144-row layers at one round of workgroups) spills 80-150 registers at
+//                the 128-VGPR budget of a 1024-thread workgroup; m = 1 launches of more than one round go to the stream kernel.
+//   long k     = a slice of more than CH super-tiles per wave (k = 14336: 14) is walked in blocks of CH with the NEXT block's
+//                words requested before the current one is consumed (two register sets).
 #pragma once
 #ifndef P16_ABL
 #define P16_ABL 0  // developer ablations (0 in the product)
@@ -47,7 +52,7 @@ struct Pair16Params {
 // I   = innerKTiles of the Bint4 layout (2, 4, 8): I / 2 words per lane and super-tile (one per 32-k chunk)
 // CPG = 32-k chunks per quantisation group (1, 2, 4, 8): a full block of CH super-tiles then has its group boundaries at fixed
 //       places of the unrolled code (no branches between the steps)
-template <typename DT, int I, bool QMX, int CPG>
+template <typename DT, int I, bool QMX, int CPG, int TPW = 1>
 __global__ void __launch_bounds__(1024) w4_gemm_pair16_kernel(const Pair16Params p) {
   constexpr int WAVES = 16;
   constexpr int NT = WAVES * 64;
@@ -61,22 +66,25 @@ __global__ void __launch_bounds__(1024) w4_gemm_pair16_kernel(const Pair16Params
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n = lane & 15, q = lane >> 4;
   const int b = blockIdx.y;
-  const int row0 = blockIdx.x * 16;
+  const int row0 = blockIdx.x * (16 * TPW);
 
   // this wave's slice of phase ph: super-tiles [ph ksuper_p + wave spw, + nl)
   const int nl = max(min(p.spw, p.ksuper_p - wave * p.spw), 0);
   int s_begin = wave * p.spw;
 
   // ---- requests, in the order they are consumed: LUT row of this thread's table column, activations, weights ----
-  const int tcol = tid & 31;                     // table column = 16 copy + row
-  const int trow = min(row0 + (tcol & 15), p.wrows - 1);
-  uint32_t lp[8];
+  const int tcol = tid & 31;                     // table column (of tile t: + 32 t) = 16 copy + row
+  uint32_t lp[TPW][8];
   if (p.qtype == TG_Q_ANY4_GLOBAL || p.qtype == TG_Q_ANY4_ROWWISE) {
-    const char* lsrc = p.lut + (int64_t)b * p.stride_lut + (p.qtype == TG_Q_ANY4_ROWWISE ? (int64_t)trow * 32 : 0);
-    const u32x4 l0 = reinterpret_cast<const u32x4*>(lsrc)[0];
-    const u32x4 l1 = reinterpret_cast<const u32x4*>(lsrc)[1];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { lp[j] = l0[j]; lp[4 + j] = l1[j]; }
+    for (int t = 0; t < TPW; ++t) {
+      const int trow = min(row0 + 16 * t + (tcol & 15), p.wrows - 1);
+      const char* lsrc = p.lut + (int64_t)b * p.stride_lut + (p.qtype == TG_Q_ANY4_ROWWISE ? (int64_t)trow * 32 : 0);
+      const u32x4 l0 = reinterpret_cast<const u32x4*>(lsrc)[0];
+      const u32x4 l1 = reinterpret_cast<const u32x4*>(lsrc)[1];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { lp[t][j] = l0[j]; lp[t][4 + j] = l1[j]; }
+    }
   } else {
 #pragma unroll
     for (int e = 0; e < 16; e += 2) {
@@ -89,7 +97,8 @@ __global__ void __launch_bounds__(1024) w4_gemm_pair16_kernel(const Pair16Params
         v0 = (e & 8 ? -1.f : 1.f) * ((e & 7) < 5 ? 0.5f * (e & 7) : ((e & 7) == 5 ? 3.f : (e & 7) == 6 ? 4.f : 6.f));
         v1 = (e1 & 8 ? -1.f : 1.f) * ((e1 & 7) < 5 ? 0.5f * (e1 & 7) : ((e1 & 7) == 5 ? 3.f : (e1 & 7) == 6 ? 4.f : 6.f));
       }
-      lp[e >> 1] = DT::pack2(v0, v1);
+#pragma unroll
+      for (int t = 0; t < TPW; ++t) lp[t][e >> 1] = DT::pack2(v0, v1);
     }
   }
 
@@ -115,42 +124,61 @@ __global__ void __launch_bounds__(1024) w4_gemm_pair16_kernel(const Pair16Params
   };
   if (tid < xtotal) x_load(tid, 0);
 
-  // weights of this lane: row n of the workgroup's 16, quad q
-  const int wrow = min(row0 + n, p.wrows - 1);
-  const int nt = min(wrow >> 3, p.ntiles - 1);
-  const char* wl = p.w + (int64_t)b * p.stride_w + ((int64_t)nt * p.ksuper * 32 + (4 * (wrow & 7) + q)) * (2 * I);
+  // weights of this lane: row n of each of the workgroup's TPW 16-row tiles, quad q
+  int wrow[TPW];
+  const char* wl[TPW];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) {
+    wrow[t] = min(row0 + 16 * t + n, p.wrows - 1);
+    const int nt = min(wrow[t] >> 3, p.ntiles - 1);
+    wl[t] = p.w + (int64_t)b * p.stride_w + ((int64_t)nt * p.ksuper * 32 + (4 * (wrow[t] & 7) + q)) * (2 * I);
+  }
   const char* qb = p.qinfo + (int64_t)b * p.stride_qinfo;
-  uint32_t wreg[CH][CPS];
-  uint32_t qreg[CH][CPS];  // scale | zero word (or mx4 exponent byte) of the group of every chunk
-  auto w_request = [&](int l0) {
+  // two register sets where they fit without spills (one tile per workgroup, groups of >= 128): set B is only used when a
+  // wave's slice is longer than one block of CH super-tiles (see the main loop)
+  constexpr bool PIPE = TPW == 1 && CPG >= 4;
+  uint32_t wregA[TPW][CH][CPS], wregB[PIPE ? TPW : 1][PIPE ? CH : 1][PIPE ? CPS : 1];
+  uint32_t qregA[TPW][CH][CPS], qregB[PIPE ? TPW : 1][PIPE ? CH : 1][PIPE ? CPS : 1];  // scale | zero word (or mx4 exponent byte) of the group of every chunk
+  // Requests the block of CH super-tiles at slice position l0.  Positions past the slice are still requested (the number of loads
+  // in flight stays the same on every path) but every lane reads the operand's first bytes: one cached request, never consumed.
+  auto w_request = [&](uint32_t (&wreg)[TPW][CH][CPS], uint32_t (&qreg)[TPW][CH][CPS], int l0) {
 #pragma unroll
     for (int j = 0; j < CH; ++j) {
       const int l = l0 + j;
-      const int s = nl > 0 ? s_begin + (l < nl ? l : 0) : 0;  // past the slice: re-read its first super-tile (never consumed)
-      const char* src = wl + (int64_t)s * (64 * I);
-      if constexpr (I == 2) {
-        wreg[j][0] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(src));
-      } else if constexpr (I == 4) {
-        const u32x2 v = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(src));
-        wreg[j][0] = v[0]; wreg[j][1] = v[1];
-      } else {
-        const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src));
-        wreg[j][0] = v[0]; wreg[j][1] = v[1]; wreg[j][2] = v[2]; wreg[j][3] = v[3];
-      }
+      const bool valid = l < nl;  // wave-uniform
+      const int s = valid ? s_begin + l : 0;
 #pragma unroll
-      for (int jc = 0; jc < CPS; ++jc) {
-        const int g = ((s * CPS + jc) * 32) >> p.gshift;
-        if constexpr (QMX) qreg[j][jc] = *reinterpret_cast<const uint8_t*>(qb + (int64_t)wrow * p.ngroups + g);
-        else qreg[j][jc] = *reinterpret_cast<const uint32_t*>(qb + ((int64_t)g * p.wrows + wrow) * 4);
+      for (int t = 0; t < TPW; ++t) {
+        const char* src = valid ? wl[t] + (int64_t)s * (64 * I) : p.w;
+        if constexpr (I == 2) {
+          wreg[t][j][0] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(src));
+        } else if constexpr (I == 4) {
+          const u32x2 v = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(src));
+          wreg[t][j][0] = v[0]; wreg[t][j][1] = v[1];
+        } else {
+          const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src));
+          wreg[t][j][0] = v[0]; wreg[t][j][1] = v[1]; wreg[t][j][2] = v[2]; wreg[t][j][3] = v[3];
+        }
+#pragma unroll
+        for (int jc = 0; jc < CPS; ++jc) {
+          // a block starts on a group boundary (slices are whole groups, CH CPS is a multiple of CPG): only the chunks that
+          // start a group need their scale | zero word
+          if (STATIC_G && (j * CPS + jc) % CPG != 0) continue;
+          const int g = ((s * CPS + jc) * 32) >> p.gshift;
+          if constexpr (QMX) qreg[t][j][jc] = *reinterpret_cast<const uint8_t*>(valid ? qb + (int64_t)wrow[t] * p.ngroups + g : qb);
+          else qreg[t][j][jc] = *reinterpret_cast<const uint32_t*>(valid ? qb + ((int64_t)g * p.wrows + wrow[t]) * 4 : qb);
+        }
       }
     }
   };
-  if (P16_ABL != 1) w_request(0);
+  if (P16_ABL != 1) w_request(wregA, qregA, 0);
   else {
 #pragma unroll
-    for (int j = 0; j < CH; ++j)
+    for (int t = 0; t < TPW; ++t)
 #pragma unroll
-      for (int jc = 0; jc < CPS; ++jc) { wreg[j][jc] = (uint32_t)(tid * 977 + j * 13 + jc); qreg[j][jc] = 0x3c003c00u; }
+      for (int j = 0; j < CH; ++j)
+#pragma unroll
+        for (int jc = 0; jc < CPS; ++jc) { wregA[t][j][jc] = (uint32_t)(tid * 977 + j * 13 + jc + t); qregA[t][j][jc] = 0x3c003c00u; }
   }
 
   // ---- stage the activations (byte order) and their group sums; build the table ----
@@ -194,20 +222,21 @@ __global__ void __launch_bounds__(1024) w4_gemm_pair16_kernel(const Pair16Params
     if (tid == 0) *(lds_u32x4ptr)(lds_x + (uint32_t)(p.m * p.x_pitch)) = u32x4{0, 0, 0, 0};  // zero piece for padding rows
   };
   x_stage(0, true);
-  {
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) {
     // thread = (column tcol, high nibble (tid >> 5) & 15, half tid >> 9 of the low nibbles): entries (lut[lo], lut[hi])
     const int hi = (tid >> 5) & 15, half = tid >> 9;
-    uint32_t hw = lp[0];
+    uint32_t hw = lp[t][0];
 #pragma unroll
-    for (int j = 1; j < 8; ++j) hw = ((hi >> 1) == j) ? lp[j] : hw;
+    for (int j = 1; j < 8; ++j) hw = ((hi >> 1) == j) ? lp[t][j] : hw;
     const uint32_t hsel = (hi & 1) ? 0x07060000u : 0x05040000u;  // the high half of the entry: value `hi` of the pair hw
-    const uint32_t base = (uint32_t)((hi * 16 + half * 8) * 256 + tcol * 4);
+    const uint32_t base = (uint32_t)((hi * 16 + half * 8) * 256 + (32 * t + tcol) * 4);
     // (masks, not `half ? lp[4 + j] : lp[j]`: a select between two array elements becomes a dynamically indexed private array,
     //  which the compiler then moves to static LDS -- and this kernel's table must start at LDS address 0)
     const uint32_t hm = half ? 0xffffffffu : 0u;
     uint32_t lq[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) lq[j] = (lp[4 + j] & hm) | (lp[j] & ~hm);
+    for (int j = 0; j < 4; ++j) lq[j] = (lp[t][4 + j] & hm) | (lp[t][j] & ~hm);
 #pragma unroll
     for (int a = 0; a < (P16_ABL == 4 ? 1 : 8); ++a) {
       const uint32_t e = __builtin_amdgcn_perm(hw, lq[a >> 1], hsel | ((a & 1) ? 0x0302u : 0x0100u));
@@ -221,69 +250,78 @@ __global__ void __launch_bounds__(1024) w4_gemm_pair16_kernel(const Pair16Params
   const uint32_t xzero = lds_x + (uint32_t)(p.m * p.x_pitch);
   const uint32_t xrow = a_on ? lds_x + (uint32_t)(n * p.x_pitch + q * 16) : xzero;
   const uint32_t xmask = a_on ? 0xffffffffu : 0u;
-  const uint32_t colreg = (uint32_t)((16 * (q & 1) + n) * 4);
+  uint32_t colreg[TPW];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) colreg[t] = (uint32_t)((32 * t + 16 * (q & 1) + n) * 4);
   // this lane's accumulator rows are activation rows 4 q + r
   const uint32_t xs_lane = lds_xs + (uint32_t)(4 * q * 4);
 
-  f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-  float yacc[4] = {0.f, 0.f, 0.f, 0.f};
-  float gs = 0.f, gz = 0.f;
-  f32x4 xsv = {0.f, 0.f, 0.f, 0.f};
   const f32x4_t zero4 = {0.f, 0.f, 0.f, 0.f};
+  f32x4_t acc[TPW];
+  float yacc[TPW][4];
+  float gs[TPW], gz[TPW];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) {
+    acc[t] = zero4;
+    gs[t] = gz[t] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) yacc[t][r] = 0.f;
+  }
+  f32x4 xsv = {0.f, 0.f, 0.f, 0.f};
 
   if (P16_ABL == 2) {  // loads consumed, nothing computed
 #pragma unroll
-    for (int j = 0; j < CH; ++j)
+    for (int t = 0; t < TPW; ++t)
 #pragma unroll
-      for (int jc = 0; jc < CPS; ++jc) yacc[0] += u2f(wreg[j][jc] ^ qreg[j][jc]);
+      for (int j = 0; j < CH; ++j)
+#pragma unroll
+        for (int jc = 0; jc < CPS; ++jc) yacc[t][0] += u2f(wregA[t][j][jc] ^ qregA[t][j][jc]);
   }
-  for (int ph = 0; ph < p.phases; ++ph) {
-  if (ph > 0) {
-    // the next part of k: its first weights are requested before the activations are re-staged (two barriers: every wave is
-    // done with the previous part's activations / the new ones are visible)
-    s_begin = ph * p.ksuper_p + wave * p.spw;
-    w_request(0);
-    __syncthreads();
-    x_stage(ph, false);
-    __syncthreads();
-  }
-  const int chunk_ph = ph * p.ksuper_p * CPS;  // first chunk of the phase: LDS holds chunks / groups relative to it
-  for (int l0 = 0; l0 < (P16_ABL == 2 ? 0 : nl); l0 += CH) {
-    if (l0 > 0) w_request(l0);
+  int chunk_ph = 0;  // first chunk of the current phase: LDS holds chunks / groups relative to it
+  // one 32-k chunk of every tile: 4 lookups + one MFMA per tile, the X fragment read once
+  auto step = [&](const uint32_t (&wreg)[TPW][CH][CPS], const uint32_t (&qreg)[TPW][CH][CPS], int j, int jc, int chunk, bool gfirst, bool glast) {
+    const u32x4 xf = *(lds_cu32x4ptr)(xrow + ((uint32_t)((chunk - chunk_ph) * 64) & xmask));
+    u32x4 bf[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+      const uint32_t w = wreg[t][j][jc];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bf[t][e] = *(lds_cu32ptr)(__builtin_amdgcn_perm(w, colreg[t], 0x0c0c0400u + ((uint32_t)e << 8)));
+    }
+    if (gfirst) {
+#pragma unroll
+      for (int t = 0; t < TPW; ++t) {
+        const uint32_t qv = qreg[t][j][jc];
+        if constexpr (QMX) {
+          gs[t] = u2f(qv == 255u ? 0x7fc00000u : (qv == 0u ? 0x00400000u : (qv << 23)));  // Dequantization.cuh:331-339
+        } else {
+          gs[t] = DT::lo_f32(qv);
+          gz[t] = DT::hi_f32(qv);
+        }
+      }
+      if constexpr (!QMX) xsv = *(lds_cf32x4ptr)(xs_lane + (uint32_t)(((((chunk - chunk_ph) * 32) >> p.gshift) * 16) * 4));
+    }
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) acc[t] = mfma16<DT>(xf, bf[t], gfirst ? zero4 : acc[t]);
+    if (glast) {
+#pragma unroll
+      for (int t = 0; t < TPW; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          yacc[t][r] = __builtin_fmaf(gs[t], acc[t][r], yacc[t][r]);
+          if constexpr (!QMX) yacc[t][r] = __builtin_fmaf(gz[t], xsv[r], yacc[t][r]);
+        }
+    }
+  };
+  // the block of CH super-tiles at slice position l0 (its words are in wreg / qreg)
+  auto consume_block = [&](const uint32_t (&wreg)[TPW][CH][CPS], const uint32_t (&qreg)[TPW][CH][CPS], int l0) {
     if (STATIC_G && l0 + CH <= nl) {
       // a whole block: the slice starts on a group boundary and CH CPS is a multiple of CPG, so step u starts a group iff
       // u % CPG == 0 -- straight-line code
       const int chunk0 = (s_begin + l0) * CPS;
 #pragma unroll
-      for (int u = 0; u < CH * CPS; ++u) {
-        const int j = u / CPS, jc = u % CPS;
-        const u32x4 xf = *(lds_cu32x4ptr)(xrow + ((uint32_t)((chunk0 + u - chunk_ph) * 64) & xmask));
-        u32x4 bf;
-        const uint32_t w = wreg[j][jc];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) bf[e] = *(lds_cu32ptr)(__builtin_amdgcn_perm(w, colreg, 0x0c0c0400u + ((uint32_t)e << 8)));
-        if (u % CPG == 0) {
-          const uint32_t qv = qreg[j][jc];
-          if constexpr (QMX) {
-            gs = u2f(qv == 255u ? 0x7fc00000u : (qv == 0u ? 0x00400000u : (qv << 23)));
-          } else {
-            gs = DT::lo_f32(qv);
-            gz = DT::hi_f32(qv);
-            xsv = *(lds_cf32x4ptr)(xs_lane + (uint32_t)(((((chunk0 + u - chunk_ph) * 32) >> p.gshift) * 16) * 4));
-          }
-          acc = mfma16<DT>(xf, bf, zero4);
-        } else {
-          acc = mfma16<DT>(xf, bf, acc);
-        }
-        if (u % CPG == CPG - 1) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            yacc[r] = __builtin_fmaf(gs, acc[r], yacc[r]);
-            if constexpr (!QMX) yacc[r] = __builtin_fmaf(gz, xsv[r], yacc[r]);
-          }
-        }
-      }
-      continue;
+      for (int u = 0; u < CH * CPS; ++u) step(wreg, qreg, u / CPS, u % CPS, chunk0 + u, u % CPG == 0, u % CPG == CPG - 1);
+      return;
     }
 #pragma unroll
     for (int j = 0; j < CH; ++j) {
@@ -292,49 +330,57 @@ __global__ void __launch_bounds__(1024) w4_gemm_pair16_kernel(const Pair16Params
 #pragma unroll
         for (int jc = 0; jc < CPS; ++jc) {
           const int chunk = s * CPS + jc;
-          const bool gfirst = (chunk & p.gch_mask) == 0, glast = (chunk & p.gch_mask) == p.gch_mask;
-          const u32x4 xf = *(lds_cu32x4ptr)(xrow + ((uint32_t)((chunk - chunk_ph) * 64) & xmask));
-          u32x4 bf;
-          const uint32_t w = wreg[j][jc];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) bf[e] = *(lds_cu32ptr)(__builtin_amdgcn_perm(w, colreg, 0x0c0c0400u + ((uint32_t)e << 8)));
-          if (gfirst) {
-            const uint32_t qv = qreg[j][jc];
-            if constexpr (QMX) {
-              gs = u2f(qv == 255u ? 0x7fc00000u : (qv == 0u ? 0x00400000u : (qv << 23)));  // Dequantization.cuh:331-339
-            } else {
-              gs = DT::lo_f32(qv);
-              gz = DT::hi_f32(qv);
-              xsv = *(lds_cf32x4ptr)(xs_lane + (uint32_t)(((((chunk - chunk_ph) * 32) >> p.gshift) * 16) * 4));
-            }
-          }
-          acc = mfma16<DT>(xf, bf, gfirst ? zero4 : acc);
-          if (glast) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              yacc[r] = __builtin_fmaf(gs, acc[r], yacc[r]);
-              if constexpr (!QMX) yacc[r] = __builtin_fmaf(gz, xsv[r], yacc[r]);
-            }
-          }
+          step(wreg, qreg, j, jc, chunk, (chunk & p.gch_mask) == 0, (chunk & p.gch_mask) == p.gch_mask);
         }
       }
     }
-  }
-
+  };
+  for (int ph = 0; ph < p.phases; ++ph) {
+    if (ph > 0) {
+      // the next part of k: its first weights are requested before the activations are re-staged (two barriers: every wave is
+      // done with the previous part's activations / the new ones are visible)
+      s_begin = ph * p.ksuper_p + wave * p.spw;
+      w_request(wregA, qregA, 0);
+      __syncthreads();
+      x_stage(ph, false);
+      __syncthreads();
+    }
+    chunk_ph = ph * p.ksuper_p * CPS;
+    if (P16_ABL == 2) continue;
+    if (nl <= CH) {  // (wave-uniform) the whole slice was requested up front
+      if (nl > 0) consume_block(wregA, qregA, 0);
+      continue;
+    }
+    if constexpr (PIPE) {
+      // long slices: two blocks per turn, the next block always requested before the current one is consumed
+      for (int l0 = 0; l0 < nl; l0 += 2 * CH) {
+        w_request(wregB, qregB, l0 + CH);
+        consume_block(wregA, qregA, l0);
+        w_request(wregA, qregA, l0 + 2 * CH);
+        if (l0 + CH < nl) consume_block(wregB, qregB, l0 + CH);
+      }
+    } else {
+      for (int l0 = 0; l0 < nl; l0 += CH) {
+        if (l0 > 0) w_request(wregA, qregA, l0);
+        consume_block(wregA, qregA, l0);
+      }
+    }
   }  // phases
 
   // ---- split-K tail: partial sums of the 16 waves meet in the (now unused) table's LDS, added in wave order ----
   __syncthreads();
 #pragma unroll
-  for (int r = 0; r < 4; ++r) *(lds_fptr)((uint32_t)(((wave * 4 + r) * 64 + lane) * 4)) = yacc[r];
+  for (int t = 0; t < TPW; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) *(lds_fptr)((uint32_t)((((t * WAVES + wave) * 4 + r) * 64 + lane) * 4)) = yacc[t][r];
   __syncthreads();
-  if (tid < 256) {
-    const int r = tid >> 6, l = tid & 63;
-    const int a = 4 * (l >> 4) + r, row = row0 + (l & 15);
+  if (tid < 256 * TPW) {
+    const int t = tid >> 8, r = (tid >> 6) & 3, l = tid & 63;
+    const int a = 4 * (l >> 4) + r, row = row0 + 16 * t + (l & 15);
     if (a < p.m && row < p.wrows) {
       float sum = 0.f;
 #pragma unroll
-      for (int w8 = 0; w8 < WAVES; ++w8) sum += *(lds_fptr)((uint32_t)(((w8 * 4 + r) * 64 + l) * 4));
+      for (int w8 = 0; w8 < WAVES; ++w8) sum += *(lds_fptr)((uint32_t)((((t * WAVES + w8) * 4 + r) * 64 + l) * 4));
       uint16_t o16 = DT::from_f32(sum);
       if (p.bias)  // rounded sum + bias, rounded again: the reference module's separate `y + bias` (modules.py:221-222)
         o16 = DT::from_f32(DT::lo_f32(o16) + DT::lo_f32(*reinterpret_cast<const uint16_t*>(p.bias + (int64_t)b * p.stride_bias + (int64_t)row * 2)));
