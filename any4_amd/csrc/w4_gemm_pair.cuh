@@ -49,6 +49,9 @@
 #ifndef TG_PAIR_PIN
 #define TG_PAIR_PIN 0  // 1: also pin the accumulator tuples in finalize() when a group's first MFMA takes a zero C operand
 #endif
+#ifndef TG_PAIR_KEEP_TABLE
+#define TG_PAIR_KEEP_TABLE 1  // 0: developer A/B, rebuild the table for every item whatever the quantisation type
+#endif
 #ifndef TG_PAIR_FIN_ASM
 #define TG_PAIR_FIN_ASM 1  // 0: developer A/B, the m = 1 group update as plain C++
 #endif
@@ -526,6 +529,7 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
 #pragma unroll
   for (int t = 0; t < TILES; ++t) colreg[t] = (uint32_t)((LA ? 32 * t + 16 * ((lane >> 4) & 1) + (lane & 15) : t * 32 + c) * 4);
 
+  int table_b = -1;  // the problem whose LUT the table in LDS was built from
   for (int it = it_begin; it < it_end; it += it_stride) {
     const Item cur = decode(it);
     const int row0 = cur.rb * RW;
@@ -538,8 +542,11 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
     if (lut_loaded && it != it_begin) lut_request(it);
 #endif
     // ---- pair table of this item: thread = (column, high nibbles 2 wave and 2 wave + 1).  The previous item's lookups are
-    // all behind the barrier that ended it. ----
-    {
+    // all behind the barrier that ended it.  Only a per-row LUT changes from item to item: int4 / mx4 / one global LUT keep the
+    // first item's table (unless the split-K partial sums reuse its LDS) -- 32 table stores per thread and item less. ----
+    if (TG_PAIR_KEEP_TABLE == 0 || it == it_begin || p.qtype == TG_Q_ANY4_ROWWISE || p.red_alias ||
+        (p.qtype == TG_Q_ANY4_GLOBAL && cur.b != table_b)) {  // (a global LUT is one per PROBLEM of the batch)
+      table_b = cur.b;
       uint32_t hw = lp[0];
 #pragma unroll
       for (int j = 1; j < 8; ++j) hw = (wave == j) ? lp[j] : hw;

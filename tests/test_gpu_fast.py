@@ -414,6 +414,24 @@ def test_benchmarked_launch_shape(T, oracle, qtype, g, m, numerics):
             assert_gemm_close(y[b], xb, oracle_weights(oracle, codes, g, qtype, qb, lb))
 
 
+@pytest.mark.parametrize("qtype,g,m,on_right", [("any4_global", 128, 1, True), ("any4_global", 128, 3, True), ("int4", 128, 1, True),
+                                                 ("mx4", 32, 1, True), ("any4_global", 128, 1, False), ("int4", 64, 2, False)])
+def test_persistent_workgroups_cross_problem_boundaries(T, oracle, qtype, g, m, on_right):
+    """The persistent kernel keeps its lookup table across work items when the LUT cannot change (int4, mx4) and rebuilds it
+    for a global LUT only when the PROBLEM changes: 700 small problems with their own global LUTs, 3 (B side) / 6 (A side)
+    work items each, so that every persistent workgroup walks across several problem boundaries."""
+    from any4_amd import _lib, ops
+
+    layers, n, k = 700, 192, 1024
+    assert ops.gemm_w4_plan(m, n, k, g, QT[qtype], on_right, 4, torch.bfloat16, layers, "fast") == "pair"
+    w, x, q, lut, y = _stacked_launch(layers, m, n, k, g, qtype, _lib.TG_NUM_FAST, seed=11, on_right=on_right)
+    assert not torch.isnan(y.float()).any()
+    for b in (0, 1, 2, 349, 350, 698, 699):
+        codes = torch.from_numpy((oracle.unpack_Bint4 if on_right else oracle.unpack_Aint4)(w[b].cpu().numpy(), n, k))
+        lb = None if lut is None else lut[b].cpu()
+        assert_fast_close(oracle, y[b], codes, x[b].cpu(), q[b].cpu(), lb, g, qtype, batch=layers, on_right=on_right)
+
+
 @pytest.mark.parametrize("numerics", ["fast", "reference"])
 def test_benchmarked_launch_shape_config3(T, oracle, numerics):
     """BASELINE config 3 as bench.py launches it: m = 8, n = k = 8192, g = 128, weights on the A side (Aint4, innerKTiles 4),
