@@ -49,6 +49,9 @@
 #ifndef TG_PAIR_PIN
 #define TG_PAIR_PIN 0  // 1: also pin the accumulator tuples in finalize() when a group's first MFMA takes a zero C operand
 #endif
+#ifndef TG_PAIR_EDW_INDEX
+#define TG_PAIR_EDW_INDEX 1  // 0: developer A/B, the mx4 exponent dword chosen by nested selects
+#endif
 #ifndef TG_PAIR_KEEP_TABLE
 #define TG_PAIR_KEEP_TABLE 1  // 0: developer A/B, rebuild the table for every item whatever the quantisation type
 #endif
@@ -395,7 +398,13 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
   // the dword of ecur[t] that holds the exponents of slice group gi (wave-uniform); the GPS groups of one super-tile share it
   auto e_dword = [&](int t, int gi) -> uint32_t {
     const int dw = (gi + ebase) >> 2;
+#if TG_PAIR_EDW_INDEX
+    // a wave-uniform dynamic element of the register vector: one relative move (nested selects on a uniform condition compile to
+    // a tree of scalar branches inside the main loop)
+    return ecur[t][dw & 3];
+#else
     return dw == 0 ? ecur[t][0] : dw == 1 ? ecur[t][1] : dw == 2 ? ecur[t][2] : ecur[t][3];
+#endif
   };
   // 2^(e - 127) as f32 bits-wise: e << 23, e = 0 -> 2^-127 (a denormal), e = 255 -> NaN (Dequantization.cuh:331-339)
   auto e_scale = [&](uint32_t d, int gi) -> float {
