@@ -806,11 +806,14 @@ int launch_pair(GemmParams& p, int64_t batch, hipStream_t st) {
                                   : launch_pair_k<DT, I, GPS_, 16, QMX, NSG_>(pp, lds, st))
   if (gps == 1) {
     // group boundaries at fixed places of the unrolled round when a group is one super-tile or one whole round
-    // (not for the m = 1 specialisation: with fixed boundaries the compiler scatters its accumulator chain over several
-    //  register tuples and spills; it keeps the run-time test, which measured faster than the general kernel with fixed ones)
+    // (the m = 1 specialisation too since its group update is spelled out instruction by instruction: before that, fixed
+    //  boundaries made the compiler scatter its accumulator chain over several register tuples and spill)
     // (a group of ONE super-tile, g = 64 at I = 4, also keeps the run-time test: its fixed-boundary build spills 27 registers,
     //  m = 8 50 % against 59 %)
-    const bool fixed = TG_PAIR_NSG2 && !(p.m == 1 && TG_PAIR_MR1 == 1);
+#ifndef TG_PAIR_NSG2_M1
+#define TG_PAIR_NSG2_M1 1  // 0: developer A/B, the m = 1 specialisation keeps the run-time group-boundary test
+#endif
+    const bool fixed = TG_PAIR_NSG2 && (TG_PAIR_NSG2_M1 || !(p.m == 1 && TG_PAIR_MR1 == 1));
     if (fixed && nsg == TG_PAIR_R) return TG_PAIR_M(1, TG_PAIR_R);
     return TG_PAIR_M(1, 0);
   }
