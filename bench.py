@@ -12,7 +12,7 @@ batch of L = 512 independent such layers (distinct weights, activations and outp
 Infinity Cache, so every step streams its weights from HBM; about the 4-bit weight volume of a Llama-3-8B
 decode step) issued as ONE stacked launch of the C-ABI entry point tg_gemm_w4 (batch = L).  Inputs are
 resident in HBM before the timed region.  Before the timed steps the GPU is kept under the same load for
-~1 s of untimed steps (`settle_steps`): the power controller needs tens of ms to reach its steady clock
+~2 s of untimed steps (`settle_steps`): the power controller needs tens of ms to reach its steady clock
 (DESIGN.md 5), and the run leaves a GPU footprint an external sampler can see.
 
 `value` = algorithmic bytes of all ranks per step / max-over-ranks step time.
@@ -236,7 +236,7 @@ def main():
     ap.add_argument("--n", type=int, default=4096)
     ap.add_argument("--k", type=int, default=4096)
     ap.add_argument("--group", type=int, default=128)
-    ap.add_argument("--settle-s", type=float, default=1.0, help="seconds of untimed steps before the timed region")
+    ap.add_argument("--settle-s", type=float, default=2.0, help="seconds of untimed steps before the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--roofline-only", action="store_true",
                     help="skip the informational legs (other configs, single-layer, cpu): every launch of the stacked "
