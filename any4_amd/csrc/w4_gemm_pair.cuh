@@ -231,6 +231,15 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
     const int ct = r / p.rblocks;
     return Item{b, ct, r - ct * p.rblocks};
   };
+  // the item it_stride further: no division on the way (a wave-uniform integer division is ~25 vector instructions, and the
+  // item loop needed four of them between its barriers)
+  const int adv_b = it_stride / per_problem, adv_r = it_stride - adv_b * per_problem;
+  auto advance = [&](const Item& e) -> Item {
+    int b = e.b + adv_b, r = e.ct * p.rblocks + e.rb + adv_r;
+    if (r >= per_problem) { r -= per_problem; ++b; }
+    const int ct = p.cblocks == 1 ? 0 : r / p.rblocks;
+    return Item{b, ct, r - ct * p.rblocks};
+  };
 
   // ---- LUT rows: 16 values of this thread's table column as 8 packed 16-bit pairs, requested one item ahead ----
   uint32_t lp[8];
@@ -250,8 +259,7 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
     }
   };
   const bool lut_loaded = p.qtype == TG_Q_ANY4_GLOBAL || p.qtype == TG_Q_ANY4_ROWWISE;
-  auto lut_request = [&](int it) {  // it is clamped by the caller to a valid item
-    const Item e = decode(it);
+  auto lut_request = [&](const Item& e) {  // a valid item
     const int lrow = min(e.rb * RW + tcol_row, p.wrows - 1);
     const char* lsrc = p.lut + (int64_t)e.b * p.stride_lut + (p.qtype == TG_Q_ANY4_ROWWISE ? (int64_t)lrow * 32 : 0);
     const u32x4 l0 = reinterpret_cast<const u32x4*>(lsrc)[0];
@@ -280,8 +288,7 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
     uint32_t xoff[NXW];  // XG: this lane's piece(s) inside a super-tile's block (A side: inside a chunk's block; lanes whose
                          // row is padding point at the block's zero row)
   };
-  auto rows_of = [&](int it) -> Rows {
-    const Item e = decode(it);
+  auto rows_of = [&](const Item& e) -> Rows {
     Rows r;
 #pragma unroll
     for (int t = 0; t < TILES; ++t) {
@@ -484,9 +491,8 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
 #endif
   constexpr int NXS = (LA && TG_XS_PREFETCH) ? 2 : 0;
   float xsn[2] = {0.f, 0.f};
-  auto xs_request = [&](int it) {  // `it` is a valid item
+  auto xs_request = [&](const Item& e) {  // a valid item
     if constexpr (XG && !QMX) {
-      const Item e = decode(it);
       const float* src = reinterpret_cast<const float*>(p.xsum + (int64_t)e.b * p.stride_xsum) + (int64_t)e.ct * p.ngroups * p.xs_rows;
       const int total = p.ngroups * p.xs_rows;
 #pragma unroll
@@ -512,10 +518,10 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
   // rows, the first batch of its activation chunks, then its first R super-tiles (one by one: the scheduler must not reorder
   // them, the ring is consumed in slot order) ----
   if (it_begin >= it_end) return;
-  if (lut_loaded) lut_request(it_begin);
-  else lut_const();
-  xs_request(it_begin);
   const Item first = decode(it_begin);
+  if (lut_loaded) lut_request(first);
+  else lut_const();
+  xs_request(first);
   int staged_b = XG ? -1 : first.b, staged_ct = first.ct;  // which activation block the LDS holds (XG: staged by the first item)
   uint32_t xd0[16];
   if constexpr (!XG) {
@@ -524,7 +530,7 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
     for (int j = 0; j < 16; ++j) xd0[j] = 0u;
     if (tid < mrows0 * nch) x_load(p.x + (int64_t)first.b * p.stride_x, first.ct * MA, tid, xd0);
   }
-  Rows rcur = rows_of(it_begin);
+  Rows rcur = rows_of(first);
   if constexpr (QMX) e_request(rcur, 0, nl > 0);
 #pragma unroll
   for (int j = 0; j < R; ++j) {
@@ -539,16 +545,18 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
   for (int t = 0; t < TILES; ++t) colreg[t] = (uint32_t)((LA ? 32 * t + 16 * ((lane >> 4) & 1) + (lane & 15) : t * 32 + c) * 4);
 
   int table_b = -1;  // the problem whose LUT the table in LDS was built from
+  Item inext = first;
   for (int it = it_begin; it < it_end; it += it_stride) {
-    const Item cur = decode(it);
+    const Item cur = inext;
     const int row0 = cur.rb * RW;
     const int a0 = cur.ct * MA;
     const int mrows = min(p.m - a0, MA);
     const bool has_next = it + it_stride < it_end;
-    Rows rnext = rows_of(has_next ? it + it_stride : it);
+    if (has_next) inext = advance(cur);  // (the last item asks for its own rows again)
+    Rows rnext = rows_of(inext);
 
 #ifdef TG_PAIR_NOLP  // experiment: no LUT prefetch across the main loop (8 VGPRs less, LUT latency exposed)
-    if (lut_loaded && it != it_begin) lut_request(it);
+    if (lut_loaded && it != it_begin) lut_request(cur);
 #endif
     // ---- pair table of this item: thread = (column, high nibbles 2 wave and 2 wave + 1).  The previous item's lookups are
     // all behind the barrier that ended it.  Only a per-row LUT changes from item to item: int4 / mx4 / one global LUT keep the
@@ -582,9 +590,9 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
     }
     // the next item's LUT rows (and activation sums) travel while this item is computed (the last item re-reads its own)
 #ifndef TG_PAIR_NOLP
-    if (lut_loaded) lut_request(has_next ? it + it_stride : it);
+    if (lut_loaded) lut_request(inext);
 #endif
-    xs_request(has_next ? it + it_stride : it);
+    xs_request(inext);
     __syncthreads();  // table and activations visible (and every thread is done with the previous item's partial sums)
 
     // ---- main loop of the item ----
