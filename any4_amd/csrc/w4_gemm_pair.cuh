@@ -572,8 +572,11 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
       for (int a = 0; a < 16; ++a) {
         const uint32_t e0 = __builtin_amdgcn_perm(hw, lp[a >> 1], (a & 1) ? 0x05040302u : 0x05040100u);
         const uint32_t e1 = __builtin_amdgcn_perm(hw, lp[a >> 1], (a & 1) ? 0x07060302u : 0x07060100u);
-        *(lds_u32ptr)(base + (uint32_t)(a * 256)) = e0;
-        *(lds_u32ptr)(base + (uint32_t)((16 + a) * 256)) = e1;
+        // (indexing ONE LDS pointer: constant offsets go into the instructions' offset fields and the pair becomes a
+        //  ds_write2st64_b32; integer address arithmetic cast to a pointer per store cost a v_or_b32 + ds_write_b32 each)
+        const lds_u32ptr tb = (lds_u32ptr)base;
+        tb[a * 64] = e0;
+        tb[(16 + a) * 64] = e1;
       }
     }
     // ---- activations: only when the activation block changes (staged: the first item's block was staged above; XG: the sums

@@ -240,7 +240,7 @@ __global__ void __launch_bounds__(1024) w4_gemm_pair16_kernel(const Pair16Params
 #pragma unroll
     for (int a = 0; a < (P16_ABL == 4 ? 1 : 8); ++a) {
       const uint32_t e = __builtin_amdgcn_perm(hw, lq[a >> 1], hsel | ((a & 1) ? 0x0302u : 0x0100u));
-      *(lds_u32ptr)(base + (uint32_t)(a * 256)) = e;
+      ((lds_u32ptr)base)[a * 64] = e;  // (one LDS pointer + constant offsets: immediate offset fields, no address arithmetic per store)
     }
   }
   __syncthreads();
