@@ -857,8 +857,13 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
     __syncthreads();  // partial sums visible; every wave is done with this item's table
     {
       char* yb = p.y + (int64_t)cur.b * p.stride_y;
+      static_assert(TILES == 2, "the output index split below assumes two tiles");
+      const int rl_shift = p.red_lanes == 64 ? 6 : 5;  // red_lanes is 32 or 64
       for (int o = tid; o < TILES * p.rused * p.red_lanes; o += 512) {
-        const int l = o % p.red_lanes, r = (o / p.red_lanes) % p.rused, t = o / (p.red_lanes * p.rused);
+        // (no integer divisions: three of them per output were ~50 vector instructions on the one wave the workgroup's next
+        //  barrier then waits for)
+        const int l = o & (p.red_lanes - 1), q = o >> rl_shift;
+        const int t = q >= p.rused ? 1 : 0, r = q - t * p.rused;
         const int a = LA ? r + 4 * (l >> 4) : (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
         const int row = row0 + (LA ? 16 * ((l & 15) >> 3) + (l & 7) + 8 * t : t * 32 + (l & 31));
         if (a < mrows && row < p.wrows) {
