@@ -93,7 +93,7 @@ struct PairParams {
   int32_t lds_xs;   //                   per-group activation sums, f32 [ngroups][xs_rows]
   int32_t lds_red;  //                   split-K partial sums, f32 [8 waves][2 tiles][rused][red_lanes]
   int32_t rused;    // accumulator registers that hold real activation rows (m < 4: m, else MREGS)
-  int32_t xs_rows;  // rows of the activation sums kept per group: 4 when m <= 4 (lane half 1 then holds no real row), else 2 * MREGS
+  int32_t xs_rows;  // rows of the activation sums kept per group (a power of two): 4 when m <= 4 (lane half 1 then holds no real row), else 2 * MREGS
   int32_t red_lanes;  // lanes whose partial sums are exchanged: 32 when m <= 4, else 64
   int32_t red_alias;  // 1: the partial sums reuse the table's LDS (m > 4: two more barriers per item), lds_red = 0
   int32_t rblocks;  // 64-row blocks per problem
@@ -474,7 +474,7 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
     // rows a >= mrows of the sums stay zero
     if constexpr (!QMX)
       for (int idx = tid; idx < p.ngroups * p.xs_rows; idx += 512)
-        if (idx % p.xs_rows >= mrows) *(lds_fptr)(lds_xs + (uint32_t)(idx * 4)) = 0.f;
+        if ((idx & (p.xs_rows - 1)) >= mrows) *(lds_fptr)(lds_xs + (uint32_t)(idx * 4)) = 0.f;
     // the zero piece behind the staged rows is one super-tile long: lanes whose A-operand row is padding read it with the same
     // immediate offsets as the real rows
     if (tid < CPS * 4) *(lds_u32x4ptr)(lds_x + (uint32_t)(mrows * p.x_pitch + tid * 16)) = u32x4{0, 0, 0, 0};
@@ -506,10 +506,10 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
 #pragma unroll
       for (int j = 0; j < NXS; ++j) {
         const int idx = tid + 512 * j;
-        if (idx < total) *(lds_fptr)(lds_xs + (uint32_t)(idx * 4)) = idx % p.xs_rows < mrows ? xsn[j] : 0.f;
+        if (idx < total) *(lds_fptr)(lds_xs + (uint32_t)(idx * 4)) = (idx & (p.xs_rows - 1)) < mrows ? xsn[j] : 0.f;
       }
       for (int idx = tid + 512 * NXS; idx < total; idx += 512)
-        *(lds_fptr)(lds_xs + (uint32_t)(idx * 4)) = idx % p.xs_rows < mrows ? src[idx] : 0.f;
+        *(lds_fptr)(lds_xs + (uint32_t)(idx * 4)) = (idx & (p.xs_rows - 1)) < mrows ? src[idx] : 0.f;
     }
     if (tid < CPS * 4) *(lds_u32x4ptr)(lds_x + (uint32_t)(WAVES * p.xw_bytes + tid * 16)) = u32x4{0, 0, 0, 0};
   };
