@@ -110,7 +110,7 @@ __global__ void __launch_bounds__(1024) w4_gemm_pair16_kernel(const Pair16Params
 #pragma unroll
   for (int j = 0; j < 16; ++j) xd[j] = 0u;
   auto x_load = [&](int xi, int ph) {
-    const int a = xi / nch, ch = xi - a * nch + ph * nch;
+    const int a = p.m == 1 ? 0 : xi / nch, ch = xi - a * nch + ph * nch;  // (m = 1: no division on the launch's critical path)
     if (p.x_tc) {
       tc_a_load_chunk(xb, a, ch, p.k >> 4, xd);
       return;
@@ -183,7 +183,7 @@ __global__ void __launch_bounds__(1024) w4_gemm_pair16_kernel(const Pair16Params
 
   // ---- stage the activations (byte order) and their group sums; build the table ----
   auto x_store = [&](int xi, bool on) {
-    const int a = on ? xi / nch : 0, ch = on ? xi - (xi / nch) * nch : 0;
+    const int a = on && p.m > 1 ? xi / nch : 0, ch = on ? xi - a * nch : 0;
     if (on) {
       const uint32_t dst = lds_x + (uint32_t)(a * p.x_pitch + ch * 64);
 #pragma unroll
