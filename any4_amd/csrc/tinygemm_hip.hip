@@ -662,6 +662,10 @@ enum { TG_PAIR_NA = -100 };
                                // it (measured per hipGraph node, one layer, m = 1: 14336 x 4096 = 224 items 12.3 us here against
                                // 18.3 us on pair16 and 13.8 us on the stream kernel; 6144 x 4096 = 96 items 10.7 against 9.9 / 8.2)
 #endif
+#ifndef TG_XG_CHUNK
+#define TG_XG_CHUNK 4  // consecutive work items per workgroup visit in the workspace variant of Bint4 weights (1: plain round-robin):
+                       // same-box, m = 8: 4096^2 66.1 -> 66.5 %, 8192^2 67.3 -> 68.6 %; Aint4 weights keep 1 (8192^2 56.5 -> 56.0 % with 4)
+#endif
 #ifndef TG_PAIR_WGS
 #define TG_PAIR_WGS 512  // persistent workgroups: two per CU
 #endif
@@ -788,6 +792,8 @@ int launch_pair(GemmParams& p, int64_t batch, hipStream_t st) {
   // split-K kernels, which spread one 16-row tile over up to 16 waves.
   if (items < TG_PAIR_MIN_ITEMS) { p.ws_need = 0; return TG_PAIR_NA; }
   pp.items = (int32_t)items;
+  // XG item dealing: chunks of consecutive items once every workgroup still gets several chunks
+  pp.chunk = items >= (int64_t)TG_PAIR_WGS * TG_XG_CHUNK * 4 ? TG_XG_CHUNK : 1;
   pp.stride_x = p.stride_x; pp.stride_w = p.stride_w; pp.stride_qinfo = p.stride_qinfo;
   pp.stride_lut = p.stride_lut; pp.stride_y = p.stride_y;
   pp.bias = p.bias; pp.stride_bias = p.stride_bias; pp.dry = p.dry;
@@ -940,6 +946,7 @@ int launch_pair_a(GemmParams& p, int64_t batch, hipStream_t st) {
   pp.xp = p.ws;
   pp.xsum = p.ws + batch * pp.stride_xp;
   pp.items = (int32_t)items;
+  pp.chunk = 1;  // plain round-robin dealing (chunks of consecutive items measured slower for the 32-row items of this layout)
   pp.stride_x = p.stride_x; pp.stride_w = p.stride_w; pp.stride_qinfo = p.stride_qinfo;
   pp.stride_lut = p.stride_lut; pp.stride_y = p.stride_y;
   pp.bias = p.bias; pp.stride_bias = p.stride_bias; pp.dry = p.dry;

@@ -109,6 +109,7 @@ struct PairParams {
   int64_t stride_xp, stride_xsum;  // bytes per problem
   int32_t xw_pitch;   // bytes per activation row in a wave's LDS buffer (32 I + 16: rotates rows over the banks)
   int32_t xw_bytes;   // bytes of one wave's buffer
+  int32_t chunk;      // XG: consecutive work items a workgroup takes before it moves on by (workgroups x chunk) items; >= 1
   int32_t x_tc, y_tc; // 1: activations / output in A-fragment order (tc_a_index) instead of row-major; y_tiles = ceil(wrows/16)
   int32_t y_tiles;
 };
@@ -214,8 +215,11 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
 #define TG_XG_ROUNDROBIN 1
 #endif
   constexpr bool RR = XG && TG_XG_ROUNDROBIN;
-  const int it_stride = RR ? (int)gridDim.x : 1;
-  const int it_begin = RR ? (int)blockIdx.x : (int)(((int64_t)blockIdx.x * p.items) / gridDim.x);
+  // XG: workgroup b takes the items [(j G + b) C, + C), j = 0, 1, ...: C = p.chunk consecutive items (one contiguous C x 128 KiB
+  // of one problem's weights), then on by G C.  C = 1 is plain round-robin.
+  const int chunk = RR ? p.chunk : 1;
+  const int it_stride = RR ? (int)gridDim.x * chunk - (chunk - 1) : 1;  // the step from the last item of a chunk
+  const int it_begin = RR ? (int)blockIdx.x * chunk : (int)(((int64_t)blockIdx.x * p.items) / gridDim.x);
   const int it_end = RR ? p.items : (int)(((int64_t)(blockIdx.x + 1) * p.items) / gridDim.x);
   const int per_problem = p.rblocks * p.cblocks;
 
@@ -234,8 +238,8 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
   // the item it_stride further: no division on the way (a wave-uniform integer division is ~25 vector instructions, and the
   // item loop needed four of them between its barriers)
   const int adv_b = it_stride / per_problem, adv_r = it_stride - adv_b * per_problem;
-  auto advance = [&](const Item& e) -> Item {
-    int b = e.b + adv_b, r = e.ct * p.rblocks + e.rb + adv_r;
+  auto advance = [&](const Item& e, bool big) -> Item {  // big: by it_stride, else by one item
+    int b = e.b + (big ? adv_b : 0), r = e.ct * p.rblocks + e.rb + (big ? adv_r : 1);
     if (r >= per_problem) { r -= per_problem; ++b; }
     const int ct = p.cblocks == 1 ? 0 : r / p.rblocks;
     return Item{b, ct, r - ct * p.rblocks};
@@ -546,13 +550,17 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
 
   int table_b = -1;  // the problem whose LUT the table in LDS was built from
   Item inext = first;
-  for (int it = it_begin; it < it_end; it += it_stride) {
+  int cpos = 0;  // position inside the chunk
+  for (int it = it_begin, step = 1; it < it_end; it += step) {
+    const bool big = cpos + 1 >= chunk;
+    step = big ? it_stride : 1;
+    cpos = big ? 0 : cpos + 1;
     const Item cur = inext;
     const int row0 = cur.rb * RW;
     const int a0 = cur.ct * MA;
     const int mrows = min(p.m - a0, MA);
-    const bool has_next = it + it_stride < it_end;
-    if (has_next) inext = advance(cur);  // (the last item asks for its own rows again)
+    const bool has_next = it + step < it_end;
+    if (has_next) inext = advance(cur, big);  // (the last item asks for its own rows again)
     Rows rnext = rows_of(inext);
 
 #ifdef TG_PAIR_NOLP  // experiment: no LUT prefetch across the main loop (8 VGPRs less, LUT latency exposed)

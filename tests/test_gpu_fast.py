@@ -432,6 +432,23 @@ def test_persistent_workgroups_cross_problem_boundaries(T, oracle, qtype, g, m, 
         assert_fast_close(oracle, y[b], codes, x[b].cpu(), q[b].cpu(), lb, g, qtype, batch=layers, on_right=on_right)
 
 
+@pytest.mark.parametrize("qtype,g", [("any4_rowwise", 128), ("any4_global", 64)])
+def test_workspace_variant_chunked_item_dealing(T, oracle, qtype, g):
+    """Launches of >= 8192 work items of the workspace variant deal the items in chunks of 4 consecutive ones per workgroup visit
+    (8400 items here: 4200 problems x 2 row blocks, m = 8 at k = 1024 does not fit next to the table), so a chunk straddles
+    problems; first / middle / last problems against the oracle, every output written."""
+    from any4_amd import _lib, ops
+
+    layers, m, n, k = 4200, 8, 128, 1024
+    assert ops.gemm_w4_plan(m, n, k, g, QT[qtype], True, 4, torch.bfloat16, layers, "fast") == "pair"
+    w, x, q, lut, y = _stacked_launch(layers, m, n, k, g, qtype, _lib.TG_NUM_FAST, seed=5)
+    assert not torch.isnan(y.float()).any()
+    for b in (0, 1, 2, 3, 2099, 2100, 4198, 4199):
+        codes = torch.from_numpy(oracle.unpack_Bint4(w[b].cpu().numpy(), n, k))
+        lb = None if lut is None else lut[b].cpu()
+        assert_fast_close(oracle, y[b], codes, x[b].cpu(), q[b].cpu(), lb, g, qtype, batch=layers)
+
+
 @pytest.mark.parametrize("numerics", ["fast", "reference"])
 def test_benchmarked_launch_shape_config3(T, oracle, numerics):
     """BASELINE config 3 as bench.py launches it: m = 8, n = k = 8192, g = 128, weights on the A side (Aint4, innerKTiles 4),
