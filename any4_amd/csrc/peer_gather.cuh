@@ -8,7 +8,7 @@
 // `rank` of p's gathered buffer with 16-byte stores (over xGMI for p != rank; every link of the point-to-point fabric carries
 // one slice), fences at system scope, and raises flags_p[rank] to this call's sequence number.  The same workgroup then
 // waits until flags_rank[p] has reached the sequence number: rank p's slice has landed HERE.  The wait is bounded
-// (s_memrealtime, 100 MHz): a missing peer sets *status instead of hanging the GPU.
+// (s_memrealtime, 100 MHz): a missing peer sets *status and has its slice filled with NaNs instead of hanging the GPU.
 #include "../../include/peer_gather_hip.h"
 
 namespace {
@@ -40,6 +40,7 @@ __global__ void __launch_bounds__(512) peer_gather_kernel(const PeerGatherParams
   }
   __threadfence_system();  // every thread's stores are performed at system scope before the flag below
   __syncthreads();
+  __shared__ int s_timed_out;
   if (threadIdx.x == 0) {
     __hip_atomic_store(p.flags[peer] + p.rank, target, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     // ---- wait for the peer's slice: its workgroup `rank` raises flags[rank][peer] ----
@@ -54,9 +55,19 @@ __global__ void __launch_bounds__(512) peer_gather_kernel(const PeerGatherParams
       __builtin_amdgcn_s_sleep(2);
     }
     if (!ok) __hip_atomic_store(p.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    s_timed_out = ok ? 0 : 1;
     p.seq[peer] = target;
   }
   __syncthreads();
+  // A slice that did not arrive is made LOUD: its column block of this rank's own buffer is filled with NaN bit patterns
+  // (0x7fff is a NaN in bf16 and in fp16), so a consumer that never looks at *status still cannot use stale numbers.
+  if (s_timed_out) {
+    char* own = p.dst[p.rank] + (int64_t)peer * p.row_bytes;
+    for (int i = threadIdx.x; i < total; i += 512) {
+      const int r = i / pieces_per_row, c = i - r * pieces_per_row;
+      *reinterpret_cast<u32x4*>(own + (int64_t)r * p.dst_pitch + c * 16) = u32x4{0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu};
+    }
+  }
 }
 
 }  // namespace

@@ -995,6 +995,9 @@ int launch_w4(GemmParams& p, int64_t coltiles, int64_t batch, hipStream_t st) {
     }
   }
   if (p.x_tc || p.y_tc) return TG_E_LAYOUT;  // only the pair-table kernels read / write fragment order themselves
+#ifdef TG_DEV_MIN  // developer A/B builds carry the pair-table kernels only (a third of the build time)
+  return TG_E_SHAPE;
+#else
   // m = 1 always streams: with private X slabs its split-K variants beat the latency kernel down to one matrix
   if (use_stream && (g.waves == 8 || p.m == 1 || use_stream == 2) && (1 << p.gshift) >= (LAYOUT_A ? 64 : 128)) {
     return launch_stream<DT, LAYOUT_A, WPL, QMX>(p, coltiles, batch, st);
@@ -1006,6 +1009,7 @@ int launch_w4(GemmParams& p, int64_t coltiles, int64_t batch, hipStream_t st) {
     hipLaunchKernelGGL((w4_gemm_kernel<DT, LAYOUT_A, CANON, QMX, 8, 2, 4>), grid, dim3(8 * 64), 0, st, p);
   }
   return launch_status();
+#endif
 }
 
 template <typename DT, bool LAYOUT_A, int CANON>
@@ -1308,6 +1312,10 @@ int tg_gemm_w8(const tg_w4_gemm* a, int device, tg_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
   p.rowtiles = (int32_t)cdiv(a->wrows, 16);
   const int64_t coltiles = cdiv(a->m, 16);
+#ifdef TG_DEV_MIN
+  (void)coltiles; (void)st;
+  return TG_E_SHAPE;
+#else
 #define TG_W8(DTT)                                                                                    \
   do {                                                                                                \
     if (on_right) {                                                                                   \
@@ -1321,6 +1329,7 @@ int tg_gemm_w8(const tg_w4_gemm* a, int device, tg_stream_t stream) {
   if (a->dtype == TG_BF16) TG_W8(BF16);
   TG_W8(F16);
 #undef TG_W8
+#endif
 }
 
 int tg_gemm_f16(const void* x, const void* w, void* y, int64_t m, int64_t wrows, int64_t k, int dtype,

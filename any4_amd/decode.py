@@ -268,6 +268,8 @@ class DecodeStack(torch.nn.Module):
         self.register_buffer("pos", torch.zeros(1, dtype=torch.long, device=device), persistent=False)
         self._graph = None
         self._out = None
+        self._decodes = 0
+        self.peer_poll_every = 16  # decode() calls between two non-blocking reads of the peer-gather status words
         # split-sequence attention: enough blocks per head to fill the 256 CUs (one scratch buffer, launches are stream-ordered)
         self._attn_scratch, self._attn_split = None, 1
         if self.fused:
@@ -357,10 +359,18 @@ class DecodeStack(torch.nn.Module):
             raise ValueError(f"position {position} outside the KV cache [0, {self.cfg.max_seq})")
         self.tokens.copy_(tokens)
         self.pos.fill_(position)
+        out = self._out if self._graph is not None else None
         if self._graph is not None:
             self._graph.replay()
-            return self._out
-        return self.step()
+        else:
+            out = self.step()
+        # peer-write gathers: a slice that did not arrive is NaN in the buffers; here the status words are read back on a
+        # cadence without synchronising the device (PeerWriteGather.poll) so that a slow / dead rank raises instead of decoding on
+        self._decodes += 1
+        if self._peer and self._decodes % self.peer_poll_every == 0:
+            for pg in self._peer.values():
+                pg.poll()
+        return out
 
 
 def memory_allocated_mb(device=None) -> float:

@@ -81,13 +81,24 @@ class PeerWriteGather:
         dist.all_gather_object(handles, mine, group=group)
         self._opened = []
         self._peer_data, self._peer_ctl = [], []
-        for r, (hd, hc) in enumerate(handles):
-            if r == self.rank:
-                self._peer_data.append(self._data)
-                self._peer_ctl.append(self._ctl)
-            else:
-                self._peer_data.append(self._open(hd))
-                self._peer_ctl.append(self._open(hc))
+        failure = None
+        try:
+            for r, (hd, hc) in enumerate(handles):
+                if r == self.rank:
+                    self._peer_data.append(self._data)
+                    self._peer_ctl.append(self._ctl)
+                else:
+                    self._peer_data.append(self._open(hd))
+                    self._peer_ctl.append(self._open(hc))
+        except RuntimeError as e:  # e.g. no IPC / peer access between these two devices
+            failure = f"rank {self.rank}: {e}"
+        # every rank learns whether every rank mapped every buffer: either all go on or all raise (a rank that raised alone
+        # would leave the others waiting in the barrier below)
+        failures = [None] * self.world
+        dist.all_gather_object(failures, failure, group=group)
+        if any(f is not None for f in failures):
+            self._release()
+            raise RuntimeError("PeerWriteGather: could not map the peers' buffers: " + "; ".join(f for f in failures if f))
         self._calls = 0
         self._args = []
         for parity in range(2):
@@ -102,6 +113,9 @@ class PeerWriteGather:
         self._views = [torch.as_tensor(_DeviceBytes(self._data + parity * self.buf_bytes, self.buf_bytes), device=self.device)
                        for parity in range(2)]
         self._status = torch.as_tensor(_DeviceBytes(self._ctl + 128, 4), device=self.device).view(torch.int32)
+        # host mirror of *status for poll(): an asynchronous copy + an event, never a device synchronisation
+        self._status_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self._status_event = None
         dist.barrier(group=group)  # every rank has mapped every buffer before the first store into one
 
     def _alloc(self, nbytes: int) -> int:
@@ -138,21 +152,40 @@ class PeerWriteGather:
                       "tg_peer_gather_launch")
         return self._views[parity][: m * self.world * self.cols_local * 2].view(self.dtype).view(m, self.world * self.cols_local)
 
+    _TIMEOUT_MSG = ("PeerWriteGather: a peer's slice did not arrive within the timeout of an earlier call (its column block was "
+                    "filled with NaNs): a rank is slow, dead, or the ranks disagree on the number of gather calls")
+
     def check(self) -> None:
         """Synchronises and raises if a peer's slice did not arrive within the timeout of some call."""
         torch.cuda.synchronize(self.device)
         if int(self._status.item()) != 0:
-            raise RuntimeError("PeerWriteGather: a peer's slice did not arrive within the timeout")
+            raise RuntimeError(self._TIMEOUT_MSG)
 
-    def close(self) -> None:
-        torch.cuda.synchronize(self.device)
-        if dist.is_initialized():
-            dist.barrier(group=self.group)  # no peer is still storing into this rank's buffers
+    def poll(self) -> None:
+        """Non-blocking health check for hot loops: raises if the status word read back by an EARLIER poll() shows a timeout,
+        then queues the next asynchronous read-back on the current stream.  Never synchronises the device; a timeout is
+        reported one or two poll() calls after it happened (the gathered data itself is already NaN by then)."""
+        if self._status_event is not None and self._status_event.query():
+            if int(self._status_host[0]) != 0:
+                raise RuntimeError(self._TIMEOUT_MSG)
+            self._status_event = None
+        if self._status_event is None:
+            self._status_host.copy_(self._status, non_blocking=True)
+            self._status_event = torch.cuda.Event()
+            self._status_event.record(torch.cuda.current_stream(self.device))
+
+    def _release(self) -> None:
         for p in self._opened:
             self.lib.tg_peer_close(self.dev_index, p)
         for p in self._own:
             self.lib.tg_peer_free(self.dev_index, p)
         self._opened, self._own = [], []
+
+    def close(self) -> None:
+        torch.cuda.synchronize(self.device)
+        if dist.is_initialized():
+            dist.barrier(group=self.group)  # no peer is still storing into this rank's buffers
+        self._release()
 
 
 class RowShardedLinear(torch.nn.Module):
@@ -163,10 +196,17 @@ class RowShardedLinear(torch.nn.Module):
     gather_output=False leaves the result sharded (for a following column-parallel consumer).
     gather="rccl" (all_gather_into_tensor) or "peer" (PeerWriteGather: one-shot stores into the peers' buffers, for inputs of
     at most peer_m_max rows; larger inputs take the RCCL collective).
+
+    Output lifetime with gather="peer": the gather lands in a two-buffer ring that peers write into, so by default forward()
+    returns a COPY (a fresh tensor, like the RCCL path; the payload is a few KiB).  alias_output=True returns the view into
+    the ring instead: it is overwritten by the second following forward() of this layer and by remote stores of peers that
+    are one call ahead, so it is only valid for a consumer enqueued on the SAME stream before the next forward() -- the decode
+    harness's pattern.  Every `poll_every` forwards the gather's status word is checked without a device synchronisation
+    (PeerWriteGather.poll); a peer that never arrived raises there, and its slice is NaN in the meantime.
     """
 
     def __init__(self, local: torch.nn.Module, out_features: int, group=None, gather_output: bool = True, gather: str = "rccl",
-                 peer_m_max: int = 16):
+                 peer_m_max: int = 16, alias_output: bool = False, poll_every: int = 64):
         super().__init__()
         if gather not in ("rccl", "peer"):
             raise ValueError("gather must be 'rccl' or 'peer'")
@@ -176,6 +216,9 @@ class RowShardedLinear(torch.nn.Module):
         self.gather_output = gather_output
         self.gather = gather
         self.peer_m_max = peer_m_max
+        self.alias_output = alias_output
+        self.poll_every = max(1, int(poll_every))
+        self._forwards = 0
         self._peer = None
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
@@ -193,7 +236,11 @@ class RowShardedLinear(torch.nn.Module):
             if self._peer is None:
                 self._peer = PeerWriteGather(self.peer_m_max, y_local.shape[-1], group=self.group, device=y_local.device,
                                              dtype=y_local.dtype)
-            return self._peer.gather(y_local.view(rows, -1)).view(*y_local.shape[:-1], self.out_features)
+            out = self._peer.gather(y_local.view(rows, -1)).view(*y_local.shape[:-1], self.out_features)
+            self._forwards += 1
+            if self._forwards % self.poll_every == 0 and not torch.cuda.is_current_stream_capturing():
+                self._peer.poll()
+            return out if self.alias_output else out.clone()
         parts = torch.empty((world,) + tuple(y_local.shape), dtype=y_local.dtype, device=y_local.device)
         if dist.get_backend(self.group) == "nccl":
             dist.all_gather_into_tensor(parts, y_local, group=self.group)

@@ -91,13 +91,13 @@ def make_batch(L, m, n, k, g, inner, device, seed, qtype="any4_rowwise", on_righ
     return w, x, q, lut, y
 
 
-def make_args(_lib, w, x, q, lut, y, m, n, k, g, qtype, on_right, inner, batch):
+def make_args(_lib, w, x, q, lut, y, m, n, k, g, qtype, on_right, inner, batch, numerics="fast"):
     return _lib.W4Gemm(
         x=x.data_ptr(), w=w.data_ptr(), qinfo=q.data_ptr(), lut=(lut.data_ptr() if lut is not None else None), y=y.data_ptr(),
         m=m, wrows=n, k=k, group=g, qtype=QT[qtype], dtype=_lib.TG_BF16, w_on_right=1 if on_right else 0,
         inner_k_tiles=inner, batch=batch, stride_x=x.stride(0) * 2, stride_w=w.stride(0) * 4,
         stride_qinfo=q.stride(0) * q.element_size(), stride_lut=(lut.stride(0) * 2 if lut is not None else 0),
-        stride_y=y.stride(0) * 2, numerics=_lib.TG_NUM_FAST)
+        stride_y=y.stride(0) * 2, numerics=_lib.TG_NUM_FAST if numerics == "fast" else _lib.TG_NUM_REFERENCE)
 
 
 def attach_workspace(lib, aa, device):
@@ -114,8 +114,16 @@ def attach_workspace(lib, aa, device):
 
 
 def check_layers(w, x, q, lut, y, g, qtype, on_right, inner, plan, layers=(0, 1, -1), rows=256):
-    """Untimed: `rows` weight rows of a few layers of the launch's output against the CPU oracle (the group-scaled
-    restatement when the pair-table kernel ran, else the reference-faithful contraction)."""
+    """Untimed: `rows` weight rows of a few layers of the launch's output against BOTH CPU oracles.
+
+    * pass / fail: the restatement of the arithmetic the kernel that ran implements -- oracle.linear_group_scaled (the derived
+      group-scaled formula, in double) when the pair-table kernel ran, oracle.linear (the reference's arithmetic: every weight
+      rounded to 16 bits, MatrixLayoutB.cuh:1042-1046) otherwise -- at half an output ulp + f32 accumulation slack;
+    * reported for every leg, in north_star's terms: the distance from the REFERENCE-FAITHFUL result (oracle.linear) --
+      max-abs against its f32 sums and against its bf16 outputs, max|y|, the same error at the captured fixture's scale
+      (max|y| = 2.2, SURVEY.md 8c: north_star's 1e-2 is quoted there), and the fraction of outputs whose bf16 bits differ
+      from the reference-faithful bf16 result (and by how many bf16 steps at most).
+    Raises SystemExit when the pass / fail check fails or when the reference distance exceeds 1e-2 * max(1, max|y| / 2.2)."""
     import numpy as np
 
     from oracle import oracle as orc
@@ -125,23 +133,45 @@ def check_layers(w, x, q, lut, y, g, qtype, on_right, inner, plan, layers=(0, 1,
 
     n, k = y.shape[2], x.shape[2]
     oq = {"int4": orc.Q_INT4, "any4_global": orc.Q_ANY4_GLOBAL, "any4_rowwise": orc.Q_ANY4_ROWWISE, "mx4": orc.Q_MX4}[qtype]
-    worst = 0.0
+    own = err_ref32 = err_ref16 = ymax = 0.0
+    differ = total = 0
+    steps = 0
     for b in layers:
         codes = (orc.unpack_Bint4 if on_right else orc.unpack_Aint4)(w[b].cpu().numpy(), n, k)[:rows]
         qi = q[b].cpu().numpy()[:rows] if qtype == "mx4" else bits(q[b][:, :rows].contiguous())
         lb = None if lut is None else (bits(lut[b][:rows]) if qtype == "any4_rowwise" else bits(lut[b]))
         xb = bits(x[b])
-        fn = orc.linear_group_scaled if plan == "pair" else orc.linear
-        _, y32 = fn(xb, codes, g, oq, qi, lb)
+        r16, r32 = orc.linear(xb, codes, g, oq, qi, lb)                      # the reference's arithmetic
+        y32 = orc.linear_group_scaled(xb, codes, g, oq, qi, lb)[1] if plan == "pair" else r32
         wq = orc.bf16_to_f32(orc.dequant(codes, g, oq, qi, lb)).astype(np.float64)
         S = np.abs(x[b].double().cpu().numpy()) @ np.abs(wq).T
         got = y[b][:, :rows].double().cpu().numpy()
         ulp = np.exp2(np.floor(np.log2(np.maximum(np.abs(y32), 1e-30))) - 7)
         err = np.abs(got - y32)
-        if not (err <= 0.5 * ulp * (1 + 2.0 ** -7) + 4e-6 * S).all():
-            raise SystemExit(f"bench.py: output of layer {b} ({qtype}) does not match the oracle: max err {err.max()}")
-        worst = max(worst, float(err.max()))
-    return worst
+        finite = np.isfinite(r32)  # (mx4 with exponent 255 gives NaN rows: not in the bench recipe, but keep the sums clean)
+        if not (err[finite] <= (0.5 * ulp * (1 + 2.0 ** -7) + 4e-6 * S)[finite]).all():
+            raise SystemExit(f"bench.py: output of layer {b} ({qtype}) does not match the oracle: max err {err[finite].max()}")
+        own = max(own, float(err[finite].max()))
+        err_ref32 = max(err_ref32, float(np.abs(got - r32.astype(np.float64))[finite].max()))
+        ref16 = orc.bf16_to_f32(r16).astype(np.float64)
+        err_ref16 = max(err_ref16, float(np.abs(got - ref16)[finite].max()))
+        ymax = max(ymax, float(np.abs(ref16[finite]).max()))
+        gb = bits(y[b][:, :rows].contiguous()).astype(np.int32)
+        # bf16 bit patterns are monotone in the value within a sign: distance in representable steps
+        key = lambda u: np.where(u & 0x8000, -(u & 0x7fff), u & 0x7fff)  # noqa: E731
+        d = np.abs(key(gb) - key(r16.astype(np.int32)))[finite]
+        differ += int((d != 0).sum())
+        total += int(d.size)
+        steps = max(steps, int(d.max()))
+    norm = err_ref16 * 2.2 / max(ymax, 2.2)
+    if not norm <= 1e-2:
+        raise SystemExit(f"bench.py: {qtype} output is {err_ref16:.3e} from the reference-faithful result at max|y| = {ymax:.3f} "
+                         f"({norm:.3e} at the fixture's scale): outside north_star's 1e-2")
+    return {"max_abs_err_vs_kernel_formula": own, "kernel_formula": "group_scaled" if plan == "pair" else "reference",
+            "max_abs_err_vs_reference_f32": err_ref32, "max_abs_err_vs_reference": err_ref16, "max_abs_y": ymax,
+            "max_abs_err_vs_reference_at_fixture_scale": norm,
+            "frac_outputs_differing_from_reference_bf16": round(differ / max(total, 1), 5), "max_bf16_steps_from_reference": steps,
+            "outputs_checked": total}
 
 
 def cpu_baseline_torch(m, n, k, g, budget_s=10.0):
@@ -226,6 +256,162 @@ def cpu_baseline_oracle(m, n, k, g, budget_s=8.0):
             "sample": f"{layers} layers in {dt:.1f} s, OpenMP over weight rows, {dt / layers * 1e3:.1f} ms per layer; fastest of thread counts {cands}"}
 
 
+def decode_leg(device, steps=48, warmup=8, start_pos=128, layers=None):
+    """BASELINE config 5 at TP = 1: one decode step (one new token, batch 1) of a Llama-3-8B-shaped stack -- 32 layers, hidden
+    4096, 32 / 8 heads, inter 14336, random any4 weights of that architecture (no checkpoints here), 16-bit LM head as in the
+    reference (quantize.py:34-36), static KV cache, the whole step replayed from one hipGraph (any4_amd/decode.py; protocol
+    of the reference's benchmark.py:113-215 minus HuggingFace's Python).  HBM bytes per token = the algorithmic bytes of the
+    4-bit linears + the 16-bit LM head + the KV cache read at the timed positions."""
+    from any4_amd.decode import Any4Factory, DecodeConfig, DecodeStack
+
+    cfg = DecodeConfig.llama3_8b(max_seq=1024)
+    if layers is not None:
+        cfg.layers = layers
+    stack = DecodeStack(cfg, Any4Factory(cfg, device, torch.bfloat16, seed=1), device, torch.bfloat16, bs=1)
+    stack.capture()
+    tok = torch.randint(0, cfg.vocab, (1,), device=device)
+    for i in range(warmup):
+        stack.decode(tok, start_pos + i)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for i in range(steps):
+        stack.decode(tok, start_pos + warmup + i)
+    e1.record()
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / steps
+    dev_ms = e0.elapsed_time(e1) / steps
+    nodes = getattr(stack, "graph_nodes", None)
+    pos_mid = start_pos + warmup + steps // 2
+    b4 = cfg.weight_bytes_4bit()
+    lm = cfg.vocab * cfg.hidden * 2
+    kv = 2 * cfg.layers * cfg.kv_heads * cfg.head_dim * 2 * pos_mid
+    total = b4 + lm + kv
+    out = {"ms_per_token": round(dev_ms, 4), "ms_per_token_wall": round(wall * 1e3, 4), "tokens_per_s": round(1e3 / dev_ms, 1),
+           "hbm_bytes_per_token": total, "bytes_4bit_linears": b4, "bytes_lm_head_16bit": lm, "bytes_kv_cache": kv,
+           "hbm_roofline_ms": round(total / (HBM_PEAK_GBPS * 1e9) * 1e3, 4),
+           "frac_of_hbm_roofline": round(total / (HBM_PEAK_GBPS * 1e9) * 1e3 / dev_ms, 4),
+           "layers": cfg.layers, "tp": 1, "bs": 1, "hipgraph": True, "kernels_per_layer": getattr(stack, "kernels_per_layer", None),
+           "note": f"Llama-3-8B shape, random any4 weights (per-row LUT, g=128), KV cache of {cfg.max_seq}, tokens at positions "
+                   f"{start_pos + warmup}..{start_pos + warmup + steps - 1}, default numerics; {steps} graph replays between one HIP-event pair"}
+    if nodes is not None:
+        out["graph_nodes"] = nodes
+    del stack
+    torch.cuda.empty_cache()
+    return out
+
+
+def decode_shaped_exchange(lib, _lib, w, x, sz, lut, y, m, n, k, g, inner, device, local_rank, stream, world, iters=256):
+    """N > 1 only: the exchange as a decode step issues it -- ONE layer per launch (this rank's [n, k] shard of an
+    [N n, k] projection), then the gather of the [m, n] partial outputs (m n 2 bytes per rank: latency-bound), back to back on
+    one stream, for (a) no exchange, (b) RCCL all_gather_into_tensor, (c) the one-shot peer-write gather of
+    include/peer_gather_hip.h.  Every rank runs the same sequence; times are the max over ranks, in us per layer."""
+    import torch.distributed as dist
+
+    nl = min(int(w.shape[0]), 64)
+    singles = [make_args(_lib, w[i:i + 1], x[i:i + 1], sz[i:i + 1], lut[i:i + 1], y[i:i + 1], m, n, k, g, "any4_rowwise", True, inner, 1)
+               for i in range(nl)]
+    parts = torch.empty(world, m, n, device=device, dtype=torch.bfloat16)
+
+    def launch(i):
+        _lib.check(lib.tg_gemm_w4(ctypes.byref(singles[i % nl]), local_rank, stream.cuda_stream), "tg_gemm_w4")
+
+    def timed(after):
+        for i in range(8):
+            launch(i)
+            after(i)
+        dist.barrier()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for i in range(iters):
+            launch(i)
+            after(i)
+        e1.record(stream)
+        torch.cuda.synchronize()
+        t = torch.tensor([e0.elapsed_time(e1) * 1e3 / iters], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return round(float(t[0]), 3)
+
+    out = {"layers_in_rotation": nl, "iters": iters, "bytes_per_rank_per_gather": m * n * 2,
+           "us_per_layer_gemv_only": timed(lambda i: None),
+           "us_per_layer_gemv_plus_rccl_all_gather": timed(lambda i: dist.all_gather_into_tensor(parts, y[i % nl]))}
+    pg, err = None, None
+    try:  # (the constructor either succeeds on every rank or raises on every rank)
+        from any4_amd.shard import PeerWriteGather
+
+        pg = PeerWriteGather(max(m, 1), n, device=device, dtype=torch.bfloat16, timeout_us=500_000)
+    except Exception as e:  # noqa: BLE001
+        err = f"{type(e).__name__}: {e}"
+    if pg is not None:
+        ok = 1
+        try:
+            for i in range(4):
+                pg.gather(y[i % nl].view(m, n))
+            pg.check()
+        except Exception as e:  # noqa: BLE001
+            ok, err = 0, f"{type(e).__name__}: {e}"
+        t = torch.tensor([ok], device=device, dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        if int(t[0]) == 1:
+            out["us_per_layer_gemv_plus_peer_write_gather"] = timed(lambda i: pg.gather(y[i % nl].view(m, n)))
+            try:
+                pg.check()
+            except RuntimeError as e:
+                err = str(e)
+        elif err is None:
+            err = "a peer rank reported a failed peer-write gather"
+        pg.close()
+    if err is not None:
+        out["peer_write_gather_error"] = err
+    out["note"] = ("one single-layer tg_gemm_w4 launch per layer + the gather of its [m, n] outputs, back to back on one stream, max over ranks; "
+                   "the stacked 4 MiB-per-rank all-gather inside `value` is the bandwidth-shaped exchange, this is the latency-shaped one a decode step issues")
+    return out
+
+
+def pmc_traffic(L, bytes_per_launch, timeout_s=240):
+    """HBM bytes per launch of the dominant kernel from the PMC counters, measured live: two rocprofv3 passes (FETCH_SIZE and
+    WRITE_SIZE do not fit one pass on gfx950) over `bench.py --roofline-only` in a child process, corrected as
+    MI355X_MICROARCH.md (HBM section) prescribes: FETCH_SIZE counts the 128-byte requests of 16-byte-per-lane streaming reads
+    at 64 bytes -> read bytes = 2 x FETCH_SIZE[KB] x 1024; WRITE_SIZE[KB] x 1024 as reported.  Returns (bytes or None, note)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return None, "rocprofv3 not found on this box"
+    vals = {}
+    tmp = tempfile.mkdtemp(prefix="bench_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, ctr)
+            cmd = [prof, "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "pmc", "--", sys.executable,
+                   os.path.abspath(__file__), "--roofline-only", "--steps", "3", "--warmup", "2", "--settle-s", "0.02", "--layers", str(L)]
+            try:
+                subprocess.run(cmd, cwd="/tmp", env=env, timeout=timeout_s, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+            except (subprocess.SubprocessError, OSError) as e:
+                return None, f"rocprofv3 --pmc {ctr} pass failed ({type(e).__name__})"
+            rows = []
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if "w4_gemm" in r["Kernel_Name"] and "xprep" not in r["Kernel_Name"] and r["Counter_Name"] == ctr:
+                        rows.append(float(r["Counter_Value"]))
+            if not rows:
+                return None, f"no {ctr} rows for the GEMM kernel in the rocprofv3 output"
+            vals[ctr] = sum(rows) / len(rows)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    rd, wr = 2.0 * vals["FETCH_SIZE"] * 1024.0, vals["WRITE_SIZE"] * 1024.0
+    return int(rd + wr), (f"live: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `bench.py --roofline-only --layers {L}`; "
+                          f"mean over the kernel's dispatches: FETCH_SIZE {vals['FETCH_SIZE']:.0f} KB x 2 (gfx950 correction for 16-B/lane streaming reads) "
+                          f"+ WRITE_SIZE {vals['WRITE_SIZE']:.0f} KB = {(rd + wr) / bytes_per_launch:.4f} x the algorithmic bytes")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -238,6 +424,8 @@ def main():
     ap.add_argument("--group", type=int, default=128)
     ap.add_argument("--settle-s", type=float, default=2.0, help="seconds of untimed steps before the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-decode", action="store_true", help="skip the Llama-3-8B decode leg (config 5)")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 PMC passes that fill roofline.traffic")
     ap.add_argument("--roofline-only", action="store_true",
                     help="skip the informational legs (other configs, single-layer, cpu): every launch of the stacked "
                          "kernel is then a timed-shape launch, which is what the rocprofv3 --stats pass wants")
@@ -336,6 +524,10 @@ def main():
     value = world * bytes_step_rank / (elapsed / a.steps) / 1e9
     achieved = bytes_step_rank / (kern_ms * 1e-3) / 1e9
 
+    exchange = None
+    if world > 1 and not a.roofline_only:
+        exchange = decode_shaped_exchange(lib, _lib, w, x, sz, lut, y, m, n, k, g, inner, device, local_rank, stream, world)
+
     if rank == 0 and a.roofline_only:
         print(json.dumps({"roofline_only": True, "launch_us": round(kern_ms * 1e3, 3), "GBps": round(achieved, 2),
                           "steps": a.steps, "warmup": a.warmup, "settle_steps": settle, "layers": L, "kernel_plan": plan}), flush=True)
@@ -357,83 +549,113 @@ def main():
         t_half, t_full = timed(half, 40), timed(args, 40)
         slope_us = (t_full - t_half) / (L - L // 2)
         # (a) the timed launch's own output against the oracle
-        max_err = check_layers(w, x, sz, lut, y, g, "any4_rowwise", True, inner, plan)
+        main_check = check_layers(w, x, sz, lut, y, g, "any4_rowwise", True, inner, plan)
 
-        def leg(qtype, mm, nn, kk, gg, on_right, layers, note):
+        def leg(qtype, mm, nn, kk, gg, on_right, layers, note, numerics="fast"):
             """One more BASELINE config as a stacked launch of `layers` layers (same protocol: steady clock, HIP events)."""
             ww, xx, qq, ll, yy = make_batch(layers, mm, nn, kk, gg, inner, device, 77, qtype, on_right)
-            aa = make_args(_lib, ww, xx, qq, ll, yy, mm, nn, kk, gg, qtype, on_right, inner, layers)
+            aa = make_args(_lib, ww, xx, qq, ll, yy, mm, nn, kk, gg, qtype, on_right, inner, layers, numerics)
             ws = attach_workspace(lib, aa, device)  # noqa: F841
-            pl = ops.gemm_w4_plan(mm, nn, kk, gg, QT[qtype], on_right, inner, torch.bfloat16, layers, "fast")
+            pl = ops.gemm_w4_plan(mm, nn, kk, gg, QT[qtype], on_right, inner, torch.bfloat16, layers, numerics)
             bl = alg_bytes(mm, nn, kk, gg, qtype)
             reps = max(10, int(0.25e6 / (layers * bl / 5e6)))  # ~0.25 s of launches
             us = timed(aa, reps) / layers
-            err = check_layers(ww, xx, qq, ll, yy, gg, qtype, on_right, inner, pl, layers=(0, -1), rows=128)
+            chk = check_layers(ww, xx, qq, ll, yy, gg, qtype, on_right, inner, pl, layers=(0, -1), rows=128)
             return {"us_per_layer": round(us, 4), "GBps": round(bl / us / 1e3, 2), "frac": round(bl / us / 1e3 / HBM_PEAK_GBPS, 4),
-                    "algorithmic_bytes_per_layer": bl, "layers_per_launch": layers, "kernel_plan": pl,
-                    "max_abs_err_vs_oracle": err, "note": note}
+                    "algorithmic_bytes_per_layer": bl, "layers_per_launch": layers, "kernel_plan": pl, "numerics": numerics,
+                    "check": chk, "note": note}
 
-        legs = {
+        # N > 1: the other configs, the single-launch figures, the decode leg and the CPU baselines are N = 1 facts (the driver's
+        # N = 1 run carries them): rank 0 does not keep the other ranks waiting in the final barrier for them
+        legs = {} if world > 1 else {
             "m8": leg("any4_rowwise", 8, n, k, g, True, L, f"the metric's second point: m=8, n=k={n}, g={g}, Bint4"),
+            "m16": leg("any4_rowwise", 16, n, k, g, True, L // 2, f"m=16 (the reference's full 16-row tile, TinyGemmImpl.cuh:53-54), n=k={n}, g={g}, Bint4"),
             "config3": leg("any4_rowwise", 8, 8192, 8192, 128, False, 128, "BASELINE config 3: m=8, n=k=8192, g=128, weights on the A side (Aint4 innerKTiles=4)"),
             "int4": leg("int4", 1, n, k, g, True, L, "BASELINE config 4: uniform int4, m=1"),
             "nf4": leg("any4_global", 1, n, k, g, True, L, "BASELINE config 4: one global 16-entry LUT (the reference's NF4 path), m=1"),
             "mx4": leg("mx4", 1, n, k, 32, True, L, "BASELINE config 4: mx4 (fp4-e2m1 codes, e8m0 exponent per 32), m=1"),
+            # the same workload with the reference's own dequant arithmetic (every weight rounded to 16 bits with one fma,
+            # MatrixLayoutB.cuh:1042-1046): the kernels whose weights are bit-identical to the reference's
+            "reference_numerics": {
+                "m1": leg("any4_rowwise", 1, n, k, g, True, L, f"TG_NUM_REFERENCE, m=1, n=k={n}, g={g}, Bint4", "reference"),
+                "m8": leg("any4_rowwise", 8, n, k, g, True, L, f"TG_NUM_REFERENCE, m=8, n=k={n}, g={g}, Bint4", "reference"),
+            },
         }
 
-        # (c) single-layer launches: what one Any4Linear.forward issues (the reference's microbenchmark shape)
-        singles = []
-        for b in range(L):
-            sa = make_args(_lib, w[b:b + 1], x[b:b + 1], sz[b:b + 1], lut[b:b + 1], y[b:b + 1], m, n, k, g, "any4_rowwise", True, inner, 1)
-            singles.append(sa)
-        for sa in singles:
-            launch(sa)
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(stream)
-        for sa in singles:
-            launch(sa)
-        e1.record(stream)
-        torch.cuda.synchronize()
-        single_us = e0.elapsed_time(e1) * 1e3 / L
-        # cold single launch: one launch between two events, a different (cold) layer every time
-        cold = []
-        for b in range(0, L, 8):
-            c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            torch.cuda.synchronize()
-            c0.record(stream)
-            launch(singles[b])
-            c1.record(stream)
-            torch.cuda.synchronize()
-            cold.append(c0.elapsed_time(c1) * 1e3)
-        cold_us = sorted(cold)[len(cold) // 2]
-        single_plan = ops.gemm_w4_plan(m, n, k, g, QT["any4_rowwise"], True, inner, torch.bfloat16, 1, "fast")
-        # the same launches replayed from one hipGraph (no per-launch host work: what the GPU needs per layer), and the host
-        # floor of this entry point: back-to-back launches of a 16 x 512 problem (5.9 KB) through the same C-ABI call
-        gr = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(gr):
-            cs = torch.cuda.current_stream().cuda_stream  # the capture stream
+        # (c) single-layer launches: what one module forward issues (the reference's microbenchmark shape) -- Any4Linear's
+        # default kernel (per-row LUT any4, weights on the B side) and Int4Linear's (modules.py:21: uniform int4, A side)
+        def single_layer(qtype, on_right, tensors=None):
+            ww, xx, qq, ll, yy = tensors or make_batch(L, m, n, k, g, inner, device, 91, qtype, on_right)
+            nl = ww.shape[0]
+            sl = lambda t, i: None if t is None else t[i:i + 1]  # noqa: E731
+            singles = [make_args(_lib, ww[i:i + 1], xx[i:i + 1], qq[i:i + 1], sl(ll, i), yy[i:i + 1], m, n, k, g, qtype, on_right, inner, 1)
+                       for i in range(nl)]
             for sa in singles:
-                _lib.check(lib.tg_gemm_w4(ctypes.byref(sa), local_rank, cs), "tg_gemm_w4 (graph capture)")
-        gr.replay()
-        torch.cuda.synchronize()
-        e0.record(stream)
-        for _ in range(5):
+                launch(sa)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            for sa in singles:
+                launch(sa)
+            e1.record(stream)
+            torch.cuda.synchronize()
+            single_us = e0.elapsed_time(e1) * 1e3 / nl
+            # cold single launch: one launch between two events, a different (cold) layer every time
+            cold = []
+            for i in range(0, nl, 8):
+                c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda.synchronize()
+                c0.record(stream)
+                launch(singles[i])
+                c1.record(stream)
+                torch.cuda.synchronize()
+                cold.append(c0.elapsed_time(c1) * 1e3)
+            cold_us = sorted(cold)[len(cold) // 2]
+            # the same launches replayed from one hipGraph (no per-launch host work: what the GPU needs per layer)
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr):
+                cs = torch.cuda.current_stream().cuda_stream  # the capture stream
+                for sa in singles:
+                    _lib.check(lib.tg_gemm_w4(ctypes.byref(sa), local_rank, cs), "tg_gemm_w4 (graph capture)")
             gr.replay()
-        e1.record(stream)
-        torch.cuda.synchronize()
-        graph_us = e0.elapsed_time(e1) * 1e3 / (5 * L)
+            torch.cuda.synchronize()
+            e0.record(stream)
+            for _ in range(5):
+                gr.replay()
+            e1.record(stream)
+            torch.cuda.synchronize()
+            graph_us = e0.elapsed_time(e1) * 1e3 / (5 * nl)
+            bl = alg_bytes(m, n, k, g, qtype)
+            return {"us_per_launch_back_to_back": round(single_us, 3), "GBps_back_to_back": round(bl / single_us / 1e3, 2),
+                    "frac_back_to_back": round(bl / single_us / 1e3 / HBM_PEAK_GBPS, 4),
+                    "us_cold_event_pair": round(cold_us, 3), "frac_cold": round(bl / cold_us / 1e3 / HBM_PEAK_GBPS, 4),
+                    "us_per_launch_in_hipgraph": round(graph_us, 3), "frac_in_hipgraph": round(bl / graph_us / 1e3 / HBM_PEAK_GBPS, 4),
+                    "kernel_plan": ops.gemm_w4_plan(m, n, k, g, QT[qtype], on_right, inner, torch.bfloat16, 1, "fast")}
+
+        single_b = single_layer("any4_rowwise", True, (w, x, sz, lut, y)) if world == 1 else {}
+        single_a = single_layer("int4", False) if world == 1 else {}
+        # the host floor of the entry point: back-to-back launches of a 16 x 512 problem (5.9 KB) through the same C-ABI call
         tw_, tx_, tq_, tl_, ty_ = make_batch(1, 1, 16, 512, g, inner, device, 5)
         tiny = make_args(_lib, tw_, tx_, tq_, tl_, ty_, 1, 16, 512, g, "any4_rowwise", True, inner, 1)
         for _ in range(20):
             launch(tiny)
         torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(stream)
         for _ in range(L):
             launch(tiny)
         e1.record(stream)
         torch.cuda.synchronize()
         floor_us = e0.elapsed_time(e1) * 1e3 / L
+
+        # (d) BASELINE config 5 (TP = 1) and the live PMC traffic of the timed kernel; the bench tensors are released first
+        decode = None
+        if not a.no_decode and world == 1:
+            try:
+                decode = decode_leg(device)
+            except Exception as e:  # noqa: BLE001  (an informational leg must not take the metric line down with it)
+                decode = {"error": f"{type(e).__name__}: {e}"}
+        traffic, traffic_note = (None, "skipped (--no-pmc or N > 1)") if (a.no_pmc or world > 1) else pmc_traffic(L, bytes_step_rank)
 
         out = {
             "metric": "any4 W4A16 GEMM achieved GB/s (m=1, n=k=4096, g=128)",
@@ -455,8 +677,12 @@ def main():
                             + (f"; rows sharded over {world} ranks + RCCL all-gather of y" if world > 1 else ""),
                 "layers_per_step": L, "m": m, "n": n, "k": k, "group": g,
                 "algorithmic_bytes_per_layer": bytes_layer,
-                "output_checked": f"3 layers x 256 rows of the timed launch's y against the CPU oracle: max abs err {max_err:.3e}",
+                "numerics": "TG_NUM_FAST (group-scaled: scale / zero applied per quantisation group to the f32 accumulator; the reference "
+                            "rounds every dequantised weight to bf16 first, MatrixLayoutB.cuh:1042-1046 -- see `numerics_check` for the distance "
+                            "and `reference_numerics` for the kernels with the reference's own arithmetic)",
             },
+            # 3 layers x 256 rows of the TIMED launch's y against both CPU oracles (see check_layers)
+            "numerics_check": main_check,
             "roofline": {
                 "bound": "hbm",
                 "kernel": {"pair": "w4_gemm_pair_kernel<BF16, I=4> (persistent, 64-row work items, pair-table lookups, group-scaled accumulators)",
@@ -465,8 +691,8 @@ def main():
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                "traffic": None,
-                "traffic_note": "PMC HBM bytes are collected in separate rocprofv3 --pmc passes of this command (tools/gpu_round.sh) and committed under profiles/ (r02_pmc_traffic.json); not measured inside this run",
+                "traffic": traffic,
+                "traffic_note": traffic_note,
                 "launch_us": round(kern_ms * 1e3, 3),
                 "bytes_per_launch": bytes_step_rank,
             },
@@ -478,21 +704,19 @@ def main():
             },
             **legs,
             "single_layer_launch": {
-                "us_per_launch_back_to_back": round(single_us, 3),
-                "GBps_back_to_back": round(bytes_layer / single_us / 1e3, 2),
-                "frac_back_to_back": round(bytes_layer / single_us / 1e3 / HBM_PEAK_GBPS, 4),
-                "us_cold_event_pair": round(cold_us, 3),
-                "frac_cold": round(bytes_layer / cold_us / 1e3 / HBM_PEAK_GBPS, 4),
-                "us_per_launch_in_hipgraph": round(graph_us, 3),
-                "frac_in_hipgraph": round(bytes_layer / graph_us / 1e3 / HBM_PEAK_GBPS, 4),
+                **single_b,
                 "us_launch_floor_back_to_back": round(floor_us, 3),
-                "kernel_plan": single_plan,
-                "note": "one 4096x4096 any4 GEMV per launch (what Any4Linear.forward issues): back-to-back launches of distinct cold layers on one "
-                        "stream (event time / launches), and the median HIP-event time of an isolated launch (event pair floor on this stack: ~4.3 us); "
-                        "in_hipgraph = the same launches replayed from one captured graph; launch_floor = a 16 x 512 problem through the same "
-                        "entry point, back to back: the host/runtime cost per launch that the back-to-back figure cannot go below",
+                "int4_a_side": single_a,
+                "note": "one 4096x4096 GEMV per launch: top level = any4 per-row LUT, weights on the B side (what Any4Linear.forward issues); "
+                        "int4_a_side = uniform int4, weights on the A side (Int4Linear's default kernel, modules.py:21).  back_to_back = launches of "
+                        "distinct cold layers on one stream (event time / launches); cold = median HIP-event time of an isolated launch (event pair "
+                        "floor on this stack: ~4.3 us); in_hipgraph = the same launches replayed from one captured graph; launch_floor = a 16 x 512 "
+                        "problem through the same entry point, back to back: the host/runtime cost per launch that back_to_back cannot go below",
             },
+            "decode_llama3_8b": decode,
         }
+        if exchange is not None:
+            out["decode_shaped_exchange"] = exchange
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_torch(m, n, k, g)
             out["cpu_baseline_c_oracle"] = cpu_baseline_oracle(m, n, k, g)

@@ -46,7 +46,8 @@ typedef struct tg_peer_gather {
   void* dst[TG_PEER_MAX_WORLD];     /* dst[r]: rank r's gathered buffer [m][world * cols_local] as mapped HERE     */
   uint32_t* flags[TG_PEER_MAX_WORLD]; /* flags[r]: rank r's flag array uint32[world] as mapped here                */
   uint32_t* seq;                    /* device word of this rank: calls so far; the kernel increments it            */
-  uint32_t* status;                 /* device word of this rank: set to 1 when a peer's flag did not arrive        */
+  uint32_t* status;                 /* device word of this rank: set to 1 when a peer's flag did not arrive (that
+                                       peer's column block of dst[rank] is then filled with NaN bit patterns)      */
   int32_t world, rank;
   int64_t m, cols_local;            /* cols_local * 2 bytes must be a multiple of 16                               */
   int64_t timeout_us;               /* bound of the wait for the peers (<= 0: 2 s)                                 */

@@ -80,7 +80,7 @@ def _linear_worker(rank, world, port):
     try:
         for m in (1, 3, 8):
             x = torch.randn(m, k, generator=gen).bfloat16().cuda()
-            y = shard(x).clone()
+            y = shard(x)  # (a copy by default: RowShardedLinear.alias_output=False)
             y_ref = full.local(x)
             torch.cuda.synchronize()
             assert torch.equal(y.view(torch.int16), y_ref.view(torch.int16)), f"rank {rank} m={m}"
@@ -153,3 +153,68 @@ def test_tensor_parallel_decode_with_peer_gather():
         assert err_eager < 3e-2, (rank, err_eager)   # bf16 GEMMs of different shapes (row shards) and summation orders
         assert err_graph < 3e-2, (rank, err_graph)
         assert all(c % 2 == 0 for c in calls), calls  # every gather object ended on an even number of calls
+
+
+@pytest.mark.timeout(300)
+def test_peer_write_gather_four_processes_fan_out():
+    """Fan-out > 1 peer: four ranks (all on the one GPU of the box) store into three peers each and wait for three flags."""
+    import torch.multiprocessing as mp
+
+    mp.spawn(_worker, args=(4, _free_port(), 1024, 4, 16, "bfloat16"), nprocs=4, join=True)
+
+
+def _absent_peer_worker(rank, world, port, results):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from any4_amd.shard import PeerWriteGather
+
+    cols, m = 256, 2
+    pg = PeerWriteGather(4, cols, device="cuda:0", dtype=torch.bfloat16, timeout_us=300_000)
+    try:
+        # call 0: both ranks take part
+        out = pg.gather(torch.full((m, cols), float(rank + 1), dtype=torch.bfloat16, device="cuda:0")).clone()
+        torch.cuda.synchronize()
+        assert torch.equal(out[:, :cols].float().cpu(), torch.full((m, cols), 1.0)) and torch.equal(out[:, cols:].float().cpu(), torch.full((m, cols), 2.0))
+        pg.check()
+        dist.barrier()
+        if rank == 0:
+            # call 1: rank 1 never arrives -> the wait ends after the timeout, *status is set, rank 1's slice is NaN
+            import time
+
+            t0 = time.perf_counter()
+            out = pg.gather(torch.full((m, cols), 5.0, dtype=torch.bfloat16, device="cuda:0")).clone()
+            torch.cuda.synchronize()
+            waited = time.perf_counter() - t0
+            own_ok = bool((out[:, :cols].float() == 5.0).all())
+            peer_nan = bool(torch.isnan(out[:, cols:].float()).all())
+            raised_check = raised_poll = False
+            try:
+                pg.check()
+            except RuntimeError:
+                raised_check = True
+            try:  # poll(): the first call queues the read-back, a later one sees it
+                for _ in range(50):
+                    pg.poll()
+                    torch.cuda.synchronize()
+            except RuntimeError:
+                raised_poll = True
+            results[0] = (waited, own_ok, peer_nan, raised_check, raised_poll)
+        dist.barrier()
+    finally:
+        pg.close()
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_peer_that_never_arrives_sets_status_and_poisons_its_slice():
+    import torch.multiprocessing as mp
+
+    results = mp.Manager().dict()
+    mp.spawn(_absent_peer_worker, args=(2, _free_port(), results), nprocs=2, join=True)
+    waited, own_ok, peer_nan, raised_check, raised_poll = results[0]
+    assert 0.25 < waited < 5.0, waited          # bounded by timeout_us = 0.3 s, never a hang
+    assert own_ok and peer_nan                  # own slice intact, the missing slice is NaN (loud)
+    assert raised_check and raised_poll         # both the synchronising and the non-blocking check report it

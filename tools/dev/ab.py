@@ -31,7 +31,7 @@ for cfg in sys.argv[1:] or ["1,4096,4096,1,any4_rowwise,128"]:
     torch.cuda.synchronize()
     try:
         err = bench.check_layers(w, x, q, lut, y, g, qtype, on_right, 4, plan, layers=(0, L // 2, -1), rows=128)
-        ok = f"ok max|err| {err:.3e}"
+        ok = f"ok max|err| {err['max_abs_err_vs_kernel_formula']:.3e} (vs reference {err['max_abs_err_vs_reference']:.3e})"
     except SystemExit as e:
         ok = f"MISMATCH {e}"
     t0 = time.perf_counter()
