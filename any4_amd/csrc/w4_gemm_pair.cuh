@@ -219,13 +219,7 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
   // of one problem's weights), then on by G C.  C = 1 is plain round-robin.
   const int chunk = RR ? p.chunk : 1;
   const int it_stride = RR ? (int)gridDim.x * chunk - (chunk - 1) : 1;  // the step from the last item of a chunk
-#ifndef TG_XG_XCD
-#define TG_XG_XCD 0
-#endif
-  // XCD-aware dealing (workgroup b runs on XCD b % 8: observed, used for speed only): the workgroups of one XCD take
-  // neighbouring chunks, so the workgroups that share a problem's activation block also share an L2
-  const int vblock = (RR && TG_XG_XCD && (gridDim.x & 7) == 0) ? (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) : (int)blockIdx.x;
-  const int it_begin = RR ? vblock * chunk : (int)(((int64_t)blockIdx.x * p.items) / gridDim.x);
+  const int it_begin = RR ? (int)blockIdx.x * chunk : (int)(((int64_t)blockIdx.x * p.items) / gridDim.x);
   const int it_end = RR ? p.items : (int)(((int64_t)(blockIdx.x + 1) * p.items) / gridDim.x);
   const int per_problem = p.rblocks * p.cblocks;
 

@@ -326,7 +326,8 @@ def test_group_scaled_distance_from_reference_at_the_benchmarked_shape(oracle):
     """The numerics contract of the library's default (group-scaled) arithmetic, written down at the BENCHMARKED shape: 512 weight
     rows of the bench recipe (k = 4096, g = 128, per-row LUT; SURVEY.md 8d generator) through both CPU restatements.  The
     group-scaled result is the reference's sum without its per-weight rounding to bf16 (MatrixLayoutB.cuh:1042-1046):
-      * max-abs distance from the reference-faithful bf16 output <= 1e-2 at the fixture's scale (max|y| = 2.2) -- north_star;
+      * before the output rounding: max-abs distance from the reference's f32 sums <= 1e-2 at the fixture's scale (max|y| = 2.2,
+        north_star); after it: within max(that, one bf16 step of the largest output) -- a flipped final rounding is one step;
       * never more than one bf16 step away for outputs of the top binade, and equal in most outputs."""
     gen = torch.Generator().manual_seed(0)
     n, k, g, m = 512, 4096, 128, 1
@@ -341,7 +342,8 @@ def test_group_scaled_distance_from_reference_at_the_benchmarked_shape(oracle):
     ref, gs = oracle.bf16_to_f32(r16).astype(np.float64), oracle.bf16_to_f32(g16).astype(np.float64)
     ymax = np.abs(ref).max()
     err = np.abs(gs - ref).max()
-    assert err * 2.2 / max(ymax, 2.2) <= 1e-2, (err, ymax)
+    step = 2.0 ** (np.floor(np.log2(ymax)) - 7)    # one bf16 step of the largest output
+    assert err <= max(1e-2 * max(1.0, ymax / 2.2), step), (err, ymax)
     assert np.abs(g32.astype(np.float64) - r32.astype(np.float64)).max() <= 1e-2 * max(1.0, ymax / 2.2)
     differ = (g16 != r16).mean()
     assert differ < 0.6, differ                      # (measured: ~0.4 of the outputs land on the neighbouring bf16 value)

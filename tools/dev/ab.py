@@ -19,9 +19,10 @@ for cfg in sys.argv[1:] or ["1,4096,4096,1,any4_rowwise,128"]:
     m, n, k, on_right, qtype, g = int(f[0]), int(f[1]), int(f[2]), int(f[3]) == 1, f[4], int(f[5])
     L = int(f[6]) if len(f) > 6 else (512 if n * k <= 4096 * 4096 else 128)
     w, x, q, lut, y = bench.make_batch(L, m, n, k, g, 4, dev, 7, qtype, on_right)
-    aa = bench.make_args(_lib, w, x, q, lut, y, m, n, k, g, qtype, on_right, 4, L)
+    num = os.environ.get("ANY4_AB_NUMERICS", "fast")
+    aa = bench.make_args(_lib, w, x, q, lut, y, m, n, k, g, qtype, on_right, 4, L, num)
     ws = bench.attach_workspace(lib, aa, dev)
-    plan = ops.gemm_w4_plan(m, n, k, g, bench.QT[qtype], on_right, 4, torch.bfloat16, L, "fast")
+    plan = ops.gemm_w4_plan(m, n, k, g, bench.QT[qtype], on_right, 4, torch.bfloat16, L, num)
 
     def launch():
         _lib.check(lib.tg_gemm_w4(ctypes.byref(aa), 0, st.cuda_stream), "tg_gemm_w4")
