@@ -11,10 +11,12 @@ LIB_PATH = os.path.join(_HERE, "lib", "libtinygemm_hip.so")
 TG_BF16, TG_F16 = 0, 1
 TG_Q_INT4, TG_Q_ANY4_GLOBAL, TG_Q_ANY4_ROWWISE, TG_Q_MX4, TG_Q_INT8 = 0, 1, 2, 3, 4
 TG_NUM_FAST, TG_NUM_REFERENCE = 0, 1
-TG_ABI_VERSION = 4
+TG_ABI_VERSION = 5
 TG_PLAN_SPLITK, TG_PLAN_STREAM, TG_PLAN_PAIR = 1, 2, 3
 TG_LAYOUT_RM, TG_LAYOUT_TC_A = 0, 1
 TG_E_LAYOUT = -12
+TG_E_FUSION = -13
+TG_EPI_NONE, TG_EPI_SWIGLU = 0, 1
 
 _i32, _i64, _vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p
 
@@ -31,6 +33,7 @@ class W4Gemm(ctypes.Structure):
         ("numerics", _i32), ("reserved", _i32), ("bias", _vp), ("stride_bias", _i64),
         ("workspace", _vp), ("workspace_bytes", _i64),
         ("x_layout", _i32), ("y_layout", _i32),
+        ("bias_row_stride", _i64), ("norm_weight", _vp), ("norm_eps", ctypes.c_float), ("epilogue", _i32),
     ]
 
 

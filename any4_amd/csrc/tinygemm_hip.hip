@@ -581,7 +581,7 @@ int launch_stream(const GemmParams& p, int64_t coltiles, int64_t batch, hipStrea
   sp.tiles_per_wave = 1;
   sp.stride_x = p.stride_x; sp.stride_w = p.stride_w; sp.stride_qinfo = p.stride_qinfo;
   sp.stride_lut = p.stride_lut; sp.stride_y = p.stride_y;
-  sp.bias = p.bias; sp.stride_bias = p.stride_bias; sp.dry = p.dry;
+  sp.bias = p.bias; sp.stride_bias = p.stride_bias; sp.bias_row_stride = p.bias_row_stride; sp.dry = p.dry;
   const int mrows = p.m < 16 ? p.m : 16;
   const int nunits = (p.k + UNIT - 1) / UNIT;
   const int upg = (1 << p.gshift) / UNIT;
@@ -669,7 +669,7 @@ enum { TG_PAIR_NA = -100 };
 #ifndef TG_PAIR_WGS
 #define TG_PAIR_WGS 512  // persistent workgroups: two per CU
 #endif
-template <typename DT, int I, int GPS, int MR, bool QMX, int NSG, bool XG = false, bool LA = false>
+template <typename DT, int I, int GPS, int MR, bool QMX, int NSG, bool XG = false, bool LA = false, bool NORM = false>
 int launch_pair_k(PairParams& pp, unsigned lds, hipStream_t st) {
 #ifdef TG_DEV_MIN  // developer builds: only the headline instantiation (fast A/B builds)
 #ifndef TG_DEV_GPS
@@ -684,7 +684,7 @@ int launch_pair_k(PairParams& pp, unsigned lds, hipStream_t st) {
 #ifndef TG_DEV_LA
 #define TG_DEV_LA false
 #endif
-  if constexpr (!(std::is_same<DT, BF16>::value && I == 4 && GPS == TG_DEV_GPS && MR == TG_DEV_MR && QMX == TG_DEV_QMX && NSG == TG_DEV_MIN && LA == TG_DEV_LA)) return TG_PAIR_NA;
+  if constexpr (!(std::is_same<DT, BF16>::value && I == 4 && GPS == TG_DEV_GPS && MR == TG_DEV_MR && QMX == TG_DEV_QMX && NSG == TG_DEV_MIN && LA == TG_DEV_LA && !NORM)) return TG_PAIR_NA;
   else {
 #endif
   if constexpr (QMX && !std::is_same<DT, BF16>::value) return TG_E_DTYPE;  // mx4 is bf16-only (TinyGemm_int4.cu:758)
@@ -692,7 +692,7 @@ int launch_pair_k(PairParams& pp, unsigned lds, hipStream_t st) {
   // several groups per super-tile (group 32 / 64 with wide super-tiles): more per-slot state, one slot in flight fits the
   // 128-VGPR budget without spills (ring depth measured irrelevant between 2 and 4)
   constexpr int RING = GPS > 1 ? (LA ? TG_PAIR_RA1 : 1) : LA ? TG_PAIR_RA : TG_PAIR_R;
-  constexpr auto kern = w4_gemm_pair_kernel<DT, I, GPS, MR, QMX, RING, NSG, TG_PAIR_ABL, XG, LA>;
+  constexpr auto kern = w4_gemm_pair_kernel<DT, I, GPS, MR, QMX, RING, NSG, TG_PAIR_ABL, XG, LA, NORM>;
   if (pp.dry) return TG_PLAN_PAIR;
   const int prc = prepare_lds_kernel<kern>();
   if (prc != 0) return prc;
@@ -720,6 +720,25 @@ int launch_xprep(const PairParams& pp, int I, int ma, int64_t batch, hipStream_t
   const int64_t chunks = (int64_t)pp.m * (pp.k / 32);
   hipLaunchKernelGGL(w4_xprep_kernel<DT>, dim3((unsigned)cdiv(chunks, 256), (unsigned)batch), dim3(256), 0, st, xq);
   return launch_status();
+}
+
+// m = 1 has its own specialisation (one accumulator register finalised per group, taken as a running difference) -- except
+// with several groups per super-tile, where the general kernel's zero-C group starts compile without spills; `norm`: the
+// instantiations with LlamaRMSNorm fused into the activation staging (staged activations, m <= 8, not mx4)
+template <typename DT, int I, int GPS, bool QMX, int NSG>
+int launch_pair_m(PairParams& pp, unsigned lds, hipStream_t st, bool xg, int m, int mregs, bool norm) {
+  const bool m1 = m == 1 && TG_PAIR_MR1 == 1 && GPS <= TG_PAIR_MR1_GPS;
+  if (xg) return m1 ? launch_pair_k<DT, I, GPS, 1, QMX, NSG, true>(pp, lds, st) : launch_pair_k<DT, I, GPS, 4, QMX, NSG, true>(pp, lds, st);
+  if (norm) {
+    if constexpr (QMX) return TG_PAIR_NA;
+    else {
+      if (mregs != 4) return TG_PAIR_NA;
+      return m1 ? launch_pair_k<DT, I, GPS, 1, false, NSG, false, false, true>(pp, lds, st)
+                : launch_pair_k<DT, I, GPS, 4, false, NSG, false, false, true>(pp, lds, st);
+    }
+  }
+  if (m1) return launch_pair_k<DT, I, GPS, 1, QMX, NSG>(pp, lds, st);
+  return mregs == 4 ? launch_pair_k<DT, I, GPS, 4, QMX, NSG>(pp, lds, st) : launch_pair_k<DT, I, GPS, 16, QMX, NSG>(pp, lds, st);
 }
 
 template <typename DT, int I, bool QMX>
@@ -756,6 +775,9 @@ int launch_pair(GemmParams& p, int64_t batch, hipStream_t st) {
   // mx4: exponent blocks of 16 bytes per row, read at 4-byte alignment (w4_gemm_pair.cuh, e_request)
   // (a slice that starts off a 4-byte boundary loses up to 3 bytes of its one block)
   if (QMX && (p.ngroups < 16 || p.ngroups % 4 != 0 || ((pp.spw * gps) % 4 != 0 && pp.spw * gps > 12))) return TG_PAIR_NA;
+  // fused RMSNorm: done in the workgroup's own staging of the whole activation block (its partial sums borrow the activation-sum
+  // area, which mx4 does not have); the workspace variant would need it in the pre-pass
+  if (p.norm_w && (QMX || lds > 80u * 1024u || p.m > ma)) return TG_PAIR_NA;
   bool xg = false;
 #ifdef TG_PAIR_FORCE_XG  // developer A/B: the workspace variant also where the staged plan fits
   if (mregs == 4 && p.m <= ma) lds = 1u << 30;
@@ -797,19 +819,13 @@ int launch_pair(GemmParams& p, int64_t batch, hipStream_t st) {
   pp.stride_x = p.stride_x; pp.stride_w = p.stride_w; pp.stride_qinfo = p.stride_qinfo;
   pp.stride_lut = p.stride_lut; pp.stride_y = p.stride_y;
   pp.bias = p.bias; pp.stride_bias = p.stride_bias; pp.dry = p.dry;
+  pp.bias_row_stride = p.bias_row_stride; pp.norm_w = p.norm_w; pp.norm_eps = p.norm_eps; pp.epilogue = p.epilogue;
   pp.x_tc = p.x_tc; pp.y_tc = p.y_tc; pp.y_tiles = (p.wrows + 15) / 16;
   if (xg && !p.dry) {
     const int rc = launch_xprep<DT>(pp, I, ma, batch, st);
     if (rc != 0) return rc;
   }
-  // m = 1 has its own specialisation (one accumulator register finalised per group, taken as a running difference) --
-  // except with several groups per super-tile, where the general kernel's zero-C group starts compile without spills
-#define TG_PAIR_M(GPS_, NSG_)                                                                      \
-  (xg ? (p.m == 1 && TG_PAIR_MR1 == 1 && GPS_ <= TG_PAIR_MR1_GPS ? launch_pair_k<DT, I, GPS_, 1, QMX, NSG_, true>(pp, lds, st)  \
-                                      : launch_pair_k<DT, I, GPS_, 4, QMX, NSG_, true>(pp, lds, st)) \
-   : p.m == 1 && TG_PAIR_MR1 == 1 && GPS_ <= TG_PAIR_MR1_GPS ? launch_pair_k<DT, I, GPS_, 1, QMX, NSG_>(pp, lds, st)            \
-   : mregs == 4                   ? launch_pair_k<DT, I, GPS_, 4, QMX, NSG_>(pp, lds, st)            \
-                                  : launch_pair_k<DT, I, GPS_, 16, QMX, NSG_>(pp, lds, st))
+#define TG_PAIR_M(GPS_, NSG_) launch_pair_m<DT, I, GPS_, QMX, NSG_>(pp, lds, st, xg, p.m, mregs, p.norm_w != nullptr)
   if (gps == 1) {
     // group boundaries at fixed places of the unrolled round when a group is one super-tile or one whole round
     // (the m = 1 specialisation too since its group update is spelled out instruction by instruction: before that, fixed
@@ -846,7 +862,9 @@ int launch_pair16(const GemmParams& p, int64_t batch, hipStream_t st) {
   if (p.m > 16 || batch > 65535) return TG_PAIR_NA;
   // m = 1 and more than one round of workgroups (one per CU): the streaming kernel's split-K launches are faster there
   // (per hipGraph node, 6144 x 4096: 8.6 us against 10.2 us; 14336 x 4096: 13.8 against 18.3)
-  if (p.m == 1 && !p.x_tc && !p.y_tc && (int64_t)((p.wrows + 15) / 16) * batch > 256 && (1 << p.gshift) >= 128) return TG_PAIR_NA;
+  // (not when a fused stage is asked for: only the pair-table kernels have them)
+  if (p.m == 1 && !p.x_tc && !p.y_tc && !p.norm_w && !p.epilogue && (int64_t)((p.wrows + 15) / 16) * batch > 256 && (1 << p.gshift) >= 128) return TG_PAIR_NA;
+  if (p.norm_w && (QMX || (int64_t)p.m * p.k > 32768)) return TG_PAIR_NA;  // the norm pass: one 32-k chunk per thread
   const int g = 1 << p.gshift;
   const int nsg = g >= 16 * I ? g / (16 * I) : 1;
   Pair16Params pp;
@@ -861,7 +879,7 @@ int launch_pair16(const GemmParams& p, int64_t batch, hipStream_t st) {
   // activation rows that do not fit next to the table are staged one part of k at a time (whole groups per part)
   unsigned lds = 0;
   int phases = 1;
-  for (; phases <= (wgs <= 512 ? 8 : 1); phases *= 2) {
+  for (; phases <= (wgs <= 512 && !p.norm_w ? 8 : 1); phases *= 2) {  // (the fused norm needs a row's whole k in one part)
     if (p.ksuper % (phases * nsg) != 0 || p.ngroups % phases != 0) return TG_PAIR_NA;
     const int kp = p.k / phases;
     pp.x_pitch = kp * 2 + 16;
@@ -876,21 +894,30 @@ int launch_pair16(const GemmParams& p, int64_t batch, hipStream_t st) {
   pp.stride_x = p.stride_x; pp.stride_w = p.stride_w; pp.stride_qinfo = p.stride_qinfo;
   pp.stride_lut = p.stride_lut; pp.stride_y = p.stride_y;
   pp.bias = p.bias; pp.stride_bias = p.stride_bias;
+  pp.bias_row_stride = p.bias_row_stride; pp.norm_w = p.norm_w; pp.norm_eps = p.norm_eps; pp.epilogue = p.epilogue;
   pp.x_tc = p.x_tc; pp.y_tc = p.y_tc; pp.y_tiles = (p.wrows + 15) / 16;
   if (p.dry) return TG_PLAN_PAIR;
   const dim3 grid((unsigned)((p.wrows + 15) / 16), (unsigned)batch);
-#define TG_P16(CPG_)                                                        \
+#define TG_P16K(CPG_, NORM_)                                                 \
   do {                                                                      \
-    constexpr auto kern = w4_gemm_pair16_kernel<DT, I, QMX, CPG_>;          \
+    constexpr auto kern = w4_gemm_pair16_kernel<DT, I, QMX, CPG_, 1, NORM_>; \
     const int prc = prepare_lds_kernel<kern>();                             \
     if (prc != 0) return prc;                                               \
     hipLaunchKernelGGL(kern, grid, dim3(1024), lds, st, pp);                \
+  } while (0)
+#define TG_P16(CPG_)                                 \
+  do {                                               \
+    if constexpr (!QMX) {                            \
+      if (p.norm_w) { TG_P16K(CPG_, true); break; }  \
+    }                                                \
+    TG_P16K(CPG_, false);                            \
   } while (0)
   if constexpr (QMX) TG_P16(1);  // mx4: group = 32
   else if (g == 32) TG_P16(1);
   else if (g == 64) TG_P16(2);
   else if (g == 128) TG_P16(4);
   else TG_P16(8);
+#undef TG_P16K
 #undef TG_P16
   return launch_status();
   }
@@ -902,11 +929,12 @@ template <typename DT, int I, bool QMX>
 int launch_pair_a(GemmParams& p, int64_t batch, hipStream_t st) {
   if constexpr (I < 2) return TG_PAIR_NA;  // one 16-k tile per word set: no word pair for a 32-k MFMA step
   else {
-  if (p.m > 16 || p.x_tc || p.y_tc) return TG_PAIR_NA;
+  if (p.m > 16 || p.x_tc || p.y_tc || p.norm_w || p.epilogue) return TG_PAIR_NA;
   const int g = 1 << p.gshift;
   const int gps = g >= 16 * I ? 1 : (16 * I) / g;
   PairParams pp;
   pp.x_tc = pp.y_tc = 0; pp.y_tiles = 0;
+  pp.bias_row_stride = p.bias_row_stride; pp.norm_w = nullptr; pp.norm_eps = 0.f; pp.epilogue = 0;
   pp.x = p.x; pp.w = p.w; pp.qinfo = p.qinfo; pp.lut = p.lut; pp.y = p.y;
   pp.m = p.m; pp.wrows = p.wrows; pp.k = p.k; pp.ntiles = p.ntiles; pp.ksuper = p.ksuper;
   pp.gshift = p.gshift; pp.ngroups = p.ngroups; pp.qtype = p.qtype;
@@ -995,6 +1023,7 @@ int launch_w4(GemmParams& p, int64_t coltiles, int64_t batch, hipStream_t st) {
     }
   }
   if (p.x_tc || p.y_tc) return TG_E_LAYOUT;  // only the pair-table kernels read / write fragment order themselves
+  if (p.norm_w || p.epilogue) return TG_E_FUSION;  // ... and only they carry the fused norm / SwiGLU stages
 #ifdef TG_DEV_MIN  // developer A/B builds carry the pair-table kernels only (a third of the build time)
   return TG_E_SHAPE;
 #else
@@ -1047,6 +1076,7 @@ const char* tg_error_string(int code) {
     case TG_E_DEVICE: return "could not select the requested device";
     case TG_E_SIZE: return "an operand is too large for the kernels' 32-bit byte offsets (activations, packed weights or quantisation info of one problem must stay below 2 GiB; at most 65535 16-row activation tiles)";
     case TG_E_INTERNAL: return "internal error: a kernel that addresses LDS from offset 0 was built with static LDS";
+    case TG_E_FUSION: return "no kernel with the requested fused stage (norm_weight / epilogue) for this problem: run that stage as its own launch (include/decode_glue_hip.h)";
     case TG_E_LAYOUT: return "fragment-order activations / outputs (x_layout, y_layout) are not available for this problem: convert with tg_convert_{from,to}_A16 around a row-major call";
     default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown tinygemm error";
   }
@@ -1171,6 +1201,13 @@ static int gemm_w4_impl(const tg_w4_gemm* a, int device, tg_stream_t stream, int
   if (a->workspace && (!aligned16(a->workspace) || a->workspace_bytes < 0)) return TG_E_ALIGN;
   if (!(a->x_layout == TG_LAYOUT_RM || a->x_layout == TG_LAYOUT_TC_A) || !(a->y_layout == TG_LAYOUT_RM || a->y_layout == TG_LAYOUT_TC_A)) return TG_E_LAYOUT;
   if ((a->x_layout || a->y_layout) && (!a->w_on_right || a->m % 16 != 0 || a->bias)) return TG_E_LAYOUT;
+  if (a->bias_row_stride < 0 || (a->bias_row_stride && !a->bias) || (a->bias_row_stride & 3)) return TG_E_SHAPE;
+  if (!(a->epilogue == TG_EPI_NONE || a->epilogue == TG_EPI_SWIGLU)) return TG_E_SHAPE;
+  if (a->norm_weight && !aligned16(a->norm_weight)) return TG_E_ALIGN;
+  // the fused stages exist in the TG_NUM_FAST pair-table kernels only (row-major operands)
+  if ((a->norm_weight || a->epilogue) && (a->numerics != TG_NUM_FAST || a->x_layout || a->y_layout)) return TG_E_FUSION;
+  if (a->norm_weight && a->k % 2048 != 0) return TG_E_FUSION;
+  if (a->epilogue == TG_EPI_SWIGLU && (!a->w_on_right || a->bias || a->wrows % 16 != 0)) return TG_E_FUSION;
   const int batch = a->batch > 1 ? a->batch : 1;
   if (batch > 1 && ((a->stride_x | a->stride_w | a->stride_lut) & 15)) return TG_E_ALIGN;
   if (batch > 1 && a->bias && (a->stride_bias & 7)) return TG_E_ALIGN;
@@ -1212,6 +1249,10 @@ static int gemm_w4_impl(const tg_w4_gemm* a, int device, tg_stream_t stream, int
 #endif
   p.bias = (const char*)a->bias;
   p.stride_bias = batch > 1 ? a->stride_bias : 0;
+  p.bias_row_stride = a->bias_row_stride;
+  p.norm_w = (const char*)a->norm_weight;
+  p.norm_eps = a->norm_eps;
+  p.epilogue = a->epilogue;
   p.stride_x = batch > 1 ? a->stride_x : 0;
   p.stride_w = batch > 1 ? a->stride_w : 0;
   p.stride_qinfo = batch > 1 ? a->stride_qinfo : 0;
@@ -1291,6 +1332,8 @@ int tg_gemm_w8(const tg_w4_gemm* a, int device, tg_stream_t stream) {
     return TG_E_ALIGN;
   if (a->bias && (reinterpret_cast<uintptr_t>(a->bias) & 7u)) return TG_E_ALIGN;
   if (a->reserved != 0) return TG_E_SHAPE;
+  if (a->norm_weight || a->epilogue) return TG_E_FUSION;
+  if (a->bias_row_stride < 0 || (a->bias_row_stride && !a->bias) || (a->bias_row_stride & 3)) return TG_E_SHAPE;
   if (a->m * a->k * 2 >= (int64_t)1 << 31 || a->wrows * a->k >= (int64_t)1 << 31 ||
       (a->k / a->group) * a->wrows * 4 >= (int64_t)1 << 31 || cdiv(a->m, 16) > 65535)
     return TG_E_SIZE;
@@ -1299,6 +1342,7 @@ int tg_gemm_w8(const tg_w4_gemm* a, int device, tg_stream_t stream) {
   GemmParams p;
   p.x = (const char*)a->x; p.w = (const char*)a->w; p.qinfo = (const char*)a->qinfo; p.lut = nullptr; p.y = (char*)a->y;
   p.bias = (const char*)a->bias; p.stride_bias = batch > 1 ? a->stride_bias : 0; p.numerics = TG_NUM_REFERENCE;
+  p.bias_row_stride = a->bias_row_stride; p.norm_w = nullptr; p.norm_eps = 0.f; p.epilogue = 0;
   p.m = (int32_t)a->m; p.wrows = (int32_t)a->wrows; p.k = (int32_t)a->k;
   p.ntiles = (int32_t)(a->wrows / rows_per_tile);
   p.ksuper = (int32_t)(a->k / (16 * I));

@@ -41,6 +41,10 @@ struct GemmParams {
   int64_t stride_x, stride_w, stride_qinfo, stride_lut, stride_y;
   const char* bias;   // optional [wrows] 16-bit, added after the first rounding (see store_rows4)
   int64_t stride_bias;
+  int64_t bias_row_stride;  // elements between the bias rows of consecutive activation rows (0: one row for all; wrows: a residual)
+  const char* norm_w;       // fused RMSNorm of the activations (pair-table kernels only) / host-side dispatch
+  float norm_eps;
+  int32_t epilogue;         // TG_EPI_* (pair-table kernels only)
   // host-side only: the caller's workspace (pair kernel, XG variant) and the planner's answer to "how much would help"
   char* ws;
   int64_t ws_bytes, ws_need;
@@ -319,6 +323,6 @@ __global__ void __launch_bounds__(WAVES * 64, MINW) w4_gemm_kernel(const GemmPar
   const int col = ct * 16 + i;
   const int rowg = row0 + 4 * Q;
   if (rt_ok && col < p.m && rowg < p.wrows) {  // wrows % 8 == 0 and rowg % 4 == 0: all four rows valid
-    store_rows4<DT>(yb, p.bias ? p.bias + b * p.stride_bias : nullptr, (int64_t)col * p.wrows + rowg, rowg, acc);
+    store_rows4<DT>(yb, p.bias ? p.bias + b * p.stride_bias + (int64_t)col * p.bias_row_stride * 2 : nullptr, (int64_t)col * p.wrows + rowg, rowg, acc);
   }
 }

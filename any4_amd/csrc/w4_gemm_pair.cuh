@@ -8,7 +8,10 @@
 //   LA   Aint4 weights: v_mfma_f32_16x16x32, duplicated table, activations straight from the workspace into the MFMA operand
 //   QMX  mx4: e8m0 exponents fetched as 16-byte blocks per row
 //   MR   1 = the m = 1 specialisation (one accumulator register per tile, group sums as running differences), 4 / 16 = general
+//   NORM LlamaRMSNorm of the activations fused into the staging (tg_w4_gemm.norm_weight; own instantiations: the extra staging
+//        code costs the m = 1 kernel registers it does not have)
 //   x_tc / y_tc (run time): activations / output in the reference's A-fragment order instead of row-major
+//   p.epilogue / p.bias_row_stride (run time): SwiGLU of gate / up row pairs, residual add in the output store
 //
 // Why another kernel: a per-element LDS lookup (w4_gemm_stream.cuh) costs one LDS access per 4-bit weight and the LDS
 // serves 32 addresses per clock -- at the HBM roofline a CU has to dequantise ~20 weights per clock, which leaves the LDS
@@ -102,6 +105,10 @@ struct PairParams {
   int64_t stride_x, stride_w, stride_qinfo, stride_lut, stride_y;
   const char* bias;   // optional [wrows] 16-bit, added after the first rounding
   int64_t stride_bias;
+  int64_t bias_row_stride;  // elements between the bias rows of consecutive activation rows: 0 = one row for all, wrows = a residual
+  const char* norm_w;       // fused RMSNorm of the activations in the staging (tg_w4_gemm.norm_weight), 16-bit [k]; nullptr = off
+  float norm_eps;
+  int32_t epilogue;         // TG_EPI_SWIGLU: rows in blocks of 8 gate + 8 up, y is [m][wrows / 2]
   int32_t dry;        // host-side only: report the kernel family instead of launching (tg_gemm_w4_plan)
   // XG variant (activation block too large to stage whole): activations pre-arranged by w4_xprep_kernel in the caller's workspace
   const char* xp;     // [problem][pass][k super-tile][row of the pass][32 I bytes in byte order]
@@ -148,6 +155,42 @@ __device__ __forceinline__ float dot2_ones(uint32_t pair, float acc) {
     return __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, pair), __builtin_bit_cast(f16x2, 0x3c003c00u), acc, false);
 }
 
+// sum of squares of the 32 values of a staged chunk (16 packed pairs), f32
+template <typename DT>
+__device__ __forceinline__ float chunk_sumsq(const uint32_t (&d)[16]) {
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    if constexpr (std::is_same<DT, BF16>::value)
+      s = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, d[j]), __builtin_bit_cast(bf16x2, d[j]), s, false);
+    else
+      s = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, d[j]), __builtin_bit_cast(f16x2, d[j]), s, false);
+  }
+  return s;
+}
+// LlamaRMSNorm of a staged chunk: x' = RNE16(RNE16(x rs) g), g = the chunk's 32 norm weights (64 bytes at gsrc): the formula
+// and rounding points of dg_add_rmsnorm (decode_glue.cuh)
+template <typename DT>
+__device__ __forceinline__ void chunk_rmsnorm(uint32_t (&d)[16], float rs, const char* gsrc) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const u32x4 g = reinterpret_cast<const u32x4*>(gsrc)[j];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const uint32_t v = d[4 * j + e];
+      const float lo = DT::to_f32(DT::from_f32(DT::lo_f32(v) * rs)) * DT::lo_f32(g[e]);
+      const float hi = DT::to_f32(DT::from_f32(DT::hi_f32(v) * rs)) * DT::hi_f32(g[e]);
+      d[4 * j + e] = DT::pack2(lo, hi);
+    }
+  }
+}
+// SwiGLU of two 16-bit GEMM outputs (dg_swiglu's formula): RNE16(RNE16(silu(g)) u)
+template <typename DT>
+__device__ __forceinline__ uint16_t swiglu16(float gsum, float usum) {
+  const float g = DT::to_f32(DT::from_f32(gsum)), u = DT::to_f32(DT::from_f32(usum));
+  return DT::from_f32(DT::to_f32(DT::from_f32(g / (1.f + __expf(-g)))) * u);
+}
+
 // I     = innerKTiles of the Bint4 layout (2, 4, 8): k super-tile = 16 I, I words per lane and super-tile
 // GPS   = quantisation groups per super-tile (1 when group >= 16 I)
 // MR    = 1: m = 1 (one accumulator register per tile is finalised and exchanged); else the accumulator registers that can
@@ -166,8 +209,9 @@ __device__ __forceinline__ float dot2_ones(uint32_t pair, float acc) {
 //         The pair bytes are (code k, code k + 8): v_bfi of the word with itself shifted by one nibble.  Two lanes of a
 //         32-lane LDS access group share a weight row, so the table holds every row twice (32 rows x 2 copies = the same
 //         64 columns), the copy chosen by kb & 1: conflict-free.
-template <typename DT, int I, int GPS, int MR, bool QMX, int R, int NSG = 0, int ABL = 0, bool XG = false, bool LA = false>
+template <typename DT, int I, int GPS, int MR, bool QMX, int R, int NSG = 0, int ABL = 0, bool XG = false, bool LA = false, bool NORM = false>
 __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p) {
+  static_assert(!NORM || (!XG && !LA && !QMX), "fused RMSNorm: the workgroup stages the whole activation block itself");
   constexpr int WAVES = 8;
   constexpr int TILES = 2;              // MFMA tiles per workgroup (B side: 32 rows each; A side: 16 rows each, sharing their words)
   constexpr int WT = LA ? 1 : TILES;    // sets of packed words per ring slot
@@ -462,9 +506,31 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
     if (on && (ch & p.gch_mask) == 0) *(lds_fptr)(lds_xs + (uint32_t)(((ch >> (p.gshift - 5)) * p.xs_rows + a) * 4)) = sum;
   };
   // stages activation rows [a0, a0 + mrows) of problem b; `pre` = the first batch of chunks is already in xd
+  // With p.norm_w the rows pass through LlamaRMSNorm on the way (tg_w4_gemm.norm_weight): sum of squares per chunk, then over the
+  // 64 chunks of a wave (one row: the host guarantees k % 2048 == 0), one partial per wave in the (not yet written) activation-sum
+  // area, added per row in wave order (deterministic); then scale, multiply by the norm weights, store.
   auto x_stage = [&](int b, int a0, int mrows, bool pre, uint32_t (&xd)[16]) {
     const char* xb = p.x + (int64_t)b * p.stride_x;
     const int xtotal = mrows * nch;
+    if constexpr (NORM) {  // (xtotal <= 512: a block that is staged whole is at most ~14 KiB = 224 chunks; the host checks)
+      const bool on = tid < xtotal;
+      if (!pre) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) xd[j] = 0u;
+        if (on) x_load(xb, a0, tid, xd);
+      }
+      float ss = chunk_sumsq<DT>(xd);
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) ss += __shfl_xor(ss, o);
+      if (lane == 0) *(lds_fptr)(lds_xs + (uint32_t)(wave * 4)) = ss;
+      __syncthreads();
+      const int a = on ? tid / nch : 0;
+      ss = 0.f;
+      for (int w0 = a * (nch >> 6); w0 < (a + 1) * (nch >> 6); ++w0) ss += *(lds_fptr)(lds_xs + (uint32_t)(w0 * 4));
+      __syncthreads();  // every thread has its row's sum before x_store's group sums land in the same area
+      if (on) chunk_rmsnorm<DT>(xd, rsqrtf(ss * (1.0f / (float)p.k) + p.norm_eps), p.norm_w + (tid - a * nch) * 64);
+      pre = true;
+    }
     for (int it0 = 0; it0 < xtotal; it0 += 512) {
       const int xi = it0 + tid;
       const bool on = xi < xtotal;
@@ -878,9 +944,19 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
           float sum = 0.f;
 #pragma unroll
           for (int w = 0; w < WAVES; ++w) sum += *(lds_fptr)(lds_red + (uint32_t)((((w * TILES + t) * p.rused + r) * p.red_lanes + l) * 4));
+          if (!LA && p.epilogue == TG_EPI_SWIGLU) {
+            // rows come in blocks of 8 gate + 8 up: lane l holds gate row `row`, lane l + 8 (same tile, same half) its up row
+            if ((l & 15) < 8) {
+              float up = 0.f;
+#pragma unroll
+              for (int w = 0; w < WAVES; ++w) up += *(lds_fptr)(lds_red + (uint32_t)((((w * TILES + t) * p.rused + r) * p.red_lanes + l + 8) * 4));
+              *reinterpret_cast<uint16_t*>(yb + ((int64_t)(a0 + a) * (p.wrows >> 1) + ((row >> 4) << 3) + (row & 7)) * 2) = swiglu16<DT>(sum, up);
+            }
+            continue;
+          }
           uint16_t o16 = DT::from_f32(sum);
           if (p.bias)  // rounded sum + bias, rounded again: bit-identical to the reference module's separate `y + bias`
-            o16 = DT::from_f32(DT::lo_f32(o16) + DT::lo_f32(*reinterpret_cast<const uint16_t*>(p.bias + (int64_t)cur.b * p.stride_bias + (int64_t)row * 2)));
+            o16 = DT::from_f32(DT::lo_f32(o16) + DT::lo_f32(*reinterpret_cast<const uint16_t*>(p.bias + (int64_t)cur.b * p.stride_bias + ((int64_t)(a0 + a) * p.bias_row_stride + row) * 2)));
           *reinterpret_cast<uint16_t*>(yb + (p.y_tc ? tc_a_index(a0 + a, row, p.y_tiles) : (int64_t)(a0 + a) * p.wrows + row) * 2) = o16;
         }
       }

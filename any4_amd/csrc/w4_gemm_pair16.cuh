@@ -45,6 +45,10 @@ struct Pair16Params {
   int64_t stride_x, stride_w, stride_qinfo, stride_lut, stride_y;
   const char* bias;
   int64_t stride_bias;
+  int64_t bias_row_stride;  // elements between the bias rows of consecutive activation rows (0: one row for all; wrows: a residual)
+  const char* norm_w;       // fused RMSNorm of the activations (tg_w4_gemm.norm_weight; phases == 1 only), nullptr = off
+  float norm_eps;
+  int32_t epilogue;         // TG_EPI_SWIGLU: rows in blocks of 8 gate + 8 up, y is [m][wrows / 2]
   int32_t x_tc, y_tc;  // 1: activations / output in A-fragment order (tc_a_index, w4_gemm_pair.cuh)
   int32_t y_tiles;     // ceil(wrows / 16)
 };
@@ -52,8 +56,9 @@ struct Pair16Params {
 // I   = innerKTiles of the Bint4 layout (2, 4, 8): I / 2 words per lane and super-tile (one per 32-k chunk)
 // CPG = 32-k chunks per quantisation group (1, 2, 4, 8): a full block of CH super-tiles then has its group boundaries at fixed
 //       places of the unrolled code (no branches between the steps)
-template <typename DT, int I, bool QMX, int CPG, int TPW = 1>
+template <typename DT, int I, bool QMX, int CPG, int TPW = 1, bool NORM = false>
 __global__ void __launch_bounds__(1024) w4_gemm_pair16_kernel(const Pair16Params p) {
+  static_assert(!NORM || !QMX, "fused RMSNorm borrows the activation-sum area");
   constexpr int WAVES = 16;
   constexpr int NT = WAVES * 64;
   constexpr int CPS = I / 2;  // 32-k chunks (= words per lane) of a super-tile
@@ -206,6 +211,28 @@ __global__ void __launch_bounds__(1024) w4_gemm_pair16_kernel(const Pair16Params
   };
   const int gpp = p.ngroups / p.phases;  // groups per phase
   auto x_stage = [&](int ph, bool pre) {  // pre: the first batch of chunks is already in xd
+    if constexpr (NORM) {
+      // LlamaRMSNorm of the rows on the way into LDS (tg_w4_gemm.norm_weight; the host only asks for it with one phase and at
+      // most NT chunks, one per thread): sum of squares per chunk, over the 64 chunks of a wave (one row: k % 2048 == 0), one
+      // partial per wave in the (not yet written) activation-sum area; per row they are added in wave order (deterministic)
+      const bool on = tid < xtotal;
+      if (!pre) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) xd[j] = 0u;
+        if (on) x_load(tid, ph);
+      }
+      float ss = chunk_sumsq<DT>(xd);
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) ss += __shfl_xor(ss, o);
+      if (lane == 0) *(lds_fptr)(lds_xs + (uint32_t)(wave * 4)) = ss;
+      __syncthreads();
+      const int a = (on && p.m > 1) ? tid / nch : 0;
+      ss = 0.f;
+      for (int w0 = a * (nch >> 6); w0 < (a + 1) * (nch >> 6); ++w0) ss += *(lds_fptr)(lds_xs + (uint32_t)(w0 * 4));
+      __syncthreads();  // the partial sums are read before x_store's group sums land in the same area
+      if (on) chunk_rmsnorm<DT>(xd, rsqrtf(ss * (1.0f / (float)p.k) + p.norm_eps), p.norm_w + (tid - a * nch) * 64);
+      x_store(tid, on);
+    } else
     for (int it0 = 0; it0 < (P16_ABL == 3 ? 0 : xtotal); it0 += NT) {
       const int xi = it0 + tid;
       const bool on = xi < xtotal;
@@ -381,9 +408,19 @@ __global__ void __launch_bounds__(1024) w4_gemm_pair16_kernel(const Pair16Params
       float sum = 0.f;
 #pragma unroll
       for (int w8 = 0; w8 < WAVES; ++w8) sum += *(lds_fptr)((uint32_t)((((t * WAVES + w8) * 4 + r) * 64 + l) * 4));
+      if (p.epilogue == TG_EPI_SWIGLU) {
+        // rows come in blocks of 8 gate + 8 up (this workgroup's 16 rows are one block): lane l + 8 holds the up row of gate row l
+        if ((l & 15) < 8) {
+          float up = 0.f;
+#pragma unroll
+          for (int w8 = 0; w8 < WAVES; ++w8) up += *(lds_fptr)((uint32_t)((((t * WAVES + w8) * 4 + r) * 64 + l + 8) * 4));
+          *reinterpret_cast<uint16_t*>(p.y + (int64_t)b * p.stride_y + ((int64_t)a * (p.wrows >> 1) + ((row >> 4) << 3) + (row & 7)) * 2) = swiglu16<DT>(sum, up);
+        }
+        return;
+      }
       uint16_t o16 = DT::from_f32(sum);
       if (p.bias)  // rounded sum + bias, rounded again: the reference module's separate `y + bias` (modules.py:221-222)
-        o16 = DT::from_f32(DT::lo_f32(o16) + DT::lo_f32(*reinterpret_cast<const uint16_t*>(p.bias + (int64_t)b * p.stride_bias + (int64_t)row * 2)));
+        o16 = DT::from_f32(DT::lo_f32(o16) + DT::lo_f32(*reinterpret_cast<const uint16_t*>(p.bias + (int64_t)b * p.stride_bias + ((int64_t)a * p.bias_row_stride + row) * 2)));
       *reinterpret_cast<uint16_t*>(p.y + (int64_t)b * p.stride_y + (p.y_tc ? tc_a_index(a, row, p.y_tiles) : (int64_t)a * p.wrows + row) * 2) = o16;
     }
   }

@@ -65,6 +65,7 @@ struct StreamParams {
   int64_t stride_x, stride_w, stride_qinfo, stride_lut, stride_y;
   const char* bias;   // optional [wrows] 16-bit, added after the first rounding (see store_rows4)
   int64_t stride_bias;
+  int64_t bias_row_stride;  // elements between the bias rows of consecutive activation rows (0: one row for all)
   int32_t dry;        // host-side only: report the kernel family instead of launching (tg_gemm_w4_plan)
 };
 
@@ -374,7 +375,7 @@ __global__ void __launch_bounds__(WAVES * 64, MINW) w4_gemm_stream_kernel(const 
   const int col = ct * 16 + i;
   const int rowg = row0 + 4 * Q;
   if (rt_ok && col < p.m && rowg < p.wrows) {
-    store_rows4<DT>(yb, p.bias ? p.bias + b * p.stride_bias : nullptr, (int64_t)col * p.wrows + rowg, rowg, acc);
+    store_rows4<DT>(yb, p.bias ? p.bias + b * p.stride_bias + (int64_t)col * p.bias_row_stride * 2 : nullptr, (int64_t)col * p.wrows + rowg, rowg, acc);
   }
   }  // tile loop
 }

@@ -139,6 +139,6 @@ __global__ void __launch_bounds__(WAVES * 64, 2) w8_gemm_kernel(const GemmParams
   const int col = ct * 16 + i;
   const int rowg = row0 + 4 * Q;
   if (rt_ok && col < p.m && rowg < p.wrows) {
-    store_rows4<DT>(yb, p.bias ? p.bias + b * p.stride_bias : nullptr, (int64_t)col * p.wrows + rowg, rowg, acc);
+    store_rows4<DT>(yb, p.bias ? p.bias + b * p.stride_bias + (int64_t)col * p.bias_row_stride * 2 : nullptr, (int64_t)col * p.wrows + rowg, rowg, acc);
   }
 }

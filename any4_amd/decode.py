@@ -42,6 +42,10 @@ class DecodeConfig:
     rope_theta: float = 500000.0
     rms_eps: float = 1e-5
     group_size: int = 128
+    # row order of the fused gate_up weight: 0 = [gate rows; up rows]; 8 = blocks of 8 gate rows followed by the 8 matching up
+    # rows, the order the GEMM's fused SwiGLU epilogue wants (tg_w4_gemm.epilogue): a gate row and its up row then meet in one
+    # 16-row tile of one workgroup.  `shard_rows` returns the row indices in this order, so a loader needs nothing else.
+    gate_up_interleave: int = 0
 
     @classmethod
     def llama3_8b(cls, **kw) -> "DecodeConfig":
@@ -83,7 +87,11 @@ def shard_rows(cfg: DecodeConfig, name: str, rank: int, world: int) -> torch.Ten
         return torch.cat([span(0, cfg.heads * d), span(cfg.heads * d, cfg.kv_heads * d),
                           span((cfg.heads + cfg.kv_heads) * d, cfg.kv_heads * d)])
     if name == "gate_up":
-        return torch.cat([span(0, cfg.inter), span(cfg.inter, cfg.inter)])
+        gate, up = span(0, cfg.inter), span(cfg.inter, cfg.inter)
+        if cfg.gate_up_interleave:
+            b = cfg.gate_up_interleave
+            return torch.stack([gate.view(-1, b), up.view(-1, b)], dim=1).reshape(-1)
+        return torch.cat([gate, up])
     if name in ("o", "down"):
         return span(0, cfg.hidden)
     raise ValueError(name)
@@ -187,6 +195,7 @@ class DecodeLayer(torch.nn.Module):
         self.norm2 = RMSNorm(cfg.hidden, cfg.rms_eps, device, dtype)
         self.register_buffer("k_cache", torch.zeros(bs, self.kvl, cfg.max_seq, d, device=device, dtype=dtype), persistent=False)
         self.register_buffer("v_cache", torch.zeros(bs, self.kvl, cfg.max_seq, d, device=device, dtype=dtype), persistent=False)
+        self._fuse = {"norm1": None, "norm2": None, "mlp": None}  # forward_fused5: which stages the library fused (set by the first step)
 
     def forward(self, h, pos, cos, sin, mask, gather):
         cfg, d, bs = self.cfg, self.cfg.head_dim, h.shape[0]
@@ -202,7 +211,7 @@ class DecodeLayer(torch.nn.Module):
         att = att.masked_fill(mask, float("-inf")).softmax(-1).to(h.dtype)
         ctx = torch.matmul(att, self.v_cache).reshape(bs, self.hl * d)
         h = h + gather(self.o(gather(ctx)))
-        gu = self.gate_up(self.norm2(h))
+        gu = self._split_gate_up(self.gate_up(self.norm2(h)))
         il = cfg.inter // self.world
         act = torch.nn.functional.silu(gu[:, :il]) * gu[:, il:]
         return h + gather(self.down(gather(act)))
@@ -221,7 +230,74 @@ class DecodeLayer(torch.nn.Module):
             ctx = G.rope_attn(self.qkv(y), cos_tab, sin_tab, pos, self.k_cache, self.v_cache, self.hl, self.kvl, d,
                               1.0 / math.sqrt(d))
         h, y = G.add_rmsnorm(h, gather(self.o(gather(ctx))), self.norm2.weight, self.norm2.eps)
-        return h, gather(self.down(gather(G.swiglu(self.gate_up(y)))))
+        return h, gather(self.down(gather(G.swiglu(self._split_gate_up(self.gate_up(y)).contiguous()))))
+
+
+    # ---- five launches per layer: every element-wise stage rides in a GEMM launch (tg_w4_gemm ABI 5) ----
+    def _w4(self, lin, x, **kw):
+        """`lin` (an Any4Linear / Int4Linear with Bint4 weights) through ops.w4_linear_fused; None if the library has no kernel
+        with the requested stages for this problem."""
+        from . import ops
+
+        lut = getattr(lin, "lut", None)
+        return ops.w4_linear_fused(x, lin.weight, lin.group_size, lin.scales_and_zeros, lut, **kw)
+
+    def fusable(self) -> bool:
+        """The four linears hold Bint4 weights behind the row-major weights-on-the-right kernel (what w4_linear_fused drives)."""
+        ok = ("linear_y_f16RM_x_f16RM_W_any4TC", "linear_y_f16RM_x_f16RM_W_int4TC")
+        return all(getattr(m, "kernel", None) in ok and getattr(m, "weight_reshaped", False) and getattr(m, "bias", None) is None
+                   for m in (self.qkv, self.o, self.gate_up, self.down))
+
+    def _split_gate_up(self, gu):
+        """[bs, 2 il] in the weight's row order -> contiguous [gate | up] halves (what dg_swiglu reads)."""
+        b = self.cfg.gate_up_interleave
+        if not b:
+            return gu
+        return gu.view(gu.shape[0], -1, 2, b).transpose(1, 2).reshape(gu.shape[0], -1)
+
+    def forward_fused5(self, h, pos, cos_tab, sin_tab, attn_scratch=None, attn_split=1):
+        """TP = 1.  qkv GEMM (RMSNorm in its activation staging) -> RoPE + KV write + attention -> o GEMM (residual add in its
+        store) -> gate_up GEMM (RMSNorm in its staging, SwiGLU in its store) -> down GEMM (residual add in its store): 5 launches
+        instead of 8.  `h` [bs, hidden] is the residual stream, updated in place.  A stage the library cannot fuse for this
+        problem (w4_linear_fused returns None) runs as its own launch, as in forward_fused."""
+        from . import decode_ops as G
+
+        cfg, d = self.cfg, self.cfg.head_dim
+        f = self._fuse
+        # ---- attention block
+        qkv = self._w4(self.qkv, h, norm_weight=self.norm1.weight, norm_eps=self.norm1.eps) if f["norm1"] is not False else None
+        if f["norm1"] is None:
+            f["norm1"] = qkv is not None
+        if qkv is None:
+            qkv = self.qkv(G.add_rmsnorm(h, None, self.norm1.weight, self.norm1.eps)[1])
+        if attn_scratch is not None:
+            ctx = G.rope_attn_split(qkv, cos_tab, sin_tab, pos, self.k_cache, self.v_cache, self.hl, self.kvl, d,
+                                    1.0 / math.sqrt(d), attn_scratch, attn_split)
+        else:
+            ctx = G.rope_attn(qkv, cos_tab, sin_tab, pos, self.k_cache, self.v_cache, self.hl, self.kvl, d, 1.0 / math.sqrt(d))
+        if self._w4(self.o, ctx, residual=h, out=h) is None:       # (a residual add is available in every 4-bit kernel)
+            G.add_rmsnorm(h, self.o(ctx), self.norm2.weight, self.norm2.eps, want_norm=False)
+        # ---- MLP block
+        act = None
+        if f["mlp"] is not False and cfg.gate_up_interleave == 8:
+            act = self._w4(self.gate_up, h, norm_weight=self.norm2.weight, norm_eps=self.norm2.eps, swiglu=True)
+        if f["mlp"] is None:
+            f["mlp"] = act is not None
+        if act is None:
+            y = None
+            if f["norm2"] is not False:
+                gu = self._w4(self.gate_up, h, norm_weight=self.norm2.weight, norm_eps=self.norm2.eps)
+                if f["norm2"] is None:
+                    f["norm2"] = gu is not None
+            else:
+                gu = None
+            if gu is None:
+                y = G.add_rmsnorm(h, None, self.norm2.weight, self.norm2.eps)[1]
+                gu = self.gate_up(y)
+            act = G.swiglu(self._split_gate_up(gu).contiguous())
+        if self._w4(self.down, act, residual=h, out=h) is None:
+            G.add_rmsnorm(h, self.down(act), self.norm2.weight, self.norm2.eps, want_norm=False)
+        return h
 
 
 class DecodeStack(torch.nn.Module):
@@ -230,12 +306,15 @@ class DecodeStack(torch.nn.Module):
 
     def __init__(self, cfg: DecodeConfig, linear_factory: Callable, device, dtype=torch.bfloat16, bs: int = 1,
                  rank: int = 0, world: int = 1, group=None, seed: int = 0, lm_head: bool = True,
-                 fused: Optional[bool] = None, emulate_gather: bool = False, gather: str = "rccl"):
+                 fused: Optional[bool] = None, emulate_gather: bool = False, gather: str = "rccl", fuse_gemm_stages: bool = True):
         """fused: run the non-GEMM parts on the HIP glue kernels (default on a GPU) or as plain torch ops
         (the formulation the glue kernels are tested against; also what runs in the CPU plumbing tests).
         emulate_gather: TIMING ONLY -- build rank `rank` of `world` in a single process and replace every all-gather
         by a local copy of the rank's shard into all `world` slots (the values are meaningless): the per-GPU compute
         of a TP=world decode step, without the interconnect.
+        fuse_gemm_stages: (fused, TP = 1, 4-bit linears with Bint4 weights) run a layer as FIVE launches -- RMSNorm inside the
+        qkv / gate_up GEMMs' activation staging, the residual adds inside the o / down GEMMs' stores, SwiGLU inside gate_up's store
+        when cfg.gate_up_interleave == 8 (DecodeLayer.forward_fused5) -- instead of 4 GEMMs + 4 glue kernels.
         gather: "rccl" = all_gather_into_tensor per exchange; "peer" = the one-shot peer-write gather of
         include/peer_gather_hip.h (any4_amd.shard.PeerWriteGather: one kernel per exchange, stores into the peers' buffers)."""
         super().__init__()
@@ -246,6 +325,7 @@ class DecodeStack(torch.nn.Module):
         self.cfg, self.bs, self.rank, self.world, self.group = cfg, bs, rank, world, group
         self.emulate_gather = emulate_gather
         self.fused = torch.device(device).type == "cuda" if fused is None else fused
+        self.fuse_gemm_stages = fuse_gemm_stages
         gen = torch.Generator(device=device).manual_seed(seed)
         self.embed = torch.nn.Embedding(cfg.vocab, cfg.hidden, device=device, dtype=dtype)
         self.embed.weight.data = torch.randn(cfg.vocab, cfg.hidden, device=device, generator=gen).to(dtype)
@@ -322,11 +402,15 @@ class DecodeStack(torch.nn.Module):
     def _step(self) -> torch.Tensor:
         pos = self.pos
         if self.fused:
-            h, delta = self.embed(self.tokens), None
-            for layer in self.layers:
-                h, delta = layer.forward_fused(h, delta, pos, self.cos, self.sin, self._gather, self._attn_scratch, self._attn_split)
             from . import decode_ops as G
 
+            h, delta = self.embed(self.tokens), None
+            if self.fuse_gemm_stages and self.world == 1 and all(layer.fusable() for layer in self.layers):
+                for layer in self.layers:
+                    h = layer.forward_fused5(h, pos, self.cos, self.sin, self._attn_scratch, self._attn_split)
+            else:
+                for layer in self.layers:
+                    h, delta = layer.forward_fused(h, delta, pos, self.cos, self.sin, self._gather, self._attn_scratch, self._attn_split)
             _, y = G.add_rmsnorm(h, delta, self.norm.weight, self.norm.eps)
             return self.lm_head(y) if self.lm_head is not None else y
         cos = self.cos.index_select(0, pos).view(1, 1, -1)

@@ -360,6 +360,61 @@ def _w4_rm(A, B, q_group, qinfo, lut, qtype, weight_on_right, opname, frag=False
     return y
 
 
+def w4_linear_fused(x, w, q_group, qinfo, lut=None, *, residual=None, norm_weight=None, norm_eps=1e-5, swiglu=False, out=None):
+    """The row-major 4-bit GEMM y = x . dequant(W)^T (weights on the right: `w` in the Bint4 layout, as Any4Linear / Int4Linear
+    hold it) with stages of a decoder layer fused into the SAME launch (include/tinygemm_hip.h, ABI 5) -- not part of the
+    reference's op surface; the decode harness (any4_amd/decode.py) calls it instead of Linear + glue kernel:
+
+      norm_weight [k]        the activations pass through LlamaRMSNorm in the kernel's staging: x' = rmsnorm(x, eps) * norm_weight
+      residual    [m][n]     y = RNE16(RNE16(acc) + residual)   (the residual stream; may be `out` itself: updated in place)
+      swiglu                 the weight rows come in blocks of 8 gate + 8 up rows and y is [m][n / 2] = silu(gate) * up
+      out                    where to write y (default: a new tensor)
+
+    Returns y, or None when the library has no kernel with these stages for this problem (TG_E_FUSION: e.g. reference numerics,
+    k % 2048 != 0, an activation block too large to stage on chip): the caller then runs the stage as its own launch."""
+    _check(x.dim() == 2 and x.is_contiguous() and x.dtype in _F16_TYPES, "activations must be a contiguous 2-D bf16 / fp16 matrix")
+    _check(w.dim() == 4 and w.dtype == torch.int32 and w.is_contiguous() and w.size(2) == 32, "weights must be a contiguous Bint4 tensor")
+    inner, wrows = w.size(3) * 2, w.size(0) * 8
+    m, k = x.shape
+    _check(w.size(1) * inner * 16 == k, "weights: k super-tiles do not match the activations' k")
+    qtype = TG_Q_INT4
+    if lut is not None:
+        _check(lut.dtype == x.dtype and lut.is_contiguous(), "LUT dtype must match the activations")
+        qtype = TG_Q_ANY4_GLOBAL if lut.dim() == 1 else TG_Q_ANY4_ROWWISE
+    elif qinfo.dtype == torch.uint8:
+        qtype = TG_Q_MX4
+    _check(qinfo.is_contiguous() and qinfo.device == x.device, "quantization info must be contiguous on the activations' device")
+    ycols = wrows // 2 if swiglu else wrows
+    if out is None:
+        out = torch.empty((m, ycols), dtype=x.dtype, device=x.device)
+    _check(out.shape == (m, ycols) and out.dtype == x.dtype and out.is_contiguous(), "out must be a contiguous [m][n] tensor of the activations' dtype")
+    if residual is not None:
+        _check(residual.dtype == x.dtype and residual.dim() == 2 and residual.shape[0] == m and residual.shape[1] >= wrows
+               and residual.stride(1) == 1, "residual must be [m][>= n] with unit inner stride")
+    if norm_weight is not None:
+        _check(norm_weight.dtype == x.dtype and norm_weight.numel() == k and norm_weight.is_contiguous(), "norm_weight must be [k] of the activations' dtype")
+    args = W4Gemm(
+        x=x.data_ptr(), w=w.data_ptr(), qinfo=qinfo.data_ptr(), lut=(lut.data_ptr() if lut is not None else None), y=out.data_ptr(),
+        m=m, wrows=wrows, k=k, group=q_group, qtype=qtype, dtype=_dt(x), w_on_right=1, inner_k_tiles=inner, batch=1,
+        numerics=_NUMERICS[get_numerics()],
+        bias=(residual.data_ptr() if residual is not None else None),
+        bias_row_stride=(residual.stride(0) if residual is not None else 0),
+        norm_weight=(norm_weight.data_ptr() if norm_weight is not None else None), norm_eps=float(norm_eps),
+        epilogue=_lib.TG_EPI_SWIGLU if swiglu else _lib.TG_EPI_NONE,
+    )
+    ws_bytes = _L.tg_gemm_w4_workspace_bytes(ctypes.byref(args))
+    if ws_bytes == _lib.TG_E_FUSION:
+        return None
+    if ws_bytes > 0:
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
+        args.workspace, args.workspace_bytes = ws.data_ptr(), ws_bytes
+    rc = _L.tg_gemm_w4(ctypes.byref(args), _dev(x), _stream(x))
+    if rc == _lib.TG_E_FUSION:
+        return None
+    _lib.check(rc, "w4_linear_fused")
+    return out
+
+
 def _w4_tc(A, B, q_group, qinfo, lut, qtype, weight_on_right, opname):
     """Fragment-order activations / output (TinyGemm_int4.cu:28-292).  Implemented as
     un-layout -> row-major GEMM -> re-layout, all on the device."""

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define TG_ABI_VERSION 4
+#define TG_ABI_VERSION 5
 
 #if defined(__GNUC__)
 #define TG_API __attribute__((visibility("default")))
@@ -81,7 +81,8 @@ enum {
   TG_E_DEVICE = -9,    /* hipSetDevice failed / no such device                             */
   TG_E_SIZE = -10,     /* one problem's operand exceeds the kernels' 32-bit byte offsets   */
   TG_E_INTERNAL = -11, /* build inconsistency (should not happen)                          */
-  TG_E_LAYOUT = -12    /* x_layout / y_layout not available for this problem               */
+  TG_E_LAYOUT = -12,   /* x_layout / y_layout not available for this problem               */
+  TG_E_FUSION = -13    /* norm_weight / epilogue: no kernel with that fused stage for this problem (issue it as its own launch) */
 };
 
 TG_API int tg_abi_version(void);
@@ -165,7 +166,26 @@ typedef struct tg_w4_gemm {
   int32_t y_layout;        /* same for the output: [m/16][ceil(wrows/16)][32][8] (allocate zero-filled when wrows % 16 != 0)   */
                            /* Only the TG_NUM_FAST kernels read / write fragment order themselves; otherwise TG_E_LAYOUT       */
                            /* (tg_gemm_w4_plan reports it without launching): convert around a row-major call instead.         */
+  /* ---- ABI version 5: stages of a decoder layer fused into the GEMM launch (all-zero = off).  A hipGraph of dependent
+   *      kernels advances at >= 4.5 us per node on MI355X whatever the node does, so the element-wise stages around the four
+   *      GEMMs of a layer (the reference times them through HuggingFace's LlamaDecoderLayer, benchmark.py:113-215) cost as
+   *      much as the GEMMs at batch 1.  Rounding points are those of the separate kernels of include/decode_glue_hip.h. ---- */
+  int64_t bias_row_stride; /* elements between the `bias` rows of consecutive ACTIVATION rows: 0 = one [wrows] row for all (a       */
+                           /* Linear's bias); wrows = a full [m][wrows] addend, i.e. the residual stream:                          */
+                           /* y[a][row] = RNE16(RNE16(acc) + bias[a * bias_row_stride + row]).  Every 4-/8-bit kernel.             */
+  const void* norm_weight; /* non-NULL: LlamaRMSNorm of the activations inside the launch's activation staging, 16-bit [k]:         */
+                           /* x'[a][j] = RNE16(RNE16(x[a][j] * rsqrt(mean_j(x[a][j]^2) + norm_eps)) * norm_weight[j])               */
+                           /* (dg_add_rmsnorm's formula).  TG_NUM_FAST pair-table kernels, row-major x, k % 2048 == 0, the          */
+                           /* activation block staged whole on chip; otherwise TG_E_FUSION.                                        */
+  float norm_eps;
+  int32_t epilogue;        /* TG_EPI_NONE or TG_EPI_SWIGLU: the weight rows come in blocks of 16 = 8 "gate" rows followed by the 8  */
+                           /* matching "up" rows, and y is [m][wrows / 2]:                                                         */
+                           /* y[a][8 B + c] = RNE16(RNE16(silu(g)) * u), g / u = RNE16(acc) of rows 16 B + c / 16 B + 8 + c         */
+                           /* (dg_swiglu's formula).  TG_NUM_FAST pair-table kernels, weights on the right, row-major y, no bias;   */
+                           /* otherwise TG_E_FUSION.                                                                               */
 } tg_w4_gemm;
+
+enum { TG_EPI_NONE = 0, TG_EPI_SWIGLU = 1 };
 
 TG_API int tg_gemm_w4(const tg_w4_gemm* args, int device, tg_stream_t stream);
 

@@ -48,6 +48,8 @@ def main():
     ap.add_argument("--max-seq", type=int, default=1024)
     ap.add_argument("--start-pos", type=int, default=128, help="sequence position of the first timed token")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--interleave", action="store_true", help="gate_up rows in blocks of 8 gate + 8 up (lets the GEMM fuse SwiGLU)")
+    ap.add_argument("--no-fuse", action="store_true", help="separate glue kernels around the GEMMs (8 launches per layer instead of 5)")
     ap.add_argument("--baseline", action="store_true", help="also time the same stack with 16-bit nn.Linear")
     ap.add_argument("--kernel", default="linear_y_f16RM_x_f16RM_W_any4TC")
     ap.add_argument("--emulate-tp", type=int, default=0,
@@ -84,6 +86,8 @@ def main():
         cfg = getattr(DecodeConfig, a.config)(max_seq=a.max_seq)
     if a.layers is not None:
         cfg.layers = a.layers
+    if a.interleave:
+        cfg.gate_up_interleave = 8
 
     def run(factory_cls, label):
         torch.cuda.reset_peak_memory_stats(device)
@@ -92,7 +96,7 @@ def main():
         if a.emulate_tp > 1:
             stack = DecodeStack(cfg, fac, device, torch.bfloat16, bs=a.bs, rank=0, world=a.emulate_tp, emulate_gather=True)
         else:
-            stack = DecodeStack(cfg, fac, device, torch.bfloat16, bs=a.bs, rank=rank, world=world, gather=a.gather)
+            stack = DecodeStack(cfg, fac, device, torch.bfloat16, bs=a.bs, rank=rank, world=world, gather=a.gather, fuse_gemm_stages=not a.no_fuse)
         graph = False
         if not a.no_graph:
             try:
