@@ -171,10 +171,10 @@ __device__ __forceinline__ float chunk_sumsq(const uint32_t (&d)[16]) {
 // LlamaRMSNorm of a staged chunk: x' = RNE16(RNE16(x rs) g), g = the chunk's 32 norm weights (64 bytes at gsrc): the formula
 // and rounding points of dg_add_rmsnorm (decode_glue.cuh)
 template <typename DT>
-__device__ __forceinline__ void chunk_rmsnorm(uint32_t (&d)[16], float rs, const char* gsrc) {
+__device__ __forceinline__ void chunk_rmsnorm(uint32_t (&d)[16], float rs, const u32x4 (&gw)[4]) {
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const u32x4 g = reinterpret_cast<const u32x4*>(gsrc)[j];
+    const u32x4 g = gw[j];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const uint32_t v = d[4 * j + e];
@@ -519,16 +519,20 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
         for (int j = 0; j < 16; ++j) xd[j] = 0u;
         if (on) x_load(xb, a0, tid, xd);
       }
+      // (the chunk's norm weights are requested before the reduction: one L2 round trip less on the launch's critical path)
+      const int a = on ? tid / nch : 0;
+      u32x4 gw[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) gw[j] = reinterpret_cast<const u32x4*>(p.norm_w + (on ? tid - a * nch : 0) * 64)[j];
       float ss = chunk_sumsq<DT>(xd);
 #pragma unroll
       for (int o = 1; o < 64; o <<= 1) ss += __shfl_xor(ss, o);
       if (lane == 0) *(lds_fptr)(lds_xs + (uint32_t)(wave * 4)) = ss;
       __syncthreads();
-      const int a = on ? tid / nch : 0;
       ss = 0.f;
       for (int w0 = a * (nch >> 6); w0 < (a + 1) * (nch >> 6); ++w0) ss += *(lds_fptr)(lds_xs + (uint32_t)(w0 * 4));
       __syncthreads();  // every thread has its row's sum before x_store's group sums land in the same area
-      if (on) chunk_rmsnorm<DT>(xd, rsqrtf(ss * (1.0f / (float)p.k) + p.norm_eps), p.norm_w + (tid - a * nch) * 64);
+      if (on) chunk_rmsnorm<DT>(xd, rsqrtf(ss * (1.0f / (float)p.k) + p.norm_eps), gw);
       pre = true;
     }
     for (int it0 = 0; it0 < xtotal; it0 += 512) {

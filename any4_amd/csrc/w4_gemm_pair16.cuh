@@ -221,16 +221,20 @@ __global__ void __launch_bounds__(1024) w4_gemm_pair16_kernel(const Pair16Params
         for (int j = 0; j < 16; ++j) xd[j] = 0u;
         if (on) x_load(tid, ph);
       }
+      // (the chunk's norm weights are requested before the reduction: one L2 round trip less on the launch's critical path)
+      const int a = (on && p.m > 1) ? tid / nch : 0;
+      u32x4 gw[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) gw[j] = reinterpret_cast<const u32x4*>(p.norm_w + (on ? tid - a * nch : 0) * 64)[j];
       float ss = chunk_sumsq<DT>(xd);
 #pragma unroll
       for (int o = 1; o < 64; o <<= 1) ss += __shfl_xor(ss, o);
       if (lane == 0) *(lds_fptr)(lds_xs + (uint32_t)(wave * 4)) = ss;
       __syncthreads();
-      const int a = (on && p.m > 1) ? tid / nch : 0;
       ss = 0.f;
       for (int w0 = a * (nch >> 6); w0 < (a + 1) * (nch >> 6); ++w0) ss += *(lds_fptr)(lds_xs + (uint32_t)(w0 * 4));
       __syncthreads();  // the partial sums are read before x_store's group sums land in the same area
-      if (on) chunk_rmsnorm<DT>(xd, rsqrtf(ss * (1.0f / (float)p.k) + p.norm_eps), p.norm_w + (tid - a * nch) * 64);
+      if (on) chunk_rmsnorm<DT>(xd, rsqrtf(ss * (1.0f / (float)p.k) + p.norm_eps), gw);
       x_store(tid, on);
     } else
     for (int it0 = 0; it0 < (P16_ABL == 3 ? 0 : xtotal); it0 += NT) {

@@ -130,3 +130,48 @@ def test_hook_profiler_splits_attention_and_mlp():
     assert not prof._handles
     with pytest.raises(ValueError):
         A.HookProfiler("gpu")
+
+
+# ---- pinned to the reference: data_gptq.llama_eval and calibrate.calibrate run by tests/golden/make_golden_accuracy.py ----
+
+def _golden_tiny_llama():
+    import numpy as np
+
+    from tests.conftest import load_golden
+    from tests.golden.make_golden_accuracy import build_model
+
+    f = load_golden("accuracy_tiny_llama.npz")
+    state = {k[len("state/"):]: np.asarray(f[k]) for k in f.files if k.startswith("state/")}
+    return f, build_model(state)
+
+
+def test_perplexity_matches_the_reference_llama_eval():
+    """any4_amd.accuracy.perplexity on the fixture's model and token stream (ragged tail included) == the value the
+    reference's data_gptq.llama_eval (data_gptq.py:196-220) returned for them."""
+    import torch
+
+    from any4_amd.accuracy import perplexity
+
+    f, model = _golden_tiny_llama()
+    ppl = perplexity(model, torch.from_numpy(f["tokens"]), seqlen=int(f["seqlen"]))
+    assert abs(ppl - float(f["ppl"])) <= 1e-4 * float(f["ppl"]), (ppl, float(f["ppl"]))
+
+
+def test_calibration_means_match_the_reference_hooks():
+    """any4_amd.accuracy.calibrate on the fixture's model and calibration tokens == the per-layer mean input activations the
+    reference's calibrate.calibrate (calibrate.py:41-73, 74-183) collected, for abs = False and abs = True, layer for layer."""
+    import numpy as np
+    import torch
+
+    from any4_amd.accuracy import calibrate
+
+    f, model = _golden_tiny_llama()
+    calib = torch.from_numpy(f["calib_tokens"])
+    for tag, use_abs in (("raw/", False), ("abs/", True)):
+        got = calibrate(model, [calib], abs=use_abs)
+        want = {k[len("mean/" + tag):]: np.asarray(f[k]) for k in f.files if k.startswith("mean/" + tag)}
+        assert set(got) == set(want) and len(want) == 15  # 7 linears x 2 layers + lm_head
+        for name, w in want.items():
+            g = got[name].numpy()
+            assert g.dtype == np.float64 and g.shape == w.shape
+            assert np.allclose(g, w, rtol=1e-9, atol=1e-12), name

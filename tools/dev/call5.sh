@@ -1,0 +1,6 @@
+set -u
+mkdir -p gpurun_out
+timeout 900 python -m pytest tests/test_gpu_fused.py tests/test_gpu_decode.py tests/test_gpu_peer.py -x -q 2>&1 | tail -8
+for v in "--no-fuse" "" "--interleave" "--interleave --bs 8" "--no-fuse --bs 8"; do
+timeout 600 python tools/llama_decode_bench.py --config llama3_8b --steps 60 --warmup 10 $v 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$v', d['any4']['ms_per_token'])"
+done
