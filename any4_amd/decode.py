@@ -281,24 +281,30 @@ class DecodeLayer(torch.nn.Module):
             ctx = G.rope_attn(qkv, cos_tab, sin_tab, pos, self.k_cache, self.v_cache, self.hl, self.kvl, d, 1.0 / math.sqrt(d))
         if self._w4(self.o, ctx, residual=h, out=h) is None:       # (a residual add is available in every 4-bit kernel)
             G.add_rmsnorm(h, self.o(ctx), self.norm2.weight, self.norm2.eps, want_norm=False)
-        # ---- MLP block
+        # ---- MLP block: norm2 + SwiGLU inside the gate_up launch; else whichever of the two the library can fuse (a block too
+        # large to stage on chip, e.g. 8 sequences at k = 4096, has no fused norm but still the SwiGLU store)
+        il8 = cfg.gate_up_interleave == 8
         act = None
-        if f["mlp"] is not False and cfg.gate_up_interleave == 8:
+        if f["mlp"] is not False and il8:
             act = self._w4(self.gate_up, h, norm_weight=self.norm2.weight, norm_eps=self.norm2.eps, swiglu=True)
         if f["mlp"] is None:
             f["mlp"] = act is not None
         if act is None:
-            y = None
-            if f["norm2"] is not False:
+            gu = None
+            if f["norm2"] is not False and not il8:
                 gu = self._w4(self.gate_up, h, norm_weight=self.norm2.weight, norm_eps=self.norm2.eps)
                 if f["norm2"] is None:
                     f["norm2"] = gu is not None
-            else:
-                gu = None
             if gu is None:
                 y = G.add_rmsnorm(h, None, self.norm2.weight, self.norm2.eps)[1]
-                gu = self.gate_up(y)
-            act = G.swiglu(self._split_gate_up(gu).contiguous())
+                if il8 and f.get("swiglu") is not False:
+                    act = self._w4(self.gate_up, y, swiglu=True)
+                    if f.get("swiglu") is None:
+                        f["swiglu"] = act is not None
+                if act is None:
+                    gu = self.gate_up(y)
+            if act is None:
+                act = G.swiglu(self._split_gate_up(gu).contiguous())
         if self._w4(self.down, act, residual=h, out=h) is None:
             G.add_rmsnorm(h, self.down(act), self.norm2.weight, self.norm2.eps, want_norm=False)
         return h
