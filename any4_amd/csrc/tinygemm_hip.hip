@@ -657,6 +657,12 @@ enum { TG_PAIR_NA = -100 };
 #ifndef TG_PAIR_RA1
 #define TG_PAIR_RA1 1  // ... with several groups per super-tile
 #endif
+#ifndef TG_PAIR_RB16
+#define TG_PAIR_RB16 2  // ring depth of the 16x16x32 kernels for Bint4 weights (m = 9 ... 16)
+#endif
+#ifndef TG_B16_CHUNK
+#define TG_B16_CHUNK 4  // consecutive 32-row work items per workgroup visit of those kernels
+#endif
 #ifndef TG_PAIR_MIN_ITEMS
 #define TG_PAIR_MIN_ITEMS 192  // fewer work items: the launch is latency-bound, w4_gemm_pair16_kernel / the reference kernels take
                                // it (measured per hipGraph node, one layer, m = 1: 14336 x 4096 = 224 items 12.3 us here against
@@ -669,7 +675,7 @@ enum { TG_PAIR_NA = -100 };
 #ifndef TG_PAIR_WGS
 #define TG_PAIR_WGS 512  // persistent workgroups: two per CU
 #endif
-template <typename DT, int I, int GPS, int MR, bool QMX, int NSG, bool XG = false, bool LA = false, bool NORM = false>
+template <typename DT, int I, int GPS, int MR, bool QMX, int NSG, bool XG = false, int LA = 0, bool NORM = false>
 int launch_pair_k(PairParams& pp, unsigned lds, hipStream_t st) {
 #ifdef TG_DEV_MIN  // developer builds: only the headline instantiation (fast A/B builds)
 #ifndef TG_DEV_GPS
@@ -682,7 +688,7 @@ int launch_pair_k(PairParams& pp, unsigned lds, hipStream_t st) {
 #define TG_DEV_MR TG_PAIR_MR1
 #endif
 #ifndef TG_DEV_LA
-#define TG_DEV_LA false
+#define TG_DEV_LA 0
 #endif
   if constexpr (!(std::is_same<DT, BF16>::value && I == 4 && GPS == TG_DEV_GPS && MR == TG_DEV_MR && QMX == TG_DEV_QMX && NSG == TG_DEV_MIN && LA == TG_DEV_LA && !NORM)) return TG_PAIR_NA;
   else {
@@ -691,7 +697,7 @@ int launch_pair_k(PairParams& pp, unsigned lds, hipStream_t st) {
   else {
   // several groups per super-tile (group 32 / 64 with wide super-tiles): more per-slot state, one slot in flight fits the
   // 128-VGPR budget without spills (ring depth measured irrelevant between 2 and 4)
-  constexpr int RING = GPS > 1 ? (LA ? TG_PAIR_RA1 : 1) : LA ? TG_PAIR_RA : TG_PAIR_R;
+  constexpr int RING = GPS > 1 ? (LA ? TG_PAIR_RA1 : 1) : LA == 1 ? TG_PAIR_RA : LA == 2 ? TG_PAIR_RB16 : TG_PAIR_R;
   constexpr auto kern = w4_gemm_pair_kernel<DT, I, GPS, MR, QMX, RING, NSG, TG_PAIR_ABL, XG, LA, NORM>;
   if (pp.dry) return TG_PLAN_PAIR;
   const int prc = prepare_lds_kernel<kern>();
@@ -994,6 +1000,79 @@ int launch_pair_a(GemmParams& p, int64_t batch, hipStream_t st) {
   }
 }
 
+// Bint4 weights with 9 ... 16 activation rows: the 16x16x32 structure of the A-side kernel (32-row work items, duplicated
+// table, activations of one pass -- all m <= 16 rows -- straight from the workspace into the MFMA operand) on B-layout words:
+// one packed word is one B operand, 4 vector ops per word.  (The 32x32x16 kernel holds 8 rows per pass; a second pass would
+// stream the weights twice.)
+template <typename DT, int I, bool QMX>
+int launch_pair_b16(GemmParams& p, int64_t batch, hipStream_t st) {
+  if (p.m > 16 || p.norm_w || p.epilogue) return TG_PAIR_NA;
+  const int g = 1 << p.gshift;
+  const int gps = g >= 16 * I ? 1 : (16 * I) / g;
+  PairParams pp;
+  pp.x_tc = p.x_tc; pp.y_tc = p.y_tc; pp.y_tiles = (p.wrows + 15) / 16;
+  pp.bias_row_stride = p.bias_row_stride; pp.norm_w = nullptr; pp.norm_eps = 0.f; pp.epilogue = 0;
+  pp.x = p.x; pp.w = p.w; pp.qinfo = p.qinfo; pp.lut = p.lut; pp.y = p.y;
+  pp.m = p.m; pp.wrows = p.wrows; pp.k = p.k; pp.ntiles = p.ntiles; pp.ksuper = p.ksuper;
+  pp.gshift = p.gshift; pp.ngroups = p.ngroups; pp.qtype = p.qtype;
+  const int nsg = g >= 16 * I ? g / (16 * I) : 1;
+  const int units = p.ksuper / nsg;
+  pp.spw = ((units + 7) / 8) * nsg;
+  pp.nsg_shift = 0;
+  while ((1 << pp.nsg_shift) < nsg) ++pp.nsg_shift;
+  pp.gch_mask = g / 32 - 1;
+  if (QMX && (p.ngroups < 16 || p.ngroups % 4 != 0 || ((pp.spw * gps) % 4 != 0 && pp.spw * gps > 12))) return TG_PAIR_NA;
+  const int mrows = p.m;
+  pp.rused = mrows < 4 ? mrows : 4;
+  pp.xs_rows = mrows <= 4 ? 4 : mrows <= 8 ? 8 : 16;
+  pp.red_lanes = mrows <= 8 ? 32 : 64;  // lanes 0..31 hold activation rows 0..7
+  pp.x_pitch = 0;
+  pp.lds_x = 65536;
+  pp.xw_pitch = 0;
+  pp.xw_bytes = 0;
+  pp.lds_xs = (pp.lds_x + 32 * I + 15) & ~15;
+  pp.lds_red = (pp.lds_xs + (QMX ? 0 : p.ngroups * pp.xs_rows * 4) + 15) & ~15;
+  unsigned lds = (unsigned)pp.lds_red + (unsigned)(8 * 2 * pp.rused * pp.red_lanes * 4);
+  pp.red_alias = lds > 80u * 1024u;
+  if (pp.red_alias) {
+    lds = (unsigned)pp.lds_red;
+    pp.lds_red = 0;
+  }
+  if (lds > 80u * 1024u) return TG_PAIR_NA;
+  pp.stride_xp = (int64_t)(p.m + 1) * p.k * 2;  // + a zero row
+  pp.stride_xsum = ((int64_t)p.ngroups * pp.xs_rows * 4 + 15) & ~(int64_t)15;
+  const int64_t need = batch * (pp.stride_xp + pp.stride_xsum);
+  pp.rblocks = (p.wrows + 31) / 32;
+  pp.cblocks = 1;
+  const int64_t items = (int64_t)pp.rblocks * batch;
+  if (items > INT32_MAX || items < 2 * TG_PAIR_MIN_ITEMS) return TG_PAIR_NA;  // (32-row items: two per 64-row item of the other kernel)
+  p.ws_need = need;
+  if (!p.ws_query && (p.ws == nullptr || p.ws_bytes < need)) return TG_PAIR_NA;
+  pp.xp = p.ws;
+  pp.xsum = p.ws + batch * pp.stride_xp;
+  pp.items = (int32_t)items;
+  pp.chunk = items >= (int64_t)TG_PAIR_WGS * TG_B16_CHUNK * 4 ? TG_B16_CHUNK : 1;
+  pp.stride_x = p.stride_x; pp.stride_w = p.stride_w; pp.stride_qinfo = p.stride_qinfo;
+  pp.stride_lut = p.stride_lut; pp.stride_y = p.stride_y;
+  pp.bias = p.bias; pp.stride_bias = p.stride_bias; pp.dry = p.dry;
+  if (!p.dry) {
+    const int rc = launch_xprep<DT>(pp, I, 16, batch, st, 1);
+    if (rc != 0) return rc;
+  }
+  if (gps == 1) {
+    if (TG_PAIR_NSG2 && nsg == 1) return launch_pair_k<DT, I, 1, 4, QMX, 1, true, 2>(pp, lds, st);
+    if (TG_PAIR_NSG2 && nsg == TG_PAIR_RB16) return launch_pair_k<DT, I, 1, 4, QMX, TG_PAIR_RB16, true, 2>(pp, lds, st);
+    return launch_pair_k<DT, I, 1, 4, QMX, 0, true, 2>(pp, lds, st);
+  }
+  if constexpr (I >= 4) {
+    if (gps == 2) return launch_pair_k<DT, I, 2, 4, QMX, 0, true, 2>(pp, lds, st);
+  }
+  if constexpr (I >= 8) {
+    if (gps == 4) return launch_pair_k<DT, I, 4, 4, QMX, 0, true, 2>(pp, lds, st);
+  }
+  return TG_PAIR_NA;
+}
+
 template <typename DT, bool LAYOUT_A, int CANON, bool QMX>
 int launch_w4(GemmParams& p, int64_t coltiles, int64_t batch, hipStream_t st) {
   constexpr int KSTEP = LAYOUT_A ? 64 : 128;
@@ -1018,6 +1097,11 @@ int launch_w4(GemmParams& p, int64_t coltiles, int64_t batch, hipStream_t st) {
     if (rc != TG_PAIR_NA) return rc;
     p.ws_need = 0;
     if constexpr (!LAYOUT_A) {
+      if (p.m > 8) {
+        rc = launch_pair_b16<DT, 2 * WPL, QMX>(p, batch, st);
+        if (rc != TG_PAIR_NA) return rc;
+        p.ws_need = 0;
+      }
       rc = launch_pair16<DT, 2 * WPL, QMX>(p, batch, st);
       if (rc != TG_PAIR_NA) return rc;
     }

@@ -6,6 +6,8 @@
 // "group-scaled" numerics described below.  Variants (template flags, all in this one kernel):
 //   XG   activations too large to stage whole: pre-arranged in a caller workspace, streamed per wave through a 1 KiB LDS buffer
 //   LA   Aint4 weights: v_mfma_f32_16x16x32, duplicated table, activations straight from the workspace into the MFMA operand
+//   LB   Bint4 weights on the same 16x16x32 structure (32-row items, up to 16 activation rows in one pass: m = 9 ... 16): one
+//        packed word = one B operand, no nibble shuffling
 //   QMX  mx4: e8m0 exponents fetched as 16-byte blocks per row
 //   MR   1 = the m = 1 specialisation (one accumulator register per tile, group sums as running differences), 4 / 16 = general
 //   NORM LlamaRMSNorm of the activations fused into the staging (tg_w4_gemm.norm_weight; own instantiations: the extra staging
@@ -209,24 +211,27 @@ __device__ __forceinline__ uint16_t swiglu16(float gsum, float usum) {
 //         The pair bytes are (code k, code k + 8): v_bfi of the word with itself shifted by one nibble.  Two lanes of a
 //         32-lane LDS access group share a weight row, so the table holds every row twice (32 rows x 2 copies = the same
 //         64 columns), the copy chosen by kb & 1: conflict-free.
-template <typename DT, int I, int GPS, int MR, bool QMX, int R, int NSG = 0, int ABL = 0, bool XG = false, bool LA = false, bool NORM = false>
+template <typename DT, int I, int GPS, int MR, bool QMX, int R, int NSG = 0, int ABL = 0, bool XG = false, int LAY = 0, bool NORM = false>
 __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p) {
-  static_assert(!NORM || (!XG && !LA && !QMX), "fused RMSNorm: the workgroup stages the whole activation block itself");
+  // LAY: 0 = Bint4 weights on 32x32x16 tiles (the description above), 1 = Aint4 weights (LA), 2 = Bint4 weights on 16x16x32 tiles (LB)
+  constexpr bool LA = LAY == 1, LB = LAY == 2, T16 = LAY != 0;
+  static_assert(!NORM || (!XG && !T16 && !QMX), "fused RMSNorm: the workgroup stages the whole activation block itself");
   constexpr int WAVES = 8;
   constexpr int TILES = 2;              // MFMA tiles per workgroup (B side: 32 rows each; A side: 16 rows each, sharing their words)
   constexpr int WT = LA ? 1 : TILES;    // sets of packed words per ring slot
-  constexpr int RW = LA ? 32 : 32 * TILES;
-  static_assert(!LA || (XG && MR == 4 && (I == 2 || I == 4)), "A side: workspace activations, one 8-row pass");
-  using acc_t = typename std::conditional<LA, f32x4_t, f32x16>::type;
+  constexpr int RW = T16 ? 32 : 32 * TILES;
+  static_assert(!T16 || (XG && MR == 4 && (LB || I == 2 || I == 4)), "16x16x32 tiles: workspace activations, one pass of up to 16 rows");
+  constexpr int NW = LB ? I / 2 : I;    // packed words per lane, word set and super-tile
+  using acc_t = typename std::conditional<T16, f32x4_t, f32x16>::type;
   constexpr int CPS = I / 2;            // 32-k chunks per super-tile
   constexpr int CPG = CPS / GPS;        // chunks per group inside a super-tile (GPS > 1 only)
   constexpr int MREGS = MR == 1 ? 4 : MR;  // accumulator registers of a row set
   constexpr int RF = MR;                   // registers that are finalised per group and exchanged at the end
-  constexpr int MA = LA ? 16 : 2 * MREGS;  // activation rows a pass can hold
+  constexpr int MA = T16 ? 16 : 2 * MREGS;  // activation rows a pass can hold
   // XG: 16-byte pieces per lane of one super-tile's activation block.  A side: the lane's own MFMA operand of every 32-k chunk,
   // straight from the workspace into registers (lane (row i, k-quad kb) of v_mfma_f32_16x16x32 needs exactly one piece per
   // chunk): no LDS round trip for the activations at all
-  constexpr int NXW = LA ? I / 2 : XG ? (MA * 2 * I + 63) / 64 : 1;
+  constexpr int NXW = T16 ? I / 2 : XG ? (MA * 2 * I + 63) / 64 : 1;
   static_assert(!XG || MR <= 4, "XG: one pass is at most 8 activation rows");
 
   // The pair table sits at LDS address 0 (a lookup address is just byte << 8 | column << 2): the kernel has no static LDS,
@@ -241,14 +246,14 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = lane & 31;
   const int h = lane >> 5;
-  const int xa = LA ? lane & 15 : c;       // activation row this lane supplies to the MFMA (X operand)
-  const int xq = LA ? lane >> 4 : 2 * h;   // first 16-byte piece (k-quad) of a 32-k chunk this lane reads
-  const int hh = LA ? lane >> 4 : h;       // this lane's accumulator registers r < 4 are activation rows 4 hh + r
+  const int xa = T16 ? lane & 15 : c;       // activation row this lane supplies to the MFMA (X operand)
+  const int xq = T16 ? lane >> 4 : 2 * h;   // first 16-byte piece (k-quad) of a 32-k chunk this lane reads
+  const int hh = T16 ? lane >> 4 : h;       // this lane's accumulator registers r < 4 are activation rows 4 hh + r
   // weight row (inside the workgroup's block) of this lane in tile t
-  auto wrow_local = [&](int t) -> int { return LA ? 16 * ((lane & 15) >> 3) + (lane & 7) + 8 * t : t * 32 + c; };
+  auto wrow_local = [&](int t) -> int { return LA ? 16 * ((lane & 15) >> 3) + (lane & 7) + 8 * t : LB ? 16 * t + (lane & 15) : t * 32 + c; };
   const int tcol = tid & 63;  // table column this thread builds
   // ... and the weight row it belongs to (A side: column = 32 tile + 16 copy + n)
-  const int tcol_row = LA ? 16 * ((tcol & 15) >> 3) + (tcol & 7) + 8 * (tcol >> 5) : tcol;
+  const int tcol_row = LA ? 16 * ((tcol & 15) >> 3) + (tcol & 7) + 8 * (tcol >> 5) : LB ? 16 * (tcol >> 5) + (tcol & 15) : tcol;
 
   // ---- this workgroup's work items; item -> (problem b, activation pass ct, row block rb) ----
   // staged activations: a contiguous range (the block in LDS is re-staged only when the problem changes).
@@ -345,7 +350,7 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
       r.qrow4[t] = (uint32_t)row * 4u;
       if constexpr (!LA) {
         const int nt = min(row >> 3, p.ntiles - 1);
-        r.wbase[t] = ((uint32_t)nt * (uint32_t)p.ksuper * 32u + (uint32_t)(4 * (row & 7) + 2 * h)) * (uint32_t)(2 * I);
+        r.wbase[t] = ((uint32_t)nt * (uint32_t)p.ksuper * 32u + (uint32_t)(4 * (row & 7) + (LB ? lane >> 4 : 2 * h))) * (uint32_t)(2 * I);
       }
     }
     if constexpr (LA) {  // [16-row tile][k super-tile][32 lanes][I words]
@@ -358,7 +363,7 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
       const int rows = min(p.m - e.ct * MA, MA);
       r.xpb = p.xp + (int64_t)e.b * p.stride_xp + (int64_t)e.ct * MA * p.k * 2;
       r.xblk = (uint32_t)(rows * 32 * I);
-      if constexpr (LA) {  // workspace [32-k chunk][k-quad][rows + 1][16 bytes]: row `rows` of every block is zero
+      if constexpr (T16) {  // workspace [32-k chunk][k-quad][rows + 1][16 bytes]: row `rows` of every block is zero
         r.xblk = (uint32_t)((rows + 1) * 64);  // bytes of one chunk's block
         r.xoff[0] = (uint32_t)(((lane >> 4) * (rows + 1) + min(lane & 15, rows)) * 16);
       } else {
@@ -392,7 +397,7 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
       // lanes beyond the block re-read its first piece (never stored): the load stays unconditional
 #pragma unroll
       for (int i = 0; i < NXW; ++i) {
-        if constexpr (LA) {  // chunk s CPS + i: a block of 4 k-quads x (rows + the zero row) pieces
+        if constexpr (T16) {  // chunk s CPS + i: a block of 4 k-quads x (rows + the zero row) pieces
           sl.xw[i] = *reinterpret_cast<const u32x4*>(rw.xpb + uni((sv * CPS + (uint32_t)i) * rw.xblk) + pin(rw.xoff[0]));
           continue;
         }
@@ -407,13 +412,15 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
         const char* src = rw.wb + uni(sv * (uint32_t)((LA ? 128 : 64) * I)) + pin(rw.wbase[tw]);
         if constexpr (ABL == 3) {
 #pragma unroll
-          for (int j = 0; j < I; ++j) sl.w[tw][j] = (uint32_t)(s * 7 + j + t);
-        } else if constexpr (I == 2) {
+          for (int j = 0; j < NW; ++j) sl.w[tw][j] = (uint32_t)(s * 7 + j + t);
+        } else if constexpr (NW == 1) {
+          sl.w[tw][0] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(src));
+        } else if constexpr (NW == 2) {
           const u32x2 v = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(src));
           sl.w[tw][0] = v[0]; sl.w[tw][1] = v[1];
         } else {
 #pragma unroll
-          for (int v4 = 0; v4 < I / 4; ++v4) {
+          for (int v4 = 0; v4 < NW / 4; ++v4) {
 #ifdef TG_PAIR_NO_NT
             const u32x4 v = reinterpret_cast<const u32x4*>(src)[v4];
 #else
@@ -563,7 +570,7 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
 #ifndef TG_XS_PREFETCH
 #define TG_XS_PREFETCH 1  // 0: developer A/B, no register prefetch on the A side either
 #endif
-  constexpr int NXS = (LA && TG_XS_PREFETCH) ? 2 : 0;
+  constexpr int NXS = (T16 && TG_XS_PREFETCH) ? 2 : 0;
   float xsn[2] = {0.f, 0.f};
   auto xs_request = [&](const Item& e) {  // a valid item
     if constexpr (XG && !QMX) {
@@ -616,7 +623,7 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
 
   uint32_t colreg[TILES];
 #pragma unroll
-  for (int t = 0; t < TILES; ++t) colreg[t] = (uint32_t)((LA ? 32 * t + 16 * ((lane >> 4) & 1) + (lane & 15) : t * 32 + c) * 4);
+  for (int t = 0; t < TILES; ++t) colreg[t] = (uint32_t)((T16 ? 32 * t + 16 * ((lane >> 4) & 1) + (lane & 15) : t * 32 + c) * 4);
 
   int table_b = -1;  // the problem whose LUT the table in LDS was built from
   Item inext = first;
@@ -692,7 +699,7 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
 #pragma unroll
     for (int t = 0; t < TILES; ++t) {
 #pragma unroll
-      for (int r = 0; r < (LA ? 4 : 16); ++r) acc[t][r] = 0.f;
+      for (int r = 0; r < (T16 ? 4 : 16); ++r) acc[t][r] = 0.f;
 #pragma unroll
       for (int r = 0; r < RF; ++r) yacc[t][r] = 0.f;
     }
@@ -762,12 +769,12 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
     bool pending = false;  // wave-uniform
     acc_t zero16;
 #pragma unroll
-    for (int r = 0; r < (LA ? 4 : 16); ++r) zero16[r] = 0.f;
+    for (int r = 0; r < (T16 ? 4 : 16); ++r) zero16[r] = 0.f;
     // one super-tile: 2 CPS MFMA steps, step = (chunk jc, quad pair qq) for both tiles: 8 table lookups + one X piece
     uint32_t edw[TILES] = {0u, 0u};  // mx4: the exponent dword of the current super-tile
     auto consume = [&](int s, const Slot& sl, int j_slot) {
       const uint32_t xst = xrow + ((uint32_t)(s * CPS * 64) & xmask);  // this lane's X pieces of the super-tile
-      if constexpr (XG && !LA) {
+      if constexpr (XG && !T16) {
         // the wave's own DS operations execute in order: the reads of the previous super-tile are behind us, the reads below
         // follow this store; no barrier
         // every lane stores (the buffer has a row for each: rows past the pass's are never read): a store under a lane mask
@@ -786,9 +793,9 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
       }
 #pragma unroll
       // B side: a step = half a 32-k chunk (quads 2 h + qq); A side: a whole chunk (one word pair = two 16-k tiles)
-      for (int u = 0; u < (LA ? CPS : 2 * CPS); ++u) {
-        const int jc = LA ? u : u >> 1, qq = LA ? 0 : u & 1;
-        const bool qfirst = LA || qq == 0, qlast = LA || qq == 1;
+      for (int u = 0; u < (T16 ? CPS : 2 * CPS); ++u) {
+        const int jc = T16 ? u : u >> 1, qq = T16 ? 0 : u & 1;
+        const bool qfirst = T16 || qq == 0, qlast = T16 || qq == 1;
         const int chunk = s * CPS + jc;
         // group boundaries: static when a super-tile holds several groups, else a wave-uniform runtime test
         constexpr bool STATIC_G = GPS > 1 || NSG > 0;
@@ -798,7 +805,7 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
         u32x4 xf;
         u32x4 bf[TILES];
         if constexpr (ABL == 5) xf = u32x4{xrow, (uint32_t)s, (uint32_t)jc, (uint32_t)qq};  // ablation: no X reads
-        else if constexpr (LA) xf = sl.xw[jc];
+        else if constexpr (T16) xf = sl.xw[jc];
         else xf = *(lds_cu32x4ptr)(xst + (uint32_t)(jc * 64 + 16 * qq));
 #pragma unroll
         for (int t = 0; t < TILES; ++t) {
@@ -816,6 +823,16 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
               const uint32_t addr = __builtin_amdgcn_perm(uw[j & 1], colreg[t], 0x0c0c0400u + ((uint32_t)(t + 2 * (j >> 1)) << 8));
+              if constexpr (ABL == 1) bf[t][j] = addr;
+              else bf[t][j] = *(lds_cu32ptr)(addr);
+            }
+          } else if constexpr (LB) {
+            // one packed word = the 8 codes of this lane's row at k = 2 q + {0, 16, 1, 17, 8, 24, 9, 25} of the chunk = one B
+            // operand of v_mfma_f32_16x16x32, in the activation pieces' order (as in w4_gemm_pair16.cuh)
+            const uint32_t w = sl.w[t][jc];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const uint32_t addr = __builtin_amdgcn_perm(w, colreg[t], 0x0c0c0400u + ((uint32_t)j << 8));
               if constexpr (ABL == 1) bf[t][j] = addr;
               else bf[t][j] = *(lds_cu32ptr)(addr);
             }
@@ -873,7 +890,7 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
 #pragma unroll
         for (int t = 0; t < TILES; ++t) {
           if constexpr (ABL == 4) acc[t][0] += u2f(bf[t][0] ^ bf[t][1] ^ bf[t][2] ^ bf[t][3] ^ xf[0] ^ xf[1] ^ xf[2] ^ xf[3]);  // ablation: no MFMA
-          else if constexpr (LA) acc[t] = mfma16<DT>(xf, bf[t], (ABL != 7 && gfirst) ? zero16 : acc[t]);
+          else if constexpr (T16) acc[t] = mfma16<DT>(xf, bf[t], (ABL != 7 && gfirst) ? zero16 : acc[t]);
           else if (ABL != 7 && !DIFF && gfirst) acc[t] = mfma32<DT>(xf, bf[t], zero16);
           else acc[t] = mfma32<DT>(xf, bf[t], acc[t]);
         }
@@ -942,13 +959,13 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
         //  barrier then waits for)
         const int l = o & (p.red_lanes - 1), q = o >> rl_shift;
         const int t = q >= p.rused ? 1 : 0, r = q - t * p.rused;
-        const int a = LA ? r + 4 * (l >> 4) : (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
-        const int row = row0 + (LA ? 16 * ((l & 15) >> 3) + (l & 7) + 8 * t : t * 32 + (l & 31));
+        const int a = T16 ? r + 4 * (l >> 4) : (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+        const int row = row0 + (LA ? 16 * ((l & 15) >> 3) + (l & 7) + 8 * t : LB ? 16 * t + (l & 15) : t * 32 + (l & 31));
         if (a < mrows && row < p.wrows) {
           float sum = 0.f;
 #pragma unroll
           for (int w = 0; w < WAVES; ++w) sum += *(lds_fptr)(lds_red + (uint32_t)((((w * TILES + t) * p.rused + r) * p.red_lanes + l) * 4));
-          if (!LA && p.epilogue == TG_EPI_SWIGLU) {
+          if (!T16 && p.epilogue == TG_EPI_SWIGLU) {
             // rows come in blocks of 8 gate + 8 up: lane l holds gate row `row`, lane l + 8 (same tile, same half) its up row
             if ((l & 15) < 8) {
               float up = 0.f;

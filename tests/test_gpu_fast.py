@@ -181,6 +181,26 @@ def test_pair_kernel_many_rows(T, oracle, m):
 
 
 @pytest.mark.parametrize("case", [
+    # (n, k, m, g, inner, qtype): 9 ... 16 activation rows at a k where the block does not fit on chip -> the 16x16x32 kernel for
+    # Bint4 weights (launch_pair_b16): every inner-k, group, quantisation type, ragged row tiles, all m of the range
+    (64, 4096, 16, 128, 4, "any4_rowwise"), (72, 4096, 9, 128, 4, "any4_rowwise"), (40, 4096, 12, 64, 4, "any4_global"),
+    (64, 4096, 16, 32, 4, "mx4"), (64, 4096, 13, 32, 4, "int4"), (96, 2048, 16, 128, 2, "any4_rowwise"), (64, 4096, 10, 256, 8, "int4"),
+    (64, 8192, 16, 128, 8, "any4_rowwise"), (136, 4096, 11, 64, 2, "int4"), (64, 14336, 16, 128, 4, "any4_rowwise"),
+    (64, 4096, 15, 32, 8, "any4_rowwise"),
+])
+def test_pair_kernel_9_to_16_rows(T, oracle, case):
+    """m = 9 ... 16 with the weights on the right (the reference's full 16-row tile, TinyGemmImpl.cuh:53-54) on the pair-table
+    kernel: `tg_gemm_w4_plan` must say pair, results against both oracles."""
+    from any4_amd import ops
+
+    n, k, m, g, inner, qtype = case
+    codes, x, qinfo, lut = rand_problem(n, k, g, m, qtype, seed=n + k + m)
+    y, copies = run_fast(T, codes, x, qinfo, lut, g, qtype, inner, min_items=768)
+    assert ops.gemm_w4_plan(m, -(-n // 8) * 8, k, g, QT[qtype], True, inner, batch=copies) == "pair"
+    assert_fast_close(oracle, y, codes, x, qinfo, lut, g, qtype, inner=inner, batch=copies)
+
+
+@pytest.mark.parametrize("case", [
     # (n, k, m, g, inner, qtype): activation blocks that do not fit next to the table -> workspace variant
     (64, 4096, 8, 64, 4, "any4_rowwise"), (72, 4096, 5, 128, 4, "any4_rowwise"), (64, 4096, 7, 256, 4, "int4"),
     (64, 8192, 1, 128, 4, "any4_rowwise"), (40, 8192, 3, 64, 4, "any4_global"), (64, 14336, 1, 128, 4, "any4_rowwise"),
@@ -416,7 +436,7 @@ def _stacked_launch(layers, m, n, k, g, qtype, numerics, seed=0, on_right=True):
 
 
 @pytest.mark.parametrize("qtype,g", [("any4_rowwise", 128), ("int4", 128), ("any4_global", 128), ("mx4", 32)])
-@pytest.mark.parametrize("m", [1, 8])
+@pytest.mark.parametrize("m", [1, 8, 16])
 @pytest.mark.parametrize("numerics", ["fast", "reference"])
 def test_benchmarked_launch_shape(T, oracle, qtype, g, m, numerics):
     """BASELINE configs 2 and 4 exactly as bench.py launches them: ONE tg_gemm_w4 call over 16 independent layers of
