@@ -203,7 +203,7 @@ __device__ __forceinline__ uint16_t swiglu16(float gsum, float usum) {
 //         the whole activation block itself
 // NSG   = super-tiles per quantisation group when that is 1 or R (group boundaries then sit at fixed places of the unrolled
 //         round: no per-step tests, scale | zero words are only requested for the first super-tile of a group); 0 = any, tested at run time
-// LA    = weights in the Aint4 layout (weightOnRight = false; I = 2, 4; workspace activations, m <= 8).  A packed word holds
+// LA    = weights in the Aint4 layout (weightOnRight = false; I = 2, 4; workspace activations, one pass of m <= 16 rows).  A packed word holds
 //         4 codes of row r and 4 of row r + 8 of a 16-row tile at k = 2 kq + {0, 1, 8, 9} of one 16-k tile
 //         (TinyGemmConvertA.cu:172-255), lane t = 4 (r & 7) + kq.  Lane (n = lane & 15, kb = lane >> 4) of a wave takes
 //         row n & 7 of 16-row tile n >> 3 at kq = kb: its word pair (two k-tiles) is the B operand of

@@ -272,6 +272,9 @@ class _FragX:
         return self.t.data_ptr()
 
 
+_WS_BYTES: dict = {}  # tg_gemm_w4_workspace_bytes per problem shape (pure function of the key below)
+
+
 def _w4_rm(A, B, q_group, qinfo, lut, qtype, weight_on_right, opname, frag=False):
     """Row-major activations / output.  Mirrors tinygemm_y_FT16RM_x_FT16RM_w_int4TC
     (TinyGemm_int4.cu:294-548).  frag=True (weights on the right only): A is a _FragX, the output comes back in A-fragment
@@ -350,9 +353,18 @@ def _w4_rm(A, B, q_group, qinfo, lut, qtype, weight_on_right, opname, frag=False
         numerics=_NUMERICS[get_numerics()], bias=(bias.data_ptr() if bias is not None else None),
         x_layout=layout, y_layout=layout,
     )
-    ws_bytes = _L.tg_gemm_w4_workspace_bytes(ctypes.byref(args))
+    # The planner's answer depends on the problem's shape only: asked once per (shape, layout, numerics), not once per call
+    # (m = 1 latency path: one planner pass and no allocation when no scratch is needed).
+    key = (m, wrows, k, q_group, qtype, args.dtype, args.w_on_right, inner, args.numerics, layout, bias is not None)
+    ws_bytes = _WS_BYTES.get(key)
+    if ws_bytes is None:
+        ws_bytes = _L.tg_gemm_w4_workspace_bytes(ctypes.byref(args))
+        if len(_WS_BYTES) < 4096:
+            _WS_BYTES[key] = ws_bytes
     if frag and ws_bytes == _lib.TG_E_LAYOUT:
         return None
+    if ws_bytes < 0:
+        _lib.check(ws_bytes, opname)
     if ws_bytes > 0:  # scratch from torch's caching allocator: stream-ordered like every other temporary of the op
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
         args.workspace, args.workspace_bytes = ws.data_ptr(), ws_bytes

@@ -20,6 +20,7 @@ This module is the step BEFORE the hot path; none of it runs per token.
 from __future__ import annotations
 
 import gc
+import warnings
 from typing import Callable, Optional
 
 import torch
@@ -199,6 +200,10 @@ def kmeans_rows(x: torch.Tensor, n_clusters: int = 16, sample_weight: Optional[t
     # the reference forwards `init` to scikit-learn (None / "k-means++" / "random", quantize.py:413): those have no meaning
     # for this batched Lloyd -> its default deterministic seedings
     if init is None or (isinstance(init, str) and init in ("k-means++", "random")):
+        if init is not None and init not in _WARNED_INIT:
+            _WARNED_INIT.add(init)
+            warnings.warn(f"kmeans_rows: init={init!r} is scikit-learn's seeding; this batched Lloyd has no random state and "
+                          f"uses its deterministic seedings {_SEEDINGS} instead (results do not depend on a seed)", stacklevel=2)
         init = _SEEDINGS
     for kind in ((init,) if isinstance(init, str) else tuple(init)):
         a, c, sse = _lloyd(x, wts, xw, _init_centers(kind, x, xs, lo, span, n_clusters), span, max_iter, tol)
@@ -217,6 +222,7 @@ def kmeans_rows(x: torch.Tensor, n_clusters: int = 16, sample_weight: Optional[t
 # --------------------------------------------------------------------------------------------------
 
 _SEEDINGS = ("uniform", "density", "quantile")
+_WARNED_INIT: set = set()  # scikit-learn seeding names already warned about (kmeans_rows)
 
 
 @torch.no_grad()

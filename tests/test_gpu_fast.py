@@ -647,3 +647,25 @@ def test_decode_layer_at_llama3_8b_shapes(oracle, bs):
         a, b = q.decode(t, i).float(), d.decode(t, i).float()
         assert torch.isfinite(a).all()
         assert (a - b).abs().max() <= 0.03 * b.abs().max() + 1e-3, (i, (a - b).abs().max(), b.abs().max())
+
+
+@pytest.mark.parametrize("qtype,g", [("any4_rowwise", 128), ("int4", 128), ("mx4", 32)])
+def test_default_numerics_row_does_not_depend_on_batch_shape(T, oracle, qtype, g):
+    """in the default numerics the kernel family changes with the launch shape (m = 1 / m <= 8 / m <= 16 / larger, one
+    layer or many), so the SAME activation row may come back with different low bits.  The contract: whatever m the row travels in,
+    its outputs stay inside the module's stated bound around the group-scaled sum -- hence within one rounding + accumulation slack
+    of each other -- and mx4 (exact weights) stays within the f32 accumulation slack alone."""
+    n, k = 256, 4096
+    codes, x, qinfo, lut = rand_problem(n, k, g, 33, qtype, seed=77)
+    y_gs = gs_reference(oracle, codes, x[:1], qinfo, lut, g, qtype)
+    w = from_bits16(oracle_weights(oracle, codes, g, qtype, qinfo, lut), torch.bfloat16).double()
+    S = (x[:1].double().abs() @ w.abs().t()).numpy()
+    tol = 0.5 * ulp16(y_gs, torch.bfloat16) * (1 + 2.0 ** -7) + (4e-6 + 2.0 ** -9) * S + 1e-37  # (reference kernels at m > 16)
+    rows = {}
+    for m in (1, 2, 8, 9, 16, 33):
+        y = run_rm(T, codes, x[:m].contiguous(), qinfo, lut, g, qtype, True, 4)
+        rows[m] = y[:1, :n].double().cpu().numpy()
+        bad = np.abs(rows[m] - y_gs) > tol
+        assert not bad.any(), f"m = {m}: row 0 is {np.abs(rows[m] - y_gs).max():.3e} from the group-scaled sum"
+    for m in (2, 8, 9, 16, 33):
+        assert (np.abs(rows[m] - rows[1]) <= 2 * tol).all(), f"row 0 at m = {m} against m = 1"

@@ -140,3 +140,22 @@ def test_quantize_model_pseudo_swaps_weights_and_skips_lm_head():
     Q.quantize_model(m2, layer_to=Q.intq_layer, pseudo=True, group_size=64, skip_modules="body.0,lm_head", unsigned=True)
     assert torch.equal(m2.body[0].weight, w0) and not torch.equal(m2.body[2].weight, w2)
     assert (m2.body[2].weight - w2).abs().max() < 0.05
+
+
+def test_kmeans_rows_sklearn_seedings_are_aliases_and_say_so():
+    """None / 'k-means++' / 'random' (what the reference forwards to scikit-learn, quantize.py:413) run the
+    deterministic seedings here -- same result as the default, announced once; an unknown name is rejected."""
+    import warnings
+
+    Q._WARNED_INIT.discard("random")
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(6, 128, generator=g)
+    a0, c0 = Q.kmeans_rows(x, 16)
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        a1, c1 = Q.kmeans_rows(x, 16, init="random")
+        a2, c2 = Q.kmeans_rows(x, 16, init="random")
+    assert sum("scikit-learn" in str(w.message) for w in rec) == 1
+    assert torch.equal(a0, a1) and torch.equal(c0, c1) and torch.equal(a1, a2)
+    with pytest.raises(ValueError):
+        Q.kmeans_rows(x, 16, init="no-such-seeding")

@@ -40,6 +40,12 @@ for cfg in sys.argv[1:] or ["1,4096,4096,1,any4_rowwise,128"]:
         for _ in range(20):
             launch()
         torch.cuda.synchronize()
+    hold = float(os.environ.get("AB_HOLD", "0"))  # seconds of continuous load before the samples (power / clock probes)
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < hold:
+        for _ in range(20):
+            launch()
+        torch.cuda.synchronize()
     best = []
     for _ in range(5):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
