@@ -636,32 +636,44 @@ int launch_stream(const GemmParams& p, int64_t coltiles, int64_t batch, hipStrea
 // Returns TG_PAIR_NA when the shape does not fit this kernel's LDS plan (the caller then takes another kernel).
 enum { TG_PAIR_NA = -100 };
 
+// Tuning constants of the pair-table launches, each with the measurement that set it.  The shipped library
+// always uses these values; only developer builds (-DTG_DEV / -DTG_DEV_MIN, dev/build_variant.sh) may override one with -D<NAME>=<v>.
+#if !defined(TG_DEV) && !defined(TG_DEV_MIN)
+#if defined(TG_PAIR_R) || defined(TG_PAIR_ABL) || defined(TG_PAIR_MR1) || defined(TG_PAIR_NSG2) || defined(TG_PAIR_MR1_GPS) || defined(TG_PAIR_RA) ||   \
+    defined(TG_PAIR_RA1) || defined(TG_PAIR_RB16) || defined(TG_B16_CHUNK) || defined(TG_PAIR_MIN_ITEMS) || defined(TG_XG_CHUNK) || defined(TG_PAIR_WGS) || \
+    defined(TG_PAIR_NSG2_M1) || defined(TG_PAIR_FORCE_XG)
+#error "the TG_PAIR_* / TG_XG_* / TG_B16_* tuning constants can only be overridden in developer builds (-DTG_DEV or -DTG_DEV_MIN)"
+#endif
+#endif
 #ifndef TG_PAIR_R
-#define TG_PAIR_R 2
+#define TG_PAIR_R 2            // super-tiles a wave keeps in flight (2, 3, 4 measured equal; 5 spills)
 #endif
 #ifndef TG_PAIR_ABL
-#define TG_PAIR_ABL 0
+#define TG_PAIR_ABL 0          // ablation stub of w4_gemm_pair.cuh (its header lists them)
 #endif
 #ifndef TG_PAIR_MR1
-#define TG_PAIR_MR1 1  // 1: m = 1 runs the one-register specialisation (measured +2-3 %), 4: the general m <= 8 kernel
+#define TG_PAIR_MR1 1          // 1: m = 1 runs the one-register specialisation (+2-3 %), 4: the general m <= 8 kernel
 #endif
 #ifndef TG_PAIR_NSG2
-#define TG_PAIR_NSG2 1  // 0: group boundaries always tested at run time (developer A/B)
+#define TG_PAIR_NSG2 1         // group boundaries at fixed places of the unrolled round when a group is one round of the ring
+#endif
+#ifndef TG_PAIR_NSG2_M1
+#define TG_PAIR_NSG2_M1 1      // ... also in the m = 1 specialisation (74.8 -> 75.8 % once its group update was spelled out)
 #endif
 #ifndef TG_PAIR_MR1_GPS
-#define TG_PAIR_MR1_GPS 1  // the m = 1 specialisation is used up to this many groups per super-tile
+#define TG_PAIR_MR1_GPS 1      // the m = 1 specialisation is used up to this many groups per super-tile (it spills beyond)
 #endif
 #ifndef TG_PAIR_RA
-#define TG_PAIR_RA 2   // ring depth of the A-side kernels (few accumulator registers: room for more)
+#define TG_PAIR_RA 2           // ring depth of the A-side kernels (4 / 6 / 8 measured 8.2 / 21 / 40 us against 6.8)
 #endif
 #ifndef TG_PAIR_RA1
-#define TG_PAIR_RA1 1  // ... with several groups per super-tile
+#define TG_PAIR_RA1 1          // ... with several groups per super-tile
 #endif
 #ifndef TG_PAIR_RB16
-#define TG_PAIR_RB16 2  // ring depth of the 16x16x32 kernels for Bint4 weights (m = 9 ... 16)
+#define TG_PAIR_RB16 2         // ring depth of the 16x16x32 kernels for Bint4 weights, m = 9 ... 16 (3 / 4: 41 % against 44 %)
 #endif
 #ifndef TG_B16_CHUNK
-#define TG_B16_CHUNK 4  // consecutive 32-row work items per workgroup visit of those kernels
+#define TG_B16_CHUNK 4         // consecutive 32-row work items per workgroup visit of those kernels (1 / 4 / 8 within 1 %)
 #endif
 #ifndef TG_PAIR_MIN_ITEMS
 #define TG_PAIR_MIN_ITEMS 192  // fewer work items: the launch is latency-bound, w4_gemm_pair16_kernel / the reference kernels take
@@ -669,11 +681,11 @@ enum { TG_PAIR_NA = -100 };
                                // 18.3 us on pair16 and 13.8 us on the stream kernel; 6144 x 4096 = 96 items 10.7 against 9.9 / 8.2)
 #endif
 #ifndef TG_XG_CHUNK
-#define TG_XG_CHUNK 4  // consecutive work items per workgroup visit in the workspace variant of Bint4 weights (1: plain round-robin):
-                       // same-box, m = 8: 4096^2 66.1 -> 66.5 %, 8192^2 67.3 -> 68.6 %; Aint4 weights keep 1 (8192^2 56.5 -> 56.0 % with 4)
+#define TG_XG_CHUNK 4          // consecutive work items per workgroup visit in the workspace variant of Bint4 weights (1: plain
+                               // round-robin): m = 8: 4096^2 66.1 -> 66.5 %, 8192^2 67.3 -> 68.6 %; Aint4 weights keep 1
 #endif
 #ifndef TG_PAIR_WGS
-#define TG_PAIR_WGS 512  // persistent workgroups: two per CU
+#define TG_PAIR_WGS 512        // persistent workgroups: two per CU (768 / 1024: +4 % / +1 % time)
 #endif
 template <typename DT, int I, int GPS, int MR, bool QMX, int NSG, bool XG = false, int LA = 0, bool NORM = false>
 int launch_pair_k(PairParams& pp, unsigned lds, hipStream_t st) {
@@ -838,9 +850,6 @@ int launch_pair(GemmParams& p, int64_t batch, hipStream_t st) {
     //  boundaries made the compiler scatter its accumulator chain over several register tuples and spill)
     // (a group of ONE super-tile, g = 64 at I = 4, also keeps the run-time test: its fixed-boundary build spills 27 registers,
     //  m = 8 50 % against 59 %)
-#ifndef TG_PAIR_NSG2_M1
-#define TG_PAIR_NSG2_M1 1  // 0: developer A/B, the m = 1 specialisation keeps the run-time group-boundary test
-#endif
     const bool fixed = TG_PAIR_NSG2 && (TG_PAIR_NSG2_M1 || !(p.m == 1 && TG_PAIR_MR1 == 1));
     if (fixed && nsg == TG_PAIR_R) return TG_PAIR_M(1, TG_PAIR_R);
     return TG_PAIR_M(1, 0);

@@ -50,19 +50,12 @@
 //                the register ring of R super-tiles of packed words (+ scale|zero words) a wave keeps in flight from HBM
 //                runs across item boundaries, and the LUT rows of the next item are requested at the start of the current
 //                one, so the weight stream never drains while a table is rebuilt.  Two barriers per item.
+//
+// ABL (template parameter, always 0 in the shipped library; developer builds set it with -DTG_PAIR_ABL=<n>, dev/README.md) stubs one
+// stage out so that its cost can be read off a same-box A/B: 1 no table lookups, 3 no weight loads, 4 no MFMA, 5 no activation
+// reads from LDS, 6 stream only (loads, table build, staging, barriers), 7 no per-group work, 8 no scale | zero loads,
+// 9 / 10 workspace variant without the activation loads / their LDS store, 11 no activation-sum staging.
 #pragma once
-#ifndef TG_PAIR_PIN
-#define TG_PAIR_PIN 0  // 1: also pin the accumulator tuples in finalize() when a group's first MFMA takes a zero C operand
-#endif
-#ifndef TG_PAIR_EDW_INDEX
-#define TG_PAIR_EDW_INDEX 1  // 0: developer A/B, the mx4 exponent dword chosen by nested selects
-#endif
-#ifndef TG_PAIR_KEEP_TABLE
-#define TG_PAIR_KEEP_TABLE 1  // 0: developer A/B, rebuild the table for every item whatever the quantisation type
-#endif
-#ifndef TG_PAIR_FIN_ASM
-#define TG_PAIR_FIN_ASM 1  // 0: developer A/B, the m = 1 group update as plain C++
-#endif
 
 // Element (r, c) of a matrix kept in the reference's m16n8k16 A-fragment order [ceil(rows/16)][ctiles = ceil(cols/16)][32][8]
 // (TinyGemmConvertA.cu:19-141: lane t = 4 (r & 7) + (c & 7) / 2 holds (r, c0) (r, c0+1) (r+8, c0) (r+8, c0+1) and the same at
@@ -260,10 +253,7 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
   // XG: items dealt round-robin, so that the workgroups running at one time read the activations of a few problems only
   // (with contiguous ranges every workgroup streams a different problem's block again and again: at m = 8, k = 4096 that is
   // 64 KiB x 64 workgroups per XCD = the whole L2, behind the weight stream -- measured as +50 % time)
-#ifndef TG_XG_ROUNDROBIN
-#define TG_XG_ROUNDROBIN 1
-#endif
-  constexpr bool RR = XG && TG_XG_ROUNDROBIN;
+  constexpr bool RR = XG;
   // XG: workgroup b takes the items [(j G + b) C, + C), j = 0, 1, ...: C = p.chunk consecutive items (one contiguous C x 128 KiB
   // of one problem's weights), then on by G C.  C = 1 is plain round-robin.
   const int chunk = RR ? p.chunk : 1;
@@ -421,11 +411,7 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
         } else {
 #pragma unroll
           for (int v4 = 0; v4 < NW / 4; ++v4) {
-#ifdef TG_PAIR_NO_NT
-            const u32x4 v = reinterpret_cast<const u32x4*>(src)[v4];
-#else
             const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src) + v4);
-#endif
 #pragma unroll
             for (int j = 0; j < 4; ++j) sl.w[tw][4 * v4 + j] = v[j];
           }
@@ -460,13 +446,9 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
   // the dword of ecur[t] that holds the exponents of slice group gi (wave-uniform); the GPS groups of one super-tile share it
   auto e_dword = [&](int t, int gi) -> uint32_t {
     const int dw = (gi + ebase) >> 2;
-#if TG_PAIR_EDW_INDEX
     // a wave-uniform dynamic element of the register vector: one relative move (nested selects on a uniform condition compile to
     // a tree of scalar branches inside the main loop)
     return ecur[t][dw & 3];
-#else
-    return dw == 0 ? ecur[t][0] : dw == 1 ? ecur[t][1] : dw == 2 ? ecur[t][2] : ecur[t][3];
-#endif
   };
   // 2^(e - 127) as f32 bits-wise: e << 23, e = 0 -> 2^-127 (a denormal), e = 255 -> NaN (Dequantization.cuh:331-339)
   auto e_scale = [&](uint32_t d, int gi) -> float {
@@ -567,10 +549,7 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
   // DRAM latency per item; same-box A/B +0.5 % at 4096^2, +1.5 % at 8192^2).  On the A side (registers to spare) the first
   // 2 x 512 sums are requested one item ahead into registers (xs_request), like the LUT rows: +0.5-1.7 %; on the B side that
   // costs 7 more spilled registers and 5 %.
-#ifndef TG_XS_PREFETCH
-#define TG_XS_PREFETCH 1  // 0: developer A/B, no register prefetch on the A side either
-#endif
-  constexpr int NXS = (T16 && TG_XS_PREFETCH) ? 2 : 0;
+  constexpr int NXS = T16 ? 2 : 0;
   float xsn[2] = {0.f, 0.f};
   auto xs_request = [&](const Item& e) {  // a valid item
     if constexpr (XG && !QMX) {
@@ -640,13 +619,10 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
     if (has_next) inext = advance(cur, big);  // (the last item asks for its own rows again)
     Rows rnext = rows_of(inext);
 
-#ifdef TG_PAIR_NOLP  // experiment: no LUT prefetch across the main loop (8 VGPRs less, LUT latency exposed)
-    if (lut_loaded && it != it_begin) lut_request(cur);
-#endif
     // ---- pair table of this item: thread = (column, high nibbles 2 wave and 2 wave + 1).  The previous item's lookups are
     // all behind the barrier that ended it.  Only a per-row LUT changes from item to item: int4 / mx4 / one global LUT keep the
     // first item's table (unless the split-K partial sums reuse its LDS) -- 32 table stores per thread and item less. ----
-    if (TG_PAIR_KEEP_TABLE == 0 || it == it_begin || p.qtype == TG_Q_ANY4_ROWWISE || p.red_alias ||
+    if (it == it_begin || p.qtype == TG_Q_ANY4_ROWWISE || p.red_alias ||
         (p.qtype == TG_Q_ANY4_GLOBAL && cur.b != table_b)) {  // (a global LUT is one per PROBLEM of the batch)
       table_b = cur.b;
       uint32_t hw = lp[0];
@@ -677,9 +653,7 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
       }
     }
     // the next item's LUT rows (and activation sums) travel while this item is computed (the last item re-reads its own)
-#ifndef TG_PAIR_NOLP
     if (lut_loaded) lut_request(inext);
-#endif
     xs_request(inext);
     __syncthreads();  // table and activations visible (and every thread is done with the previous item's partial sums)
 
@@ -734,7 +708,7 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
     auto finalize = [&]() {
 #pragma unroll
       for (int t = 0; t < TILES; ++t) {
-        if constexpr (DIFF && RF == 1 && !QMX && TG_PAIR_FIN_ASM) {
+        if constexpr (DIFF && RF == 1 && !QMX) {
           // m = 1: four single-register instructions per tile, spelled out.  Left to the compiler the two tiles' updates become
           // v_pk_* on register PAIRS; at the 128-VGPR budget the only aligned pair it finds overlaps an accumulator tuple, which
           // it then moves out of the way and back (17 v_mov_b64 per group and wave).
@@ -762,7 +736,7 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
         // keep the accumulator one opaque 16-register value: when only element 0 is read (m = 1) the compiler's
         // sub-register liveness otherwise scatters the MFMA chain over several overlapping tuples and spills.  (Not with
         // zero-C group starts: there the pin made the compiler copy the finished tuple, 16 v_mov_b64 per group.)
-        if constexpr (DIFF || TG_PAIR_PIN) asm volatile("" : "+v"(acc[t]));
+        if constexpr (DIFF) asm volatile("" : "+v"(acc[t]));
         if constexpr (RF == 1) asm volatile("" ::"v"(acc[t][1]), "v"(acc[t][2]), "v"(acc[t][3]));  // same purpose: as live as with m > 1
       }
     };

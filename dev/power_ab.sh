@@ -1,11 +1,11 @@
-# developer probe: steady time + sclk + power per library variant:  power_ab.sh "CFG" NAME NAME ...
+# developer probe: sustained time + sclk + socket power per library variant:  bash dev/power_ab.sh "CFG" NAME NAME ...
 set -u
 mkdir -p gpurun_out
 cfg=$1; shift
 cp any4_amd/lib/libtinygemm_hip.so /tmp/orig.so
 for v in "$@"; do
   if [ "$v" = orig ]; then cp /tmp/orig.so any4_amd/lib/libtinygemm_hip.so; else cp variants/$v.so any4_amd/lib/libtinygemm_hip.so; fi
-  AB_HOLD=5 python tools/dev/ab.py $cfg > /tmp/ab.out 2>&1 &
+  AB_HOLD=5 python tools/ab.py $cfg > /tmp/ab.out 2>&1 &
   pid=$!
   sleep 6.5
   s=""

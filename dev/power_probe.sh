@@ -3,7 +3,7 @@ set -u
 mkdir -p gpurun_out
 for cfg in "1,4096,4096,1,any4_rowwise,128" "8,4096,4096,1,any4_rowwise,128" "8,8192,8192,0,any4_rowwise,128"; do
   echo "=== $cfg"
-  AB_HOLD=8 python tools/dev/ab.py $cfg > /tmp/ab.out 2>&1 &
+  AB_HOLD=8 python tools/ab.py $cfg > /tmp/ab.out 2>&1 &
   pid=$!
   sleep 6
   for i in 1 2 3 4 5 6 7 8 9 10 11 12; do

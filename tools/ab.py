@@ -1,11 +1,13 @@
-"""Developer A/B on one GPU box: for the installed any4_amd/lib/libtinygemm_hip.so, check a stacked launch against the CPU
-oracle and time it in the steady state.   python tools/dev/ab.py [m,n,k,on_right,qtype,g[,L]] ...   (one process per library)"""
+"""One stacked tg_gemm_w4 launch per shape, checked against the CPU oracle and timed in the steady state: the command the counter
+passes of tools/gpu_round.sh profile, and the unit of a same-box A/B (dev/exp.sh).
+    python tools/ab.py [m,n,k,on_right,qtype,g[,L]] ...      AB_HOLD=<s>: seconds of continuous load before the samples (the chip
+    is power-capped: the first second after idle runs at a higher clock than the sustained state, dev/README.md)"""
 import ctypes
 import os
 import sys
 import time
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
 import bench

@@ -3,7 +3,7 @@
 counters of the kernels whose name contains a given substring into one JSON object.
 
     python tools/collect_counters.py --out gpurun_out/r03_counters_m8.json --match w4_gemm_pair_kernel \
-        --label "m=8 Bint4 4096^2" -- python tools/dev/ab.py 8,4096,4096,1,any4_rowwise,128
+        --label "m=8 Bint4 4096^2" -- python tools/ab.py 8,4096,4096,1,any4_rowwise,128
 
 Counters are collected in their own passes (never together with a trace); each pass holds what fits the gfx950 PMC slots
 (MI355X_MICROARCH.md, 'rocprofv3 PMC slots').  Values are the MEAN over the matching dispatches of a pass.
