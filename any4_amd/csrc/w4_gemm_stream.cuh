@@ -282,17 +282,9 @@ __global__ void __launch_bounds__(WAVES * 64, MINW) w4_gemm_stream_kernel(const 
       const uint32_t a0 = __builtin_amdgcn_perm(src, lane4, 0x0c0c0400u + ((uint32_t)byte_lo << 8));
       const uint32_t a1 = __builtin_amdgcn_perm(src, lane4, 0x0c0c0400u + ((uint32_t)byte_hi << 8));
       if constexpr (ABL == 1) return a0 ^ a1;  // ablation: no LDS lookups
-#ifdef TG_STREAM_D16  // experiment: two 16-bit reads into the halves of one register (ds_read_u16_d16 / _d16_hi), no merge op
-      typedef __attribute__((ext_vector_type(2))) uint16_t u16x2_t;
-      u16x2_t v;
-      v[0] = *(lds_cu16ptr)(a0 + 2u);
-      v[1] = *(lds_cu16ptr)(a1 + 2u);
-      return __builtin_bit_cast(uint32_t, v);
-#else
       const uint32_t lo = *(lds_cu16ptr)(a0 + 2u);
       const uint32_t hi = *(lds_cu32ptr)(a1);
       return lo | hi;
-#endif
     };
 
     // chunk c of the unit whose words are in L; X fragments come from the staged slab `xbuf`
