@@ -99,6 +99,7 @@ __device__ __forceinline__ void store_rows4(char* yb, const char* bias, int64_t 
 #include "w4_gemm_stream.cuh"
 #include "w4_gemm_pair.cuh"
 #include "w4_gemm_pair16.cuh"
+#include "w4_gemm_xr.cuh"
 #include "w8_gemm.cuh"
 
 #ifndef STREAM_MINW
@@ -641,7 +642,7 @@ enum { TG_PAIR_NA = -100 };
 #if !defined(TG_DEV) && !defined(TG_DEV_MIN)
 #if defined(TG_PAIR_R) || defined(TG_PAIR_ABL) || defined(TG_PAIR_MR1) || defined(TG_PAIR_NSG2) || defined(TG_PAIR_MR1_GPS) || defined(TG_PAIR_RA) ||   \
     defined(TG_PAIR_RA1) || defined(TG_PAIR_RB16) || defined(TG_B16_CHUNK) || defined(TG_PAIR_MIN_ITEMS) || defined(TG_XG_CHUNK) || defined(TG_PAIR_WGS) || \
-    defined(TG_PAIR_NSG2_M1) || defined(TG_PAIR_FORCE_XG)
+    defined(TG_PAIR_NSG2_M1) || defined(TG_PAIR_FORCE_XG) || defined(TG_XR_MIN_M) || defined(TG_XR_R)
 #error "the TG_PAIR_* / TG_XG_* / TG_B16_* tuning constants can only be overridden in developer builds (-DTG_DEV or -DTG_DEV_MIN)"
 #endif
 #endif
@@ -683,6 +684,14 @@ enum { TG_PAIR_NA = -100 };
 #ifndef TG_XG_CHUNK
 #define TG_XG_CHUNK 4          // consecutive work items per workgroup visit in the workspace variant of Bint4 weights (1: plain
                                // round-robin): m = 8: 4096^2 66.1 -> 66.5 %, 8192^2 67.3 -> 68.6 %; Aint4 weights keep 1
+#endif
+#ifndef TG_XR_MIN_M
+#define TG_XR_MIN_M 2          // activation rows from which the register-resident-activation kernel (w4_gemm_xr.cuh) takes stacked launches
+                               // (same-box A/B against the kernels it replaces, 4096^2: m = 2 71.9 vs 69.7 %, 4: 68.9 vs 66.9, 8: 66.2 vs 62.7,
+                               //  16: 65.2 vs 46.0; m = 1 stays on the 32x32x16 kernel, 77 %)
+#endif
+#ifndef TG_XR_R
+#define TG_XR_R 4              // super-tiles a wave of that kernel keeps in flight
 #endif
 #ifndef TG_PAIR_WGS
 #define TG_PAIR_WGS 512        // persistent workgroups: two per CU (768 / 1024: +4 % / +1 % time)
@@ -1082,6 +1091,77 @@ int launch_pair_b16(GemmParams& p, int64_t batch, hipStream_t st) {
   return TG_PAIR_NA;
 }
 
+// Bint4 weights, stacked launches, TG_XR_MIN_M ... 16 activation rows, k = 4096: w4_gemm_xr_kernel (one 8-wave workgroup per CU, the
+// activations of a wave's k-slice resident in its registers, 64-row work items, two tables).  Workspace as for the 16x16x32 kernels.
+template <typename DT, int I, bool QMX>
+int launch_pair_xr(GemmParams& p, int64_t batch, hipStream_t st) {
+  if constexpr (QMX || I != 4) return TG_PAIR_NA;
+  else {
+#ifdef TG_DEV_MIN
+  if constexpr (!std::is_same<DT, BF16>::value) return TG_PAIR_NA;
+  else {
+#endif
+  constexpr int NCH = 16;
+  if (p.m > 16 || p.m < TG_XR_MIN_M || p.norm_w || p.epilogue) return TG_PAIR_NA;
+  if (p.k != 256 * NCH || p.ksuper * 16 * I != p.k || p.wrows % 64 != 0 || p.ntiles * 8 != p.wrows) return TG_PAIR_NA;
+  const int g = 1 << p.gshift;
+  const int cpg = g / 32 < NCH ? g / 32 : NCH;  // 32-k chunks per group inside a wave's slice
+#ifdef TG_DEV_MIN
+  if (cpg != 4) return TG_PAIR_NA;
+#endif
+  if (cpg != 4 && cpg != 8) return TG_PAIR_NA;  // g = 128, 256 (g = 64: scale | zero words in every ring slot, 436 bytes of spills; g = 32: not instantiated)
+  XrParams xp;
+  xp.w = p.w; xp.qinfo = p.qinfo; xp.lut = p.lut; xp.y = p.y;
+  xp.m = p.m; xp.wrows = p.wrows; xp.k = p.k; xp.ntiles = p.ntiles; xp.ksuper = p.ksuper;
+  xp.gshift = p.gshift; xp.ngroups = p.ngroups; xp.qtype = p.qtype;
+  xp.xs_rows = p.m <= 4 ? 4 : p.m <= 8 ? 8 : 16;
+  xp.rblocks = (p.wrows + 63) / 64;
+  const int64_t items = (int64_t)xp.rblocks * batch;
+  if (items > INT32_MAX || items < 2 * 256) return TG_PAIR_NA;  // two items per workgroup at least
+  xp.items = (int32_t)items;
+  xp.lds_xs = 2 * 65536;
+  const unsigned lds = (unsigned)xp.lds_xs + (unsigned)p.ngroups * 64u;  // two tables, the activation sums
+  if (lds > 160u * 1024u) return TG_PAIR_NA;
+  xp.stride_xp = (int64_t)(p.m + 1) * p.k * 2;  // + a zero row
+  xp.stride_xsum = ((int64_t)p.ngroups * xp.xs_rows * 4 + 15) & ~(int64_t)15;
+  const int64_t need = batch * (xp.stride_xp + xp.stride_xsum);
+  p.ws_need = need;
+  if (!p.ws_query && (p.ws == nullptr || p.ws_bytes < need)) return TG_PAIR_NA;
+  xp.xp = p.ws;
+  xp.xsum = p.ws + batch * xp.stride_xp;
+  xp.stride_w = p.stride_w; xp.stride_qinfo = p.stride_qinfo; xp.stride_lut = p.stride_lut; xp.stride_y = p.stride_y;
+  xp.bias = p.bias; xp.stride_bias = p.stride_bias; xp.bias_row_stride = p.bias_row_stride;
+  xp.y_tc = p.y_tc; xp.y_tiles = (p.wrows + 15) / 16; xp.dry = p.dry;
+  if (p.dry) return TG_PLAN_PAIR_XR;
+  {  // the pre-pass shared with the 16x16x32 kernels (w4_xprep_kernel, la = 1)
+    PairParams pp;
+    pp.x = p.x; pp.xp = xp.xp; pp.xsum = xp.xsum; pp.x_tc = p.x_tc;
+    pp.m = p.m; pp.k = p.k; pp.gshift = p.gshift; pp.gch_mask = g / 32 - 1; pp.ngroups = p.ngroups; pp.xs_rows = xp.xs_rows;
+    pp.stride_x = p.stride_x; pp.stride_xp = xp.stride_xp; pp.stride_xsum = xp.stride_xsum;
+    const int rc = launch_xprep<DT>(pp, I, 16, batch, st, 1);
+    if (rc != 0) return rc;
+  }
+#define TG_XR_LAUNCH(CPG_)                                                  \
+  do {                                                                      \
+    constexpr auto kern = w4_gemm_xr_kernel<DT, I, NCH, CPG_, TG_XR_R>;     \
+    const int prc = prepare_lds_kernel<kern>();                             \
+    if (prc != 0) return prc;                                               \
+    hipLaunchKernelGGL(kern, dim3(256), dim3(512), lds, st, xp);            \
+  } while (0)
+#ifdef TG_DEV_MIN
+  TG_XR_LAUNCH(4);
+#else
+  if (cpg == 4) TG_XR_LAUNCH(4);
+  else TG_XR_LAUNCH(8);
+#endif
+#undef TG_XR_LAUNCH
+  return launch_status();
+#ifdef TG_DEV_MIN
+  }
+#endif
+  }
+}
+
 template <typename DT, bool LAYOUT_A, int CANON, bool QMX>
 int launch_w4(GemmParams& p, int64_t coltiles, int64_t batch, hipStream_t st) {
   constexpr int KSTEP = LAYOUT_A ? 64 : 128;
@@ -1101,6 +1181,11 @@ int launch_w4(GemmParams& p, int64_t coltiles, int64_t batch, hipStream_t st) {
   // TG_NUM_FAST, weights on the B side: the pair-table kernel (group-scaled numerics) whenever its LDS plan fits
   if (p.numerics == TG_NUM_FAST) {
     int rc;
+    if constexpr (!LAYOUT_A) {
+      rc = launch_pair_xr<DT, 2 * WPL, QMX>(p, batch, st);
+      if (rc != TG_PAIR_NA) return rc;
+      p.ws_need = 0;
+    }
     if constexpr (LAYOUT_A) rc = launch_pair_a<DT, WPL, QMX>(p, batch, st);
     else rc = launch_pair<DT, 2 * WPL, QMX>(p, batch, st);
     if (rc != TG_PAIR_NA) return rc;
@@ -1363,7 +1448,7 @@ static int gemm_w4_impl(const tg_w4_gemm* a, int device, tg_stream_t stream, int
   int rc;
   if (a->dtype == TG_BF16) rc = on_right ? launch_w4_c<BF16, false>(p, canon, coltiles, batch, st) : launch_w4_c<BF16, true>(p, canon, coltiles, batch, st);
   else rc = on_right ? launch_w4_c<F16, false>(p, canon, coltiles, batch, st) : launch_w4_c<F16, true>(p, canon, coltiles, batch, st);
-  if (ws_need) *ws_need = rc == TG_PLAN_PAIR ? p.ws_need : 0;
+  if (ws_need) *ws_need = (rc == TG_PLAN_PAIR || rc == TG_PLAN_PAIR_XR) ? p.ws_need : 0;
   return rc;
 }
 

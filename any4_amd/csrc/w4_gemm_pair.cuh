@@ -388,7 +388,9 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
 #pragma unroll
       for (int i = 0; i < NXW; ++i) {
         if constexpr (T16) {  // chunk s CPS + i: a block of 4 k-quads x (rows + the zero row) pieces
-          sl.xw[i] = *reinterpret_cast<const u32x4*>(rw.xpb + uni((sv * CPS + (uint32_t)i) * rw.xblk) + pin(rw.xoff[0]));
+          if constexpr (ABL == 9 || ABL == 13) sl.xw[i] = u32x4{rw.xoff[0], (uint32_t)s, 0x3f803f80u, 0x3f803f80u};  // ablation: no activation loads
+          else if constexpr (ABL == 12) sl.xw[i] = *reinterpret_cast<const u32x4*>(rw.xpb + uni((uint32_t)i * rw.xblk) + pin(rw.xoff[0]));  // ablation: every chunk reads the first block (L1 hits)
+          else sl.xw[i] = *reinterpret_cast<const u32x4*>(rw.xpb + uni((sv * CPS + (uint32_t)i) * rw.xblk) + pin(rw.xoff[0]));
           continue;
         }
         if constexpr (ABL == 9) sl.xw[i] = u32x4{rw.xoff[i], (uint32_t)s, 0x3f803f80u, 0x3f803f80u};  // ablation: no activation loads
@@ -400,7 +402,7 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
       if (t < WT) {  // (compile-time; the A side's two tiles share one set of words)
         const int tw = t < WT ? t : 0;
         const char* src = rw.wb + uni(sv * (uint32_t)((LA ? 128 : 64) * I)) + pin(rw.wbase[tw]);
-        if constexpr (ABL == 3) {
+        if constexpr (ABL == 3 || ABL == 13) {
 #pragma unroll
           for (int j = 0; j < NW; ++j) sl.w[tw][j] = (uint32_t)(s * 7 + j + t);
         } else if constexpr (NW == 1) {

@@ -1,0 +1,396 @@
+// w4_gemm_xr.cuh -- the pair-table W4A16 kernel with REGISTER-RESIDENT activations ("XR"): Bint4 weights, up to 16 activation rows,
+// k = 32 * 8 * NCH (k = 4096: NCH = 16).
+//
+// Same contract and numerics as w4_gemm_pair.cuh (TG_NUM_FAST, group-scaled; reference TinyGemmImpl.cuh:23-345 with
+// BLayout_TC_int4, MatrixLayoutB.cuh:686-1101, Dequantization.cuh:55-178).  Why another decomposition: with 9 ... 16 activation
+// rows the 16x16x32 variant of w4_gemm_pair.cuh re-reads the whole activation block for every 32-row work item -- two bytes of
+// activations through the vector-memory path per byte of weights, measured as 26 % of its time (same-box ablation)
+// -- and the 64 KiB pair table leaves no LDS to keep the block in.  The register file does: a wave only ever needs the
+// activations of ITS k-slice, 16 rows x 512 k = 16 KiB = 64 VGPRs, IF the wave may use 256 registers.  So:
+//
+//   workgroup  = 8 waves, ONE per CU (256 VGPRs per lane), persistent over a contiguous range of work items; item = 64 weight
+//                rows (four 16-row MFMA tiles) x the whole k; wave w walks the k-slice w (split-K 8, partial sums meet in LDS
+//                and are added in wave order: deterministic).
+//   MFMA       = v_mfma_f32_16x16x32: A operand = activations (lane (i = lane & 15, kb = lane >> 4): row i, the 16-byte
+//                piece (chunk, kb) of the byte-order arrangement of w4_xprep_kernel), B operand = weights, D[i][n]: lane (n, kb)
+//                holds activation rows 4 kb + r of ITS weight row, so scale / zero are per-lane scalars.
+//   activations= xr[NCH]: the wave's NCH pieces, loaded from the workspace once per PROBLEM of the batch (not per item).
+//   weights    = "load layout": lane (n = lane & 15, b = (lane >> 4) & 1, a = lane >> 5) reads the 4 I bytes of row
+//                32 u + 16 b + n (tile 2 u + b of the item) at lane-quads 2 a, 2 a + 1 of the reference layout: one wave-load =
+//                four fully used 256-byte segments (I = 4).
+//   table      = [256 byte values][64 columns] x 4 bytes, column = row of the item, every row ONCE: in the load layout a 32-lane
+//                LDS access group (n, b) touches 32 distinct rows = 32 distinct banks.  The looked-up registers V (quad 2 a) and
+//                W (quad 2 a + 1) then go through ONE v_permlane16_swap: V' = tile 2 u at quad 2 a + b = kb, W' = tile 2 u + 1 at
+//                quad kb -- the two B operands.  6 vector ops per packed word instead of 4; the LDS work per weight is that of
+//                the m = 1 kernel and the table is built once per 64 rows.
+//   two tables = the NEXT item's table is built into the other 64 KiB buffer by steps interleaved with the second half of the
+//                main loop (its LUT rows are requested at the item's start), so no wave ever waits for a table.
+//   tail       = partial sums over the (finished) current table, three barriers per item; the weight ring (R super-tiles per
+//                wave, refilled with the next item's positions) keeps streaming through it.
+#pragma once
+#ifndef XR_ABL
+#define XR_ABL 0  // developer ablations (dev/README.md): 1 no table lookups, 3 no weight loads, 4 no MFMA, 5 no table build, 6 no split-K tail; 0 in the product
+#endif
+
+struct XrParams {
+  const char* w;
+  const char* qinfo;
+  const char* lut;
+  char* y;
+  const char* xp;    // workspace: [problem][32-k chunk][k-quad][m + 1 rows][16 bytes] (w4_xprep_kernel, la = 1)
+  const char* xsum;  // f32 [problem][group][xs_rows]
+  int64_t stride_xp, stride_xsum;
+  int32_t m, wrows, k;
+  int32_t ntiles, ksuper, gshift, ngroups, qtype;
+  int32_t xs_rows;   // rows per group in xsum (4, 8 or 16)
+  int32_t rblocks;   // 64-row blocks per problem
+  int32_t items;     // rblocks * batch
+  int32_t lds_xs;    // LDS byte offset of the staged activation sums, f32 [ngroups][16] (behind the two tables)
+  int64_t stride_w, stride_qinfo, stride_lut, stride_y;
+  const char* bias;
+  int64_t stride_bias, bias_row_stride;
+  int32_t y_tc, y_tiles;
+  int32_t dry;
+};
+
+// I   = innerKTiles of the Bint4 layout (2, 4, 8)
+// NCH = 32-k chunks of a wave's k-slice (k = 256 NCH)
+// CPG = 32-k chunks per quantisation group, at most NCH (a group that spans several waves' slices: CPG = NCH)
+// R   = super-tiles a wave keeps in flight
+template <typename DT, int I, int NCH, int CPG, int R>
+__global__ void __launch_bounds__(512, 2) w4_gemm_xr_kernel(const XrParams p) {
+  constexpr int WAVES = 8;
+  constexpr int CPS = I / 2;                       // 32-k chunks per super-tile
+  constexpr int NST = NCH / CPS;                   // super-tiles of a wave's slice
+  constexpr int NWL = 2 * CPS;                     // packed words per lane, tile pair and super-tile
+  constexpr int GPS = CPG < CPS ? CPS / CPG : 1;   // groups per super-tile
+  constexpr int SPG = CPG > CPS ? CPG / CPS : 1;   // super-tiles per group
+  static_assert(NCH % CPS == 0 && NST % R == 0 && NCH % CPG == 0, "slice = whole super-tiles, whole rounds of the ring, whole groups");
+  static_assert(NCH >= 8 && NCH % 8 == 0, "the table build is spread over the second half of the slice");
+  constexpr uint32_t TABLE = 65536u;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ln = lane & 15, lb = (lane >> 4) & 1, la = lane >> 5;
+  const uint32_t lds_xs = (uint32_t)p.lds_xs;
+
+  // ---- work items: a contiguous range per workgroup (the activation registers change only when the problem does) ----
+  const int it_begin = (int)(((int64_t)blockIdx.x * p.items) / gridDim.x);
+  const int it_end = (int)(((int64_t)(blockIdx.x + 1) * p.items) / gridDim.x);
+  if (it_begin >= it_end) return;
+  struct Item {
+    int b, rb;
+  };
+  Item cur{it_begin / p.rblocks, it_begin % p.rblocks};
+
+  // ---- per-lane addressing of an item ----
+  // (the host guarantees wrows % 64 == 0: no row of an item is padding, so tile pair u / tile t are at wave-uniform distances
+  //  from the lane's first row and need no registers of their own)
+  struct Rows {
+    uint32_t wbase;  // byte offset of this lane's words in super-tile 0 of tile pair 0
+    uint32_t qrow4;  // byte offset of tile 0's row (lane & 15) in a group's scale | zero words
+    const char* wb;
+    const char* qb;
+  };
+  const uint32_t pair_stride = (uint32_t)(4 * p.ksuper * 32 * 2 * I);  // bytes between the tile pairs' words (four 8-row tiles)
+  auto rows_of = [&](const Item& e) -> Rows {
+    Rows r;
+    const int row = e.rb * 64 + 16 * lb + ln;
+    r.wbase = ((uint32_t)(row >> 3) * (uint32_t)p.ksuper * 32u + (uint32_t)(4 * (row & 7) + 2 * la)) * (uint32_t)(2 * I);
+    r.qrow4 = (uint32_t)(e.rb * 64 + ln) * 4u;
+    r.wb = p.w + (int64_t)e.b * p.stride_w;
+    r.qb = p.qinfo + (int64_t)e.b * p.stride_qinfo;
+    return r;
+  };
+
+  // ---- ring of R super-tiles ----
+  struct Slot {
+    uint32_t w[2][NWL];
+    uint32_t q[4][GPS];
+  };
+  Slot ring[R];
+  auto pin = [](uint32_t& v) -> uint32_t { asm volatile("" : "+v"(v)); return v; };
+  auto uni = [](uint32_t v) -> uint32_t { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
+  const int s_begin = wave * NST;
+  // position l of the slice (compile-time after unrolling); an invalid request (past the last item) re-reads super-tile 0:
+  // issued all the same so that the number of loads in flight is the same on every path (w4_gemm_pair.cuh, issue)
+  auto issue = [&](Rows& rw, int l, Slot& sl, bool valid) {
+    const uint32_t sv = valid ? (uint32_t)(s_begin + l) : 0u;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const char* src = rw.wb + uni(sv * (uint32_t)(64 * I) + (uint32_t)u * pair_stride) + pin(rw.wbase);
+      if constexpr (XR_ABL == 3) {  // ablation: no weight loads
+#pragma unroll
+        for (int j = 0; j < NWL; ++j) sl.w[u][j] = (uint32_t)(l * 0x01030507 + j * 0x11 + u) + rw.wbase;
+      } else if constexpr (NWL == 2) {
+        const u32x2 v = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(src));
+        sl.w[u][0] = v[0]; sl.w[u][1] = v[1];
+      } else {
+#pragma unroll
+        for (int v4 = 0; v4 < NWL / 4; ++v4) {
+          const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src) + v4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) sl.w[u][4 * v4 + j] = v[j];
+        }
+      }
+    }
+    if (l % SPG == 0) {  // (compile-time) the first super-tile of its group(s): scale | zero words
+#pragma unroll
+      for (int gg = 0; gg < GPS; ++gg) {
+        const uint32_t g = (uint32_t)(((sv * CPS + gg * CPG) * 32) >> p.gshift);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          sl.q[t][gg] = *reinterpret_cast<const uint32_t*>(rw.qb + uni(g * (uint32_t)p.wrows * 4u + (uint32_t)(t * 64)) + pin(rw.qrow4));
+      }
+    }
+  };
+
+  // ---- LUT rows of this thread's table column (= row of the item), requested one item ahead ----
+  u32x4 lpa, lpb;  // (two register vectors, every element index a constant: a private ARRAY here was promoted to static LDS)
+  uint32_t lhw;    // the LUT values 2 wave, 2 wave + 1 of the column: its own load (a select chain over the eight dwords by the wave
+                   // index became a dynamically indexed stack object: scratch loads behind vmcnt(0) in the main loop)
+  auto lpe = [&](int i) -> uint32_t { return i < 4 ? lpa[i & 3] : lpb[i & 3]; };
+  const int tcol = tid & 63;
+  const bool lut_loaded = p.qtype == TG_Q_ANY4_GLOBAL || p.qtype == TG_Q_ANY4_ROWWISE;
+  auto lut_request = [&](const Item& e) {
+    const int lrow = min(e.rb * 64 + tcol, p.wrows - 1);
+    const char* lsrc = p.lut + (int64_t)e.b * p.stride_lut + (p.qtype == TG_Q_ANY4_ROWWISE ? (int64_t)lrow * 32 : 0);
+    lpa = reinterpret_cast<const u32x4*>(lsrc)[0];
+    lpb = reinterpret_cast<const u32x4*>(lsrc)[1];
+    lhw = reinterpret_cast<const uint32_t*>(lsrc)[wave];
+  };
+  if (lut_loaded) {
+    lut_request(cur);
+  } else {  // int4: code - 8, exact
+#pragma unroll
+    for (int e = 0; e < 16; e += 2) {
+      const uint32_t v = DT::pack2((float)(e - 8), (float)(e - 7));
+      if (e < 8) lpa[(e >> 1) & 3] = v;
+      else lpb[(e >> 1) & 3] = v;
+    }
+    lhw = DT::pack2((float)(2 * wave - 8), (float)(2 * wave - 7));
+  }
+  // table build: thread = (column, high nibbles 2 wave and 2 wave + 1); step a = low nibble a: entries (lut[a], lut[2 wave (+1)])
+  auto build_step = [&](uint32_t buf, int a, uint32_t hw) {
+    const uint32_t e0 = __builtin_amdgcn_perm(hw, lpe(a >> 1), (a & 1) ? 0x05040302u : 0x05040100u);
+    const uint32_t e1 = __builtin_amdgcn_perm(hw, lpe(a >> 1), (a & 1) ? 0x07060302u : 0x07060100u);
+    const lds_u32ptr tb = (lds_u32ptr)(buf * TABLE + (uint32_t)(wave * 2 * 16 * 256 + tcol * 4));
+    tb[a * 64] = e0;
+    tb[(16 + a) * 64] = e1;
+  };
+
+  // ---- activations of a problem: this lane's NCH pieces and the staged sums ----
+  u32x4 xr[NCH];
+  const uint32_t xblk = (uint32_t)((p.m + 1) * 64);  // bytes of one chunk's block: 4 k-quads x (m rows + the zero row)
+  uint32_t xoff = (uint32_t)(((lane >> 4) * (p.m + 1) + min(lane & 15, p.m)) * 16);
+  auto x_load = [&](int b) {
+    const char* xb = p.xp + (int64_t)b * p.stride_xp;
+#pragma unroll
+    for (int ci = 0; ci < NCH; ++ci) xr[ci] = *reinterpret_cast<const u32x4*>(xb + uni((uint32_t)(wave * NCH + ci) * xblk) + pin(xoff));
+  };
+  auto xs_stage = [&](int b, int t0) {  // f32 [ngroups][16] in LDS, rows >= m zero; t0 = the thread's index
+    const float* src = reinterpret_cast<const float*>(p.xsum + (int64_t)b * p.stride_xsum);
+    for (int idx = t0; idx < p.ngroups * 16; idx += 512) {
+      const int g = idx >> 4, a = idx & 15;
+      *(lds_fptr)(lds_xs + (uint32_t)(idx * 4)) = a < p.m ? src[g * p.xs_rows + a] : 0.f;
+    }
+  };
+
+  // ---- prologue: first item's table (buffer 0) and activations, the first R super-tiles ----
+  Rows rcur = rows_of(cur);
+  x_load(cur.b);
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+    __builtin_amdgcn_sched_barrier(0);
+    issue(rcur, j, ring[j], true);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  {
+    const uint32_t hw = lhw;
+#pragma unroll
+    for (int a = 0; a < 16; ++a) build_step(0u, a, hw);
+  }
+  xs_stage(cur.b, tid);
+  __syncthreads();
+
+  // lookup address = byte << 8 | column << 2 | buffer << 16: one v_perm_b32 of the word with (column << 2 | buffer << 8)
+  uint32_t colreg[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) colreg[u] = (uint32_t)((32 * u + 16 * lb + ln) * 4);
+  uint32_t buf = 0u;
+  f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+  for (int it = it_begin; it < it_end; ++it) {
+    const bool has_next = it + 1 < it_end;
+    Item inext = cur;
+    if (has_next) {
+      inext.rb = cur.rb + 1;
+      if (inext.rb == p.rblocks) { inext.rb = 0; inext.b = cur.b + 1; }
+    }
+    Rows rnext = rows_of(inext);
+    if (lut_loaded) lut_request(inext);  // (the last item asks for its own rows again)
+    const int row0 = cur.rb * 64;
+
+    f32x4 acc[4];
+    float yacc[4][4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      acc[t] = zero4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) yacc[t][r] = 0.f;
+    }
+    uint32_t gq[4] = {0u, 0u, 0u, 0u};  // scale | zero of the current group, packed as loaded
+    // a finished group gi of tile pair u: y += scale * acc + zero * sum(x); the sums come from LDS here (two reads per group)
+    auto finalize_pair = [&](int u, int gi) {
+      const uint32_t g = (uint32_t)(((wave * NCH + gi * CPG) * 32) >> p.gshift);
+      const f32x4 xsv = *(lds_cf32x4ptr)(lds_xs + uni(g * 64u) + (uint32_t)((lane >> 4) * 16));
+#pragma unroll
+      for (int t = 2 * u; t < 2 * u + 2; ++t) {
+        const float gs = DT::lo_f32(gq[t]), gz = DT::hi_f32(gq[t]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) yacc[t][r] = __builtin_fmaf(gz, xsv[r], __builtin_fmaf(gs, acc[t][r], yacc[t][r]));
+      }
+    };
+    uint32_t hw = 0u;
+
+    // ---- main loop, fully unrolled (every register index is a constant).  Stage = (chunk ci, tile pair u): 8 table lookups, one
+    // swap per looked-up register pair, two MFMAs.  Software-pipelined by hand: the lookups of stage st + 1 are issued before stage st
+    // is consumed (a workgroup has the CU to itself, two waves per SIMD: nobody else hides the LDS latency); lgkmcnt counts to 15, so
+    // one stage of 8 reads ahead is what the counter can express.
+    constexpr int NSTG = 2 * NCH;
+    u32x4 pv[2], pw[2];  // looked-up registers of two stages: V (quad 2 a), W (quad 2 a + 1)
+    auto look = [&](int st) {
+      const int ci = st >> 1, u = st & 1, l = ci / CPS, c = ci % CPS;
+      const Slot& sl = ring[l % R];
+      const uint32_t wv = sl.w[u][c], ww = sl.w[u][CPS + c];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t av = __builtin_amdgcn_perm(wv, colreg[u], 0x0c010400u + ((uint32_t)j << 8));
+        const uint32_t aw = __builtin_amdgcn_perm(ww, colreg[u], 0x0c010400u + ((uint32_t)j << 8));
+        if constexpr (XR_ABL == 1) { pv[st & 1][j] = av; pw[st & 1][j] = aw; }  // ablation: no lookups
+        else { pv[st & 1][j] = *(lds_cu32ptr)(av); pw[st & 1][j] = *(lds_cu32ptr)(aw); }
+      }
+    };
+    look(0);
+#pragma unroll
+    for (int st = 0; st < NSTG; ++st) {
+      const int ci = st >> 1, u = st & 1, l = ci / CPS, c = ci % CPS;
+      Slot& sl = ring[l % R];
+      const bool gfirst = ci % CPG == 0;
+      const int gi = ci / CPG;
+      if (st + 1 < NSTG) look(st + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (gfirst) {
+        if (ci > 0) finalize_pair(u, gi - 1);  // the previous group of this pair's tiles, behind the next stage's lookups
+        const int gg = GPS == 1 ? 0 : c / CPG;
+#pragma unroll
+        for (int t = 2 * u; t < 2 * u + 2; ++t) gq[t] = sl.q[t][gg];
+      }
+      {
+        u32x4 b0, b1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const auto sw = __builtin_amdgcn_permlane16_swap(pv[st & 1][j], pw[st & 1][j], false, false);
+          b0[j] = sw[0];
+          b1[j] = sw[1];
+        }
+        if constexpr (XR_ABL == 4) {  // ablation: no MFMA
+          acc[2 * u][0] += u2f(b0[0] ^ b0[1] ^ b0[2] ^ b0[3] ^ xr[ci][0]);
+          acc[2 * u + 1][0] += u2f(b1[0] ^ b1[1] ^ b1[2] ^ b1[3] ^ xr[ci][1]);
+        } else {
+          acc[2 * u] = DT::mfma(xr[ci], b0, gfirst ? zero4 : acc[2 * u]);
+          acc[2 * u + 1] = DT::mfma(xr[ci], b1, gfirst ? zero4 : acc[2 * u + 1]);
+        }
+      }
+      if (u == 1) {
+        // the next item's table, one step per chunk of the slice's second half
+        if (ci >= NCH / 2 && XR_ABL != 5) {
+          if (ci == NCH / 2) hw = lhw;
+          constexpr int SPC = 32 / NCH;  // build steps per chunk
+#pragma unroll
+          for (int e = 0; e < SPC; ++e) build_step(buf ^ 1u, (ci - NCH / 2) * SPC + e, hw);
+        }
+        // refill: position l + R of this item, or of the next one (the stage's lookups of this slot were issued a stage ago)
+        if (c == CPS - 1) {
+          if (l + R < NST) issue(rcur, l + R, sl, true);
+          else issue(rnext, l + R - NST, sl, has_next);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    finalize_pair(0, NCH / CPG - 1);
+    finalize_pair(1, NCH / CPG - 1);
+
+    // ---- the next problem's activations (rare: once per rblocks items) ----
+    const bool new_problem = has_next && inext.b != cur.b;
+    if (new_problem) x_load(inext.b);
+
+    // ---- split-K tail: the partial sums of the 8 waves meet in LDS (over the finished table) and are added in wave order ----
+    if constexpr (XR_ABL == 6) {  // ablation: no split-K tail (one barrier per item, nothing stored)
+      __syncthreads();
+      if (yacc[0][0] == 123.f) *reinterpret_cast<float*>(p.y) = yacc[1][1] + yacc[2][2] + yacc[3][3];
+      if (new_problem) xs_stage(inext.b, tid);
+      rcur = rnext; cur = inext; buf ^= 1u; colreg[0] ^= 0x100u; colreg[1] ^= 0x100u;
+      continue;
+    }
+    // The tail's per-thread indices are re-derived from a lane id read HERE (v_mbcnt, opaque): derived from the kernel's `tid` they
+    // are loop-invariant, get hoisted in front of the item loop, spilled around the 256-register main loop and reloaded from
+    // scratch behind s_waitcnt vmcnt(0) -- which drains the weight ring once per item.
+    uint32_t lane_t;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_t));
+    const int tid_t = wave * 64 + (int)lane_t;
+    __syncthreads();  // every wave is done with this item's table; the next item's table is complete
+    const uint32_t lds_red = buf * TABLE;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) *(lds_fptr)(lds_red + (uint32_t)((((wave * 4 + t) * 4 + r) * 64 + (int)lane_t) * 4)) = yacc[t][r];
+    if (new_problem) xs_stage(inext.b, tid_t);
+    __syncthreads();
+    {
+      // this thread's two outputs o = tid, tid + 512: (tile t, register r, lane l) -> activation row a, weight row; their eight
+      // partial sums each: eight ds_read2st64_b32 issued together, spelled out (at the kernel's register limit the compiler's own
+      // schedule was a dependent read -> wait -> add round per partial sum: sixteen LDS round trips with the CU otherwise idle)
+      const int l = tid_t & 63, q0 = tid_t >> 6;  // (o + 512 >> 6 = q0 + 8: tile t + 2, the same r and l)
+      const int t0 = q0 >> 2, r = q0 & 3;
+      const int a = r + 4 * (l >> 4);
+      const uint32_t pa = lds_red + (uint32_t)(((t0 * 4 + r) * 64 + l) * 4);
+      f32x2 v0, v1, v2, v3, w0, w1, w2, w3;
+      asm volatile(
+          "ds_read2st64_b32 %0, %8 offset1:16\n\t"
+          "ds_read2st64_b32 %1, %8 offset0:32 offset1:48\n\t"
+          "ds_read2st64_b32 %2, %8 offset0:64 offset1:80\n\t"
+          "ds_read2st64_b32 %3, %8 offset0:96 offset1:112\n\t"
+          "ds_read2st64_b32 %4, %9 offset1:16\n\t"
+          "ds_read2st64_b32 %5, %9 offset0:32 offset1:48\n\t"
+          "ds_read2st64_b32 %6, %9 offset0:64 offset1:80\n\t"
+          "ds_read2st64_b32 %7, %9 offset0:96 offset1:112\n\t"
+          "s_waitcnt lgkmcnt(0)"
+          : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3), "=&v"(w0), "=&v"(w1), "=&v"(w2), "=&v"(w3)
+          : "v"(pa), "v"(pa + 2u * 4u * 64u * 4u)
+          : "memory");
+      float sums[2];
+      sums[0] = ((((((v0[0] + v0[1]) + v1[0]) + v1[1]) + v2[0]) + v2[1]) + v3[0]) + v3[1];
+      sums[1] = ((((((w0[0] + w0[1]) + w1[0]) + w1[1]) + w2[0]) + w2[1]) + w3[0]) + w3[1];
+      char* yb = p.y + (int64_t)cur.b * p.stride_y;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int row = row0 + 16 * (t0 + 2 * e) + (l & 15);
+        if (a < p.m && (XR_ABL != 7 || sums[e] == 123.456f)) {  // (ablation 7: no output stores)
+          uint16_t o16 = DT::from_f32(sums[e]);
+          if (p.bias)  // rounded sum + bias, rounded again: bit-identical to the reference module's separate `y + bias`
+            o16 = DT::from_f32(DT::lo_f32(o16) + DT::lo_f32(*reinterpret_cast<const uint16_t*>(p.bias + (int64_t)cur.b * p.stride_bias + ((int64_t)a * p.bias_row_stride + row) * 2)));
+          *reinterpret_cast<uint16_t*>(yb + (p.y_tc ? tc_a_index(a, row, p.y_tiles) : (int64_t)a * p.wrows + row) * 2) = o16;
+        }
+      }
+    }
+    if constexpr (XR_ABL != 8)  // (ablation 8: without this barrier -- a race, timing only)
+    __syncthreads();  // the partial sums are consumed before the next item's build steps write into this buffer
+    rcur = rnext;
+    cur = inext;
+    buf ^= 1u;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) colreg[u] ^= 0x100u;
+  }
+}

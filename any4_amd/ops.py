@@ -90,14 +90,15 @@ def numerics(name: str):
             _tls.numerics = prev
 
 
-_PLANS = {_lib.TG_PLAN_SPLITK: "splitk", _lib.TG_PLAN_STREAM: "stream", _lib.TG_PLAN_PAIR: "pair"}
+_PLANS = {_lib.TG_PLAN_SPLITK: "splitk", _lib.TG_PLAN_STREAM: "stream", _lib.TG_PLAN_PAIR: "pair", _lib.TG_PLAN_PAIR_XR: "pair_xr"}
 
 
 def gemm_w4_plan(m: int, wrows: int, k: int, group: int, qtype: int, weight_on_right: bool = True, inner_k_tiles: int = 4,
-                 dtype=torch.bfloat16, batch: int = 1, numerics: str | None = None, workspace: bool = True) -> str:
+                 dtype=torch.bfloat16, batch: int = 1, numerics: str | None = None, workspace: bool = True, detail: bool = False) -> str:
     """Which kernel family tg_gemm_w4 launches for this problem (tg_gemm_w4_plan; nothing is launched, no GPU needed):
-    'pair' = pair-table kernel, group-scaled numerics; 'stream' / 'splitk' = reference-numerics kernels.
-    `workspace`: the caller provides the scratch tg_gemm_w4_workspace_bytes asks for (the ops of this module do)."""
+    'pair' = pair-table kernels, group-scaled numerics; 'stream' / 'splitk' = reference-numerics kernels.
+    `workspace`: the caller provides the scratch tg_gemm_w4_workspace_bytes asks for (the ops of this module do).
+    `detail`: name the member of the pair-table family too ('pair_xr' = w4_gemm_xr_kernel, activations resident in registers)."""
     buf = ctypes.create_string_buffer(256)
     p = (ctypes.addressof(buf) + 63) & ~63  # a non-NULL, aligned dummy: the planner never dereferences data pointers
     args = W4Gemm(x=p, w=p, qinfo=p, lut=p, y=p, m=m, wrows=wrows, k=k, group=group, qtype=qtype,
@@ -111,7 +112,8 @@ def gemm_w4_plan(m: int, wrows: int, k: int, group: int, qtype: int, weight_on_r
             args.workspace, args.workspace_bytes = p, need
     rc = _L.tg_gemm_w4_plan(ctypes.byref(args), 0)
     _lib.check(rc if rc < 0 else 0, "tg_gemm_w4_plan")
-    return _PLANS[rc]
+    plan = _PLANS[rc]
+    return plan if detail else plan.split("_")[0]
 
 
 class _FusedBias:

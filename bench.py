@@ -571,12 +571,13 @@ def main():
             aa = make_args(_lib, ww, xx, qq, ll, yy, mm, nn, kk, gg, qtype, on_right, inner, layers, numerics)
             ws = attach_workspace(lib, aa, device)  # noqa: F841
             pl = ops.gemm_w4_plan(mm, nn, kk, gg, QT[qtype], on_right, inner, torch.bfloat16, layers, numerics)
+            pld = ops.gemm_w4_plan(mm, nn, kk, gg, QT[qtype], on_right, inner, torch.bfloat16, layers, numerics, detail=True)
             bl = alg_bytes(mm, nn, kk, gg, qtype)
             reps = max(10, int(0.25e6 / (layers * bl / 5e6)))  # ~0.25 s of launches
             us = timed(aa, reps) / layers
             chk = check_layers(ww, xx, qq, ll, yy, gg, qtype, on_right, inner, pl, layers=(0, -1), rows=128)
             return {"us_per_layer": round(us, 4), "GBps": round(bl / us / 1e3, 2), "frac": round(bl / us / 1e3 / HBM_PEAK_GBPS, 4),
-                    "algorithmic_bytes_per_layer": bl, "layers_per_launch": layers, "kernel_plan": pl, "numerics": numerics,
+                    "algorithmic_bytes_per_layer": bl, "layers_per_launch": layers, "kernel_plan": pld, "numerics": numerics,
                     "check": chk, "note": note}
 
         # N > 1: the other configs, the single-launch figures, the decode leg and the CPU baselines are N = 1 facts (the driver's

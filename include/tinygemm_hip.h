@@ -193,8 +193,10 @@ TG_API int tg_gemm_w4(const tg_w4_gemm* args, int device, tg_stream_t stream);
  * pointers are only checked for NULL / alignment).  Negative: the TG_E_* code tg_gemm_w4 would return.
  *   TG_PLAN_SPLITK  w4_gemm_kernel         one 16-wave split-K workgroup per 16-row tile (small launches), reference numerics
  *   TG_PLAN_STREAM  w4_gemm_stream_kernel  per-(row, group) tables of final 16-bit weights, reference numerics
- *   TG_PLAN_PAIR    w4_gemm_pair_kernel    per-row tables of LUT pairs, group-scaled numerics (TG_NUM_FAST only)  */
-enum { TG_PLAN_SPLITK = 1, TG_PLAN_STREAM = 2, TG_PLAN_PAIR = 3 };
+ *   TG_PLAN_PAIR    w4_gemm_pair_kernel    per-row tables of LUT pairs, group-scaled numerics (TG_NUM_FAST only)
+ *   TG_PLAN_PAIR_XR w4_gemm_xr_kernel      the same tables and numerics, activations resident in registers (Bint4 weights,
+ *                                          2 ... 16 activation rows, k = 4096, stacked launches)  */
+enum { TG_PLAN_SPLITK = 1, TG_PLAN_STREAM = 2, TG_PLAN_PAIR = 3, TG_PLAN_PAIR_XR = 4 };
 enum { TG_LAYOUT_RM = 0, TG_LAYOUT_TC_A = 1 };
 TG_API int tg_gemm_w4_plan(const tg_w4_gemm* args, int device);
 

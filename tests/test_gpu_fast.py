@@ -200,6 +200,103 @@ def test_pair_kernel_9_to_16_rows(T, oracle, case):
     assert_fast_close(oracle, y, codes, x, qinfo, lut, g, qtype, inner=inner, batch=copies)
 
 
+def _run_xr(T, codes, x, qinfo, lut, g, qtype, copies, bias=None, residual=False, tc=False):
+    """One stacked tg_gemm_w4 launch over `copies` problems with the SAME weights and DIFFERENT activations (problem j's rows are
+    x rolled by j along the batch: the register-resident activations of w4_gemm_xr_kernel must follow the problem); optional
+    fused bias / residual (bias_row_stride = wrows) and A-fragment-order activations / outputs.  Returns y [copies][m][n]."""
+    from any4_amd import _lib
+
+    L = _lib.load()
+    n, k = codes.shape
+    m = x.shape[0]
+    dt = x.dtype
+    packed1 = T.convert_matrix_to_m16n8k16_Bint4_layout(codes.to(DEV), 4)
+    rep = lambda t: None if t is None else t.to(DEV).unsqueeze(0).repeat(copies, *([1] * t.dim())).contiguous()
+    packed, qs, luts = rep(packed1.cpu()), rep(qinfo), rep(lut)
+    xs = torch.stack([torch.roll(x, j % m, 0) for j in range(copies)]).to(DEV).contiguous()
+    xin = xs
+    if tc:
+        xin = torch.stack([T.convert_matrix_to_m16n8k16_A_layout(xs[j], 1) for j in range(copies)]).contiguous()
+    bs = None
+    if bias is not None:
+        bs = rep(bias)
+    ys = torch.full((copies, m, n), float("nan"), dtype=dt, device=DEV)
+    yout = ys
+    if tc:
+        yout = torch.stack([T.convert_matrix_to_m16n8k16_A_layout(ys[j], 1) for j in range(copies)]).contiguous()
+    args = _lib.W4Gemm(x=xin.data_ptr(), w=packed.data_ptr(), qinfo=qs.data_ptr(), lut=(luts.data_ptr() if luts is not None else None),
+                       y=yout.data_ptr(), m=m, wrows=n, k=k, group=g, qtype=QT[qtype],
+                       dtype=_lib.TG_BF16 if dt == torch.bfloat16 else _lib.TG_F16, w_on_right=1, inner_k_tiles=4, batch=copies,
+                       stride_x=xin.stride(0) * 2, stride_w=packed.stride(0) * 4, stride_qinfo=qs.stride(0) * 2,
+                       stride_lut=(luts.stride(0) * 2 if luts is not None else 0), stride_y=yout.stride(0) * 2,
+                       numerics=_lib.TG_NUM_FAST, bias=(bs.data_ptr() if bs is not None else None),
+                       stride_bias=(bs.stride(0) * 2 if bs is not None else 0), bias_row_stride=(n if residual else 0),
+                       x_layout=1 if tc else 0, y_layout=1 if tc else 0)
+    need = L.tg_gemm_w4_workspace_bytes(ctypes.byref(args))
+    assert need > 0
+    ws = torch.empty(need + 64, dtype=torch.uint8, device=DEV)
+    ws.fill_(0xff)
+    args.workspace, args.workspace_bytes = ws.data_ptr(), need
+    assert L.tg_gemm_w4_plan(ctypes.byref(args), 0) == _lib.TG_PLAN_PAIR_XR
+    _lib.check(L.tg_gemm_w4(ctypes.byref(args), 0, torch.cuda.current_stream().cuda_stream), "stacked launch (xr)")
+    torch.cuda.synchronize()
+    if tc:
+        ys = torch.stack([T.convert_matrix_from_m16n8k16_A_layout(yout[j], m, n) for j in range(copies)])
+    return xs.cpu(), ys
+
+
+@pytest.mark.parametrize("case", [
+    # (n, m, g, qtype, dtype): w4_gemm_xr_kernel -- Bint4 weights, k = 4096, innerKTiles 4, 2 ... 16 activation rows, both
+    # instantiated group sizes, every quantisation type with a 16-bit LUT, both dtypes; n = 64: EVERY work item starts a new
+    # problem, n = 192: every third one
+    (64, 16, 128, "any4_rowwise", torch.bfloat16), (64, 9, 256, "any4_global", torch.bfloat16), (64, 2, 256, "int4", torch.bfloat16),
+    (192, 5, 128, "any4_rowwise", torch.bfloat16), (64, 13, 256, "any4_rowwise", torch.bfloat16), (64, 8, 128, "int4", torch.bfloat16),
+    (128, 16, 128, "any4_rowwise", torch.float16), (64, 3, 256, "int4", torch.float16), (64, 12, 128, "any4_global", torch.bfloat16),
+])
+def test_xr_kernel_vs_oracle(T, oracle, case):
+    """The register-resident-activation kernel against both oracles, problem by problem (each problem of the stacked launch has
+    its own activations), with workgroups that change problem every item / every third item."""
+    n, m, g, qtype, dtype = case
+    k = 4096
+    codes, x, qinfo, lut = rand_problem(n, k, g, m, qtype, dtype=dtype, seed=n + m + g)
+    copies = 512 * 64 // n + 5
+    xs, ys = _run_xr(T, codes, x, qinfo, lut, g, qtype, copies)
+    assert not torch.isnan(ys.float()).any()
+    for j in (0, 1, copies // 2, copies - 1):
+        assert_fast_close(oracle, ys[j], codes, xs[j], qinfo, lut, g, qtype, dtype=dtype, batch=copies)
+    # problems with the same activations (j and j + m: the same roll) give the same bits whichever workgroup computed them
+    assert torch.equal(ys[0].view(torch.int16), ys[m].view(torch.int16))
+    assert torch.equal(ys[1].view(torch.int16), ys[copies - 1 - (copies - 2) % m].view(torch.int16))
+
+
+def test_xr_kernel_bias_and_residual(T, oracle):
+    """Fused bias and fused residual (one bias row per activation row) on the xr kernel: bit-equal to the plain launch's result
+    plus a separate rounded add."""
+    n, m, g, k = 128, 11, 128, 4096
+    codes, x, qinfo, lut = rand_problem(n, k, g, m, "any4_rowwise", seed=77)
+    copies = 300
+    xs, y0 = _run_xr(T, codes, x, qinfo, lut, g, "any4_rowwise", copies)
+    gen = torch.Generator().manual_seed(5)
+    bias = torch.randn(n, generator=gen).bfloat16()
+    _, y1 = _run_xr(T, codes, x, qinfo, lut, g, "any4_rowwise", copies, bias=bias)
+    assert torch.equal((y0.float() + bias.to(DEV).float()).bfloat16().view(torch.int16), y1.view(torch.int16))
+    res = torch.randn(m, n, generator=gen).bfloat16()
+    _, y2 = _run_xr(T, codes, x, qinfo, lut, g, "any4_rowwise", copies, bias=res, residual=True)
+    assert torch.equal((y0.float() + res.to(DEV).float()).bfloat16().view(torch.int16), y2.view(torch.int16))
+
+
+def test_xr_kernel_fragment_order(T, oracle):
+    """A-fragment-order activations and outputs (x_layout = y_layout = TG_LAYOUT_TC_A; m a multiple of 16) on the xr kernel: the
+    row-major launch's bits, re-laid out."""
+    n, m, g, k = 128, 16, 128, 4096
+    codes, x, qinfo, lut = rand_problem(n, k, g, m, "any4_rowwise", seed=78)
+    copies = 300
+    xs, y_tc = _run_xr(T, codes, x, qinfo, lut, g, "any4_rowwise", copies, tc=True)
+    _, y_rm = _run_xr(T, codes, x, qinfo, lut, g, "any4_rowwise", copies)
+    assert torch.equal(y_tc.view(torch.int16), y_rm.view(torch.int16))
+    assert_fast_close(oracle, y_tc[7], codes, xs[7], qinfo, lut, g, "any4_rowwise", batch=copies)
+
+
 @pytest.mark.parametrize("case", [
     # (n, k, m, g, inner, qtype): activation blocks that do not fit next to the table -> workspace variant
     (64, 4096, 8, 64, 4, "any4_rowwise"), (72, 4096, 5, 128, 4, "any4_rowwise"), (64, 4096, 7, 256, 4, "int4"),

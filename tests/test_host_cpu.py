@@ -275,3 +275,25 @@ def test_bench_cpu_baseline_leg_and_byte_formula():
     assert "layers of the bench workload" in cb["sample"] and "physical cores" in cb["sample"]
     co = bench.cpu_baseline_oracle(1, 512, 512, 128, budget_s=0.2)
     assert co["value"] > 0 and co["cores"] >= 1
+
+
+def test_xr_kernel_routing():
+    """Which stacked launches the xr kernel takes (tg_gemm_w4_plan, no GPU work): Bint4, k = 4096, innerKTiles 4, rows a multiple
+    of 64, 2 <= m <= 16, g = 128 or 256, at least two work items per CU; everything else stays where it was."""
+    from any4_amd import ops
+
+    plan = lambda m, n, k, g, q, inner=4, batch=64, right=True: ops.gemm_w4_plan(m, n, k, g, {'int4': 0, 'any4_global': 1, 'any4_rowwise': 2, 'mx4': 3}[q], right, inner, batch=batch, detail=True)
+    for m in (2, 8, 9, 16):
+        for q in ("int4", "any4_global", "any4_rowwise"):
+            for g in (128, 256):
+                assert plan(m, 4096, 4096, g, q) == "pair_xr", (m, q, g)
+    assert plan(1, 4096, 4096, 128, "any4_rowwise") == "pair"             # m = 1: the 32x32x16 kernel
+    assert plan(8, 4096, 4096, 32, "int4") != "pair_xr"                   # g = 32
+    assert plan(8, 4096, 4096, 64, "int4") != "pair_xr"                   # g = 64
+    assert plan(8, 4096, 4096, 32, "mx4") != "pair_xr"                    # mx4
+    assert plan(8, 4096, 8192, 128, "any4_rowwise") != "pair_xr"          # k = 8192: 128 registers of activations per lane
+    assert plan(8, 4096, 4096, 128, "any4_rowwise", inner=8) != "pair_xr"
+    assert plan(8, 4104, 4096, 128, "any4_rowwise") != "pair_xr"          # rows not a multiple of 64
+    assert plan(8, 4096, 4096, 128, "any4_rowwise", batch=4) != "pair_xr"  # 256 items: fewer than two per CU
+    assert plan(8, 4096, 4096, 128, "any4_rowwise", right=False) != "pair_xr"  # Aint4 weights
+    assert plan(17, 4096, 4096, 128, "any4_rowwise") != "pair_xr"
