@@ -1092,7 +1092,7 @@ int launch_pair_b16(GemmParams& p, int64_t batch, hipStream_t st) {
 }
 
 // Bint4 weights, stacked launches, TG_XR_MIN_M ... 16 activation rows, k = 4096: w4_gemm_xr_kernel (one 8-wave workgroup per CU, the
-// activations of a wave's k-slice resident in its registers, 64-row work items, two tables).  Workspace as for the 16x16x32 kernels.
+// activations of a wave's k-slice resident in its registers, 64-row work items, two tables).  No workspace, no pre-pass.
 template <typename DT, int I, bool QMX>
 int launch_pair_xr(GemmParams& p, int64_t batch, hipStream_t st) {
   if constexpr (QMX || I != 4) return TG_PAIR_NA;
@@ -1109,12 +1109,11 @@ int launch_pair_xr(GemmParams& p, int64_t batch, hipStream_t st) {
 #ifdef TG_DEV_MIN
   if (cpg != 4) return TG_PAIR_NA;
 #endif
-  if (cpg != 4 && cpg != 8) return TG_PAIR_NA;  // g = 128, 256 (g = 64: scale | zero words in every ring slot, 436 bytes of spills; g = 32: not instantiated)
+  if (cpg != 2 && cpg != 4 && cpg != 8) return TG_PAIR_NA;  // g = 64, 128, 256 (g = 32: two groups per super-tile, not instantiated)
   XrParams xp;
   xp.w = p.w; xp.qinfo = p.qinfo; xp.lut = p.lut; xp.y = p.y;
   xp.m = p.m; xp.wrows = p.wrows; xp.k = p.k; xp.ntiles = p.ntiles; xp.ksuper = p.ksuper;
   xp.gshift = p.gshift; xp.ngroups = p.ngroups; xp.qtype = p.qtype;
-  xp.xs_rows = p.m <= 4 ? 4 : p.m <= 8 ? 8 : 16;
   xp.rblocks = (p.wrows + 63) / 64;
   const int64_t items = (int64_t)xp.rblocks * batch;
   if (items > INT32_MAX || items < 2 * 256) return TG_PAIR_NA;  // two items per workgroup at least
@@ -1122,25 +1121,12 @@ int launch_pair_xr(GemmParams& p, int64_t batch, hipStream_t st) {
   xp.lds_xs = 2 * 65536;
   const unsigned lds = (unsigned)xp.lds_xs + (unsigned)p.ngroups * 64u;  // two tables, the activation sums
   if (lds > 160u * 1024u) return TG_PAIR_NA;
-  xp.stride_xp = (int64_t)(p.m + 1) * p.k * 2;  // + a zero row
-  xp.stride_xsum = ((int64_t)p.ngroups * xp.xs_rows * 4 + 15) & ~(int64_t)15;
-  const int64_t need = batch * (xp.stride_xp + xp.stride_xsum);
-  p.ws_need = need;
-  if (!p.ws_query && (p.ws == nullptr || p.ws_bytes < need)) return TG_PAIR_NA;
-  xp.xp = p.ws;
-  xp.xsum = p.ws + batch * xp.stride_xp;
+  xp.x = p.x; xp.stride_x = p.stride_x; xp.x_tc = p.x_tc;  // (no pre-pass, no workspace: the kernel arranges the activations itself)
+  p.ws_need = 0;
   xp.stride_w = p.stride_w; xp.stride_qinfo = p.stride_qinfo; xp.stride_lut = p.stride_lut; xp.stride_y = p.stride_y;
   xp.bias = p.bias; xp.stride_bias = p.stride_bias; xp.bias_row_stride = p.bias_row_stride;
   xp.y_tc = p.y_tc; xp.y_tiles = (p.wrows + 15) / 16; xp.dry = p.dry;
   if (p.dry) return TG_PLAN_PAIR_XR;
-  {  // the pre-pass shared with the 16x16x32 kernels (w4_xprep_kernel, la = 1)
-    PairParams pp;
-    pp.x = p.x; pp.xp = xp.xp; pp.xsum = xp.xsum; pp.x_tc = p.x_tc;
-    pp.m = p.m; pp.k = p.k; pp.gshift = p.gshift; pp.gch_mask = g / 32 - 1; pp.ngroups = p.ngroups; pp.xs_rows = xp.xs_rows;
-    pp.stride_x = p.stride_x; pp.stride_xp = xp.stride_xp; pp.stride_xsum = xp.stride_xsum;
-    const int rc = launch_xprep<DT>(pp, I, 16, batch, st, 1);
-    if (rc != 0) return rc;
-  }
 #define TG_XR_LAUNCH(CPG_)                                                  \
   do {                                                                      \
     constexpr auto kern = w4_gemm_xr_kernel<DT, I, NCH, CPG_, TG_XR_R>;     \
@@ -1151,7 +1137,8 @@ int launch_pair_xr(GemmParams& p, int64_t batch, hipStream_t st) {
 #ifdef TG_DEV_MIN
   TG_XR_LAUNCH(4);
 #else
-  if (cpg == 4) TG_XR_LAUNCH(4);
+  if (cpg == 2) TG_XR_LAUNCH(2);
+  else if (cpg == 4) TG_XR_LAUNCH(4);
   else TG_XR_LAUNCH(8);
 #endif
 #undef TG_XR_LAUNCH

@@ -37,12 +37,11 @@ struct XrParams {
   const char* qinfo;
   const char* lut;
   char* y;
-  const char* xp;    // workspace: [problem][32-k chunk][k-quad][m + 1 rows][16 bytes] (w4_xprep_kernel, la = 1)
-  const char* xsum;  // f32 [problem][group][xs_rows]
-  int64_t stride_xp, stride_xsum;
+  const char* x;     // activations [problem][m][k] 16-bit, row-major or (x_tc) in A-fragment order
+  int64_t stride_x;
+  int32_t x_tc;
   int32_t m, wrows, k;
   int32_t ntiles, ksuper, gshift, ngroups, qtype;
-  int32_t xs_rows;   // rows per group in xsum (4, 8 or 16)
   int32_t rblocks;   // 64-row blocks per problem
   int32_t items;     // rblocks * batch
   int32_t lds_xs;    // LDS byte offset of the staged activation sums, f32 [ngroups][16] (behind the two tables)
@@ -182,24 +181,48 @@ __global__ void __launch_bounds__(512, 2) w4_gemm_xr_kernel(const XrParams p) {
 
   // ---- activations of a problem: this lane's NCH pieces and the staged sums ----
   u32x4 xr[NCH];
-  const uint32_t xblk = (uint32_t)((p.m + 1) * 64);  // bytes of one chunk's block: 4 k-quads x (m rows + the zero row)
-  uint32_t xoff = (uint32_t)(((lane >> 4) * (p.m + 1) + min(lane & 15, p.m)) * 16);
-  auto x_load = [&](int b) {
-    const char* xb = p.xp + (int64_t)b * p.stride_xp;
+  // x_prepare: straight from the caller's activations, no pre-pass and no workspace.  Lane (row i, k-quad kb) reads the four dwords
+  // (k, k + 1), k = 32 c + 2 kb + {0, 8, 16, 24}, of row i and rearranges them into the "byte order" of the packed words
+  // (w4_gemm_pair.cuh: x[2q], x[2q+8], x[2q+16], x[2q+24], x[2q+1], x[2q+9], x[2q+17], x[2q+25]); rows >= m are zero.  The
+  // per-group sums of the wave's slice (its NCH / CPG groups) are formed from the same registers -- two-element dot products, the
+  // group's chunks, then the four k-quads across lanes -- and written to LDS by the lanes of k-quad 0.  Runs once per PROBLEM and
+  // workgroup, behind the barrier that ends the previous problem's last main loop.
+  auto x_prepare = [&](int b) {
+    const char* xb = p.x + (int64_t)b * p.stride_x;
+    // (the lane id read HERE, opaque: derived from the kernel's `tid` the 64 per-lane offsets below are loop-invariant, get hoisted
+    //  in front of the item loop and spilled -- 500 bytes of scratch)
+    uint32_t lane_p;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_p));
+    const int xi = min((int)(lane_p & 15u), p.m - 1);
+    const bool on = (int)(lane_p & 15u) < p.m;
+    const int kq = (int)(lane_p >> 4);
+    float gsum = 0.f;
 #pragma unroll
-    for (int ci = 0; ci < NCH; ++ci) xr[ci] = *reinterpret_cast<const u32x4*>(xb + uni((uint32_t)(wave * NCH + ci) * xblk) + pin(xoff));
-  };
-  auto xs_stage = [&](int b, int t0) {  // f32 [ngroups][16] in LDS, rows >= m zero; t0 = the thread's index
-    const float* src = reinterpret_cast<const float*>(p.xsum + (int64_t)b * p.stride_xsum);
-    for (int idx = t0; idx < p.ngroups * 16; idx += 512) {
-      const int g = idx >> 4, a = idx & 15;
-      *(lds_fptr)(lds_xs + (uint32_t)(idx * 4)) = a < p.m ? src[g * p.xs_rows + a] : 0.f;
+    for (int ci = 0; ci < NCH; ++ci) {
+      const int k0 = (wave * NCH + ci) * 32 + 2 * kq;
+      uint32_t d[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int64_t idx = p.x_tc ? tc_a_index(xi, k0 + 8 * e, p.k >> 4) : (int64_t)xi * p.k + k0 + 8 * e;
+        const uint32_t v = *reinterpret_cast<const uint32_t*>(xb + idx * 2);
+        d[e] = on ? v : 0u;
+      }
+      xr[ci] = u32x4{__builtin_amdgcn_perm(d[1], d[0], 0x05040100u), __builtin_amdgcn_perm(d[3], d[2], 0x05040100u),
+                     __builtin_amdgcn_perm(d[1], d[0], 0x07060302u), __builtin_amdgcn_perm(d[3], d[2], 0x07060302u)};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) gsum = dot2_ones<DT>(d[e], gsum);
+      if (ci % CPG == CPG - 1) {  // (compile-time) the group is complete in this lane: add the other three k-quads' shares
+        gsum += __shfl_xor(gsum, 16);
+        gsum += __shfl_xor(gsum, 32);
+        const uint32_t g = (uint32_t)(((wave * NCH + ci) * 32) >> p.gshift);
+        if (lane_p < 16u) *(lds_fptr)(lds_xs + (g * 16u + lane_p) * 4u) = gsum;
+        gsum = 0.f;
+      }
     }
   };
 
   // ---- prologue: first item's table (buffer 0) and activations, the first R super-tiles ----
   Rows rcur = rows_of(cur);
-  x_load(cur.b);
 #pragma unroll
   for (int j = 0; j < R; ++j) {
     __builtin_amdgcn_sched_barrier(0);
@@ -211,7 +234,7 @@ __global__ void __launch_bounds__(512, 2) w4_gemm_xr_kernel(const XrParams p) {
 #pragma unroll
     for (int a = 0; a < 16; ++a) build_step(0u, a, hw);
   }
-  xs_stage(cur.b, tid);
+  x_prepare(cur.b);
   __syncthreads();
 
   // lookup address = byte << 8 | column << 2 | buffer << 16: one v_perm_b32 of the word with (column << 2 | buffer << 8)
@@ -322,15 +345,13 @@ __global__ void __launch_bounds__(512, 2) w4_gemm_xr_kernel(const XrParams p) {
     finalize_pair(0, NCH / CPG - 1);
     finalize_pair(1, NCH / CPG - 1);
 
-    // ---- the next problem's activations (rare: once per rblocks items) ----
     const bool new_problem = has_next && inext.b != cur.b;
-    if (new_problem) x_load(inext.b);
 
     // ---- split-K tail: the partial sums of the 8 waves meet in LDS (over the finished table) and are added in wave order ----
     if constexpr (XR_ABL == 6) {  // ablation: no split-K tail (one barrier per item, nothing stored)
       __syncthreads();
       if (yacc[0][0] == 123.f) *reinterpret_cast<float*>(p.y) = yacc[1][1] + yacc[2][2] + yacc[3][3];
-      if (new_problem) xs_stage(inext.b, tid);
+      if (new_problem) x_prepare(inext.b);
       rcur = rnext; cur = inext; buf ^= 1u; colreg[0] ^= 0x100u; colreg[1] ^= 0x100u;
       continue;
     }
@@ -346,7 +367,7 @@ __global__ void __launch_bounds__(512, 2) w4_gemm_xr_kernel(const XrParams p) {
     for (int t = 0; t < 4; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) *(lds_fptr)(lds_red + (uint32_t)((((wave * 4 + t) * 4 + r) * 64 + (int)lane_t) * 4)) = yacc[t][r];
-    if (new_problem) xs_stage(inext.b, tid_t);
+    if (new_problem) x_prepare(inext.b);  // (every wave is behind its last use of the old registers and sums)
     __syncthreads();
     {
       // this thread's two outputs o = tid, tid + 512: (tile t, register r, lane l) -> activation row a, weight row; their eight
