@@ -32,6 +32,7 @@
 #include <string.h>
 #include <atomic>
 #include <type_traits>
+#include <utility>
 
 #include "../../include/tinygemm_hip.h"
 
@@ -642,7 +643,7 @@ enum { TG_PAIR_NA = -100 };
 #if !defined(TG_DEV) && !defined(TG_DEV_MIN)
 #if defined(TG_PAIR_R) || defined(TG_PAIR_ABL) || defined(TG_PAIR_MR1) || defined(TG_PAIR_NSG2) || defined(TG_PAIR_MR1_GPS) || defined(TG_PAIR_RA) ||   \
     defined(TG_PAIR_RA1) || defined(TG_PAIR_RB16) || defined(TG_B16_CHUNK) || defined(TG_PAIR_MIN_ITEMS) || defined(TG_XG_CHUNK) || defined(TG_PAIR_WGS) || \
-    defined(TG_PAIR_NSG2_M1) || defined(TG_PAIR_FORCE_XG) || defined(TG_XR_MIN_M) || defined(TG_XR_R)
+    defined(TG_PAIR_NSG2_M1) || defined(TG_PAIR_FORCE_XG) || defined(TG_XR_MIN_M) || defined(TG_XR_R) || defined(TG_XR_R8K)
 #error "the TG_PAIR_* / TG_XG_* / TG_B16_* tuning constants can only be overridden in developer builds (-DTG_DEV or -DTG_DEV_MIN)"
 #endif
 #endif
@@ -689,6 +690,9 @@ enum { TG_PAIR_NA = -100 };
 #define TG_XR_MIN_M 2          // activation rows from which the register-resident-activation kernel (w4_gemm_xr.cuh) takes stacked launches
                                // (same-box A/B against the kernels it replaces, 4096^2: m = 2 71.9 vs 69.7 %, 4: 68.9 vs 66.9, 8: 66.2 vs 62.7,
                                //  16: 65.2 vs 46.0; m = 1 stays on the 32x32x16 kernel, 77 %)
+#endif
+#ifndef TG_XR_R8K
+#define TG_XR_R8K 2            // ... at k = 8192 (128 registers of activations per lane: 4 in flight spill 25)
 #endif
 #ifndef TG_XR_R
 #define TG_XR_R 4              // super-tiles a wave of that kernel keeps in flight
@@ -1093,17 +1097,16 @@ int launch_pair_b16(GemmParams& p, int64_t batch, hipStream_t st) {
 
 // Bint4 weights, stacked launches, TG_XR_MIN_M ... 16 activation rows, k = 4096: w4_gemm_xr_kernel (one 8-wave workgroup per CU, the
 // activations of a wave's k-slice resident in its registers, 64-row work items, two tables).  No workspace, no pre-pass.
-template <typename DT, int I, bool QMX>
-int launch_pair_xr(GemmParams& p, int64_t batch, hipStream_t st) {
+template <typename DT, int I, bool QMX, int NCH>
+int launch_pair_xr_n(GemmParams& p, int64_t batch, hipStream_t st) {
   if constexpr (QMX || I != 4) return TG_PAIR_NA;
   else {
 #ifdef TG_DEV_MIN
   if constexpr (!std::is_same<DT, BF16>::value) return TG_PAIR_NA;
   else {
 #endif
-  constexpr int NCH = 16;
   if (p.m > 16 || p.m < TG_XR_MIN_M || p.norm_w || p.epilogue) return TG_PAIR_NA;
-  if (p.k != 256 * NCH || p.ksuper * 16 * I != p.k || p.wrows % 64 != 0 || p.ntiles * 8 != p.wrows) return TG_PAIR_NA;
+  if (p.ksuper * 16 * I != p.k || p.wrows % 64 != 0 || p.ntiles * 8 != p.wrows) return TG_PAIR_NA;
   const int g = 1 << p.gshift;
   const int cpg = g / 32 < NCH ? g / 32 : NCH;  // 32-k chunks per group inside a wave's slice
 #ifdef TG_DEV_MIN
@@ -1129,7 +1132,7 @@ int launch_pair_xr(GemmParams& p, int64_t batch, hipStream_t st) {
   if (p.dry) return TG_PLAN_PAIR_XR;
 #define TG_XR_LAUNCH(CPG_)                                                  \
   do {                                                                      \
-    constexpr auto kern = w4_gemm_xr_kernel<DT, I, NCH, CPG_, TG_XR_R>;     \
+    constexpr auto kern = w4_gemm_xr_kernel<DT, I, NCH, CPG_, (NCH > 16 ? TG_XR_R8K : TG_XR_R)>; \
     const int prc = prepare_lds_kernel<kern>();                             \
     if (prc != 0) return prc;                                               \
     hipLaunchKernelGGL(kern, dim3(256), dim3(512), lds, st, xp);            \
@@ -1147,6 +1150,16 @@ int launch_pair_xr(GemmParams& p, int64_t batch, hipStream_t st) {
   }
 #endif
   }
+}
+
+template <typename DT, int I, bool QMX>
+int launch_pair_xr(GemmParams& p, int64_t batch, hipStream_t st) {
+  if (p.k == 4096) return launch_pair_xr_n<DT, I, QMX, 16>(p, batch, st);
+  // k = 8192: 128 registers of activations per lane leave room for two super-tiles in flight only -- faster than the 16x16x32
+  // workspace kernel it replaces at 9 ... 16 rows (8192^2, m = 16: 62 vs 47-51 %), slower than the 32x32x16 one below that
+  // (m = 8: 66 vs 70 %)
+  if (p.k == 8192 && p.m >= 9) return launch_pair_xr_n<DT, I, QMX, 32>(p, batch, st);
+  return TG_PAIR_NA;
 }
 
 template <typename DT, bool LAYOUT_A, int CANON, bool QMX>

@@ -1,5 +1,5 @@
 // w4_gemm_xr.cuh -- the pair-table W4A16 kernel with REGISTER-RESIDENT activations ("XR"): Bint4 weights, up to 16 activation rows,
-// k = 32 * 8 * NCH (k = 4096: NCH = 16).
+// k = 32 * 8 * NCH (k = 4096: NCH = 16; k = 8192: NCH = 32).
 //
 // Same contract and numerics as w4_gemm_pair.cuh (TG_NUM_FAST, group-scaled; reference TinyGemmImpl.cuh:23-345 with
 // BLayout_TC_int4, MatrixLayoutB.cuh:686-1101, Dequantization.cuh:55-178).  Why another decomposition: with 9 ... 16 activation
@@ -31,6 +31,17 @@
 #ifndef XR_ABL
 #define XR_ABL 0  // developer ablations (dev/README.md): 1 no table lookups, 3 no weight loads, 4 no MFMA, 5 no table build, 6 no split-K tail; 0 in the product
 #endif
+
+// f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N - 1>{}): the stage loop of the kernel as a fold expression
+// (`#pragma unroll` gives up on the 64 stages of k = 8192 -- and every register array becomes scratch)
+template <int... I, class F>
+__device__ __forceinline__ void xr_static_for_impl(std::integer_sequence<int, I...>, F&& f) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void xr_static_for(F&& f) {
+  xr_static_for_impl(std::make_integer_sequence<int, N>{}, f);
+}
 
 struct XrParams {
   const char* w;
@@ -140,7 +151,7 @@ __global__ void __launch_bounds__(512, 2) w4_gemm_xr_kernel(const XrParams p) {
         const uint32_t g = (uint32_t)(((sv * CPS + gg * CPG) * 32) >> p.gshift);
 #pragma unroll
         for (int t = 0; t < 4; ++t)
-          sl.q[t][gg] = *reinterpret_cast<const uint32_t*>(rw.qb + uni(g * (uint32_t)p.wrows * 4u + (uint32_t)(t * 64)) + pin(rw.qrow4));
+          sl.q[t][gg] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(rw.qb + uni(g * (uint32_t)p.wrows * 4u + (uint32_t)(t * 64)) + pin(rw.qrow4)));
       }
     }
   };
@@ -296,9 +307,9 @@ __global__ void __launch_bounds__(512, 2) w4_gemm_xr_kernel(const XrParams p) {
       }
     };
     look(0);
-#pragma unroll
-    for (int st = 0; st < NSTG; ++st) {
-      const int ci = st >> 1, u = st & 1, l = ci / CPS, c = ci % CPS;
+    xr_static_for<NSTG>([&](auto ST) {
+      constexpr int st = decltype(ST)::value;
+      constexpr int ci = st >> 1, u = st & 1, l = ci / CPS, c = ci % CPS;
       Slot& sl = ring[l % R];
       const bool gfirst = ci % CPG == 0;
       const int gi = ci / CPG;
@@ -341,7 +352,7 @@ __global__ void __launch_bounds__(512, 2) w4_gemm_xr_kernel(const XrParams p) {
         }
       }
       __builtin_amdgcn_sched_barrier(0);
-    }
+    });
     finalize_pair(0, NCH / CPG - 1);
     finalize_pair(1, NCH / CPG - 1);
 

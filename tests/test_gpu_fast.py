@@ -248,12 +248,14 @@ def _run_xr(T, codes, x, qinfo, lut, g, qtype, copies, bias=None, residual=False
     (64, 16, 128, "any4_rowwise", torch.bfloat16), (64, 9, 64, "any4_global", torch.bfloat16), (64, 2, 256, "int4", torch.bfloat16),
     (192, 5, 128, "any4_rowwise", torch.bfloat16), (64, 13, 256, "any4_rowwise", torch.bfloat16), (64, 8, 128, "int4", torch.bfloat16),
     (128, 16, 128, "any4_rowwise", torch.float16), (64, 3, 64, "int4", torch.float16), (64, 12, 128, "any4_global", torch.bfloat16),
+    # k = 8192 (9 ... 16 rows): 32 chunks of activations per lane, two super-tiles in flight
+    (64, 16, 128, "any4_rowwise", torch.bfloat16, 8192), (64, 9, 256, "int4", torch.float16, 8192),
 ])
 def test_xr_kernel_vs_oracle(T, oracle, case):
     """The register-resident-activation kernel against both oracles, problem by problem (each problem of the stacked launch has
     its own activations), with workgroups that change problem every item / every third item."""
-    n, m, g, qtype, dtype = case
-    k = 4096
+    n, m, g, qtype, dtype = case[:5]
+    k = case[5] if len(case) > 5 else 4096
     codes, x, qinfo, lut = rand_problem(n, k, g, m, qtype, dtype=dtype, seed=n + m + g)
     copies = 512 * 64 // n + 5
     xs, ys = _run_xr(T, codes, x, qinfo, lut, g, qtype, copies)

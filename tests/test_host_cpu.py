@@ -278,7 +278,7 @@ def test_bench_cpu_baseline_leg_and_byte_formula():
 
 
 def test_xr_kernel_routing():
-    """Which stacked launches the xr kernel takes (tg_gemm_w4_plan, no GPU work): Bint4, k = 4096, innerKTiles 4, rows a multiple
+    """Which stacked launches the xr kernel takes (tg_gemm_w4_plan, no GPU work): Bint4, k = 4096 (k = 8192 from 9 rows), innerKTiles 4, rows a multiple
     of 64, 2 <= m <= 16, g = 64, 128 or 256, at least two work items per CU; everything else stays where it was."""
     from any4_amd import ops
 
@@ -290,7 +290,9 @@ def test_xr_kernel_routing():
     assert plan(1, 4096, 4096, 128, "any4_rowwise") == "pair"             # m = 1: the 32x32x16 kernel
     assert plan(8, 4096, 4096, 32, "int4") != "pair_xr"                   # g = 32
     assert plan(8, 4096, 4096, 32, "mx4") != "pair_xr"                    # mx4
-    assert plan(8, 4096, 8192, 128, "any4_rowwise") != "pair_xr"          # k = 8192: 128 registers of activations per lane
+    assert plan(8, 4096, 8192, 128, "any4_rowwise") != "pair_xr"          # k = 8192: only above 8 rows (two super-tiles in flight)
+    assert plan(9, 4096, 8192, 128, "any4_rowwise", batch=16) == "pair_xr" and plan(16, 8192, 8192, 256, "int4", batch=8) == "pair_xr"
+    assert plan(16, 4096, 2048, 128, "any4_rowwise") != "pair_xr" and plan(16, 4096, 14336, 128, "any4_rowwise") != "pair_xr"
     assert plan(8, 4096, 4096, 128, "any4_rowwise", inner=8) != "pair_xr"
     assert plan(8, 4104, 4096, 128, "any4_rowwise") != "pair_xr"          # rows not a multiple of 64
     assert plan(8, 4096, 4096, 128, "any4_rowwise", batch=4) != "pair_xr"  # 256 items: fewer than two per CU
