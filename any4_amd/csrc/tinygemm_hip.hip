@@ -722,7 +722,8 @@ int launch_pair_k(PairParams& pp, unsigned lds, hipStream_t st) {
   else {
   // several groups per super-tile (group 32 / 64 with wide super-tiles): more per-slot state, one slot in flight fits the
   // 128-VGPR budget without spills (ring depth measured irrelevant between 2 and 4)
-  constexpr int RING = GPS > 1 ? (LA ? TG_PAIR_RA1 : 1) : LA == 1 ? TG_PAIR_RA : LA == 2 ? TG_PAIR_RB16 : TG_PAIR_R;
+  // (mx4 on the 32x32x16 tiles converts its weights in registers and has no per-group state in the slots: the usual depth)
+  constexpr int RING = (QMX && LA == 0) ? TG_PAIR_R : GPS > 1 ? (LA ? TG_PAIR_RA1 : 1) : LA == 1 ? TG_PAIR_RA : LA == 2 ? TG_PAIR_RB16 : TG_PAIR_R;
   constexpr auto kern = w4_gemm_pair_kernel<DT, I, GPS, MR, QMX, RING, NSG, TG_PAIR_ABL, XG, LA, NORM>;
   if (pp.dry) return TG_PLAN_PAIR;
   const int prc = prepare_lds_kernel<kern>();
@@ -794,10 +795,10 @@ int launch_pair(GemmParams& p, int64_t batch, hipStream_t st) {
   pp.xs_rows = mrows <= 4 ? 4 : ma;
   pp.red_lanes = mrows <= 4 ? 32 : 64;
   pp.x_pitch = p.k * 2 + 16;
-  pp.lds_x = 65536;
+  pp.lds_x = QMX ? 0 : 65536;  // mx4 converts its weights in registers (v_cvt_scalef32_pk_bf16_fp4): no table, the LDS starts with the activations
   pp.lds_xs = (pp.lds_x + mrows * pp.x_pitch + 32 * I + 15) & ~15;  // staged rows + a zero piece of one super-tile
   pp.lds_red = (pp.lds_xs + (QMX ? 0 : p.ngroups * pp.xs_rows * 4) + 15) & ~15;  // mx4: no zero point, no activation sums
-  pp.red_alias = mrows > 4;  // 16 KiB and more of partial sums: reuse the table's LDS instead
+  pp.red_alias = !QMX && mrows > 4;  // 16 KiB and more of partial sums: reuse the table's LDS instead
   unsigned lds = (unsigned)pp.lds_red + (unsigned)(8 * 2 * pp.rused * pp.red_lanes * 4);
   if (pp.red_alias) {
     lds = (unsigned)pp.lds_red;
@@ -822,6 +823,7 @@ int launch_pair(GemmParams& p, int64_t batch, hipStream_t st) {
     pp.lds_red = (pp.lds_xs + (QMX ? 0 : p.ngroups * pp.xs_rows * 4) + 15) & ~15;  // mx4: no zero point, no activation sums
     lds = (unsigned)pp.lds_red + (unsigned)(8 * 2 * pp.rused * pp.red_lanes * 4);
     if (lds > 80u * 1024u) pp.red_alias = 1;
+    if (QMX && pp.red_alias) return TG_PAIR_NA;  // (no table to put the partial sums over; cannot happen: 8 one-KiB buffers + 16 KiB)
     if (pp.red_alias) {
       lds = (unsigned)pp.lds_red;
       pp.lds_red = 0;
@@ -978,7 +980,7 @@ int launch_pair_a(GemmParams& p, int64_t batch, hipStream_t st) {
   pp.xs_rows = mrows <= 4 ? 4 : mrows <= 8 ? 8 : 16;
   pp.red_lanes = mrows <= 8 ? 32 : 64;  // lanes 0..31 hold activation rows 0..7
   pp.x_pitch = 0;
-  pp.lds_x = 65536;
+  pp.lds_x = QMX ? 0 : 65536;
   pp.xw_pitch = 0;  // the lanes' MFMA operands come straight from the workspace: LDS only holds a zero piece here
   pp.xw_bytes = 0;
   pp.lds_xs = (pp.lds_x + 32 * I + 15) & ~15;
@@ -1049,7 +1051,7 @@ int launch_pair_b16(GemmParams& p, int64_t batch, hipStream_t st) {
   pp.xs_rows = mrows <= 4 ? 4 : mrows <= 8 ? 8 : 16;
   pp.red_lanes = mrows <= 8 ? 32 : 64;  // lanes 0..31 hold activation rows 0..7
   pp.x_pitch = 0;
-  pp.lds_x = 65536;
+  pp.lds_x = QMX ? 0 : 65536;
   pp.xw_pitch = 0;
   pp.xw_bytes = 0;
   pp.lds_xs = (pp.lds_x + 32 * I + 15) & ~15;

@@ -71,6 +71,30 @@ __device__ __forceinline__ void tc_a_load_chunk(const char* xb, int a, int ch, i
   for (int dw = 0; dw < 16; ++dw) d[dw] = *reinterpret_cast<const uint32_t*>(xb + tc_a_index(a, ch * 32 + 2 * dw, ktiles) * 2);
 }
 
+// mx4 on gfx950 without a table: v_cvt_scalef32_pk_bf16_fp4 converts the two fp4-e2m1 codes of one byte of a packed word into a pair
+// of bf16 values times an f32 scale -- the dequantised weights (fp4[code] * 2^(e - 127), exact) in ONE vector instruction per two
+// weights, no LDS lookup, and with the group's scale already inside the operand no per-group accumulator update either.  Checked
+// against the e2m1 table for every byte value, every byte position and scales from 2^-127 (denormal) to 2^127 and NaN (e = 255):
+// tools/ubench/mx4_cvt_probe.hip.
+__device__ __forceinline__ u32x4 mx4_cvt_word(uint32_t w, float scale) {
+  u32x4 r;
+  r[0] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(w, scale, 0));
+  r[1] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(w, scale, 1));
+  r[2] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(w, scale, 2));
+  r[3] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(w, scale, 3));
+  return r;
+}
+
+// ... one byte (sel = 0 ... 3, a constant after unrolling: the switch folds)
+__device__ __forceinline__ uint32_t mx4_cvt_byte(uint32_t w, float scale, int sel) {
+  switch (sel) {
+    case 0: return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(w, scale, 0));
+    case 1: return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(w, scale, 1));
+    case 2: return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(w, scale, 2));
+    default: return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(w, scale, 3));
+  }
+}
+
 struct PairParams {
   const char* x;
   const char* w;
@@ -208,6 +232,7 @@ template <typename DT, int I, int GPS, int MR, bool QMX, int R, int NSG = 0, int
 __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p) {
   // LAY: 0 = Bint4 weights on 32x32x16 tiles (the description above), 1 = Aint4 weights (LA), 2 = Bint4 weights on 16x16x32 tiles (LB)
   constexpr bool LA = LAY == 1, LB = LAY == 2, T16 = LAY != 0;
+  constexpr bool MXC = QMX;  // mx4: weights converted by v_cvt_scalef32_pk_bf16_fp4 (mx4_cvt_word), no table, no group updates
   static_assert(!NORM || (!XG && !T16 && !QMX), "fused RMSNorm: the workgroup stages the whole activation block itself");
   constexpr int WAVES = 8;
   constexpr int TILES = 2;              // MFMA tiles per workgroup (B side: 32 rows each; A side: 16 rows each, sharing their words)
@@ -624,8 +649,8 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
     // ---- pair table of this item: thread = (column, high nibbles 2 wave and 2 wave + 1).  The previous item's lookups are
     // all behind the barrier that ended it.  Only a per-row LUT changes from item to item: int4 / mx4 / one global LUT keep the
     // first item's table (unless the split-K partial sums reuse its LDS) -- 32 table stores per thread and item less. ----
-    if (it == it_begin || p.qtype == TG_Q_ANY4_ROWWISE || p.red_alias ||
-        (p.qtype == TG_Q_ANY4_GLOBAL && cur.b != table_b)) {  // (a global LUT is one per PROBLEM of the batch)
+    if (!MXC && (it == it_begin || p.qtype == TG_Q_ANY4_ROWWISE || p.red_alias ||
+        (p.qtype == TG_Q_ANY4_GLOBAL && cur.b != table_b))) {  // (a global LUT is one per PROBLEM of the batch)
       table_b = cur.b;
       uint32_t hw = lp[0];
 #pragma unroll
@@ -785,6 +810,15 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
         else xf = *(lds_cu32x4ptr)(xst + (uint32_t)(jc * 64 + 16 * qq));
 #pragma unroll
         for (int t = 0; t < TILES; ++t) {
+          if constexpr (MXC) {
+            // the step's group scale first (a group is one 32-k chunk), then one conversion per pair byte
+            if (gfirst) {
+              const int gg0 = GPS == 1 ? 0 : jc / CPG;
+              const int gi = (s - s_begin) * GPS + gg0;
+              if (gg0 == 0) edw[t] = e_dword(t, gi);
+              gs[t] = e_scale(edw[t], gi);
+            }
+          }
           if constexpr (LA) {
             // tile 0 = the low nibbles (rows r), tile 1 = the high nibbles (rows r + 8) of the chunk's two words; pair byte =
             // (code k, code k + 8): bytes 0 / 2 of the low-nibble word, 1 / 3 of the high-nibble word; operand order
@@ -798,6 +832,10 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
+              if constexpr (MXC) {
+                bf[t][j] = mx4_cvt_byte(uw[j & 1], gs[t], t + 2 * (j >> 1));
+                continue;
+              }
               const uint32_t addr = __builtin_amdgcn_perm(uw[j & 1], colreg[t], 0x0c0c0400u + ((uint32_t)(t + 2 * (j >> 1)) << 8));
               if constexpr (ABL == 1) bf[t][j] = addr;
               else bf[t][j] = *(lds_cu32ptr)(addr);
@@ -806,12 +844,18 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
             // one packed word = the 8 codes of this lane's row at k = 2 q + {0, 16, 1, 17, 8, 24, 9, 25} of the chunk = one B
             // operand of v_mfma_f32_16x16x32, in the activation pieces' order (as in w4_gemm_pair16.cuh)
             const uint32_t w = sl.w[t][jc];
+            if constexpr (MXC) {
+              bf[t] = mx4_cvt_word(w, gs[t]);
+            } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const uint32_t addr = __builtin_amdgcn_perm(w, colreg[t], 0x0c0c0400u + ((uint32_t)j << 8));
-              if constexpr (ABL == 1) bf[t][j] = addr;
-              else bf[t][j] = *(lds_cu32ptr)(addr);
+              for (int j = 0; j < 4; ++j) {
+                const uint32_t addr = __builtin_amdgcn_perm(w, colreg[t], 0x0c0c0400u + ((uint32_t)j << 8));
+                if constexpr (ABL == 1) bf[t][j] = addr;
+                else bf[t][j] = *(lds_cu32ptr)(addr);
+              }
             }
+          } else if constexpr (MXC) {
+            bf[t] = mx4_cvt_word(sl.w[t][qq * CPS + jc], gs[t]);
           } else {
             const uint32_t w = sl.w[t < WT ? t : 0][qq * CPS + jc];
 #pragma unroll
@@ -823,7 +867,9 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
           }
         }
         // the previous step ended a group: its finalize runs here, behind this step's lookups (MFMA results ready, no stall)
-        if constexpr (STATIC_G) {
+        if constexpr (MXC) {
+          // (nothing per group: the scale is inside the operands, the accumulators run through the whole slice)
+        } else if constexpr (STATIC_G) {
           // fixed boundaries: the step that starts a group finalises the previous one (before the first group of an item
           // the accumulators and scales are zero: it adds nothing)
           if (gfirst) finalize();
@@ -834,7 +880,7 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
         // the finished group's accumulators must be dead before the next group's first MFMA: if the scheduler sinks the
         // finalize below it, the two groups need two accumulator tuples (32 VGPRs more)
         __builtin_amdgcn_sched_barrier(0);
-        if (ABL != 7 && gfirst) {  // a group starts: its scale | zero and (not mx4) its activation sums
+        if (ABL != 7 && gfirst && !MXC) {  // a group starts: its scale | zero and (not mx4) its activation sums
           const int gg = GPS == 1 ? 0 : jc / CPG;
 #pragma unroll
           for (int t = 0; t < TILES; ++t) {
@@ -866,15 +912,15 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
 #pragma unroll
         for (int t = 0; t < TILES; ++t) {
           if constexpr (ABL == 4) acc[t][0] += u2f(bf[t][0] ^ bf[t][1] ^ bf[t][2] ^ bf[t][3] ^ xf[0] ^ xf[1] ^ xf[2] ^ xf[3]);  // ablation: no MFMA
-          else if constexpr (T16) acc[t] = mfma16<DT>(xf, bf[t], (ABL != 7 && gfirst) ? zero16 : acc[t]);
-          else if (ABL != 7 && !DIFF && gfirst) acc[t] = mfma32<DT>(xf, bf[t], zero16);
+          else if constexpr (T16) acc[t] = mfma16<DT>(xf, bf[t], (ABL != 7 && gfirst && !MXC) ? zero16 : acc[t]);
+          else if (ABL != 7 && !DIFF && gfirst && !MXC) acc[t] = mfma32<DT>(xf, bf[t], zero16);
           else acc[t] = mfma32<DT>(xf, bf[t], acc[t]);
         }
         if constexpr (STATIC_G) {
 #pragma unroll
           for (int t = 0; t < TILES; ++t) asm volatile("" : "+v"(acc[t]));  // see finalize()
         }
-        if (ABL != 7 && !STATIC_G && glast) pending = true;
+        if (ABL != 7 && !STATIC_G && glast && !MXC) pending = true;
         // keep the scheduler from hoisting the lookups of later steps above this point: it would trade the 4-waves-per-SIMD
         // register budget for instruction-level parallelism the other waves already provide
         __builtin_amdgcn_sched_barrier(0);
@@ -912,7 +958,12 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
       if (l0 + j < nl) consume(s_begin + l0 + j, ring[j], j);
       issue(rnext, s_begin + j, ring[j], has_next && j < nl, NSG == 0 || j % NSG == 0);
     }
-    if (pending || GPS > 1 || NSG > 0) finalize();  // the last group of the slice
+    if constexpr (MXC) {  // the slice's sums as they are
+#pragma unroll
+      for (int t = 0; t < TILES; ++t)
+#pragma unroll
+        for (int r = 0; r < RF; ++r) yacc[t][r] = acc[t][r];
+    } else if (pending || GPS > 1 || NSG > 0) finalize();  // the last group of the slice
     if constexpr (ABL == 6) yacc[0][0] += acc[0][0] + acc[0][1] + acc[1][0];
     if constexpr (ABL == 7) { yacc[0][0] = acc[0][0]; yacc[1][0] = acc[1][0]; }
 
