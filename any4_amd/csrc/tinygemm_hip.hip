@@ -643,7 +643,7 @@ enum { TG_PAIR_NA = -100 };
 #if !defined(TG_DEV) && !defined(TG_DEV_MIN)
 #if defined(TG_PAIR_R) || defined(TG_PAIR_ABL) || defined(TG_PAIR_MR1) || defined(TG_PAIR_NSG2) || defined(TG_PAIR_MR1_GPS) || defined(TG_PAIR_RA) ||   \
     defined(TG_PAIR_RA1) || defined(TG_PAIR_RB16) || defined(TG_B16_CHUNK) || defined(TG_PAIR_MIN_ITEMS) || defined(TG_XG_CHUNK) || defined(TG_PAIR_WGS) || \
-    defined(TG_PAIR_NSG2_M1) || defined(TG_PAIR_FORCE_XG) || defined(TG_XR_MIN_M) || defined(TG_XR_R) || defined(TG_XR_R8K)
+    defined(TG_PAIR_NSG2_M1) || defined(TG_PAIR_FORCE_XG) || defined(TG_XR_MIN_M) || defined(TG_XR_R) || defined(TG_XR_R8K) || defined(TG_XR_RMX)
 #error "the TG_PAIR_* / TG_XG_* / TG_B16_* tuning constants can only be overridden in developer builds (-DTG_DEV or -DTG_DEV_MIN)"
 #endif
 #endif
@@ -690,6 +690,9 @@ enum { TG_PAIR_NA = -100 };
 #define TG_XR_MIN_M 2          // activation rows from which the register-resident-activation kernel (w4_gemm_xr.cuh) takes stacked launches
                                // (same-box A/B against the kernels it replaces, 4096^2: m = 2 71.9 vs 69.7 %, 4: 68.9 vs 66.9, 8: 66.2 vs 62.7,
                                //  16: 65.2 vs 46.0; m = 1 stays on the 32x32x16 kernel, 77 %)
+#endif
+#ifndef TG_XR_RMX
+#define TG_XR_RMX 8            // ... for mx4 (no lookups: latency-bound; the whole slice in flight: m = 16 75.4 -> 79.0 %, m = 2 81.7 -> 85.3 %)
 #endif
 #ifndef TG_XR_R8K
 #define TG_XR_R8K 2            // ... at k = 8192 (128 registers of activations per lane: 4 in flight spill 25)
@@ -1101,7 +1104,7 @@ int launch_pair_b16(GemmParams& p, int64_t batch, hipStream_t st) {
 // activations of a wave's k-slice resident in its registers, 64-row work items, two tables).  No workspace, no pre-pass.
 template <typename DT, int I, bool QMX, int NCH>
 int launch_pair_xr_n(GemmParams& p, int64_t batch, hipStream_t st) {
-  if constexpr (QMX || I != 4) return TG_PAIR_NA;
+  if constexpr (I != 4 || (QMX && (NCH != 16 || !std::is_same<DT, BF16>::value))) return TG_PAIR_NA;  // (mx4: bf16, k = 4096)
   else {
 #ifdef TG_DEV_MIN
   if constexpr (!std::is_same<DT, BF16>::value) return TG_PAIR_NA;
@@ -1112,9 +1115,10 @@ int launch_pair_xr_n(GemmParams& p, int64_t batch, hipStream_t st) {
   const int g = 1 << p.gshift;
   const int cpg = g / 32 < NCH ? g / 32 : NCH;  // 32-k chunks per group inside a wave's slice
 #ifdef TG_DEV_MIN
-  if (cpg != 4) return TG_PAIR_NA;
+  if (cpg != (QMX ? 1 : 4)) return TG_PAIR_NA;
 #endif
-  if (cpg != 2 && cpg != 4 && cpg != 8) return TG_PAIR_NA;  // g = 64, 128, 256 (g = 32: two groups per super-tile, not instantiated)
+  if (QMX ? cpg != 1 : (cpg != 2 && cpg != 4 && cpg != 8)) return TG_PAIR_NA;  // g = 64, 128, 256; mx4: g = 32 (int4 / any4 at g = 32: not instantiated)
+  if (QMX && p.ngroups % 16 != 0) return TG_PAIR_NA;  // 16-byte exponent blocks
   XrParams xp;
   xp.w = p.w; xp.qinfo = p.qinfo; xp.lut = p.lut; xp.y = p.y;
   xp.m = p.m; xp.wrows = p.wrows; xp.k = p.k; xp.ntiles = p.ntiles; xp.ksuper = p.ksuper;
@@ -1124,7 +1128,7 @@ int launch_pair_xr_n(GemmParams& p, int64_t batch, hipStream_t st) {
   if (items > INT32_MAX || items < 2 * 256) return TG_PAIR_NA;  // two items per workgroup at least
   xp.items = (int32_t)items;
   xp.lds_xs = 2 * 65536;
-  const unsigned lds = (unsigned)xp.lds_xs + (unsigned)p.ngroups * 64u;  // two tables, the activation sums
+  const unsigned lds = QMX ? 32768u : (unsigned)xp.lds_xs + (unsigned)p.ngroups * 64u;  // two tables, the activation sums (mx4: the partial sums only)
   if (lds > 160u * 1024u) return TG_PAIR_NA;
   xp.x = p.x; xp.stride_x = p.stride_x; xp.x_tc = p.x_tc;  // (no pre-pass, no workspace: the kernel arranges the activations itself)
   p.ws_need = 0;
@@ -1139,6 +1143,12 @@ int launch_pair_xr_n(GemmParams& p, int64_t batch, hipStream_t st) {
     if (prc != 0) return prc;                                               \
     hipLaunchKernelGGL(kern, dim3(256), dim3(512), lds, st, xp);            \
   } while (0)
+  if constexpr (QMX) {
+    constexpr auto kern = w4_gemm_xr_kernel<DT, I, NCH, 1, TG_XR_RMX, true>;
+    const int prc = prepare_lds_kernel<kern>();
+    if (prc != 0) return prc;
+    hipLaunchKernelGGL(kern, dim3(256), dim3(512), lds, st, xp);
+  } else {
 #ifdef TG_DEV_MIN
   TG_XR_LAUNCH(4);
 #else
@@ -1146,6 +1156,7 @@ int launch_pair_xr_n(GemmParams& p, int64_t batch, hipStream_t st) {
   else if (cpg == 4) TG_XR_LAUNCH(4);
   else TG_XR_LAUNCH(8);
 #endif
+  }
 #undef TG_XR_LAUNCH
   return launch_status();
 #ifdef TG_DEV_MIN
@@ -1181,7 +1192,9 @@ int launch_w4(GemmParams& p, int64_t coltiles, int64_t batch, hipStream_t st) {
 #endif
   constexpr int WPL = CANON == CANON_NONE ? 1 : (CANON == CANON_PAIR ? 2 : 4);
   // TG_NUM_FAST, weights on the B side: the pair-table kernel (group-scaled numerics) whenever its LDS plan fits
-  if (p.numerics == TG_NUM_FAST) {
+  // (mx4 in BOTH numerics: its dequantised weights, fp4 * 2^(e - 127), are exact 16-bit values however they are formed, so the
+  //  pair-table kernels -- which convert them with v_cvt_scalef32_pk_bf16_fp4 -- ARE the reference arithmetic for it)
+  if (p.numerics == TG_NUM_FAST || QMX) {
     int rc;
     if constexpr (!LAYOUT_A) {
       rc = launch_pair_xr<DT, 2 * WPL, QMX>(p, batch, st);

@@ -67,7 +67,11 @@ struct XrParams {
 // NCH = 32-k chunks of a wave's k-slice (k = 256 NCH)
 // CPG = 32-k chunks per quantisation group, at most NCH (a group that spans several waves' slices: CPG = NCH)
 // R   = super-tiles a wave keeps in flight
-template <typename DT, int I, int NCH, int CPG, int R>
+// QMX = mx4: the weights are converted in registers (v_cvt_scalef32_pk_bf16_fp4, w4_gemm_pair.cuh: mx4_cvt_word) with the group's
+//       scale 2^(e - 127) inside the conversion: no table, no lookups, no per-group accumulator updates; the word pair of a lane is
+//       swapped BEFORE the conversion (one v_permlane16_swap per stage); the e8m0 exponents of a lane's four rows over its k-slice
+//       are one 16-byte load per row and item, requested one item ahead.  CPG is 1 (a group is one 32-k chunk).
+template <typename DT, int I, int NCH, int CPG, int R, bool QMX = false>
 __global__ void __launch_bounds__(512, 2) w4_gemm_xr_kernel(const XrParams p) {
   constexpr int WAVES = 8;
   constexpr int CPS = I / 2;                       // 32-k chunks per super-tile
@@ -78,6 +82,7 @@ __global__ void __launch_bounds__(512, 2) w4_gemm_xr_kernel(const XrParams p) {
   static_assert(NCH % CPS == 0 && NST % R == 0 && NCH % CPG == 0, "slice = whole super-tiles, whole rounds of the ring, whole groups");
   static_assert(NCH >= 8 && NCH % 8 == 0, "the table build is spread over the second half of the slice");
   constexpr uint32_t TABLE = 65536u;
+  static_assert(!QMX || (CPG == 1 && NCH == 16), "mx4: one group per chunk, one 16-byte exponent block per row and slice");
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -145,7 +150,7 @@ __global__ void __launch_bounds__(512, 2) w4_gemm_xr_kernel(const XrParams p) {
         }
       }
     }
-    if (l % SPG == 0) {  // (compile-time) the first super-tile of its group(s): scale | zero words
+    if (!QMX && l % SPG == 0) {  // (compile-time) the first super-tile of its group(s): scale | zero words
 #pragma unroll
       for (int gg = 0; gg < GPS; ++gg) {
         const uint32_t g = (uint32_t)(((sv * CPS + gg * CPG) * 32) >> p.gshift);
@@ -170,7 +175,22 @@ __global__ void __launch_bounds__(512, 2) w4_gemm_xr_kernel(const XrParams p) {
     lpb = reinterpret_cast<const u32x4*>(lsrc)[1];
     lhw = reinterpret_cast<const uint32_t*>(lsrc)[wave];
   };
-  if (lut_loaded) {
+  // mx4: the 16 exponent bytes of row 16 t + (lane & 15) over this wave's slice, tile t = 0 ... 3, current and next item
+  u32x4 ecur[4], enext[4];
+  auto e_request = [&](const Item& e, u32x4 (&dst)[4]) {
+    const char* eb = p.qinfo + (int64_t)e.b * p.stride_qinfo + (uint32_t)(wave * NCH);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) dst[t] = *reinterpret_cast<const u32x4*>(eb + (int64_t)(e.rb * 64 + 16 * t + ln) * p.ngroups);
+  };
+  // 2^(e - 127) as f32 bits-wise: e << 23, e = 0 -> 2^-127 (a denormal), e = 255 -> NaN (Dequantization.cuh:331-339)
+  auto e_scale = [](const u32x4& ev, int ci) -> float {
+    const uint32_t e23 = __builtin_amdgcn_ubfe(ev[(ci >> 2) & 3], (uint32_t)((ci & 3) * 8), 8u) << 23;
+    const float sc = u2f(e23 > 0x00400000u ? e23 : 0x00400000u);
+    return __builtin_fmaf(sc, 0.f, sc);  // inf (e = 255) -> NaN, everything else unchanged
+  };
+  if constexpr (QMX) {
+    e_request(cur, ecur);
+  } else if (lut_loaded) {
     lut_request(cur);
   } else {  // int4: code - 8, exact
 #pragma unroll
@@ -222,7 +242,7 @@ __global__ void __launch_bounds__(512, 2) w4_gemm_xr_kernel(const XrParams p) {
                      __builtin_amdgcn_perm(d[1], d[0], 0x07060302u), __builtin_amdgcn_perm(d[3], d[2], 0x07060302u)};
 #pragma unroll
       for (int e = 0; e < 4; ++e) gsum = dot2_ones<DT>(d[e], gsum);
-      if (ci % CPG == CPG - 1) {  // (compile-time) the group is complete in this lane: add the other three k-quads' shares
+      if (!QMX && ci % CPG == CPG - 1) {  // (compile-time) the group is complete in this lane: add the other three k-quads' shares (mx4 has no zero point: no sums)
         gsum += __shfl_xor(gsum, 16);
         gsum += __shfl_xor(gsum, 32);
         const uint32_t g = (uint32_t)(((wave * NCH + ci) * 32) >> p.gshift);
@@ -240,7 +260,7 @@ __global__ void __launch_bounds__(512, 2) w4_gemm_xr_kernel(const XrParams p) {
     issue(rcur, j, ring[j], true);
   }
   __builtin_amdgcn_sched_barrier(0);
-  {
+  if constexpr (!QMX) {
     const uint32_t hw = lhw;
 #pragma unroll
     for (int a = 0; a < 16; ++a) build_step(0u, a, hw);
@@ -263,7 +283,8 @@ __global__ void __launch_bounds__(512, 2) w4_gemm_xr_kernel(const XrParams p) {
       if (inext.rb == p.rblocks) { inext.rb = 0; inext.b = cur.b + 1; }
     }
     Rows rnext = rows_of(inext);
-    if (lut_loaded) lut_request(inext);  // (the last item asks for its own rows again)
+    if constexpr (QMX) e_request(inext, enext);
+    else if (lut_loaded) lut_request(inext);  // (the last item asks for its own rows again)
     const int row0 = cur.rb * 64;
 
     f32x4 acc[4];
@@ -306,11 +327,25 @@ __global__ void __launch_bounds__(512, 2) w4_gemm_xr_kernel(const XrParams p) {
         else { pv[st & 1][j] = *(lds_cu32ptr)(av); pw[st & 1][j] = *(lds_cu32ptr)(aw); }
       }
     };
-    look(0);
+    if constexpr (!QMX) look(0);
     xr_static_for<NSTG>([&](auto ST) {
       constexpr int st = decltype(ST)::value;
       constexpr int ci = st >> 1, u = st & 1, l = ci / CPS, c = ci % CPS;
       Slot& sl = ring[l % R];
+      if constexpr (QMX) {
+        // mx4 stage: swap the lane's word pair into (tile 2 u, tile 2 u + 1) at quad kb, convert each word with its row's scale
+        // of this chunk, two MFMAs into accumulators that run through the whole slice
+        const auto sw = __builtin_amdgcn_permlane16_swap(sl.w[u][c], sl.w[u][CPS + c], false, false);
+        const u32x4 b0 = mx4_cvt_word(sw[0], e_scale(ecur[2 * u], ci));
+        const u32x4 b1 = mx4_cvt_word(sw[1], e_scale(ecur[2 * u + 1], ci));
+        acc[2 * u] = DT::mfma(xr[ci], b0, acc[2 * u]);
+        acc[2 * u + 1] = DT::mfma(xr[ci], b1, acc[2 * u + 1]);
+        if (u == 1 && c == CPS - 1) {
+          if (l + R < NST) issue(rcur, l + R, sl, true);
+          else issue(rnext, l + R - NST, sl, has_next);
+        }
+        return;
+      }
       const bool gfirst = ci % CPG == 0;
       const int gi = ci / CPG;
       if (st + 1 < NSTG) look(st + 1);
@@ -353,8 +388,17 @@ __global__ void __launch_bounds__(512, 2) w4_gemm_xr_kernel(const XrParams p) {
       }
       __builtin_amdgcn_sched_barrier(0);
     });
-    finalize_pair(0, NCH / CPG - 1);
-    finalize_pair(1, NCH / CPG - 1);
+    if constexpr (QMX) {  // the slice's sums as they are; the next item's exponents become the current ones
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) yacc[t][r] = acc[t][r];
+        ecur[t] = enext[t];
+      }
+    } else {
+      finalize_pair(0, NCH / CPG - 1);
+      finalize_pair(1, NCH / CPG - 1);
+    }
 
     const bool new_problem = has_next && inext.b != cur.b;
 
@@ -372,8 +416,8 @@ __global__ void __launch_bounds__(512, 2) w4_gemm_xr_kernel(const XrParams p) {
     uint32_t lane_t;
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_t));
     const int tid_t = wave * 64 + (int)lane_t;
-    __syncthreads();  // every wave is done with this item's table; the next item's table is complete
-    const uint32_t lds_red = buf * TABLE;
+    if constexpr (!QMX) __syncthreads();  // every wave is done with this item's table; the next item's table is complete (mx4: no table)
+    const uint32_t lds_red = QMX ? 0u : buf * TABLE;
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll

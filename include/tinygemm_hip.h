@@ -62,7 +62,8 @@ enum {
  *                       y = sum_g ( scale_g * sum_{k in g} x_k * lut[code_k]  +  zero_g * sum_{k in g} x_k ).
  *                     No per-weight rounding to 16 bits, so y differs from the reference's by at most the reference's own
  *                     rounding of its dequantised weights (<= 2^-9 * sum_k |x_k w_k|, about one output ulp at k = 4096);
- *                     mx4 weights are exact either way.  Other shapes run the TG_NUM_REFERENCE kernels.
+ *                     mx4 weights are exact either way (and its kernels the same in both settings).  Other shapes run the
+ *                     TG_NUM_REFERENCE kernels.
  *   TG_NUM_REFERENCE  w = RNE16(fma(lut[code], scale, zero)) per element exactly as the reference kernels compute it
  *                     (MatrixLayoutB.cuh:1042-1046, MatrixLayoutA.cuh:747-754): bit-identical weights, e.g. the identity
  *                     known-answer tests of the reference come out bit-equal.                                           */
@@ -193,7 +194,8 @@ TG_API int tg_gemm_w4(const tg_w4_gemm* args, int device, tg_stream_t stream);
  * pointers are only checked for NULL / alignment).  Negative: the TG_E_* code tg_gemm_w4 would return.
  *   TG_PLAN_SPLITK  w4_gemm_kernel         one 16-wave split-K workgroup per 16-row tile (small launches), reference numerics
  *   TG_PLAN_STREAM  w4_gemm_stream_kernel  per-(row, group) tables of final 16-bit weights, reference numerics
- *   TG_PLAN_PAIR    w4_gemm_pair_kernel    per-row tables of LUT pairs, group-scaled numerics (TG_NUM_FAST only)
+ *   TG_PLAN_PAIR    w4_gemm_pair_kernel    per-row tables of LUT pairs, group-scaled numerics (TG_NUM_FAST; mx4 -- converted in
+ *                                          registers by v_cvt_scalef32_pk_bf16_fp4, exact -- in both numerics)
  *   TG_PLAN_PAIR_XR w4_gemm_xr_kernel      the same tables and numerics, activations resident in registers (Bint4 weights,
  *                                          2 ... 16 activation rows, k = 4096, stacked launches)  */
 enum { TG_PLAN_SPLITK = 1, TG_PLAN_STREAM = 2, TG_PLAN_PAIR = 3, TG_PLAN_PAIR_XR = 4 };

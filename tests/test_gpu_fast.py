@@ -227,7 +227,7 @@ def _run_xr(T, codes, x, qinfo, lut, g, qtype, copies, bias=None, residual=False
     args = _lib.W4Gemm(x=xin.data_ptr(), w=packed.data_ptr(), qinfo=qs.data_ptr(), lut=(luts.data_ptr() if luts is not None else None),
                        y=yout.data_ptr(), m=m, wrows=n, k=k, group=g, qtype=QT[qtype],
                        dtype=_lib.TG_BF16 if dt == torch.bfloat16 else _lib.TG_F16, w_on_right=1, inner_k_tiles=4, batch=copies,
-                       stride_x=xin.stride(0) * 2, stride_w=packed.stride(0) * 4, stride_qinfo=qs.stride(0) * 2,
+                       stride_x=xin.stride(0) * 2, stride_w=packed.stride(0) * 4, stride_qinfo=qs.stride(0) * qs.element_size(),
                        stride_lut=(luts.stride(0) * 2 if luts is not None else 0), stride_y=yout.stride(0) * 2,
                        numerics=_lib.TG_NUM_FAST, bias=(bs.data_ptr() if bs is not None else None),
                        stride_bias=(bs.stride(0) * 2 if bs is not None else 0), bias_row_stride=(n if residual else 0),
@@ -248,6 +248,8 @@ def _run_xr(T, codes, x, qinfo, lut, g, qtype, copies, bias=None, residual=False
     (64, 16, 128, "any4_rowwise", torch.bfloat16), (64, 9, 64, "any4_global", torch.bfloat16), (64, 2, 256, "int4", torch.bfloat16),
     (192, 5, 128, "any4_rowwise", torch.bfloat16), (64, 13, 256, "any4_rowwise", torch.bfloat16), (64, 8, 128, "int4", torch.bfloat16),
     (128, 16, 128, "any4_rowwise", torch.float16), (64, 3, 64, "int4", torch.float16), (64, 12, 128, "any4_global", torch.bfloat16),
+    # mx4 (g = 32): weights converted in registers, exponent blocks per row, no table
+    (64, 16, 32, "mx4", torch.bfloat16), (128, 5, 32, "mx4", torch.bfloat16), (64, 2, 32, "mx4", torch.bfloat16),
     # k = 8192 (9 ... 16 rows): 32 chunks of activations per lane, two super-tiles in flight
     (64, 16, 128, "any4_rowwise", torch.bfloat16, 8192), (64, 9, 256, "int4", torch.float16, 8192),
 ])
@@ -265,6 +267,21 @@ def test_xr_kernel_vs_oracle(T, oracle, case):
     # problems with the same activations (j and j + m: the same roll) give the same bits whichever workgroup computed them
     assert torch.equal(ys[0].view(torch.int16), ys[m].view(torch.int16))
     assert torch.equal(ys[1].view(torch.int16), ys[copies - 1 - (copies - 2) % m].view(torch.int16))
+
+
+def test_xr_kernel_mx4_nan_exponent(T, oracle):
+    """e = 255 is NaN (Dequantization.cuh:331-339): one such group makes its weight row's outputs NaN -- for every activation row and
+    every problem -- and nothing else; the other outputs are bit-equal to the run without it."""
+    n, m, g, k = 64, 9, 32, 4096
+    codes, x, qinfo, lut = rand_problem(n, k, g, m, "mx4", seed=9)
+    copies = 520
+    _, y0 = _run_xr(T, codes, x, qinfo, lut, g, "mx4", copies)
+    q2 = qinfo.clone()
+    q2[5, 77] = 255
+    _, y1 = _run_xr(T, codes, x, q2, lut, g, "mx4", copies)
+    assert torch.isnan(y1[:, :, 5].float()).all()
+    keep = [c for c in range(n) if c != 5]
+    assert torch.equal(y1[:, :, keep].view(torch.int16), y0[:, :, keep].view(torch.int16))
 
 
 def test_xr_kernel_bias_and_residual(T, oracle):

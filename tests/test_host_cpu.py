@@ -289,7 +289,8 @@ def test_xr_kernel_routing():
                 assert plan(m, 4096, 4096, g, q) == "pair_xr", (m, q, g)
     assert plan(1, 4096, 4096, 128, "any4_rowwise") == "pair"             # m = 1: the 32x32x16 kernel
     assert plan(8, 4096, 4096, 32, "int4") != "pair_xr"                   # g = 32
-    assert plan(8, 4096, 4096, 32, "mx4") != "pair_xr"                    # mx4
+    assert plan(8, 4096, 4096, 32, "mx4") == "pair_xr" and plan(16, 4096, 4096, 32, "mx4") == "pair_xr"  # mx4: bf16, g = 32, k = 4096
+    assert plan(8, 4096, 8192, 32, "mx4") != "pair_xr"
     assert plan(8, 4096, 8192, 128, "any4_rowwise") != "pair_xr"          # k = 8192: only above 8 rows (two super-tiles in flight)
     assert plan(9, 4096, 8192, 128, "any4_rowwise", batch=16) == "pair_xr" and plan(16, 8192, 8192, 256, "int4", batch=8) == "pair_xr"
     assert plan(16, 4096, 2048, 128, "any4_rowwise") != "pair_xr" and plan(16, 4096, 14336, 128, "any4_rowwise") != "pair_xr"
