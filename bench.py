@@ -588,7 +588,8 @@ def main():
             "config3": leg("any4_rowwise", 8, 8192, 8192, 128, False, 128, "BASELINE config 3: m=8, n=k=8192, g=128, weights on the A side (Aint4 innerKTiles=4)"),
             "int4": leg("int4", 1, n, k, g, True, L, "BASELINE config 4: uniform int4, m=1"),
             "nf4": leg("any4_global", 1, n, k, g, True, L, "BASELINE config 4: one global 16-entry LUT (the reference's NF4 path), m=1"),
-            "mx4": leg("mx4", 1, n, k, 32, True, L, "BASELINE config 4: mx4 (fp4-e2m1 codes, e8m0 exponent per 32), m=1"),
+            "mx4": leg("mx4", 1, n, k, 32, True, L, "BASELINE config 4: mx4 (fp4-e2m1 codes, e8m0 exponent per 32), m=1; weights converted by v_cvt_scalef32_pk_bf16_fp4"),
+            "mx4_m16": leg("mx4", 16, n, k, 32, True, L // 2, "mx4, m=16 (w4_gemm_xr_kernel, weights converted in registers)"),
             # the same workload with the reference's own dequant arithmetic (every weight rounded to 16 bits with one fma,
             # MatrixLayoutB.cuh:1042-1046): the kernels whose weights are bit-identical to the reference's
             "reference_numerics": {
