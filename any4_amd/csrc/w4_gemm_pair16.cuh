@@ -253,8 +253,9 @@ __global__ void __launch_bounds__(1024) w4_gemm_pair16_kernel(const Pair16Params
     if (tid == 0) *(lds_u32x4ptr)(lds_x + (uint32_t)(p.m * p.x_pitch)) = u32x4{0, 0, 0, 0};  // zero piece for padding rows
   };
   x_stage(0, true);
+  // (mx4: no table -- the weights are converted in registers by v_cvt_scalef32_pk_bf16_fp4, w4_gemm_pair.cuh: mx4_cvt_word)
 #pragma unroll
-  for (int t = 0; t < TPW; ++t) {
+  for (int t = 0; t < (QMX ? 0 : TPW); ++t) {
     // thread = (column tcol, high nibble (tid >> 5) & 15, half tid >> 9 of the low nibbles): entries (lut[lo], lut[hi])
     const int hi = (tid >> 5) & 15, half = tid >> 9;
     uint32_t hw = lp[t][0];
@@ -313,6 +314,19 @@ __global__ void __launch_bounds__(1024) w4_gemm_pair16_kernel(const Pair16Params
   auto step = [&](const uint32_t (&wreg)[TPW][CH][CPS], const uint32_t (&qreg)[TPW][CH][CPS], int j, int jc, int chunk, bool gfirst, bool glast) {
     const u32x4 xf = *(lds_cu32x4ptr)(xrow + ((uint32_t)((chunk - chunk_ph) * 64) & xmask));
     u32x4 bf[TPW];
+    if constexpr (QMX) {  // the group's scale inside the conversion: accumulators run through the whole slice, nothing per group
+#pragma unroll
+      for (int t = 0; t < TPW; ++t) {
+        if (gfirst) {
+          const uint32_t qv = qreg[t][j][jc];
+          const float sc = u2f(qv == 0u ? 0x00400000u : (qv << 23));  // Dequantization.cuh:331-339; e = 255: inf ...
+          gs[t] = __builtin_fmaf(sc, 0.f, sc);                         // ... -> NaN
+        }
+        bf[t] = mx4_cvt_word(wreg[t][j][jc], gs[t]);
+        acc[t] = mfma16<DT>(xf, bf[t], acc[t]);
+      }
+      return;
+    }
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
       const uint32_t w = wreg[t][j][jc];
@@ -398,6 +412,12 @@ __global__ void __launch_bounds__(1024) w4_gemm_pair16_kernel(const Pair16Params
     }
   }  // phases
 
+  if constexpr (QMX) {  // the slice's sums as they are
+#pragma unroll
+    for (int t = 0; t < TPW; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) yacc[t][r] = acc[t][r];
+  }
   // ---- split-K tail: partial sums of the 16 waves meet in the (now unused) table's LDS, added in wave order ----
   __syncthreads();
 #pragma unroll
