@@ -4,17 +4,18 @@
 // Same contract and numerics as w4_gemm_pair.cuh (TG_NUM_FAST, group-scaled; reference TinyGemmImpl.cuh:23-345 with
 // BLayout_TC_int4, MatrixLayoutB.cuh:686-1101, Dequantization.cuh:55-178).  Why another decomposition: with 9 ... 16 activation
 // rows the 16x16x32 variant of w4_gemm_pair.cuh re-reads the whole activation block for every 32-row work item -- two bytes of
-// activations through the vector-memory path per byte of weights, measured as 26 % of its time (same-box ablation)
-// -- and the 64 KiB pair table leaves no LDS to keep the block in.  The register file does: a wave only ever needs the
+// activations through the vector-memory path per byte of weights, measured as 26 % of its time (same-box ablation, DESIGN.md section 9;
+// the workspace variant for m <= 8 pays 0.5 bytes per byte) -- and the 64 KiB pair table leaves no LDS to keep the block in.  The register file does: a wave only ever needs the
 // activations of ITS k-slice, 16 rows x 512 k = 16 KiB = 64 VGPRs, IF the wave may use 256 registers.  So:
 //
 //   workgroup  = 8 waves, ONE per CU (256 VGPRs per lane), persistent over a contiguous range of work items; item = 64 weight
 //                rows (four 16-row MFMA tiles) x the whole k; wave w walks the k-slice w (split-K 8, partial sums meet in LDS
 //                and are added in wave order: deterministic).
 //   MFMA       = v_mfma_f32_16x16x32: A operand = activations (lane (i = lane & 15, kb = lane >> 4): row i, the 16-byte
-//                piece (chunk, kb) of the byte-order arrangement of w4_xprep_kernel), B operand = weights, D[i][n]: lane (n, kb)
+//                piece (chunk, kb) of the "byte order" of w4_gemm_pair.cuh), B operand = weights, D[i][n]: lane (n, kb)
 //                holds activation rows 4 kb + r of ITS weight row, so scale / zero are per-lane scalars.
-//   activations= xr[NCH]: the wave's NCH pieces, loaded from the workspace once per PROBLEM of the batch (not per item).
+//   activations= xr[NCH]: the wave's NCH pieces, arranged by the kernel itself from the caller's x (x_prepare: no pre-pass launch,
+//                no workspace) once per PROBLEM of the batch and workgroup, together with the per-group sums of the slice.
 //   weights    = "load layout": lane (n = lane & 15, b = (lane >> 4) & 1, a = lane >> 5) reads the 4 I bytes of row
 //                32 u + 16 b + n (tile 2 u + b of the item) at lane-quads 2 a, 2 a + 1 of the reference layout: one wave-load =
 //                four fully used 256-byte segments (I = 4).
@@ -27,9 +28,10 @@
 //                main loop (its LUT rows are requested at the item's start), so no wave ever waits for a table.
 //   tail       = partial sums over the (finished) current table, three barriers per item; the weight ring (R super-tiles per
 //                wave, refilled with the next item's positions) keeps streaming through it.
+//   mx4        = template flag QMX below: no table at all.
 #pragma once
 #ifndef XR_ABL
-#define XR_ABL 0  // developer ablations (dev/README.md): 1 no table lookups, 3 no weight loads, 4 no MFMA, 5 no table build, 6 no split-K tail; 0 in the product
+#define XR_ABL 0  // developer ablations (dev/README.md): 1 no table lookups, 3 no weight loads, 5 no table build, 6 no split-K tail, 7 no output stores, 8 no third barrier (a race: timing only); 0 in the product
 #endif
 
 // f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N - 1>{}): the stage loop of the kernel as a fold expression
@@ -364,13 +366,8 @@ __global__ void __launch_bounds__(512, 2) w4_gemm_xr_kernel(const XrParams p) {
           b0[j] = sw[0];
           b1[j] = sw[1];
         }
-        if constexpr (XR_ABL == 4) {  // ablation: no MFMA
-          acc[2 * u][0] += u2f(b0[0] ^ b0[1] ^ b0[2] ^ b0[3] ^ xr[ci][0]);
-          acc[2 * u + 1][0] += u2f(b1[0] ^ b1[1] ^ b1[2] ^ b1[3] ^ xr[ci][1]);
-        } else {
-          acc[2 * u] = DT::mfma(xr[ci], b0, gfirst ? zero4 : acc[2 * u]);
-          acc[2 * u + 1] = DT::mfma(xr[ci], b1, gfirst ? zero4 : acc[2 * u + 1]);
-        }
+        acc[2 * u] = DT::mfma(xr[ci], b0, gfirst ? zero4 : acc[2 * u]);
+        acc[2 * u + 1] = DT::mfma(xr[ci], b1, gfirst ? zero4 : acc[2 * u + 1]);
       }
       if (u == 1) {
         // the next item's table, one step per chunk of the slice's second half
