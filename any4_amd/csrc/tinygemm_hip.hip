@@ -1117,8 +1117,9 @@ int launch_pair_xr_n(GemmParams& p, int64_t batch, hipStream_t st) {
 #ifdef TG_DEV_MIN
   if (cpg != (QMX ? 1 : 4)) return TG_PAIR_NA;
 #endif
-  if (QMX ? cpg != 1 : (cpg != 2 && cpg != 4 && cpg != 8)) return TG_PAIR_NA;  // g = 64, 128, 256; mx4: g = 32 (int4 / any4 at g = 32: not instantiated)
+  if (QMX ? cpg != 1 : (cpg != 1 && cpg != 2 && cpg != 4 && cpg != 8)) return TG_PAIR_NA;  // g = 32, 64, 128, 256; mx4: g = 32
   if (QMX && p.ngroups % 16 != 0) return TG_PAIR_NA;  // 16-byte exponent blocks
+  if (NCH > 16 && cpg == 2) return TG_PAIR_NA;          // (k = 8192, g = 64: that instantiation spills four registers)
   XrParams xp;
   xp.w = p.w; xp.qinfo = p.qinfo; xp.lut = p.lut; xp.y = p.y;
   xp.m = p.m; xp.wrows = p.wrows; xp.k = p.k; xp.ntiles = p.ntiles; xp.ksuper = p.ksuper;
@@ -1152,7 +1153,8 @@ int launch_pair_xr_n(GemmParams& p, int64_t batch, hipStream_t st) {
 #ifdef TG_DEV_MIN
   TG_XR_LAUNCH(4);
 #else
-  if (cpg == 2) TG_XR_LAUNCH(2);
+  if (cpg == 1) TG_XR_LAUNCH(1);
+  else if (cpg == 2) TG_XR_LAUNCH(2);
   else if (cpg == 4) TG_XR_LAUNCH(4);
   else TG_XR_LAUNCH(8);
 #endif

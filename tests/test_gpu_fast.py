@@ -248,6 +248,8 @@ def _run_xr(T, codes, x, qinfo, lut, g, qtype, copies, bias=None, residual=False
     (64, 16, 128, "any4_rowwise", torch.bfloat16), (64, 9, 64, "any4_global", torch.bfloat16), (64, 2, 256, "int4", torch.bfloat16),
     (192, 5, 128, "any4_rowwise", torch.bfloat16), (64, 13, 256, "any4_rowwise", torch.bfloat16), (64, 8, 128, "int4", torch.bfloat16),
     (128, 16, 128, "any4_rowwise", torch.float16), (64, 3, 64, "int4", torch.float16), (64, 12, 128, "any4_global", torch.bfloat16),
+    # g = 32: two groups per 64-k super-tile
+    (64, 8, 32, "int4", torch.bfloat16), (128, 16, 32, "any4_rowwise", torch.bfloat16), (64, 11, 32, "any4_global", torch.float16),
     # mx4 (g = 32): weights converted in registers, exponent blocks per row, no table
     (64, 16, 32, "mx4", torch.bfloat16), (128, 5, 32, "mx4", torch.bfloat16), (64, 2, 32, "mx4", torch.bfloat16),
     # k = 8192 (9 ... 16 rows): 32 chunks of activations per lane, two super-tiles in flight

@@ -279,16 +279,15 @@ def test_bench_cpu_baseline_leg_and_byte_formula():
 
 def test_xr_kernel_routing():
     """Which stacked launches the xr kernel takes (tg_gemm_w4_plan, no GPU work): Bint4, k = 4096 (k = 8192 from 9 rows), innerKTiles 4, rows a multiple
-    of 64, 2 <= m <= 16, g = 64, 128 or 256, at least two work items per CU; everything else stays where it was."""
+    of 64, 2 <= m <= 16, every group size, at least two work items per CU; everything else stays where it was."""
     from any4_amd import ops
 
     plan = lambda m, n, k, g, q, inner=4, batch=64, right=True: ops.gemm_w4_plan(m, n, k, g, {'int4': 0, 'any4_global': 1, 'any4_rowwise': 2, 'mx4': 3}[q], right, inner, batch=batch, detail=True)
     for m in (2, 8, 9, 16):
         for q in ("int4", "any4_global", "any4_rowwise"):
-            for g in (64, 128, 256):
+            for g in (32, 64, 128, 256):
                 assert plan(m, 4096, 4096, g, q) == "pair_xr", (m, q, g)
     assert plan(1, 4096, 4096, 128, "any4_rowwise") == "pair"             # m = 1: the 32x32x16 kernel
-    assert plan(8, 4096, 4096, 32, "int4") != "pair_xr"                   # g = 32
     assert plan(8, 4096, 4096, 32, "mx4") == "pair_xr" and plan(16, 4096, 4096, 32, "mx4") == "pair_xr"  # mx4: bf16, g = 32, k = 4096
     assert plan(8, 4096, 8192, 32, "mx4") != "pair_xr"
     assert plan(8, 4096, 8192, 128, "any4_rowwise") != "pair_xr"          # k = 8192: only above 8 rows (two super-tiles in flight)
