@@ -95,6 +95,17 @@ __device__ __forceinline__ uint32_t mx4_cvt_byte(uint32_t w, float scale, int se
   }
 }
 
+#ifndef TG_PAIR_M1_DOT
+#define TG_PAIR_M1_DOT 1  // the m = 1 specialisation contracts with v_dot2_f32_bf16 per lane instead of the MFMA (0: MFMA, for A/B builds)
+#endif
+template <typename DT>
+__device__ __forceinline__ float dot2_pair(uint32_t a, uint32_t b, float acc) {
+  if constexpr (std::is_same<DT, BF16>::value)
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, a), __builtin_bit_cast(bf16x2, b), acc, false);
+  else
+    return __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, a), __builtin_bit_cast(f16x2, b), acc, false);
+}
+
 struct PairParams {
   const char* x;
   const char* w;
@@ -232,6 +243,11 @@ template <typename DT, int I, int GPS, int MR, bool QMX, int R, int NSG = 0, int
 __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p) {
   // LAY: 0 = Bint4 weights on 32x32x16 tiles (the description above), 1 = Aint4 weights (LA), 2 = Bint4 weights on 16x16x32 tiles (LB)
   constexpr bool LA = LAY == 1, LB = LAY == 2, T16 = LAY != 0;
+  // m = 1 by per-lane dot products (every lane reads activation row 0's piece of ITS k-slot): a 32x32x16 MFMA spends 16384
+  // multiplier slots on 512 useful products and, under the 1400 W cap, clock -- 4 v_dot2 per word instead: 76.3 -> 80.6 % on the
+  // headline shape, int4 82.6 -> 84.4 %, global LUT 79.4 -> 84.0 % same-box.  Only with fixed group boundaries (NSG > 0): the
+  // run-time group test around it compiles to 128 VGPRs + 200-500 bytes of scratch.
+  constexpr bool DOT = TG_PAIR_M1_DOT && MR == 1 && !T16 && !QMX && NSG > 0;
   constexpr bool MXC = QMX;  // mx4: weights converted by v_cvt_scalef32_pk_bf16_fp4 (mx4_cvt_word), no table, no group updates
   static_assert(!NORM || (!XG && !T16 && !QMX), "fused RMSNorm: the workgroup stages the whole activation block itself");
   constexpr int WAVES = 8;
@@ -264,7 +280,7 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = lane & 31;
   const int h = lane >> 5;
-  const int xa = T16 ? lane & 15 : c;       // activation row this lane supplies to the MFMA (X operand)
+  const int xa = DOT ? 0 : T16 ? lane & 15 : c;       // activation row this lane supplies to the MFMA (X operand)
   const int xq = T16 ? lane >> 4 : 2 * h;   // first 16-byte piece (k-quad) of a 32-k chunk this lane reads
   const int hh = T16 ? lane >> 4 : h;       // this lane's accumulator registers r < 4 are activation rows 4 hh + r
   // weight row (inside the workgroup's block) of this lane in tile t
@@ -717,12 +733,13 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
         z = 0.f;
       } else {
         s = DT::lo_f32(q);
-        z = DT::hi_f32(q);
+        z = DOT && h ? 0.f : DT::hi_f32(q);  // (DOT: both lane halves of a row accumulate, the zero-point term only once)
       }
     };
     // m = 1: the accumulator tuples run through the whole slice (cleared per item) and a group's sum is taken as a difference;
     // otherwise a group's first MFMA takes a zero C operand
     constexpr bool DIFF = MR == 1;
+    float dacc[TILES] = {0.f, 0.f};  // DOT: this lane's running sum over its k-slot
     float prev[TILES][RF];
 #pragma unroll
     for (int t = 0; t < TILES; ++t)
@@ -735,6 +752,12 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
     auto finalize = [&]() {
 #pragma unroll
       for (int t = 0; t < TILES; ++t) {
+        if constexpr (DOT) {
+          const float d = dacc[t] - prev[t][0];
+          prev[t][0] = dacc[t];
+          yacc[t][0] = __builtin_fmaf(gz[t], xsv[0], __builtin_fmaf(gs[t], d, yacc[t][0]));
+          continue;
+        }
         if constexpr (DIFF && RF == 1 && !QMX) {
           // m = 1: four single-register instructions per tile, spelled out.  Left to the compiler the two tiles' updates become
           // v_pk_* on register PAIRS; at the 128-VGPR budget the only aligned pair it finds overlaps an accumulator tuple, which
@@ -911,12 +934,16 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
         }
 #pragma unroll
         for (int t = 0; t < TILES; ++t) {
+          if constexpr (DOT) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dacc[t] = dot2_pair<DT>(bf[t][j], xf[j], dacc[t]);
+          } else
           if constexpr (ABL == 4) acc[t][0] += u2f(bf[t][0] ^ bf[t][1] ^ bf[t][2] ^ bf[t][3] ^ xf[0] ^ xf[1] ^ xf[2] ^ xf[3]);  // ablation: no MFMA
           else if constexpr (T16) acc[t] = mfma16<DT>(xf, bf[t], (ABL != 7 && gfirst && !MXC) ? zero16 : acc[t]);
           else if (ABL != 7 && !DIFF && gfirst && !MXC) acc[t] = mfma32<DT>(xf, bf[t], zero16);
           else acc[t] = mfma32<DT>(xf, bf[t], acc[t]);
         }
-        if constexpr (STATIC_G) {
+        if constexpr (STATIC_G && !DOT) {
 #pragma unroll
           for (int t = 0; t < TILES; ++t) asm volatile("" : "+v"(acc[t]));  // see finalize()
         }
@@ -964,6 +991,10 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
 #pragma unroll
         for (int r = 0; r < RF; ++r) yacc[t][r] = acc[t][r];
     } else if (pending || GPS > 1 || NSG > 0) finalize();  // the last group of the slice
+    if constexpr (DOT) {  // the two k-slots of a row live in lanes c and c + 32: lane half 0 gets the sum
+#pragma unroll
+      for (int t = 0; t < TILES; ++t) yacc[t][0] += __shfl_xor(yacc[t][0], 32);
+    }
     if constexpr (ABL == 6) yacc[0][0] += acc[0][0] + acc[0][1] + acc[1][0];
     if constexpr (ABL == 7) { yacc[0][0] = acc[0][0]; yacc[1][0] = acc[1][0]; }
 
