@@ -762,7 +762,7 @@ int launch_xprep(const PairParams& pp, int I, int ma, int64_t batch, hipStream_t
 // instantiations with LlamaRMSNorm fused into the activation staging (staged activations, m <= 8, not mx4)
 template <typename DT, int I, int GPS, bool QMX, int NSG>
 int launch_pair_m(PairParams& pp, unsigned lds, hipStream_t st, bool xg, int m, int mregs, bool norm) {
-  const bool m1 = m == 1 && TG_PAIR_MR1 == 1 && GPS <= TG_PAIR_MR1_GPS;
+  const bool m1 = m == 1 && TG_PAIR_MR1 == 1 && (QMX || GPS <= TG_PAIR_MR1_GPS);  // (mx4: no per-group state, the specialisation fits at any GPS)
   if (xg) return m1 ? launch_pair_k<DT, I, GPS, 1, QMX, NSG, true>(pp, lds, st) : launch_pair_k<DT, I, GPS, 4, QMX, NSG, true>(pp, lds, st);
   if (norm) {
     if constexpr (QMX) return TG_PAIR_NA;

@@ -247,7 +247,7 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
   // multiplier slots on 512 useful products and, under the 1400 W cap, clock -- 4 v_dot2 per word instead: 76.3 -> 80.6 % on the
   // headline shape, int4 82.6 -> 84.4 %, global LUT 79.4 -> 84.0 % same-box.  Only with fixed group boundaries (NSG > 0): the
   // run-time group test around it compiles to 128 VGPRs + 200-500 bytes of scratch.
-  constexpr bool DOT = TG_PAIR_M1_DOT && MR == 1 && !T16 && !QMX && NSG > 0;
+  constexpr bool DOT = TG_PAIR_M1_DOT && MR == 1 && !T16 && (QMX || NSG > 0);  // (mx4 has no group updates: any NSG)
   constexpr bool MXC = QMX;  // mx4: weights converted by v_cvt_scalef32_pk_bf16_fp4 (mx4_cvt_word), no table, no group updates
   static_assert(!NORM || (!XG && !T16 && !QMX), "fused RMSNorm: the workgroup stages the whole activation block itself");
   constexpr int WAVES = 8;
@@ -989,7 +989,7 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
 #pragma unroll
       for (int t = 0; t < TILES; ++t)
 #pragma unroll
-        for (int r = 0; r < RF; ++r) yacc[t][r] = acc[t][r];
+        for (int r = 0; r < RF; ++r) yacc[t][r] = DOT ? dacc[t] : acc[t][r];
     } else if (pending || GPS > 1 || NSG > 0) finalize();  // the last group of the slice
     if constexpr (DOT) {  // the two k-slots of a row live in lanes c and c + 32: lane half 0 gets the sum
 #pragma unroll

@@ -701,7 +701,7 @@ def main():
             "numerics_check": main_check,
             "roofline": {
                 "bound": "hbm",
-                "kernel": {"pair": "w4_gemm_pair_kernel<BF16, I=4> (persistent, 64-row work items, pair-table lookups, group-scaled accumulators)",
+                "kernel": {"pair": "w4_gemm_pair_kernel<BF16, I=4> (persistent, 64-row work items, pair-table lookups, v_dot2 contraction at m = 1, group-scaled accumulators)",
                            "stream": "w4_gemm_stream_kernel<BF16, Bint4 innerK=4>", "splitk": "w4_gemm_kernel<BF16>"}[plan],
                 "achieved": round(achieved, 2),
                 "peak": HBM_PEAK_GBPS,
