@@ -726,7 +726,7 @@ int launch_pair_k(PairParams& pp, unsigned lds, hipStream_t st) {
   // several groups per super-tile (group 32 / 64 with wide super-tiles): more per-slot state, one slot in flight fits the
   // 128-VGPR budget without spills (ring depth measured irrelevant between 2 and 4)
   // (mx4 on the 32x32x16 tiles converts its weights in registers and has no per-group state in the slots: the usual depth)
-  constexpr int RING = (QMX && LA == 0) ? TG_PAIR_R : GPS > 1 ? (LA ? TG_PAIR_RA1 : 1) : LA == 1 ? TG_PAIR_RA : LA == 2 ? TG_PAIR_RB16 : TG_PAIR_R;
+  constexpr int RING = (QMX && LA == 0) ? TG_PAIR_R : (MR == 1 && NSG == 4 && LA == 0) ? 4 : GPS > 1 ? (LA ? TG_PAIR_RA1 : 1) : LA == 1 ? TG_PAIR_RA : LA == 2 ? TG_PAIR_RB16 : TG_PAIR_R;
   constexpr auto kern = w4_gemm_pair_kernel<DT, I, GPS, MR, QMX, RING, NSG, TG_PAIR_ABL, XG, LA, NORM>;
   if (pp.dry) return TG_PLAN_PAIR;
   const int prc = prepare_lds_kernel<kern>();
@@ -870,6 +870,17 @@ int launch_pair(GemmParams& p, int64_t batch, hipStream_t st) {
     //  m = 8 50 % against 59 %)
     const bool fixed = TG_PAIR_NSG2 && (TG_PAIR_NSG2_M1 || !(p.m == 1 && TG_PAIR_MR1 == 1));
     if (fixed && nsg == TG_PAIR_R) return TG_PAIR_M(1, TG_PAIR_R);
+    // m = 1, a group of ONE super-tile (g = 64 at innerKTiles 4): fixed boundaries too since the dot2 contraction freed the registers
+    // (with the MFMA this build spilled 27; 77 -> 81 %), and a group of FOUR super-tiles (g = 256) as one round of a ring of four
+    // (76.7 -> 84.0 %; a ring of four at g = 128 / 64 measured 1-1.5 points below the ring of two).  Only the m = 1 kernels are
+    // instantiated for these (launch_pair_k directly: launch_pair_m would drag the general kernels in as well).
+    if constexpr (!QMX) {
+      if (fixed && p.m == 1 && TG_PAIR_MR1 == 1 && !p.norm_w && (nsg == 1 || nsg == 4)) {
+        if (nsg == 1) return xg ? launch_pair_k<DT, I, 1, 1, false, 1, true>(pp, lds, st) : launch_pair_k<DT, I, 1, 1, false, 1>(pp, lds, st);
+        if constexpr (I <= 4)  // (innerKTiles 8: four super-tiles would be g = 512)
+          return xg ? launch_pair_k<DT, I, 1, 1, false, 4, true>(pp, lds, st) : launch_pair_k<DT, I, 1, 1, false, 4>(pp, lds, st);
+      }
+    }
     return TG_PAIR_M(1, 0);
   }
   if constexpr (I >= 4) {
