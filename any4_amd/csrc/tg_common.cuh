@@ -1,0 +1,271 @@
+// tg_common.cuh -- what every translation unit of libtinygemm_hip.so shares: type traits, host helpers, the parameter block the
+// C ABI fills in (GemmParams) and the entry points of the kernel families' launch paths (namespace tgx).
+//
+// The library is built from one translation unit per kernel family (any4_amd/build.py compiles them in parallel):
+//   tinygemm_hip.hip   the C ABI, validation, dispatch (launch_w4), packers / converters, 16-bit and 8-bit weights, decode glue
+//   tg_splitk.hip      w4_gemm_kernel            (w4_gemm.cuh)
+//   tg_stream.hip      w4_gemm_stream_kernel     (w4_gemm_stream.cuh)      compiled once per 16-bit type (-DTG_TU_F16)
+//   tg_pair.hip        w4_gemm_pair_kernel       (w4_gemm_pair.cuh)        compiled once per 16-bit type
+//   tg_pair16.hip      w4_gemm_pair16_kernel     (w4_gemm_pair16.cuh)
+//   tg_xr.hip          w4_gemm_xr_kernel         (w4_gemm_xr.cuh)
+//   tg_gemv.hip        w4_gemv_kernel            (w4_gemv.cuh)
+// Kernels and their helpers stay in each unit's anonymous namespace (one device code object per unit, no symbol shared between
+// them); only GemmParams and the tgx:: functions cross unit boundaries.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <atomic>
+#include <type_traits>
+#include <utility>
+
+#include "../../include/tinygemm_hip.h"
+
+struct GemmParams {
+  const char* x;
+  const char* w;
+  const char* qinfo;
+  const char* lut;
+  char* y;
+  int32_t m, wrows, k;
+  int32_t ntiles;    // packed.size(0): 8-row (Bint4) or 16-row (Aint4) tiles
+  int32_t ksuper;    // packed.size(1)
+  int32_t gshift;    // log2(group)
+  int32_t ngroups;   // k / group
+  int32_t qtype;
+  int32_t splitk;    // waves per tile (power of two, <= WAVES)
+  int32_t sk_shift;  // log2(splitk)
+  int32_t rowtiles;  // ceil(wrows / 16)
+  int32_t dbg;       // developer ablation flags (0 in production)
+  int32_t numerics;  // TG_NUM_* (host-side dispatch only)
+  int32_t dry;       // host-side only: report the kernel family instead of launching (tg_gemm_w4_plan)
+  int64_t stride_x, stride_w, stride_qinfo, stride_lut, stride_y;
+  const char* bias;   // optional [wrows] 16-bit, added after the first rounding (see store_rows4)
+  int64_t stride_bias;
+  int64_t bias_row_stride;  // elements between the bias rows of consecutive activation rows (0: one row for all; wrows: a residual)
+  const char* norm_w;       // fused RMSNorm of the activations (pair-table kernels only) / host-side dispatch
+  float norm_eps;
+  int32_t epilogue;         // TG_EPI_* (pair-table kernels only)
+  // host-side only: the caller's workspace (pair kernel, XG variant) and the planner's answer to "how much would help"
+  char* ws;
+  int64_t ws_bytes, ws_need;
+  int32_t ws_query;
+  int32_t x_tc, y_tc;  // fragment-order activations / output (pair-table kernels only)
+};
+
+enum { CANON_NONE = 0, CANON_PAIR = 1, CANON_QUAD = 2 };
+
+// Returned by a family's launch path when the shape does not fit its plan (the caller then takes another kernel).
+enum { TG_PAIR_NA = -100 };
+
+// launch paths of the kernel families (dt = TG_BF16 / TG_F16; the other arguments as in the templates they wrap).  The two largest
+// families are compiled once per 16-bit type.
+namespace tgx {
+int pair_bf16(int I, bool qmx, GemmParams& p, int64_t batch, hipStream_t st);
+int pair_f16(int I, bool qmx, GemmParams& p, int64_t batch, hipStream_t st);
+int pair_a_bf16(int I, bool qmx, GemmParams& p, int64_t batch, hipStream_t st);
+int pair_a_f16(int I, bool qmx, GemmParams& p, int64_t batch, hipStream_t st);
+int pair_b16_bf16(int I, bool qmx, GemmParams& p, int64_t batch, hipStream_t st);
+int pair_b16_f16(int I, bool qmx, GemmParams& p, int64_t batch, hipStream_t st);
+int stream_bf16(bool layout_a, int wpl, bool qmx, const GemmParams& p, int64_t coltiles, int64_t batch, hipStream_t st);
+int stream_f16(bool layout_a, int wpl, bool qmx, const GemmParams& p, int64_t coltiles, int64_t batch, hipStream_t st);
+int pair_xr(int dt, int I, bool qmx, GemmParams& p, int64_t batch, hipStream_t st);
+int pair16(int dt, int I, bool qmx, const GemmParams& p, int64_t batch, hipStream_t st);
+int splitk(int dt, bool layout_a, int canon, bool qmx, int waves, const GemmParams& p, dim3 grid, hipStream_t st);
+int gemv(int dt, int I, bool qmx, GemmParams& p, int64_t batch, hipStream_t st);
+inline int pair(int dt, int I, bool qmx, GemmParams& p, int64_t batch, hipStream_t st) {
+  return dt == TG_BF16 ? pair_bf16(I, qmx, p, batch, st) : pair_f16(I, qmx, p, batch, st);
+}
+inline int pair_a(int dt, int I, bool qmx, GemmParams& p, int64_t batch, hipStream_t st) {
+  return dt == TG_BF16 ? pair_a_bf16(I, qmx, p, batch, st) : pair_a_f16(I, qmx, p, batch, st);
+}
+inline int pair_b16(int dt, int I, bool qmx, GemmParams& p, int64_t batch, hipStream_t st) {
+  return dt == TG_BF16 ? pair_b16_bf16(I, qmx, p, batch, st) : pair_b16_f16(I, qmx, p, batch, st);
+}
+inline int stream(int dt, bool layout_a, int wpl, bool qmx, const GemmParams& p, int64_t coltiles, int64_t batch, hipStream_t st) {
+  return dt == TG_BF16 ? stream_bf16(layout_a, wpl, qmx, p, coltiles, batch, st) : stream_f16(layout_a, wpl, qmx, p, coltiles, batch, st);
+}
+}  // namespace tgx
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+
+// LDS pointers (address space 3: ds_* instructions with constant offsets)
+typedef const __attribute__((address_space(3))) float* lds_cfptr;
+typedef __attribute__((address_space(3))) float* lds_fptr;
+typedef const __attribute__((address_space(3))) uint16_t* lds_cu16ptr;
+typedef const __attribute__((address_space(3))) uint32_t* lds_cu32ptr;
+typedef __attribute__((address_space(3))) uint32_t* lds_u32ptr;
+typedef const __attribute__((address_space(3))) u32x4* lds_cu32x4ptr;
+typedef __attribute__((address_space(3))) u32x4* lds_u32x4ptr;
+typedef const __attribute__((address_space(3))) f32x4* lds_cf32x4ptr;
+typedef __attribute__((address_space(3))) f32x4* lds_f32x4ptr;
+
+__device__ __forceinline__ float u2f(uint32_t u) { return __builtin_bit_cast(float, u); }
+__device__ __forceinline__ uint32_t f2u(float f) { return __builtin_bit_cast(uint32_t, f); }
+
+// ---- 16-bit float traits ---------------------------------------------------------------------
+struct BF16 {
+  static __device__ __forceinline__ float to_f32(uint16_t h) { return u2f(((uint32_t)h) << 16); }
+  static __device__ __forceinline__ float lo_f32(uint32_t pair) { return u2f(pair << 16); }
+  static __device__ __forceinline__ float hi_f32(uint32_t pair) { return u2f(pair & 0xffff0000u); }
+  // round-to-nearest-even pack; lowers to v_cvt_pk_bf16_f32 on gfx950
+  static __device__ __forceinline__ uint32_t pack2(float a, float b) {
+    f32x2 v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+  }
+  static __device__ __forceinline__ uint16_t from_f32(float a) { return (uint16_t)(pack2(a, 0.f) & 0xffffu); }
+  static __device__ __forceinline__ f32x4 mfma(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  }
+};
+struct F16 {
+  static __device__ __forceinline__ float to_f32(uint16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
+  static __device__ __forceinline__ float lo_f32(uint32_t pair) { return to_f32((uint16_t)(pair & 0xffffu)); }
+  static __device__ __forceinline__ float hi_f32(uint32_t pair) { return to_f32((uint16_t)(pair >> 16)); }
+  static __device__ __forceinline__ uint32_t pack2(float a, float b) {
+    f32x2 v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2));
+  }
+  static __device__ __forceinline__ uint16_t from_f32(float a) { return (uint16_t)(pack2(a, 0.f) & 0xffffu); }
+  static __device__ __forceinline__ f32x4 mfma(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  }
+};
+
+// fp4-e2m1 values in code order (reference FloatDefs.cuh:18-34)
+__device__ const float kMX4Values[16] = {0.0f,  0.5f,  1.0f,  1.5f,  2.0f,  3.0f,  4.0f,  6.0f,
+                                         -0.0f, -0.5f, -1.0f, -1.5f, -2.0f, -3.0f, -4.0f, -6.0f};
+
+// Output store of four consecutive weight rows of one activation row.  With a bias the sum is first rounded to 16 bits and
+// the bias added in a second rounded step: bit-identical to the reference module's separate `y + bias` (modules.py:221-222).
+template <typename DT>
+__device__ __forceinline__ void store_rows4(char* yb, const char* bias, int64_t elem, int rowg, f32x4 acc) {
+  u32x2 o = {DT::pack2(acc[0], acc[1]), DT::pack2(acc[2], acc[3])};
+  if (bias) {
+    const u32x2 bv = *reinterpret_cast<const u32x2*>(bias + (int64_t)rowg * 2);
+    o[0] = DT::pack2(DT::lo_f32(o[0]) + DT::lo_f32(bv[0]), DT::hi_f32(o[0]) + DT::hi_f32(bv[0]));
+    o[1] = DT::pack2(DT::lo_f32(o[1]) + DT::lo_f32(bv[1]), DT::hi_f32(o[1]) + DT::hi_f32(bv[1]));
+  }
+  *reinterpret_cast<u32x2*>(yb + elem * 2) = o;
+}
+
+
+struct DeviceScope {
+  int prev = -1;
+  bool ok = true;
+  explicit DeviceScope(int device) {
+    if (device < 0) return;
+    if (hipGetDevice(&prev) != hipSuccess) { ok = false; return; }
+    if (prev != device && hipSetDevice(device) != hipSuccess) ok = false;
+    if (prev == device) prev = -1;
+  }
+  ~DeviceScope() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+
+inline int launch_status() {
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : (int)e;
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Kernels that address LDS from offset 0 (lookup tables at the start of the dynamic region) and / or need more than 64 KiB
+// of dynamic LDS: once per device, check that the kernel has no static LDS (the dynamic region then starts at 0) and raise
+// its dynamic-LDS limit.  State = one write-once bit per device and kernel; racing threads repeat the same idempotent calls.
+template <auto KERN>
+int prepare_lds_kernel() {
+  static std::atomic<uint64_t> done{0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return TG_E_DEVICE;
+  if (dev >= 0 && dev < 64 && ((done.load(std::memory_order_relaxed) >> dev) & 1u)) return 0;
+  hipFuncAttributes fa;
+  hipError_t e = hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(KERN));
+  if (e != hipSuccess) return (int)e;
+  if (fa.sharedSizeBytes != 0) return TG_E_INTERNAL;
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(KERN), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e != hipSuccess) return (int)e;
+  if (dev >= 0 && dev < 64) done.fetch_or(1ull << dev, std::memory_order_relaxed);
+  return 0;
+}
+
+
+// Tuning constants of the pair-table launches, each with the measurement that set it.  The shipped library
+// always uses these values; only developer builds (-DTG_DEV / -DTG_DEV_MIN, dev/build_variant.sh) may override one with -D<NAME>=<v>.
+#if !defined(TG_DEV) && !defined(TG_DEV_MIN)
+#if defined(TG_PAIR_R) || defined(TG_PAIR_ABL) || defined(TG_PAIR_MR1) || defined(TG_PAIR_NSG2) || defined(TG_PAIR_MR1_GPS) || defined(TG_PAIR_RA) ||   \
+    defined(TG_PAIR_RA1) || defined(TG_PAIR_RB16) || defined(TG_B16_CHUNK) || defined(TG_PAIR_MIN_ITEMS) || defined(TG_XG_CHUNK) || defined(TG_PAIR_WGS) || \
+    defined(TG_PAIR_NSG2_M1) || defined(TG_PAIR_FORCE_XG) || defined(TG_XR_MIN_M) || defined(TG_XR_R) || defined(TG_XR_R8K) || defined(TG_XR_RMX)
+#error "the TG_PAIR_* / TG_XG_* / TG_B16_* tuning constants can only be overridden in developer builds (-DTG_DEV or -DTG_DEV_MIN)"
+#endif
+#endif
+#ifndef TG_PAIR_R
+#define TG_PAIR_R 2            // super-tiles a wave keeps in flight (2, 3, 4 measured equal; 5 spills)
+#endif
+#ifndef TG_PAIR_ABL
+#define TG_PAIR_ABL 0          // ablation stub of w4_gemm_pair.cuh (its header lists them)
+#endif
+#ifndef TG_PAIR_MR1
+#define TG_PAIR_MR1 1          // 1: m = 1 runs the one-register specialisation (+2-3 %), 4: the general m <= 8 kernel
+#endif
+#ifndef TG_PAIR_NSG2
+#define TG_PAIR_NSG2 1         // group boundaries at fixed places of the unrolled round when a group is one round of the ring
+#endif
+#ifndef TG_PAIR_NSG2_M1
+#define TG_PAIR_NSG2_M1 1      // ... also in the m = 1 specialisation (74.8 -> 75.8 % once its group update was spelled out)
+#endif
+#ifndef TG_PAIR_MR1_GPS
+#define TG_PAIR_MR1_GPS 1      // the m = 1 specialisation is used up to this many groups per super-tile (it spills beyond)
+#endif
+#ifndef TG_PAIR_RA
+#define TG_PAIR_RA 2           // ring depth of the A-side kernels (4 / 6 / 8 measured 8.2 / 21 / 40 us against 6.8)
+#endif
+#ifndef TG_PAIR_RA1
+#define TG_PAIR_RA1 1          // ... with several groups per super-tile
+#endif
+#ifndef TG_PAIR_RB16
+#define TG_PAIR_RB16 2         // ring depth of the 16x16x32 kernels for Bint4 weights, m = 9 ... 16 (3 / 4: 41 % against 44 %)
+#endif
+#ifndef TG_B16_CHUNK
+#define TG_B16_CHUNK 4         // consecutive 32-row work items per workgroup visit of those kernels (1 / 4 / 8 within 1 %)
+#endif
+#ifndef TG_PAIR_MIN_ITEMS
+#define TG_PAIR_MIN_ITEMS 192  // fewer work items: the launch is latency-bound, w4_gemm_pair16_kernel / the reference kernels take
+                               // it (measured per hipGraph node, one layer, m = 1: 14336 x 4096 = 224 items 12.3 us here against
+                               // 18.3 us on pair16 and 13.8 us on the stream kernel; 6144 x 4096 = 96 items 10.7 against 9.9 / 8.2)
+#endif
+#ifndef TG_XG_CHUNK
+#define TG_XG_CHUNK 4          // consecutive work items per workgroup visit in the workspace variant of Bint4 weights (1: plain
+                               // round-robin): m = 8: 4096^2 66.1 -> 66.5 %, 8192^2 67.3 -> 68.6 %; Aint4 weights keep 1
+#endif
+#ifndef TG_XR_MIN_M
+#define TG_XR_MIN_M 2          // activation rows from which the register-resident-activation kernel (w4_gemm_xr.cuh) takes stacked launches
+                               // (same-box A/B against the kernels it replaces, 4096^2: m = 2 71.9 vs 69.7 %, 4: 68.9 vs 66.9, 8: 66.2 vs 62.7,
+                               //  16: 65.2 vs 46.0; m = 1 stays on the 32x32x16 kernel, 77 %)
+#endif
+#ifndef TG_XR_RMX
+#define TG_XR_RMX 8            // ... for mx4 (no lookups: latency-bound; the whole slice in flight: m = 16 75.4 -> 79.0 %, m = 2 81.7 -> 85.3 %)
+#endif
+#ifndef TG_XR_R8K
+#define TG_XR_R8K 2            // ... at k = 8192 (128 registers of activations per lane: 4 in flight spill 25)
+#endif
+#ifndef TG_XR_R
+#define TG_XR_R 4              // super-tiles a wave of that kernel keeps in flight
+#endif
+#ifndef TG_PAIR_WGS
+#define TG_PAIR_WGS 512        // persistent workgroups: two per CU (768 / 1024: +4 % / +1 % time)
+#endif
+
+}  // namespace

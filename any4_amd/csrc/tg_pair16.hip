@@ -1,0 +1,91 @@
+// tg_pair16.hip -- launch path of w4_gemm_pair16_kernel (one layer per launch); see tg_common.cuh
+#include "tg_common.cuh"
+namespace {
+#include "w4_gemm_pair.cuh"   // shared device helpers (tc_a_index, dot2, chunk_rmsnorm, swiglu16, PairParams); its kernel is not instantiated here
+#include "w4_gemm_pair16.cuh"
+// Small launches of Bint4 weights (one layer per call): w4_gemm_pair16_kernel, 16 weight rows per workgroup, the whole k-slice
+// of a wave requested up front.  Taken when the launch is too small for the persistent kernel (or its LDS plan does not fit)
+// and the activations (m <= 16 rows) fit in LDS next to the table.
+template <typename DT, int I, bool QMX>
+int launch_pair16(const GemmParams& p, int64_t batch, hipStream_t st) {
+  if constexpr (QMX && !std::is_same<DT, BF16>::value) return TG_E_DTYPE;  // mx4 is bf16-only (TinyGemm_int4.cu:758)
+  else {
+#ifdef TG_DEV_MIN
+  if constexpr (!(std::is_same<DT, BF16>::value && I == 4 && !QMX)) return TG_PAIR_NA;
+#endif
+  if (p.m > 16 || batch > 65535) return TG_PAIR_NA;
+  // m = 1 and more than one round of workgroups (one per CU): the streaming kernel's split-K launches are faster there
+  // (per hipGraph node, 6144 x 4096: 8.6 us against 10.2 us; 14336 x 4096: 13.8 against 18.3)
+  // (not when a fused stage is asked for: only the pair-table kernels have them)
+  if (p.m == 1 && !p.x_tc && !p.y_tc && !p.norm_w && !p.epilogue && (int64_t)((p.wrows + 15) / 16) * batch > 256 && (1 << p.gshift) >= 128) return TG_PAIR_NA;
+  if (p.norm_w && (QMX || (int64_t)p.m * p.k > 32768)) return TG_PAIR_NA;  // the norm pass: one 32-k chunk per thread
+  const int g = 1 << p.gshift;
+  const int nsg = g >= 16 * I ? g / (16 * I) : 1;
+  Pair16Params pp;
+  pp.x = p.x; pp.w = p.w; pp.qinfo = p.qinfo; pp.lut = p.lut; pp.y = p.y;
+  pp.m = p.m; pp.wrows = p.wrows; pp.k = p.k; pp.ntiles = p.ntiles; pp.ksuper = p.ksuper;
+  pp.gshift = p.gshift; pp.ngroups = p.ngroups; pp.qtype = p.qtype;
+  pp.gch_mask = g / 32 - 1;
+  pp.lds_x = 65536;
+  const int64_t wgs = (int64_t)((p.wrows + 15) / 16) * batch;
+  // one workgroup per CU may take the whole LDS; a launch of more than two rounds of workgroups should fit two per CU
+  const unsigned lds_limit = (wgs <= 512 ? 160u : 80u) * 1024u;
+  // activation rows that do not fit next to the table are staged one part of k at a time (whole groups per part)
+  unsigned lds = 0;
+  int phases = 1;
+  for (; phases <= (wgs <= 512 && !p.norm_w ? 8 : 1); phases *= 2) {  // (the fused norm needs a row's whole k in one part)
+    if (p.ksuper % (phases * nsg) != 0 || p.ngroups % phases != 0) return TG_PAIR_NA;
+    const int kp = p.k / phases;
+    pp.x_pitch = kp * 2 + 16;
+    pp.lds_xs = (pp.lds_x + p.m * pp.x_pitch + 16 + 15) & ~15;
+    lds = (unsigned)pp.lds_xs + (QMX ? 0u : (unsigned)(p.ngroups / phases) * 64u);
+    if (lds <= lds_limit) break;
+  }
+  if (lds > lds_limit) return TG_PAIR_NA;
+  pp.phases = phases;
+  pp.ksuper_p = p.ksuper / phases;
+  pp.spw = ((pp.ksuper_p / nsg + 15) / 16) * nsg;
+  pp.stride_x = p.stride_x; pp.stride_w = p.stride_w; pp.stride_qinfo = p.stride_qinfo;
+  pp.stride_lut = p.stride_lut; pp.stride_y = p.stride_y;
+  pp.bias = p.bias; pp.stride_bias = p.stride_bias;
+  pp.bias_row_stride = p.bias_row_stride; pp.norm_w = p.norm_w; pp.norm_eps = p.norm_eps; pp.epilogue = p.epilogue;
+  pp.x_tc = p.x_tc; pp.y_tc = p.y_tc; pp.y_tiles = (p.wrows + 15) / 16;
+  if (p.dry) return TG_PLAN_PAIR;
+  const dim3 grid((unsigned)((p.wrows + 15) / 16), (unsigned)batch);
+#define TG_P16K(CPG_, NORM_)                                                 \
+  do {                                                                      \
+    constexpr auto kern = w4_gemm_pair16_kernel<DT, I, QMX, CPG_, 1, NORM_>; \
+    const int prc = prepare_lds_kernel<kern>();                             \
+    if (prc != 0) return prc;                                               \
+    hipLaunchKernelGGL(kern, grid, dim3(1024), lds, st, pp);                \
+  } while (0)
+#define TG_P16(CPG_)                                 \
+  do {                                               \
+    if constexpr (!QMX) {                            \
+      if (p.norm_w) { TG_P16K(CPG_, true); break; }  \
+    }                                                \
+    TG_P16K(CPG_, false);                            \
+  } while (0)
+  if constexpr (QMX) TG_P16(1);  // mx4: group = 32
+  else if (g == 32) TG_P16(1);
+  else if (g == 64) TG_P16(2);
+  else if (g == 128) TG_P16(4);
+  else TG_P16(8);
+#undef TG_P16K
+#undef TG_P16
+  return launch_status();
+  }
+}
+
+template <typename DT, int I>
+int p16_q(bool qmx, const GemmParams& p, int64_t batch, hipStream_t st) {
+  return qmx ? launch_pair16<DT, I, true>(p, batch, st) : launch_pair16<DT, I, false>(p, batch, st);
+}
+template <typename DT>
+int p16_i(int I, bool qmx, const GemmParams& p, int64_t batch, hipStream_t st) {
+  return I == 2 ? p16_q<DT, 2>(qmx, p, batch, st) : I == 4 ? p16_q<DT, 4>(qmx, p, batch, st) : p16_q<DT, 8>(qmx, p, batch, st);
+}
+}  // namespace
+int tgx::pair16(int dt, int I, bool qmx, const GemmParams& p, int64_t batch, hipStream_t st) {
+  return dt == TG_BF16 ? p16_i<BF16>(I, qmx, p, batch, st) : p16_i<F16>(I, qmx, p, batch, st);
+}

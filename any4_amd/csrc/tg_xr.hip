@@ -1,0 +1,90 @@
+// tg_xr.hip -- launch path of w4_gemm_xr_kernel (stacked launches, activations resident in registers); see tg_common.cuh
+#include "tg_common.cuh"
+namespace {
+#include "w4_gemm_pair.cuh"   // shared device helpers; its kernel is not instantiated here
+#include "w4_gemm_xr.cuh"
+// Bint4 weights, stacked launches, TG_XR_MIN_M ... 16 activation rows, k = 4096: w4_gemm_xr_kernel (one 8-wave workgroup per CU, the
+// activations of a wave's k-slice resident in its registers, 64-row work items, two tables).  No workspace, no pre-pass.
+template <typename DT, int I, bool QMX, int NCH>
+int launch_pair_xr_n(GemmParams& p, int64_t batch, hipStream_t st) {
+  if constexpr (I != 4 || (QMX && (NCH != 16 || !std::is_same<DT, BF16>::value))) return TG_PAIR_NA;  // (mx4: bf16, k = 4096)
+  else {
+#ifdef TG_DEV_MIN
+  if constexpr (!std::is_same<DT, BF16>::value) return TG_PAIR_NA;
+  else {
+#endif
+  if (p.m > 16 || p.m < TG_XR_MIN_M || p.norm_w || p.epilogue) return TG_PAIR_NA;
+  if (p.ksuper * 16 * I != p.k || p.wrows % 64 != 0 || p.ntiles * 8 != p.wrows) return TG_PAIR_NA;
+  const int g = 1 << p.gshift;
+  const int cpg = g / 32 < NCH ? g / 32 : NCH;  // 32-k chunks per group inside a wave's slice
+#ifdef TG_DEV_MIN
+  if (cpg != (QMX ? 1 : 4)) return TG_PAIR_NA;
+#endif
+  if (QMX ? cpg != 1 : (cpg != 1 && cpg != 2 && cpg != 4 && cpg != 8)) return TG_PAIR_NA;  // g = 32, 64, 128, 256; mx4: g = 32
+  if (QMX && p.ngroups % 16 != 0) return TG_PAIR_NA;  // 16-byte exponent blocks
+  if (NCH > 16 && cpg == 2) return TG_PAIR_NA;          // (k = 8192, g = 64: that instantiation spills four registers)
+  XrParams xp;
+  xp.w = p.w; xp.qinfo = p.qinfo; xp.lut = p.lut; xp.y = p.y;
+  xp.m = p.m; xp.wrows = p.wrows; xp.k = p.k; xp.ntiles = p.ntiles; xp.ksuper = p.ksuper;
+  xp.gshift = p.gshift; xp.ngroups = p.ngroups; xp.qtype = p.qtype;
+  xp.rblocks = (p.wrows + 63) / 64;
+  const int64_t items = (int64_t)xp.rblocks * batch;
+  if (items > INT32_MAX || items < 2 * 256) return TG_PAIR_NA;  // two items per workgroup at least
+  xp.items = (int32_t)items;
+  xp.lds_xs = 2 * 65536;
+  const unsigned lds = QMX ? 32768u : (unsigned)xp.lds_xs + (unsigned)p.ngroups * 64u;  // two tables, the activation sums (mx4: the partial sums only)
+  if (lds > 160u * 1024u) return TG_PAIR_NA;
+  xp.x = p.x; xp.stride_x = p.stride_x; xp.x_tc = p.x_tc;  // (no pre-pass, no workspace: the kernel arranges the activations itself)
+  p.ws_need = 0;
+  xp.stride_w = p.stride_w; xp.stride_qinfo = p.stride_qinfo; xp.stride_lut = p.stride_lut; xp.stride_y = p.stride_y;
+  xp.bias = p.bias; xp.stride_bias = p.stride_bias; xp.bias_row_stride = p.bias_row_stride;
+  xp.y_tc = p.y_tc; xp.y_tiles = (p.wrows + 15) / 16; xp.dry = p.dry;
+  if (p.dry) return TG_PLAN_PAIR_XR;
+#define TG_XR_LAUNCH(CPG_)                                                  \
+  do {                                                                      \
+    constexpr auto kern = w4_gemm_xr_kernel<DT, I, NCH, CPG_, (NCH > 16 ? TG_XR_R8K : TG_XR_R)>; \
+    const int prc = prepare_lds_kernel<kern>();                             \
+    if (prc != 0) return prc;                                               \
+    hipLaunchKernelGGL(kern, dim3(256), dim3(512), lds, st, xp);            \
+  } while (0)
+  if constexpr (QMX) {
+    constexpr auto kern = w4_gemm_xr_kernel<DT, I, NCH, 1, TG_XR_RMX, true>;
+    const int prc = prepare_lds_kernel<kern>();
+    if (prc != 0) return prc;
+    hipLaunchKernelGGL(kern, dim3(256), dim3(512), lds, st, xp);
+  } else {
+#ifdef TG_DEV_MIN
+  TG_XR_LAUNCH(4);
+#else
+  if (cpg == 1) TG_XR_LAUNCH(1);
+  else if (cpg == 2) TG_XR_LAUNCH(2);
+  else if (cpg == 4) TG_XR_LAUNCH(4);
+  else TG_XR_LAUNCH(8);
+#endif
+  }
+#undef TG_XR_LAUNCH
+  return launch_status();
+#ifdef TG_DEV_MIN
+  }
+#endif
+  }
+}
+
+template <typename DT, int I, bool QMX>
+int launch_pair_xr(GemmParams& p, int64_t batch, hipStream_t st) {
+  if (p.k == 4096) return launch_pair_xr_n<DT, I, QMX, 16>(p, batch, st);
+  // k = 8192: 128 registers of activations per lane leave room for two super-tiles in flight only -- faster than the 16x16x32
+  // workspace kernel it replaces at 9 ... 16 rows (8192^2, m = 16: 62 vs 47-51 %), slower than the 32x32x16 one below that
+  // (m = 8: 66 vs 70 %)
+  if (p.k == 8192 && p.m >= 9) return launch_pair_xr_n<DT, I, QMX, 32>(p, batch, st);
+  return TG_PAIR_NA;
+}
+template <typename DT>
+int xr_i(int I, bool qmx, GemmParams& p, int64_t batch, hipStream_t st) {
+  if (I != 4) return TG_PAIR_NA;
+  return qmx ? launch_pair_xr<DT, 4, true>(p, batch, st) : launch_pair_xr<DT, 4, false>(p, batch, st);
+}
+}  // namespace
+int tgx::pair_xr(int dt, int I, bool qmx, GemmParams& p, int64_t batch, hipStream_t st) {
+  return dt == TG_BF16 ? xr_i<BF16>(I, qmx, p, batch, st) : xr_i<F16>(I, qmx, p, batch, st);
+}

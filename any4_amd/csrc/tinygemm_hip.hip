@@ -26,86 +26,11 @@
 //     two 16-bit floats is exact, so this equals the reference's single-rounding bf16 fma;
 //   * fp32 partial tiles meet in LDS, a fixed-order sum gives a deterministic result.
 
-#include <hip/hip_runtime.h>
-#include <stdint.h>
-#include <stdlib.h>
-#include <string.h>
-#include <atomic>
-#include <type_traits>
-#include <utility>
-
-#include "../../include/tinygemm_hip.h"
+#include "tg_common.cuh"
 
 namespace {
 
-typedef __attribute__((ext_vector_type(4))) float f32x4;
-typedef __attribute__((ext_vector_type(2))) float f32x2;
-typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
-typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
-typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
-
-__device__ __forceinline__ float u2f(uint32_t u) { return __builtin_bit_cast(float, u); }
-__device__ __forceinline__ uint32_t f2u(float f) { return __builtin_bit_cast(uint32_t, f); }
-
-// ---- 16-bit float traits ---------------------------------------------------------------------
-struct BF16 {
-  static __device__ __forceinline__ float to_f32(uint16_t h) { return u2f(((uint32_t)h) << 16); }
-  static __device__ __forceinline__ float lo_f32(uint32_t pair) { return u2f(pair << 16); }
-  static __device__ __forceinline__ float hi_f32(uint32_t pair) { return u2f(pair & 0xffff0000u); }
-  // round-to-nearest-even pack; lowers to v_cvt_pk_bf16_f32 on gfx950
-  static __device__ __forceinline__ uint32_t pack2(float a, float b) {
-    f32x2 v = {a, b};
-    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
-  }
-  static __device__ __forceinline__ uint16_t from_f32(float a) { return (uint16_t)(pack2(a, 0.f) & 0xffffu); }
-  static __device__ __forceinline__ f32x4 mfma(u32x4 a, u32x4 b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-  }
-};
-struct F16 {
-  static __device__ __forceinline__ float to_f32(uint16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
-  static __device__ __forceinline__ float lo_f32(uint32_t pair) { return to_f32((uint16_t)(pair & 0xffffu)); }
-  static __device__ __forceinline__ float hi_f32(uint32_t pair) { return to_f32((uint16_t)(pair >> 16)); }
-  static __device__ __forceinline__ uint32_t pack2(float a, float b) {
-    f32x2 v = {a, b};
-    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2));
-  }
-  static __device__ __forceinline__ uint16_t from_f32(float a) { return (uint16_t)(pack2(a, 0.f) & 0xffffu); }
-  static __device__ __forceinline__ f32x4 mfma(u32x4 a, u32x4 b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
-  }
-};
-
-// fp4-e2m1 values in code order (reference FloatDefs.cuh:18-34)
-__device__ const float kMX4Values[16] = {0.0f,  0.5f,  1.0f,  1.5f,  2.0f,  3.0f,  4.0f,  6.0f,
-                                         -0.0f, -0.5f, -1.0f, -1.5f, -2.0f, -3.0f, -4.0f, -6.0f};
-
-// Output store of four consecutive weight rows of one activation row.  With a bias the sum is first rounded to 16 bits and
-// the bias added in a second rounded step: bit-identical to the reference module's separate `y + bias` (modules.py:221-222).
-template <typename DT>
-__device__ __forceinline__ void store_rows4(char* yb, const char* bias, int64_t elem, int rowg, f32x4 acc) {
-  u32x2 o = {DT::pack2(acc[0], acc[1]), DT::pack2(acc[2], acc[3])};
-  if (bias) {
-    const u32x2 bv = *reinterpret_cast<const u32x2*>(bias + (int64_t)rowg * 2);
-    o[0] = DT::pack2(DT::lo_f32(o[0]) + DT::lo_f32(bv[0]), DT::hi_f32(o[0]) + DT::hi_f32(bv[0]));
-    o[1] = DT::pack2(DT::lo_f32(o[1]) + DT::lo_f32(bv[1]), DT::hi_f32(o[1]) + DT::hi_f32(bv[1]));
-  }
-  *reinterpret_cast<u32x2*>(yb + elem * 2) = o;
-}
-
-#include "w4_gemm.cuh"
-#include "w4_gemm_stream.cuh"
-#include "w4_gemm_pair.cuh"
-#include "w4_gemm_pair16.cuh"
-#include "w4_gemm_xr.cuh"
 #include "w8_gemm.cuh"
-
-#ifndef STREAM_MINW
-#define STREAM_MINW 4
-#endif
 
 // ---- 16-bit weights (reference TinyGemm_bf16.cu) ---------------------------------------------
 // Same tile/split-K structure; the A operand is gathered dword-wise from the fragment-order
@@ -363,48 +288,6 @@ __global__ void __launch_bounds__(256) dequant_int4_kernel(const int32_t* __rest
   }
 }
 
-// ---- host side ---------------------------------------------------------------------------------
-
-struct DeviceScope {
-  int prev = -1;
-  bool ok = true;
-  explicit DeviceScope(int device) {
-    if (device < 0) return;
-    if (hipGetDevice(&prev) != hipSuccess) { ok = false; return; }
-    if (prev != device && hipSetDevice(device) != hipSuccess) ok = false;
-    if (prev == device) prev = -1;
-  }
-  ~DeviceScope() {
-    if (prev >= 0) (void)hipSetDevice(prev);
-  }
-};
-
-inline int launch_status() {
-  const hipError_t e = hipGetLastError();
-  return e == hipSuccess ? 0 : (int)e;
-}
-
-inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
-inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
-
-// Kernels that address LDS from offset 0 (lookup tables at the start of the dynamic region) and / or need more than 64 KiB
-// of dynamic LDS: once per device, check that the kernel has no static LDS (the dynamic region then starts at 0) and raise
-// its dynamic-LDS limit.  State = one write-once bit per device and kernel; racing threads repeat the same idempotent calls.
-template <auto KERN>
-int prepare_lds_kernel() {
-  static std::atomic<uint64_t> done{0};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return TG_E_DEVICE;
-  if (dev >= 0 && dev < 64 && ((done.load(std::memory_order_relaxed) >> dev) & 1u)) return 0;
-  hipFuncAttributes fa;
-  hipError_t e = hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(KERN));
-  if (e != hipSuccess) return (int)e;
-  if (fa.sharedSizeBytes != 0) return TG_E_INTERNAL;
-  e = hipFuncSetAttribute(reinterpret_cast<const void*>(KERN), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  if (e != hipSuccess) return (int)e;
-  if (dev >= 0 && dev < 64) done.fetch_or(1ull << dev, std::memory_order_relaxed);
-  return 0;
-}
 
 #ifdef TG_DEV  // developer builds only (-DTG_DEV): geometry override through the environment, never in the shipped library
 int g_dbg_variant = 0;
@@ -496,701 +379,11 @@ int launch_w8(GemmParams& p, int64_t coltiles, int64_t batch, hipStream_t st) {
   return launch_status();
 }
 
-// ---- streaming kernel launch ---------------------------------------------------------------------
-// LDS per workgroup: lookup tables (4 KiB per wave and row set) + two X slabs (+ split-K tiles).
-template <bool LAYOUT_A>
-inline unsigned stream_lds_bytes(int sw, int mrows, int sk, bool privx = false) {
-  const unsigned nr = 1u;  // lookup tables per wave
-  const unsigned unit = LAYOUT_A ? 64u : 128u;
-  // shared slab: rows of all k-slices; private slabs: one per wave with the rows of its own slice; + the all-zero row
-  const unsigned slab = (unsigned)(mrows * 4 * (privx ? 1 : sk) + 1) * (unit * 2u + 16u);
-  return (unsigned)sw * nr * 4096u + 2u * slab * (privx ? (unsigned)sw : 1u) + (sk > 1 ? (unsigned)sw * nr * 1024u : 0u);
-}
 
-template <typename DT, bool LAYOUT_A, int WPL, bool QMX, int SW, bool privx = (SW == 1)>
-int launch_stream_sw(StreamParams& sp, int sk, int64_t coltiles, int64_t batch, hipStream_t st) {
-  constexpr int UNIT = LAYOUT_A ? 64 : 128;
-  constexpr unsigned NR = 1u;
-  const int nunits = (sp.k + UNIT - 1) / UNIT;
-  const int upg = (1 << sp.gshift) / UNIT;  // units per quantisation group (>= 1)
-  const int mrows = sp.m < 16 ? sp.m : 16;
-  int nu = (nunits + 4 * sk - 1) / (4 * sk);
-  nu = (nu + upg - 1) / upg * upg;
-  sp.splitk = sk;
-  sp.sk_shift = 0;
-  while ((1 << sp.sk_shift) < sk) ++sp.sk_shift;
-  sp.units_per_lane = nu;
-  sp.upg_mask = upg - 1;
-  const int xrows = mrows * 4 * (privx ? 1 : sk);
-  sp.xslab_bytes = (xrows + 1) * (UNIT * 2 + 16);
-  sp.red_off = (int32_t)(SW * NR * 4096u + 2u * (unsigned)sp.xslab_bytes * (privx ? SW : 1));
-  const int pieces = xrows * (UNIT * 2 / 16);
-  // privx: every wave stages its own X slab (no barrier in the main loop)
-  const int nstage = privx ? 64 : SW * 64;
-  const int xl = pieces <= nstage ? 1 : (pieces <= 2 * nstage ? 2 : 4);
-  const unsigned lds = stream_lds_bytes<LAYOUT_A>(SW, mrows, sk, privx);
-  const int tpb = SW / sk;
-  dim3 grid((unsigned)((sp.rowtiles + tpb - 1) / tpb), (unsigned)coltiles, (unsigned)batch);
-#define TG_LAUNCH_STREAM(XL)                                                                              \
-  do {                                                                                                    \
-    constexpr auto kern = w4_gemm_stream_kernel<DT, LAYOUT_A, WPL, QMX, SW, STREAM_MINW, XL, privx>;      \
-    if (sp.dry) return TG_PLAN_STREAM;                                                                    \
-    const int prc = prepare_lds_kernel<kern>();                                                           \
-    if (prc != 0) return prc;                                                                             \
-    hipLaunchKernelGGL(kern, grid, dim3(SW * 64), lds, st, sp);                                           \
-  } while (0)
-  if constexpr (privx && SW > 1) {
-    if (xl != 1) return TG_E_SHAPE;  // private slabs with split-K are only instantiated for one piece per lane (m = 1)
-    TG_LAUNCH_STREAM(1);
-  } else if constexpr (SW == 1) {
-    if (xl == 1) TG_LAUNCH_STREAM(1);
-    else TG_LAUNCH_STREAM(2);
-  } else {
-    if (xl == 1) TG_LAUNCH_STREAM(1);
-    else if (xl == 2) TG_LAUNCH_STREAM(2);
-    else TG_LAUNCH_STREAM(4);
-  }
-#undef TG_LAUNCH_STREAM
-  return launch_status();
-}
-
-// Resident-X launch: 16-wave workgroups, the whole [mrows][k] activation block staged once per workgroup.
-template <typename DT, bool LAYOUT_A, int WPL, bool QMX>
-int launch_stream_xres(StreamParams& sp, int64_t coltiles, int64_t batch, unsigned lds, hipStream_t st) {
-  // one workgroup walks up to 4 consecutive groups of 16 tiles of its layer (X staged once, tile-granularity tail
-  // amortised) as long as that leaves at least two workgroups per CU
-  int tpw = 4;
-  while (tpw > 1 && ((sp.rowtiles + 16 * tpw - 1) / (16 * tpw)) * coltiles * batch < 512) tpw >>= 1;
-  sp.tiles_per_wave = tpw;
-  constexpr auto kern = w4_gemm_stream_kernel<DT, LAYOUT_A, WPL, QMX, 16, STREAM_MINW, 1, false, 0, true>;
-  if (sp.dry) return TG_PLAN_STREAM;
-  const int prc = prepare_lds_kernel<kern>();
-  if (prc != 0) return prc;
-  dim3 grid((unsigned)((sp.rowtiles + 16 * tpw - 1) / (16 * tpw)), (unsigned)coltiles, (unsigned)batch);
-  hipLaunchKernelGGL(kern, grid, dim3(16 * 64), lds, st, sp);
-  return launch_status();
-}
-
-template <typename DT, bool LAYOUT_A, int WPL, bool QMX>
-int launch_stream(const GemmParams& p, int64_t coltiles, int64_t batch, hipStream_t st) {
-  constexpr int UNIT = LAYOUT_A ? 64 : 128;
-  constexpr int RPW = 16;  // weight rows per wave
-  StreamParams sp;
-  sp.x = p.x; sp.w = p.w; sp.qinfo = p.qinfo; sp.lut = p.lut; sp.y = p.y;
-  sp.m = p.m; sp.wrows = p.wrows; sp.k = p.k; sp.ntiles = p.ntiles; sp.ksuper = p.ksuper;
-  sp.gshift = p.gshift; sp.ngroups = p.ngroups; sp.qtype = p.qtype;
-  sp.rowtiles = (p.wrows + RPW - 1) / RPW;
-  sp.tiles_per_wave = 1;
-  sp.stride_x = p.stride_x; sp.stride_w = p.stride_w; sp.stride_qinfo = p.stride_qinfo;
-  sp.stride_lut = p.stride_lut; sp.stride_y = p.stride_y;
-  sp.bias = p.bias; sp.stride_bias = p.stride_bias; sp.bias_row_stride = p.bias_row_stride; sp.dry = p.dry;
-  const int mrows = p.m < 16 ? p.m : 16;
-  const int nunits = (p.k + UNIT - 1) / UNIT;
-  const int upg = (1 << p.gshift) / UNIT;
-  // split-K: aim for at least two rounds of 16 waves on every CU; the X slab limits act rows * splitk to 16
-  const int64_t wave_tiles = (int64_t)sp.rowtiles * coltiles * batch;
-  int sk = 1;
-  // (m = 1, private slabs: one round of 16 waves per CU is enough -- measured on the Llama-3-8B shapes)
-  const int64_t want = mrows == 1 ? 256 * 16 : 2 * 256 * 16;
-  while (sk < 8 && wave_tiles * sk < want && nunits >= 8 * sk * upg && mrows * sk * 2 <= 16) sk *= 2;
-#ifdef TG_DEV
-  static const int sk_env = getenv("TG_SK") ? atoi(getenv("TG_SK")) : 0;  // developer override
-  if (sk_env > 0) sk = sk_env;
-#endif
-  // m == 1: every wave stages its own X slab (no barrier in the main loop); a workgroup is the sk waves of one tile
-#ifdef TG_DEV
-  static const int xres_env = getenv("TG_XRES") ? atoi(getenv("TG_XRES")) : 1;  // developer knob: 0 off, 2 also for m = 1
-#else
-  constexpr int xres_env = 1;
-#endif
-  if (mrows == 1 && xres_env != 2) {
-    switch (sk) {
-      case 1: return launch_stream_sw<DT, LAYOUT_A, WPL, QMX, 1>(sp, 1, coltiles, batch, st);
-      case 2: return launch_stream_sw<DT, LAYOUT_A, WPL, QMX, 2, true>(sp, 2, coltiles, batch, st);
-      case 4: return launch_stream_sw<DT, LAYOUT_A, WPL, QMX, 4, true>(sp, 4, coltiles, batch, st);
-      default: return launch_stream_sw<DT, LAYOUT_A, WPL, QMX, 8, true>(sp, 8, coltiles, batch, st);
-    }
-  }
-  // m >= 2, one tile per wave: keep the whole activation block resident in LDS when it fits next to 16 lookup
-  // tables (m = 8 at k = 4096 does: 66 KiB + 64 KiB) -- one barrier per workgroup instead of one per unit
-  // (measured: wins for m >= 8 at k = 4096 and for m >= 2 at k = 8192; the 16-wave workgroup costs ~15 % in tile-granularity
-  //  tail against 4-wave workgroups, which the small slabs of m <= 4 at k = 4096 do not pay back)
-  if (sk == 1 && xres_env && (mrows * UNIT >= 1024 || sp.k >= 8192 || xres_env == 2)) {
-    const int nu = (int)(((nunits + 3) / 4 + upg - 1) / upg * upg);
-    const unsigned xrow = (unsigned)(nu * UNIT * 2 + 16);
-    const unsigned lds = 16u * 4096u + (unsigned)(mrows * 4) * xrow + (unsigned)(UNIT * 2 + 16);
-    if (lds <= 160u * 1024u) {
-      sp.splitk = 1; sp.sk_shift = 0; sp.units_per_lane = nu; sp.upg_mask = upg - 1;
-      sp.xslab_bytes = (int32_t)xrow; sp.red_off = 0;
-      return launch_stream_xres<DT, LAYOUT_A, WPL, QMX>(sp, coltiles, batch, lds, st);
-    }
-  }
-  // otherwise 4-wave workgroups while their LDS footprint lets 16 waves live on a CU and the X slab is small;
-  // X slabs of 8 KiB or more per unit (Bint4: m >= 8, Aint4: m = 16): 8-wave workgroups halve the staging work per wave
-  const int sk4 = sk < 4 ? sk : 4;
-  if (mrows * UNIT < 1024 && 160u * 1024u / stream_lds_bytes<LAYOUT_A>(4, mrows, sk4) >= 4)
-    return launch_stream_sw<DT, LAYOUT_A, WPL, QMX, 4>(sp, sk4, coltiles, batch, st);
-  return launch_stream_sw<DT, LAYOUT_A, WPL, QMX, 8>(sp, sk, coltiles, batch, st);
-}
-
-
-// ---- pair-table kernel launch (w4_gemm_pair.cuh) ---------------------------------------------------
-// Returns TG_PAIR_NA when the shape does not fit this kernel's LDS plan (the caller then takes another kernel).
-enum { TG_PAIR_NA = -100 };
-
-// Tuning constants of the pair-table launches, each with the measurement that set it.  The shipped library
-// always uses these values; only developer builds (-DTG_DEV / -DTG_DEV_MIN, dev/build_variant.sh) may override one with -D<NAME>=<v>.
-#if !defined(TG_DEV) && !defined(TG_DEV_MIN)
-#if defined(TG_PAIR_R) || defined(TG_PAIR_ABL) || defined(TG_PAIR_MR1) || defined(TG_PAIR_NSG2) || defined(TG_PAIR_MR1_GPS) || defined(TG_PAIR_RA) ||   \
-    defined(TG_PAIR_RA1) || defined(TG_PAIR_RB16) || defined(TG_B16_CHUNK) || defined(TG_PAIR_MIN_ITEMS) || defined(TG_XG_CHUNK) || defined(TG_PAIR_WGS) || \
-    defined(TG_PAIR_NSG2_M1) || defined(TG_PAIR_FORCE_XG) || defined(TG_XR_MIN_M) || defined(TG_XR_R) || defined(TG_XR_R8K) || defined(TG_XR_RMX)
-#error "the TG_PAIR_* / TG_XG_* / TG_B16_* tuning constants can only be overridden in developer builds (-DTG_DEV or -DTG_DEV_MIN)"
-#endif
-#endif
-#ifndef TG_PAIR_R
-#define TG_PAIR_R 2            // super-tiles a wave keeps in flight (2, 3, 4 measured equal; 5 spills)
-#endif
-#ifndef TG_PAIR_ABL
-#define TG_PAIR_ABL 0          // ablation stub of w4_gemm_pair.cuh (its header lists them)
-#endif
-#ifndef TG_PAIR_MR1
-#define TG_PAIR_MR1 1          // 1: m = 1 runs the one-register specialisation (+2-3 %), 4: the general m <= 8 kernel
-#endif
-#ifndef TG_PAIR_NSG2
-#define TG_PAIR_NSG2 1         // group boundaries at fixed places of the unrolled round when a group is one round of the ring
-#endif
-#ifndef TG_PAIR_NSG2_M1
-#define TG_PAIR_NSG2_M1 1      // ... also in the m = 1 specialisation (74.8 -> 75.8 % once its group update was spelled out)
-#endif
-#ifndef TG_PAIR_MR1_GPS
-#define TG_PAIR_MR1_GPS 1      // the m = 1 specialisation is used up to this many groups per super-tile (it spills beyond)
-#endif
-#ifndef TG_PAIR_RA
-#define TG_PAIR_RA 2           // ring depth of the A-side kernels (4 / 6 / 8 measured 8.2 / 21 / 40 us against 6.8)
-#endif
-#ifndef TG_PAIR_RA1
-#define TG_PAIR_RA1 1          // ... with several groups per super-tile
-#endif
-#ifndef TG_PAIR_RB16
-#define TG_PAIR_RB16 2         // ring depth of the 16x16x32 kernels for Bint4 weights, m = 9 ... 16 (3 / 4: 41 % against 44 %)
-#endif
-#ifndef TG_B16_CHUNK
-#define TG_B16_CHUNK 4         // consecutive 32-row work items per workgroup visit of those kernels (1 / 4 / 8 within 1 %)
-#endif
-#ifndef TG_PAIR_MIN_ITEMS
-#define TG_PAIR_MIN_ITEMS 192  // fewer work items: the launch is latency-bound, w4_gemm_pair16_kernel / the reference kernels take
-                               // it (measured per hipGraph node, one layer, m = 1: 14336 x 4096 = 224 items 12.3 us here against
-                               // 18.3 us on pair16 and 13.8 us on the stream kernel; 6144 x 4096 = 96 items 10.7 against 9.9 / 8.2)
-#endif
-#ifndef TG_XG_CHUNK
-#define TG_XG_CHUNK 4          // consecutive work items per workgroup visit in the workspace variant of Bint4 weights (1: plain
-                               // round-robin): m = 8: 4096^2 66.1 -> 66.5 %, 8192^2 67.3 -> 68.6 %; Aint4 weights keep 1
-#endif
-#ifndef TG_XR_MIN_M
-#define TG_XR_MIN_M 2          // activation rows from which the register-resident-activation kernel (w4_gemm_xr.cuh) takes stacked launches
-                               // (same-box A/B against the kernels it replaces, 4096^2: m = 2 71.9 vs 69.7 %, 4: 68.9 vs 66.9, 8: 66.2 vs 62.7,
-                               //  16: 65.2 vs 46.0; m = 1 stays on the 32x32x16 kernel, 77 %)
-#endif
-#ifndef TG_XR_RMX
-#define TG_XR_RMX 8            // ... for mx4 (no lookups: latency-bound; the whole slice in flight: m = 16 75.4 -> 79.0 %, m = 2 81.7 -> 85.3 %)
-#endif
-#ifndef TG_XR_R8K
-#define TG_XR_R8K 2            // ... at k = 8192 (128 registers of activations per lane: 4 in flight spill 25)
-#endif
-#ifndef TG_XR_R
-#define TG_XR_R 4              // super-tiles a wave of that kernel keeps in flight
-#endif
-#ifndef TG_PAIR_WGS
-#define TG_PAIR_WGS 512        // persistent workgroups: two per CU (768 / 1024: +4 % / +1 % time)
-#endif
-template <typename DT, int I, int GPS, int MR, bool QMX, int NSG, bool XG = false, int LA = 0, bool NORM = false>
-int launch_pair_k(PairParams& pp, unsigned lds, hipStream_t st) {
-#ifdef TG_DEV_MIN  // developer builds: only the headline instantiation (fast A/B builds)
-#ifndef TG_DEV_GPS
-#define TG_DEV_GPS 1
-#endif
-#ifndef TG_DEV_QMX
-#define TG_DEV_QMX false
-#endif
-#ifndef TG_DEV_MR
-#define TG_DEV_MR TG_PAIR_MR1
-#endif
-#ifndef TG_DEV_LA
-#define TG_DEV_LA 0
-#endif
-  if constexpr (!(std::is_same<DT, BF16>::value && I == 4 && GPS == TG_DEV_GPS && MR == TG_DEV_MR && QMX == TG_DEV_QMX && NSG == TG_DEV_MIN && LA == TG_DEV_LA && !NORM)) return TG_PAIR_NA;
-  else {
-#endif
-  if constexpr (QMX && !std::is_same<DT, BF16>::value) return TG_E_DTYPE;  // mx4 is bf16-only (TinyGemm_int4.cu:758)
-  else {
-  // several groups per super-tile (group 32 / 64 with wide super-tiles): more per-slot state, one slot in flight fits the
-  // 128-VGPR budget without spills (ring depth measured irrelevant between 2 and 4)
-  // (mx4 on the 32x32x16 tiles converts its weights in registers and has no per-group state in the slots: the usual depth)
-  constexpr int RING = (QMX && LA == 0) ? TG_PAIR_R : (MR == 1 && NSG == 4 && LA == 0) ? 4 : GPS > 1 ? (LA ? TG_PAIR_RA1 : 1) : LA == 1 ? TG_PAIR_RA : LA == 2 ? TG_PAIR_RB16 : TG_PAIR_R;
-  constexpr auto kern = w4_gemm_pair_kernel<DT, I, GPS, MR, QMX, RING, NSG, TG_PAIR_ABL, XG, LA, NORM>;
-  if (pp.dry) return TG_PLAN_PAIR;
-  const int prc = prepare_lds_kernel<kern>();
-  if (prc != 0) return prc;
-  const unsigned wgs = (unsigned)(pp.items < TG_PAIR_WGS ? pp.items : TG_PAIR_WGS);
-  hipLaunchKernelGGL(kern, dim3(wgs), dim3(512), lds, st, pp);
-  return launch_status();
-  }
-#ifdef TG_DEV_MIN
-  }
-#endif
-}
-
-// The activation block of one pass does not fit next to the table (m = 8 at k = 4096, m = 1 at k >= 8192): the XG variant
-// takes the activations pre-arranged from a caller-provided workspace (w4_xprep_kernel, one small launch in front).
-// Workspace = [batch][m k 2 bytes] arranged activations, then [batch][passes][groups][xs_rows] f32 sums.
-template <typename DT>
-int launch_xprep(const PairParams& pp, int I, int ma, int64_t batch, hipStream_t st, int la = 0) {
-  XPrepParams xq;
-  xq.la = la;
-  xq.x = pp.x; xq.xp = const_cast<char*>(pp.xp); xq.xsum = const_cast<char*>(pp.xsum);
-  xq.x_tc = pp.x_tc;
-  xq.m = pp.m; xq.k = pp.k; xq.ma = ma; xq.cps = I / 2; xq.gshift = pp.gshift; xq.gch_mask = pp.gch_mask;
-  xq.ngroups = pp.ngroups; xq.xs_rows = pp.xs_rows;
-  xq.stride_x = pp.stride_x; xq.stride_xp = pp.stride_xp; xq.stride_xsum = pp.stride_xsum;
-  const int64_t chunks = (int64_t)pp.m * (pp.k / 32);
-  hipLaunchKernelGGL(w4_xprep_kernel<DT>, dim3((unsigned)cdiv(chunks, 256), (unsigned)batch), dim3(256), 0, st, xq);
-  return launch_status();
-}
-
-// m = 1 has its own specialisation (one accumulator register finalised per group, taken as a running difference) -- except
-// with several groups per super-tile, where the general kernel's zero-C group starts compile without spills; `norm`: the
-// instantiations with LlamaRMSNorm fused into the activation staging (staged activations, m <= 8, not mx4)
-template <typename DT, int I, int GPS, bool QMX, int NSG>
-int launch_pair_m(PairParams& pp, unsigned lds, hipStream_t st, bool xg, int m, int mregs, bool norm) {
-  const bool m1 = m == 1 && TG_PAIR_MR1 == 1 && (QMX || GPS <= TG_PAIR_MR1_GPS);  // (mx4: no per-group state, the specialisation fits at any GPS)
-  if (xg) return m1 ? launch_pair_k<DT, I, GPS, 1, QMX, NSG, true>(pp, lds, st) : launch_pair_k<DT, I, GPS, 4, QMX, NSG, true>(pp, lds, st);
-  if (norm) {
-    if constexpr (QMX) return TG_PAIR_NA;
-    else {
-      if (mregs != 4) return TG_PAIR_NA;
-      return m1 ? launch_pair_k<DT, I, GPS, 1, false, NSG, false, false, true>(pp, lds, st)
-                : launch_pair_k<DT, I, GPS, 4, false, NSG, false, false, true>(pp, lds, st);
-    }
-  }
-  if (m1) return launch_pair_k<DT, I, GPS, 1, QMX, NSG>(pp, lds, st);
-  return mregs == 4 ? launch_pair_k<DT, I, GPS, 4, QMX, NSG>(pp, lds, st) : launch_pair_k<DT, I, GPS, 16, QMX, NSG>(pp, lds, st);
-}
-
-template <typename DT, int I, bool QMX>
-int launch_pair(GemmParams& p, int64_t batch, hipStream_t st) {
-  constexpr int RW = 64;
-  const int g = 1 << p.gshift;
-  const int gps = g >= 16 * I ? 1 : (16 * I) / g;
-  const int mregs = p.m <= 8 ? 4 : 16;  // accumulator registers of a row set (8 or 32 activation rows per pass)
-  const int ma = 2 * mregs;
-  PairParams pp;
-  pp.x = p.x; pp.w = p.w; pp.qinfo = p.qinfo; pp.lut = p.lut; pp.y = p.y;
-  pp.m = p.m; pp.wrows = p.wrows; pp.k = p.k; pp.ntiles = p.ntiles; pp.ksuper = p.ksuper;
-  pp.gshift = p.gshift; pp.ngroups = p.ngroups; pp.qtype = p.qtype;
-  const int nsg = g >= 16 * I ? g / (16 * I) : 1;  // super-tiles per group
-  const int units = p.ksuper / nsg;
-  pp.spw = ((units + 7) / 8) * nsg;
-  pp.nsg_shift = 0;
-  while ((1 << pp.nsg_shift) < nsg) ++pp.nsg_shift;
-  pp.gch_mask = g / 32 - 1;
-  const int mrows = p.m < ma ? p.m : ma;
-  pp.rused = mrows < 4 ? mrows : mregs;
-  pp.xs_rows = mrows <= 4 ? 4 : ma;
-  pp.red_lanes = mrows <= 4 ? 32 : 64;
-  pp.x_pitch = p.k * 2 + 16;
-  pp.lds_x = QMX ? 0 : 65536;  // mx4 converts its weights in registers (v_cvt_scalef32_pk_bf16_fp4): no table, the LDS starts with the activations
-  pp.lds_xs = (pp.lds_x + mrows * pp.x_pitch + 32 * I + 15) & ~15;  // staged rows + a zero piece of one super-tile
-  pp.lds_red = (pp.lds_xs + (QMX ? 0 : p.ngroups * pp.xs_rows * 4) + 15) & ~15;  // mx4: no zero point, no activation sums
-  pp.red_alias = !QMX && mrows > 4;  // 16 KiB and more of partial sums: reuse the table's LDS instead
-  unsigned lds = (unsigned)pp.lds_red + (unsigned)(8 * 2 * pp.rused * pp.red_lanes * 4);
-  if (pp.red_alias) {
-    lds = (unsigned)pp.lds_red;
-    pp.lds_red = 0;
-  }
-  // mx4: exponent blocks of 16 bytes per row, read at 4-byte alignment (w4_gemm_pair.cuh, e_request)
-  // (a slice that starts off a 4-byte boundary loses up to 3 bytes of its one block)
-  if (QMX && (p.ngroups < 16 || p.ngroups % 4 != 0 || ((pp.spw * gps) % 4 != 0 && pp.spw * gps > 12))) return TG_PAIR_NA;
-  // fused RMSNorm: done in the workgroup's own staging of the whole activation block (its partial sums borrow the activation-sum
-  // area, which mx4 does not have); the workspace variant would need it in the pre-pass
-  if (p.norm_w && (QMX || lds > 80u * 1024u || p.m > ma)) return TG_PAIR_NA;
-  bool xg = false;
-#ifdef TG_PAIR_FORCE_XG  // developer A/B: the workspace variant also where the staged plan fits
-  if (mregs == 4 && p.m <= ma) lds = 1u << 30;
-#endif
-  if (lds > 80u * 1024u) {  // two workgroups per CU
-    // XG: every wave keeps one super-tile of the pass's activations (<= 8 rows) in a private buffer
-    if (mregs != 4 || p.m > ma) return TG_PAIR_NA;
-    pp.xw_pitch = 32 * I + 16;
-    pp.xw_bytes = (I == 2 ? 16 : 8) * pp.xw_pitch;  // a row for every 2 I lanes of the wave's (unmasked) store
-    pp.lds_xs = (pp.lds_x + 8 * pp.xw_bytes + 32 * I + 15) & ~15;  // 8 buffers + the zero piece
-    pp.lds_red = (pp.lds_xs + (QMX ? 0 : p.ngroups * pp.xs_rows * 4) + 15) & ~15;  // mx4: no zero point, no activation sums
-    lds = (unsigned)pp.lds_red + (unsigned)(8 * 2 * pp.rused * pp.red_lanes * 4);
-    if (lds > 80u * 1024u) pp.red_alias = 1;
-    if (QMX && pp.red_alias) return TG_PAIR_NA;  // (no table to put the partial sums over; cannot happen: 8 one-KiB buffers + 16 KiB)
-    if (pp.red_alias) {
-      lds = (unsigned)pp.lds_red;
-      pp.lds_red = 0;
-    }
-    if (lds > 80u * 1024u) return TG_PAIR_NA;
-    pp.stride_xp = (int64_t)p.m * p.k * 2;
-    pp.stride_xsum = ((int64_t)p.ngroups * pp.xs_rows * 4 + 15) & ~(int64_t)15;
-    const int64_t need = batch * (pp.stride_xp + pp.stride_xsum);
-    p.ws_need = need;
-    if (!p.ws_query && (p.ws == nullptr || p.ws_bytes < need)) return TG_PAIR_NA;
-    pp.xp = p.ws;
-    pp.xsum = p.ws + batch * pp.stride_xp;
-    xg = true;
-  }
-  pp.rblocks = (p.wrows + RW - 1) / RW;
-  pp.cblocks = (p.m + ma - 1) / ma;
-  const int64_t items = (int64_t)pp.rblocks * pp.cblocks * batch;
-  if (items > INT32_MAX) return TG_PAIR_NA;
-  // The kernel's unit of work is a 64-row block over the whole k (8 waves): a launch needs about one item per workgroup slot
-  // (2 per CU) to fill the chip.  Smaller launches (one 4096-row layer = 64 items) are latency-bound and stay on the
-  // split-K kernels, which spread one 16-row tile over up to 16 waves.
-  if (items < TG_PAIR_MIN_ITEMS) { p.ws_need = 0; return TG_PAIR_NA; }
-  pp.items = (int32_t)items;
-  // XG item dealing: chunks of consecutive items once every workgroup still gets several chunks
-  pp.chunk = items >= (int64_t)TG_PAIR_WGS * TG_XG_CHUNK * 4 ? TG_XG_CHUNK : 1;
-  pp.stride_x = p.stride_x; pp.stride_w = p.stride_w; pp.stride_qinfo = p.stride_qinfo;
-  pp.stride_lut = p.stride_lut; pp.stride_y = p.stride_y;
-  pp.bias = p.bias; pp.stride_bias = p.stride_bias; pp.dry = p.dry;
-  pp.bias_row_stride = p.bias_row_stride; pp.norm_w = p.norm_w; pp.norm_eps = p.norm_eps; pp.epilogue = p.epilogue;
-  pp.x_tc = p.x_tc; pp.y_tc = p.y_tc; pp.y_tiles = (p.wrows + 15) / 16;
-  if (xg && !p.dry) {
-    const int rc = launch_xprep<DT>(pp, I, ma, batch, st);
-    if (rc != 0) return rc;
-  }
-#define TG_PAIR_M(GPS_, NSG_) launch_pair_m<DT, I, GPS_, QMX, NSG_>(pp, lds, st, xg, p.m, mregs, p.norm_w != nullptr)
-  if (gps == 1) {
-    // group boundaries at fixed places of the unrolled round when a group is one super-tile or one whole round
-    // (the m = 1 specialisation too since its group update is spelled out instruction by instruction: before that, fixed
-    //  boundaries made the compiler scatter its accumulator chain over several register tuples and spill)
-    // (a group of ONE super-tile, g = 64 at I = 4, also keeps the run-time test: its fixed-boundary build spills 27 registers,
-    //  m = 8 50 % against 59 %)
-    const bool fixed = TG_PAIR_NSG2 && (TG_PAIR_NSG2_M1 || !(p.m == 1 && TG_PAIR_MR1 == 1));
-    if (fixed && nsg == TG_PAIR_R) return TG_PAIR_M(1, TG_PAIR_R);
-    // m = 1, a group of ONE super-tile (g = 64 at innerKTiles 4): fixed boundaries too since the dot2 contraction freed the registers
-    // (with the MFMA this build spilled 27; 77 -> 81 %), and a group of FOUR super-tiles (g = 256) as one round of a ring of four
-    // (76.7 -> 84.0 %; a ring of four at g = 128 / 64 measured 1-1.5 points below the ring of two).  Only the m = 1 kernels are
-    // instantiated for these (launch_pair_k directly: launch_pair_m would drag the general kernels in as well).
-    if constexpr (!QMX) {
-      if (fixed && p.m == 1 && TG_PAIR_MR1 == 1 && !p.norm_w && (nsg == 1 || nsg == 4)) {
-        if (nsg == 1) return xg ? launch_pair_k<DT, I, 1, 1, false, 1, true>(pp, lds, st) : launch_pair_k<DT, I, 1, 1, false, 1>(pp, lds, st);
-        if constexpr (I <= 4)  // (innerKTiles 8: four super-tiles would be g = 512)
-          return xg ? launch_pair_k<DT, I, 1, 1, false, 4, true>(pp, lds, st) : launch_pair_k<DT, I, 1, 1, false, 4>(pp, lds, st);
-      }
-    }
-    return TG_PAIR_M(1, 0);
-  }
-  if constexpr (I >= 4) {
-    if (gps == 2) return TG_PAIR_M(2, 0);
-  }
-  if constexpr (I >= 8) {
-    if (gps == 4) return TG_PAIR_M(4, 0);
-  }
-#undef TG_PAIR_M
-  return TG_PAIR_NA;
-}
-
-// Small launches of Bint4 weights (one layer per call): w4_gemm_pair16_kernel, 16 weight rows per workgroup, the whole k-slice
-// of a wave requested up front.  Taken when the launch is too small for the persistent kernel (or its LDS plan does not fit)
-// and the activations (m <= 16 rows) fit in LDS next to the table.
-template <typename DT, int I, bool QMX>
-int launch_pair16(const GemmParams& p, int64_t batch, hipStream_t st) {
-  if constexpr (QMX && !std::is_same<DT, BF16>::value) return TG_E_DTYPE;  // mx4 is bf16-only (TinyGemm_int4.cu:758)
-  else {
-#ifdef TG_DEV_MIN
-  if constexpr (!(std::is_same<DT, BF16>::value && I == 4 && !QMX)) return TG_PAIR_NA;
-#endif
-  if (p.m > 16 || batch > 65535) return TG_PAIR_NA;
-  // m = 1 and more than one round of workgroups (one per CU): the streaming kernel's split-K launches are faster there
-  // (per hipGraph node, 6144 x 4096: 8.6 us against 10.2 us; 14336 x 4096: 13.8 against 18.3)
-  // (not when a fused stage is asked for: only the pair-table kernels have them)
-  if (p.m == 1 && !p.x_tc && !p.y_tc && !p.norm_w && !p.epilogue && (int64_t)((p.wrows + 15) / 16) * batch > 256 && (1 << p.gshift) >= 128) return TG_PAIR_NA;
-  if (p.norm_w && (QMX || (int64_t)p.m * p.k > 32768)) return TG_PAIR_NA;  // the norm pass: one 32-k chunk per thread
-  const int g = 1 << p.gshift;
-  const int nsg = g >= 16 * I ? g / (16 * I) : 1;
-  Pair16Params pp;
-  pp.x = p.x; pp.w = p.w; pp.qinfo = p.qinfo; pp.lut = p.lut; pp.y = p.y;
-  pp.m = p.m; pp.wrows = p.wrows; pp.k = p.k; pp.ntiles = p.ntiles; pp.ksuper = p.ksuper;
-  pp.gshift = p.gshift; pp.ngroups = p.ngroups; pp.qtype = p.qtype;
-  pp.gch_mask = g / 32 - 1;
-  pp.lds_x = 65536;
-  const int64_t wgs = (int64_t)((p.wrows + 15) / 16) * batch;
-  // one workgroup per CU may take the whole LDS; a launch of more than two rounds of workgroups should fit two per CU
-  const unsigned lds_limit = (wgs <= 512 ? 160u : 80u) * 1024u;
-  // activation rows that do not fit next to the table are staged one part of k at a time (whole groups per part)
-  unsigned lds = 0;
-  int phases = 1;
-  for (; phases <= (wgs <= 512 && !p.norm_w ? 8 : 1); phases *= 2) {  // (the fused norm needs a row's whole k in one part)
-    if (p.ksuper % (phases * nsg) != 0 || p.ngroups % phases != 0) return TG_PAIR_NA;
-    const int kp = p.k / phases;
-    pp.x_pitch = kp * 2 + 16;
-    pp.lds_xs = (pp.lds_x + p.m * pp.x_pitch + 16 + 15) & ~15;
-    lds = (unsigned)pp.lds_xs + (QMX ? 0u : (unsigned)(p.ngroups / phases) * 64u);
-    if (lds <= lds_limit) break;
-  }
-  if (lds > lds_limit) return TG_PAIR_NA;
-  pp.phases = phases;
-  pp.ksuper_p = p.ksuper / phases;
-  pp.spw = ((pp.ksuper_p / nsg + 15) / 16) * nsg;
-  pp.stride_x = p.stride_x; pp.stride_w = p.stride_w; pp.stride_qinfo = p.stride_qinfo;
-  pp.stride_lut = p.stride_lut; pp.stride_y = p.stride_y;
-  pp.bias = p.bias; pp.stride_bias = p.stride_bias;
-  pp.bias_row_stride = p.bias_row_stride; pp.norm_w = p.norm_w; pp.norm_eps = p.norm_eps; pp.epilogue = p.epilogue;
-  pp.x_tc = p.x_tc; pp.y_tc = p.y_tc; pp.y_tiles = (p.wrows + 15) / 16;
-  if (p.dry) return TG_PLAN_PAIR;
-  const dim3 grid((unsigned)((p.wrows + 15) / 16), (unsigned)batch);
-#define TG_P16K(CPG_, NORM_)                                                 \
-  do {                                                                      \
-    constexpr auto kern = w4_gemm_pair16_kernel<DT, I, QMX, CPG_, 1, NORM_>; \
-    const int prc = prepare_lds_kernel<kern>();                             \
-    if (prc != 0) return prc;                                               \
-    hipLaunchKernelGGL(kern, grid, dim3(1024), lds, st, pp);                \
-  } while (0)
-#define TG_P16(CPG_)                                 \
-  do {                                               \
-    if constexpr (!QMX) {                            \
-      if (p.norm_w) { TG_P16K(CPG_, true); break; }  \
-    }                                                \
-    TG_P16K(CPG_, false);                            \
-  } while (0)
-  if constexpr (QMX) TG_P16(1);  // mx4: group = 32
-  else if (g == 32) TG_P16(1);
-  else if (g == 64) TG_P16(2);
-  else if (g == 128) TG_P16(4);
-  else TG_P16(8);
-#undef TG_P16K
-#undef TG_P16
-  return launch_status();
-  }
-}
-
-// Aint4 weights (weightOnRight = false) on the pair-table kernel: 32 weight rows per work item, v_mfma_f32_16x16x32,
-// activations always through the workspace (one pass of at most 8 rows).
-template <typename DT, int I, bool QMX>
-int launch_pair_a(GemmParams& p, int64_t batch, hipStream_t st) {
-  if constexpr (I < 2) return TG_PAIR_NA;  // one 16-k tile per word set: no word pair for a 32-k MFMA step
-  else {
-  if (p.m > 16 || p.x_tc || p.y_tc || p.norm_w || p.epilogue) return TG_PAIR_NA;
-  const int g = 1 << p.gshift;
-  const int gps = g >= 16 * I ? 1 : (16 * I) / g;
-  PairParams pp;
-  pp.x_tc = pp.y_tc = 0; pp.y_tiles = 0;
-  pp.bias_row_stride = p.bias_row_stride; pp.norm_w = nullptr; pp.norm_eps = 0.f; pp.epilogue = 0;
-  pp.x = p.x; pp.w = p.w; pp.qinfo = p.qinfo; pp.lut = p.lut; pp.y = p.y;
-  pp.m = p.m; pp.wrows = p.wrows; pp.k = p.k; pp.ntiles = p.ntiles; pp.ksuper = p.ksuper;
-  pp.gshift = p.gshift; pp.ngroups = p.ngroups; pp.qtype = p.qtype;
-  const int nsg = g >= 16 * I ? g / (16 * I) : 1;
-  const int units = p.ksuper / nsg;
-  pp.spw = ((units + 7) / 8) * nsg;
-  pp.nsg_shift = 0;
-  while ((1 << pp.nsg_shift) < nsg) ++pp.nsg_shift;
-  pp.gch_mask = g / 32 - 1;
-  if (QMX && (p.ngroups < 16 || p.ngroups % 4 != 0 || ((pp.spw * gps) % 4 != 0 && pp.spw * gps > 12))) return TG_PAIR_NA;
-  const int mrows = p.m;
-  pp.rused = mrows < 4 ? mrows : 4;
-  pp.xs_rows = mrows <= 4 ? 4 : mrows <= 8 ? 8 : 16;
-  pp.red_lanes = mrows <= 8 ? 32 : 64;  // lanes 0..31 hold activation rows 0..7
-  pp.x_pitch = 0;
-  pp.lds_x = QMX ? 0 : 65536;
-  pp.xw_pitch = 0;  // the lanes' MFMA operands come straight from the workspace: LDS only holds a zero piece here
-  pp.xw_bytes = 0;
-  pp.lds_xs = (pp.lds_x + 32 * I + 15) & ~15;
-  pp.lds_red = (pp.lds_xs + (QMX ? 0 : p.ngroups * pp.xs_rows * 4) + 15) & ~15;  // mx4: no zero point, no activation sums
-  unsigned lds = (unsigned)pp.lds_red + (unsigned)(8 * 2 * pp.rused * pp.red_lanes * 4);
-  pp.red_alias = lds > 80u * 1024u;
-  if (pp.red_alias) {
-    lds = (unsigned)pp.lds_red;
-    pp.lds_red = 0;
-  }
-  if (lds > 80u * 1024u) return TG_PAIR_NA;
-  pp.stride_xp = (int64_t)(p.m + 1) * p.k * 2;  // + a zero row
-  pp.stride_xsum = ((int64_t)p.ngroups * pp.xs_rows * 4 + 15) & ~(int64_t)15;
-  const int64_t need = batch * (pp.stride_xp + pp.stride_xsum);
-  pp.rblocks = (p.wrows + 31) / 32;
-  pp.cblocks = 1;
-  const int64_t items = (int64_t)pp.rblocks * batch;
-  if (items > INT32_MAX || items < TG_PAIR_MIN_ITEMS) return TG_PAIR_NA;
-  p.ws_need = need;
-  if (!p.ws_query && (p.ws == nullptr || p.ws_bytes < need)) return TG_PAIR_NA;
-  pp.xp = p.ws;
-  pp.xsum = p.ws + batch * pp.stride_xp;
-  pp.items = (int32_t)items;
-  pp.chunk = 1;  // plain round-robin dealing (chunks of consecutive items measured slower for the 32-row items of this layout)
-  pp.stride_x = p.stride_x; pp.stride_w = p.stride_w; pp.stride_qinfo = p.stride_qinfo;
-  pp.stride_lut = p.stride_lut; pp.stride_y = p.stride_y;
-  pp.bias = p.bias; pp.stride_bias = p.stride_bias; pp.dry = p.dry;
-  if (!p.dry) {
-    const int rc = launch_xprep<DT>(pp, I, 16, batch, st, 1);
-    if (rc != 0) return rc;
-  }
-  if (gps == 1) {
-    if (TG_PAIR_NSG2 && nsg == 1) return launch_pair_k<DT, I, 1, 4, QMX, 1, true, true>(pp, lds, st);
-    if (TG_PAIR_NSG2 && nsg == TG_PAIR_R) return launch_pair_k<DT, I, 1, 4, QMX, TG_PAIR_R, true, true>(pp, lds, st);
-    return launch_pair_k<DT, I, 1, 4, QMX, 0, true, true>(pp, lds, st);
-  }
-  if constexpr (I >= 4) {
-    if (gps == 2) return launch_pair_k<DT, I, 2, 4, QMX, 0, true, true>(pp, lds, st);
-  }
-  return TG_PAIR_NA;
-  }
-}
-
-// Bint4 weights with 9 ... 16 activation rows: the 16x16x32 structure of the A-side kernel (32-row work items, duplicated
-// table, activations of one pass -- all m <= 16 rows -- straight from the workspace into the MFMA operand) on B-layout words:
-// one packed word is one B operand, 4 vector ops per word.  (The 32x32x16 kernel holds 8 rows per pass; a second pass would
-// stream the weights twice.)
-template <typename DT, int I, bool QMX>
-int launch_pair_b16(GemmParams& p, int64_t batch, hipStream_t st) {
-  if (p.m > 16 || p.norm_w || p.epilogue) return TG_PAIR_NA;
-  const int g = 1 << p.gshift;
-  const int gps = g >= 16 * I ? 1 : (16 * I) / g;
-  PairParams pp;
-  pp.x_tc = p.x_tc; pp.y_tc = p.y_tc; pp.y_tiles = (p.wrows + 15) / 16;
-  pp.bias_row_stride = p.bias_row_stride; pp.norm_w = nullptr; pp.norm_eps = 0.f; pp.epilogue = 0;
-  pp.x = p.x; pp.w = p.w; pp.qinfo = p.qinfo; pp.lut = p.lut; pp.y = p.y;
-  pp.m = p.m; pp.wrows = p.wrows; pp.k = p.k; pp.ntiles = p.ntiles; pp.ksuper = p.ksuper;
-  pp.gshift = p.gshift; pp.ngroups = p.ngroups; pp.qtype = p.qtype;
-  const int nsg = g >= 16 * I ? g / (16 * I) : 1;
-  const int units = p.ksuper / nsg;
-  pp.spw = ((units + 7) / 8) * nsg;
-  pp.nsg_shift = 0;
-  while ((1 << pp.nsg_shift) < nsg) ++pp.nsg_shift;
-  pp.gch_mask = g / 32 - 1;
-  if (QMX && (p.ngroups < 16 || p.ngroups % 4 != 0 || ((pp.spw * gps) % 4 != 0 && pp.spw * gps > 12))) return TG_PAIR_NA;
-  const int mrows = p.m;
-  pp.rused = mrows < 4 ? mrows : 4;
-  pp.xs_rows = mrows <= 4 ? 4 : mrows <= 8 ? 8 : 16;
-  pp.red_lanes = mrows <= 8 ? 32 : 64;  // lanes 0..31 hold activation rows 0..7
-  pp.x_pitch = 0;
-  pp.lds_x = QMX ? 0 : 65536;
-  pp.xw_pitch = 0;
-  pp.xw_bytes = 0;
-  pp.lds_xs = (pp.lds_x + 32 * I + 15) & ~15;
-  pp.lds_red = (pp.lds_xs + (QMX ? 0 : p.ngroups * pp.xs_rows * 4) + 15) & ~15;
-  unsigned lds = (unsigned)pp.lds_red + (unsigned)(8 * 2 * pp.rused * pp.red_lanes * 4);
-  pp.red_alias = lds > 80u * 1024u;
-  if (pp.red_alias) {
-    lds = (unsigned)pp.lds_red;
-    pp.lds_red = 0;
-  }
-  if (lds > 80u * 1024u) return TG_PAIR_NA;
-  pp.stride_xp = (int64_t)(p.m + 1) * p.k * 2;  // + a zero row
-  pp.stride_xsum = ((int64_t)p.ngroups * pp.xs_rows * 4 + 15) & ~(int64_t)15;
-  const int64_t need = batch * (pp.stride_xp + pp.stride_xsum);
-  pp.rblocks = (p.wrows + 31) / 32;
-  pp.cblocks = 1;
-  const int64_t items = (int64_t)pp.rblocks * batch;
-  if (items > INT32_MAX || items < 2 * TG_PAIR_MIN_ITEMS) return TG_PAIR_NA;  // (32-row items: two per 64-row item of the other kernel)
-  p.ws_need = need;
-  if (!p.ws_query && (p.ws == nullptr || p.ws_bytes < need)) return TG_PAIR_NA;
-  pp.xp = p.ws;
-  pp.xsum = p.ws + batch * pp.stride_xp;
-  pp.items = (int32_t)items;
-  pp.chunk = items >= (int64_t)TG_PAIR_WGS * TG_B16_CHUNK * 4 ? TG_B16_CHUNK : 1;
-  pp.stride_x = p.stride_x; pp.stride_w = p.stride_w; pp.stride_qinfo = p.stride_qinfo;
-  pp.stride_lut = p.stride_lut; pp.stride_y = p.stride_y;
-  pp.bias = p.bias; pp.stride_bias = p.stride_bias; pp.dry = p.dry;
-  if (!p.dry) {
-    const int rc = launch_xprep<DT>(pp, I, 16, batch, st, 1);
-    if (rc != 0) return rc;
-  }
-  if (gps == 1) {
-    if (TG_PAIR_NSG2 && nsg == 1) return launch_pair_k<DT, I, 1, 4, QMX, 1, true, 2>(pp, lds, st);
-    if (TG_PAIR_NSG2 && nsg == TG_PAIR_RB16) return launch_pair_k<DT, I, 1, 4, QMX, TG_PAIR_RB16, true, 2>(pp, lds, st);
-    return launch_pair_k<DT, I, 1, 4, QMX, 0, true, 2>(pp, lds, st);
-  }
-  if constexpr (I >= 4) {
-    if (gps == 2) return launch_pair_k<DT, I, 2, 4, QMX, 0, true, 2>(pp, lds, st);
-  }
-  if constexpr (I >= 8) {
-    if (gps == 4) return launch_pair_k<DT, I, 4, 4, QMX, 0, true, 2>(pp, lds, st);
-  }
-  return TG_PAIR_NA;
-}
-
-// Bint4 weights, stacked launches, TG_XR_MIN_M ... 16 activation rows, k = 4096: w4_gemm_xr_kernel (one 8-wave workgroup per CU, the
-// activations of a wave's k-slice resident in its registers, 64-row work items, two tables).  No workspace, no pre-pass.
-template <typename DT, int I, bool QMX, int NCH>
-int launch_pair_xr_n(GemmParams& p, int64_t batch, hipStream_t st) {
-  if constexpr (I != 4 || (QMX && (NCH != 16 || !std::is_same<DT, BF16>::value))) return TG_PAIR_NA;  // (mx4: bf16, k = 4096)
-  else {
-#ifdef TG_DEV_MIN
-  if constexpr (!std::is_same<DT, BF16>::value) return TG_PAIR_NA;
-  else {
-#endif
-  if (p.m > 16 || p.m < TG_XR_MIN_M || p.norm_w || p.epilogue) return TG_PAIR_NA;
-  if (p.ksuper * 16 * I != p.k || p.wrows % 64 != 0 || p.ntiles * 8 != p.wrows) return TG_PAIR_NA;
-  const int g = 1 << p.gshift;
-  const int cpg = g / 32 < NCH ? g / 32 : NCH;  // 32-k chunks per group inside a wave's slice
-#ifdef TG_DEV_MIN
-  if (cpg != (QMX ? 1 : 4)) return TG_PAIR_NA;
-#endif
-  if (QMX ? cpg != 1 : (cpg != 1 && cpg != 2 && cpg != 4 && cpg != 8)) return TG_PAIR_NA;  // g = 32, 64, 128, 256; mx4: g = 32
-  if (QMX && p.ngroups % 16 != 0) return TG_PAIR_NA;  // 16-byte exponent blocks
-  if (NCH > 16 && cpg == 2) return TG_PAIR_NA;          // (k = 8192, g = 64: that instantiation spills four registers)
-  XrParams xp;
-  xp.w = p.w; xp.qinfo = p.qinfo; xp.lut = p.lut; xp.y = p.y;
-  xp.m = p.m; xp.wrows = p.wrows; xp.k = p.k; xp.ntiles = p.ntiles; xp.ksuper = p.ksuper;
-  xp.gshift = p.gshift; xp.ngroups = p.ngroups; xp.qtype = p.qtype;
-  xp.rblocks = (p.wrows + 63) / 64;
-  const int64_t items = (int64_t)xp.rblocks * batch;
-  if (items > INT32_MAX || items < 2 * 256) return TG_PAIR_NA;  // two items per workgroup at least
-  xp.items = (int32_t)items;
-  xp.lds_xs = 2 * 65536;
-  const unsigned lds = QMX ? 32768u : (unsigned)xp.lds_xs + (unsigned)p.ngroups * 64u;  // two tables, the activation sums (mx4: the partial sums only)
-  if (lds > 160u * 1024u) return TG_PAIR_NA;
-  xp.x = p.x; xp.stride_x = p.stride_x; xp.x_tc = p.x_tc;  // (no pre-pass, no workspace: the kernel arranges the activations itself)
-  p.ws_need = 0;
-  xp.stride_w = p.stride_w; xp.stride_qinfo = p.stride_qinfo; xp.stride_lut = p.stride_lut; xp.stride_y = p.stride_y;
-  xp.bias = p.bias; xp.stride_bias = p.stride_bias; xp.bias_row_stride = p.bias_row_stride;
-  xp.y_tc = p.y_tc; xp.y_tiles = (p.wrows + 15) / 16; xp.dry = p.dry;
-  if (p.dry) return TG_PLAN_PAIR_XR;
-#define TG_XR_LAUNCH(CPG_)                                                  \
-  do {                                                                      \
-    constexpr auto kern = w4_gemm_xr_kernel<DT, I, NCH, CPG_, (NCH > 16 ? TG_XR_R8K : TG_XR_R)>; \
-    const int prc = prepare_lds_kernel<kern>();                             \
-    if (prc != 0) return prc;                                               \
-    hipLaunchKernelGGL(kern, dim3(256), dim3(512), lds, st, xp);            \
-  } while (0)
-  if constexpr (QMX) {
-    constexpr auto kern = w4_gemm_xr_kernel<DT, I, NCH, 1, TG_XR_RMX, true>;
-    const int prc = prepare_lds_kernel<kern>();
-    if (prc != 0) return prc;
-    hipLaunchKernelGGL(kern, dim3(256), dim3(512), lds, st, xp);
-  } else {
-#ifdef TG_DEV_MIN
-  TG_XR_LAUNCH(4);
-#else
-  if (cpg == 1) TG_XR_LAUNCH(1);
-  else if (cpg == 2) TG_XR_LAUNCH(2);
-  else if (cpg == 4) TG_XR_LAUNCH(4);
-  else TG_XR_LAUNCH(8);
-#endif
-  }
-#undef TG_XR_LAUNCH
-  return launch_status();
-#ifdef TG_DEV_MIN
-  }
-#endif
-  }
-}
-
-template <typename DT, int I, bool QMX>
-int launch_pair_xr(GemmParams& p, int64_t batch, hipStream_t st) {
-  if (p.k == 4096) return launch_pair_xr_n<DT, I, QMX, 16>(p, batch, st);
-  // k = 8192: 128 registers of activations per lane leave room for two super-tiles in flight only -- faster than the 16x16x32
-  // workspace kernel it replaces at 9 ... 16 rows (8192^2, m = 16: 62 vs 47-51 %), slower than the 32x32x16 one below that
-  // (m = 8: 66 vs 70 %)
-  if (p.k == 8192 && p.m >= 9) return launch_pair_xr_n<DT, I, QMX, 32>(p, batch, st);
-  return TG_PAIR_NA;
-}
-
-template <typename DT, bool LAYOUT_A, int CANON, bool QMX>
-int launch_w4(GemmParams& p, int64_t coltiles, int64_t batch, hipStream_t st) {
-  constexpr int KSTEP = LAYOUT_A ? 64 : 128;
+// Dispatch of one validated 4-bit GEMM call to a kernel family (each family's launch path is its own translation unit, tg_common.cuh).
+// dt = TG_BF16 / TG_F16, canon = words per lane-quad of the packed layout (CANON_*), qmx = mx4.
+int launch_w4(int dt, bool LAYOUT_A, int canon, bool QMX, GemmParams& p, int64_t coltiles, int64_t batch, hipStream_t st) {
+  const int KSTEP = LAYOUT_A ? 64 : 128;
   const Geometry g = pick_geometry(p.rowtiles, coltiles, batch, (p.k + KSTEP - 1) / KSTEP);
   p.splitk = g.splitk;
   p.sk_shift = g.sk_shift;
@@ -1203,28 +396,30 @@ int launch_w4(GemmParams& p, int64_t coltiles, int64_t batch, hipStream_t st) {
 #else
   constexpr int use_stream = 1;
 #endif
-  constexpr int WPL = CANON == CANON_NONE ? 1 : (CANON == CANON_PAIR ? 2 : 4);
+  const int WPL = canon == CANON_NONE ? 1 : (canon == CANON_PAIR ? 2 : 4);
   // TG_NUM_FAST, weights on the B side: the pair-table kernel (group-scaled numerics) whenever its LDS plan fits
   // (mx4 in BOTH numerics: its dequantised weights, fp4 * 2^(e - 127), are exact 16-bit values however they are formed, so the
   //  pair-table kernels -- which convert them with v_cvt_scalef32_pk_bf16_fp4 -- ARE the reference arithmetic for it)
   if (p.numerics == TG_NUM_FAST || QMX) {
     int rc;
-    if constexpr (!LAYOUT_A) {
-      rc = launch_pair_xr<DT, 2 * WPL, QMX>(p, batch, st);
+    if (!LAYOUT_A) {
+      rc = tgx::pair_xr(dt, 2 * WPL, QMX, p, batch, st);
       if (rc != TG_PAIR_NA) return rc;
       p.ws_need = 0;
     }
-    if constexpr (LAYOUT_A) rc = launch_pair_a<DT, WPL, QMX>(p, batch, st);
-    else rc = launch_pair<DT, 2 * WPL, QMX>(p, batch, st);
+    if (LAYOUT_A) rc = tgx::pair_a(dt, WPL, QMX, p, batch, st);
+    else rc = tgx::pair(dt, 2 * WPL, QMX, p, batch, st);
     if (rc != TG_PAIR_NA) return rc;
     p.ws_need = 0;
-    if constexpr (!LAYOUT_A) {
+    if (!LAYOUT_A) {
       if (p.m > 8) {
-        rc = launch_pair_b16<DT, 2 * WPL, QMX>(p, batch, st);
+        rc = tgx::pair_b16(dt, 2 * WPL, QMX, p, batch, st);
         if (rc != TG_PAIR_NA) return rc;
         p.ws_need = 0;
       }
-      rc = launch_pair16<DT, 2 * WPL, QMX>(p, batch, st);
+      rc = tgx::gemv(dt, 2 * WPL, QMX, p, batch, st);
+      if (rc != TG_PAIR_NA) return rc;
+      rc = tgx::pair16(dt, 2 * WPL, QMX, p, batch, st);
       if (rc != TG_PAIR_NA) return rc;
     }
   }
@@ -1235,34 +430,15 @@ int launch_w4(GemmParams& p, int64_t coltiles, int64_t batch, hipStream_t st) {
 #else
   // m = 1 always streams: with private X slabs its split-K variants beat the latency kernel down to one matrix
   if (use_stream && (g.waves == 8 || p.m == 1 || use_stream == 2) && (1 << p.gshift) >= (LAYOUT_A ? 64 : 128)) {
-    return launch_stream<DT, LAYOUT_A, WPL, QMX>(p, coltiles, batch, st);
+    return tgx::stream(dt, LAYOUT_A, WPL, QMX, p, coltiles, batch, st);
   }
   if (p.dry) return TG_PLAN_SPLITK;
-  if (g.waves == 16) {
-    hipLaunchKernelGGL((w4_gemm_kernel<DT, LAYOUT_A, CANON, QMX, 16, 2, 4>), grid, dim3(16 * 64), 0, st, p);
-  } else {
-    hipLaunchKernelGGL((w4_gemm_kernel<DT, LAYOUT_A, CANON, QMX, 8, 2, 4>), grid, dim3(8 * 64), 0, st, p);
-  }
-  return launch_status();
+  return tgx::splitk(dt, LAYOUT_A, canon, QMX, g.waves, p, grid, st);
 #endif
 }
 
-template <typename DT, bool LAYOUT_A, int CANON>
-int launch_w4_q(GemmParams& p, int64_t coltiles, int64_t batch, hipStream_t st) {
-  return p.qtype == TG_Q_MX4 ? launch_w4<DT, LAYOUT_A, CANON, true>(p, coltiles, batch, st)
-                             : launch_w4<DT, LAYOUT_A, CANON, false>(p, coltiles, batch, st);
-}
-
-template <typename DT, bool LAYOUT_A>
-int launch_w4_c(GemmParams& p, int canon, int64_t coltiles, int64_t batch, hipStream_t st) {
-  switch (canon) {
-    case CANON_NONE: return launch_w4_q<DT, LAYOUT_A, CANON_NONE>(p, coltiles, batch, st);
-    case CANON_PAIR: return launch_w4_q<DT, LAYOUT_A, CANON_PAIR>(p, coltiles, batch, st);
-    default: return launch_w4_q<DT, LAYOUT_A, CANON_QUAD>(p, coltiles, batch, st);
-  }
-}
-
 }  // namespace
+
 
 extern "C" {
 
@@ -1473,9 +649,7 @@ static int gemm_w4_impl(const tg_w4_gemm* a, int device, tg_stream_t stream, int
   // packed words per lane-quad in the layout decide the in-register transpose
   const int canon = on_right ? (I == 2 ? CANON_NONE : I == 4 ? CANON_PAIR : CANON_QUAD)
                              : (I == 1 ? CANON_NONE : I == 2 ? CANON_PAIR : CANON_QUAD);
-  int rc;
-  if (a->dtype == TG_BF16) rc = on_right ? launch_w4_c<BF16, false>(p, canon, coltiles, batch, st) : launch_w4_c<BF16, true>(p, canon, coltiles, batch, st);
-  else rc = on_right ? launch_w4_c<F16, false>(p, canon, coltiles, batch, st) : launch_w4_c<F16, true>(p, canon, coltiles, batch, st);
+  const int rc = launch_w4(a->dtype, !on_right, canon, a->qtype == TG_Q_MX4, p, coltiles, batch, st);
   if (ws_need) *ws_need = (rc == TG_PLAN_PAIR || rc == TG_PLAN_PAIR_XR) ? p.ws_need : 0;
   return rc;
 }

@@ -20,41 +20,8 @@
 //     and get scale = zero = 0, so they contribute exact zeros.
 #pragma once
 
-struct GemmParams {
-  const char* x;
-  const char* w;
-  const char* qinfo;
-  const char* lut;
-  char* y;
-  int32_t m, wrows, k;
-  int32_t ntiles;    // packed.size(0): 8-row (Bint4) or 16-row (Aint4) tiles
-  int32_t ksuper;    // packed.size(1)
-  int32_t gshift;    // log2(group)
-  int32_t ngroups;   // k / group
-  int32_t qtype;
-  int32_t splitk;    // waves per tile (power of two, <= WAVES)
-  int32_t sk_shift;  // log2(splitk)
-  int32_t rowtiles;  // ceil(wrows / 16)
-  int32_t dbg;       // developer ablation flags (0 in production)
-  int32_t numerics;  // TG_NUM_* (host-side dispatch only)
-  int32_t dry;       // host-side only: report the kernel family instead of launching (tg_gemm_w4_plan)
-  int64_t stride_x, stride_w, stride_qinfo, stride_lut, stride_y;
-  const char* bias;   // optional [wrows] 16-bit, added after the first rounding (see store_rows4)
-  int64_t stride_bias;
-  int64_t bias_row_stride;  // elements between the bias rows of consecutive activation rows (0: one row for all; wrows: a residual)
-  const char* norm_w;       // fused RMSNorm of the activations (pair-table kernels only) / host-side dispatch
-  float norm_eps;
-  int32_t epilogue;         // TG_EPI_* (pair-table kernels only)
-  // host-side only: the caller's workspace (pair kernel, XG variant) and the planner's answer to "how much would help"
-  char* ws;
-  int64_t ws_bytes, ws_need;
-  int32_t ws_query;
-  int32_t x_tc, y_tc;  // fragment-order activations / output (pair-table kernels only)
-};
+// (GemmParams and the CANON_* values live in tg_common.cuh: the launch paths of the kernel families are separate translation units)
 
-enum { CANON_NONE = 0, CANON_PAIR = 1, CANON_QUAD = 2 };
-
-typedef const __attribute__((address_space(3))) float* lds_cfptr;
 
 // Word transpose between the four 16-lane rows of a wave so that every lane ends up with the
 // four words (q = 0..3) of ONE k-chunk.  See DESIGN.md "canonical chunk".

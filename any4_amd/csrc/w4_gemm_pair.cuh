@@ -152,7 +152,6 @@ struct PairParams {
 };
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
-typedef __attribute__((address_space(3))) float* lds_fptr;
 
 template <typename DT>
 __device__ __forceinline__ f32x16 mfma32(u32x4 a, u32x4 b, f32x16 c) {

@@ -35,13 +35,6 @@
 // select) are OR-ed into the nibble bytes before the v_perm_b32.
 #pragma once
 
-typedef const __attribute__((address_space(3))) uint16_t* lds_cu16ptr;
-typedef const __attribute__((address_space(3))) uint32_t* lds_cu32ptr;
-typedef __attribute__((address_space(3))) uint32_t* lds_u32ptr;
-typedef const __attribute__((address_space(3))) u32x4* lds_cu32x4ptr;
-typedef __attribute__((address_space(3))) u32x4* lds_u32x4ptr;
-typedef const __attribute__((address_space(3))) f32x4* lds_cf32x4ptr;
-typedef __attribute__((address_space(3))) f32x4* lds_f32x4ptr;
 
 struct StreamParams {
   const char* x;
