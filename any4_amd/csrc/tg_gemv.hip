@@ -1,3 +1,97 @@
-// tg_gemv.hip -- launch path of w4_gemv_kernel (one layer per launch, m <= 4: the decode step's GEMMs); see tg_common.cuh
+// tg_gemv.hip -- launch path of w4_gemv_kernel (one layer per launch, 1 ... 4 activation rows: the GEMMs of a batch-1 decode step
+// and of Any4Linear.forward / Int4Linear.forward at batch 1); see tg_common.cuh and w4_gemv.cuh
 #include "tg_common.cuh"
-int tgx::gemv(int dt, int I, bool qmx, GemmParams& p, int64_t batch, hipStream_t st) { return TG_PAIR_NA; }
+namespace {
+#include "w4_gemm_pair.cuh"   // shared device helpers (dot2, chunk_rmsnorm, swiglu16); its kernel is not instantiated here
+#include "w4_gemv.cuh"
+
+#ifndef TG_GEMV_MAX_TILES
+#define TG_GEMV_MAX_TILES 16384  // 8-row tiles per launch up to which this kernel takes single-problem launches (131072 rows)
+#endif
+
+// compute units of the current device (write-once cache per device index; racing threads store the same value)
+int cu_count() {
+  static std::atomic<int> cache[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  int v = cache[dev].load(std::memory_order_relaxed);
+  if (v > 0) return v;
+  if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+  cache[dev].store(v, std::memory_order_relaxed);
+  return v;
+}
+
+template <typename DT, int M, int GPS, int D, bool NORM>
+int go(const GemvParams& gp, dim3 grid, unsigned lds, hipStream_t st) {
+  constexpr auto kern = w4_gemv_kernel<DT, M, GPS, D, NORM>;
+  const int prc = prepare_lds_kernel<kern>();
+  if (prc != 0) return prc == TG_E_INTERNAL ? prc : TG_PAIR_NA;  // (a part with less LDS: the older kernels take over)
+  hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, gp);
+  return launch_status();
+}
+template <typename DT, int M, int GPS, int D>
+int go_n(bool norm, const GemvParams& gp, dim3 grid, unsigned lds, hipStream_t st) {
+  return norm ? go<DT, M, GPS, D, true>(gp, grid, lds, st) : go<DT, M, GPS, D, false>(gp, grid, lds, st);
+}
+template <typename DT, int M, int GPS>
+int go_d(int d, bool norm, const GemvParams& gp, dim3 grid, unsigned lds, hipStream_t st) {
+  return d == 4 ? go_n<DT, M, GPS, 4>(norm, gp, grid, lds, st) : go_n<DT, M, GPS, 8>(norm, gp, grid, lds, st);
+}
+template <typename DT, int M>
+int go_g(int gps, int d, bool norm, const GemvParams& gp, dim3 grid, unsigned lds, hipStream_t st) {
+  return gps == 1 ? go_d<DT, M, 1>(d, norm, gp, grid, lds, st) : go_d<DT, M, 2>(d, norm, gp, grid, lds, st);
+}
+template <typename DT>
+int go_m(int m, int gps, int d, bool norm, const GemvParams& gp, dim3 grid, unsigned lds, hipStream_t st) {
+  switch (m) {
+    case 1: return go_g<DT, 1>(gps, d, norm, gp, grid, lds, st);
+    case 2: return go_g<DT, 2>(gps, d, norm, gp, grid, lds, st);
+    case 3: return go_g<DT, 3>(gps, d, norm, gp, grid, lds, st);
+    default: return go_g<DT, 4>(gps, d, norm, gp, grid, lds, st);
+  }
+}
+}  // namespace
+
+int tgx::gemv(int dt, int I, bool qmx, GemmParams& p, int64_t batch, hipStream_t st) {
+  if (I != 4 || qmx || p.m > 4 || p.x_tc || p.y_tc || batch != 1) return TG_PAIR_NA;
+  if (p.ksuper * 64 != p.k || p.ntiles * 8 != p.wrows || p.ntiles > TG_GEMV_MAX_TILES) return TG_PAIR_NA;
+  const int g = 1 << p.gshift;
+  const int gps = g == 32 ? 2 : 1;
+  GemvParams gp;
+  gp.x = p.x; gp.w = p.w; gp.qinfo = p.qinfo; gp.lut = p.lut; gp.y = p.y; gp.bias = p.bias; gp.norm_w = p.norm_w;
+  gp.stride_x = p.stride_x; gp.stride_w = p.stride_w; gp.stride_qinfo = p.stride_qinfo; gp.stride_lut = p.stride_lut;
+  gp.stride_y = p.stride_y; gp.stride_bias = p.stride_bias; gp.bias_row_stride = p.bias_row_stride;
+  gp.m = p.m; gp.wrows = p.wrows; gp.k = p.k; gp.ntiles = p.ntiles; gp.ksuper = p.ksuper; gp.qtype = p.qtype;
+  gp.sg_shift = g <= 64 ? 0 : g == 128 ? 1 : 2;
+  gp.norm_eps = p.norm_eps; gp.epilogue = p.epilogue; gp.trace = nullptr;
+  gp.unit = p.epilogue == TG_EPI_SWIGLU ? 2 : 1;
+  if (p.ntiles % gp.unit != 0) return TG_PAIR_NA;
+  const int units = p.ntiles / gp.unit;
+  const int cus = p.dry ? 256 : cu_count();
+  const int wgs = units < cus ? units : cus;
+  const int tpw = ((units + wgs - 1) / wgs) * gp.unit;  // tiles of the largest range
+  gp.P = tpw <= 1 ? 8 : tpw <= 2 ? 16 : 32;
+  gp.p_shift = gp.P == 8 ? 3 : gp.P == 16 ? 4 : 5;
+  const int tpp = gp.P / 8;
+  const int passes = (tpw + tpp - 1) / tpp;
+  gp.spw = (p.ksuper + 7) / 8;
+  const int SS = 32 / gp.P;
+  gp.spp = (gp.spw + SS - 1) / SS;
+  const int total = passes * gp.spp;
+  const int d = total <= 4 ? 4 : 8;
+  // fused RMSNorm: every chunk of the activation block is one thread's
+  if (p.norm_w && (int64_t)p.m * (p.k / 32) > 512) return TG_PAIR_NA;
+  gp.lds_lut = 65536;
+  const bool stage_lut = p.qtype == TG_Q_ANY4_ROWWISE && passes > 1;
+  gp.x_pitch = p.k * 2 + (p.m > 1 ? 16 : 0);
+  gp.lds_x = gp.lds_lut + (stage_lut ? tpw * 8 * 32 : 0);
+  gp.xs_pitch = p.k / 4;
+  gp.lds_xs = gp.lds_x + p.m * gp.x_pitch;
+  gp.lds_red = gp.lds_xs + p.m * gp.xs_pitch;
+  const unsigned lds = (unsigned)gp.lds_red + (unsigned)(2 * 8 * p.m * 32 * 4);
+  if (lds > 160u * 1024u) return TG_PAIR_NA;
+  if (p.dry) return TG_PLAN_GEMV;
+  const dim3 grid((unsigned)wgs, (unsigned)batch);
+  return dt == TG_BF16 ? go_m<BF16>(p.m, gps, d, p.norm_w != nullptr, gp, grid, lds, st)
+                       : go_m<F16>(p.m, gps, d, p.norm_w != nullptr, gp, grid, lds, st);
+}

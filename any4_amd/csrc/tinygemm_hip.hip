@@ -403,6 +403,9 @@ int launch_w4(int dt, bool LAYOUT_A, int canon, bool QMX, GemmParams& p, int64_t
   if (p.numerics == TG_NUM_FAST || QMX) {
     int rc;
     if (!LAYOUT_A) {
+      // one layer per launch with up to 4 activation rows (a decode step's GEMMs): its own kernel (w4_gemv.cuh)
+      rc = tgx::gemv(dt, 2 * WPL, QMX, p, batch, st);
+      if (rc != TG_PAIR_NA) return rc;
       rc = tgx::pair_xr(dt, 2 * WPL, QMX, p, batch, st);
       if (rc != TG_PAIR_NA) return rc;
       p.ws_need = 0;
@@ -417,8 +420,6 @@ int launch_w4(int dt, bool LAYOUT_A, int canon, bool QMX, GemmParams& p, int64_t
         if (rc != TG_PAIR_NA) return rc;
         p.ws_need = 0;
       }
-      rc = tgx::gemv(dt, 2 * WPL, QMX, p, batch, st);
-      if (rc != TG_PAIR_NA) return rc;
       rc = tgx::pair16(dt, 2 * WPL, QMX, p, batch, st);
       if (rc != TG_PAIR_NA) return rc;
     }

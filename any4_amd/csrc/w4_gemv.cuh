@@ -1,0 +1,401 @@
+// w4_gemv.cuh -- the W4A16 kernel for ONE layer per launch with 1 ... 4 activation rows: what a batch-1 decode step issues
+// four times per decoder layer (BASELINE config 5; the reference times it through HuggingFace's LlamaDecoderLayer,
+// benchmark.py:113-215) and what Any4Linear.forward / Int4Linear.forward issue at batch 1 (modules.py:207-227, 56-80).
+//
+// Same contract and numerics as w4_gemm_pair.cuh (TG_NUM_FAST: the per-group affine map applied to f32 partial sums; reference
+// TinyGemmImpl.cuh:23-345 with BLayout_TC_int4, MatrixLayoutB.cuh:686-1101, Dequantization.cuh:55-178), Bint4 weights at
+// innerKTiles 4, int4 / any4 (global or row-wise LUT).  What is different is the decomposition, chosen for a launch that is
+// latency-bound (tools/ubench/graph_chain.hip: a dependent graph node costs 2.8 us before its first byte and streams at
+// ~6.3 TB/s after it, so a 9 MB layer is 4.1 us of which 1.4 are bandwidth):
+//
+//   grid       = one 8-wave workgroup per CU, each owns a CONTIGUOUS range of 8-row tiles of the packed layout and the whole k:
+//                every CU streams from the first cycle whatever the layer's row count (4096 rows = 2 tiles per CU, 6144 = 3,
+//                28672 = 14), nothing is persistent, nothing is reduced across workgroups.
+//   pass       = P = 8, 16 or 32 weight rows of the range at a time (the smallest P that holds the whole range, else 32 and
+//                several passes).  lane = (row of the pass, sub-slot); a sub-slot is (k super-tile offset, half of the
+//                super-tile's lane-quads): P = 32 -> 2 sub-slots (the halves), P = 16 -> 4 (2 super-tiles), P = 8 -> 8 (4).
+//                A wave-load is therefore always whole 256-byte super-tile blocks of the packed layout, and the lanes of a
+//                32-lane LDS access group always use 32 distinct table columns (column = lane & 31): conflict-free lookups.
+//   step       = one 16-byte load per lane = the 32 codes of ONE row in ONE half of ONE 64-k super-tile: 16 pair lookups
+//                (v_perm_b32 address + ds_read_b32), 4 activation pieces per activation row (ds_read_b128, broadcast), 16
+//                v_dot2_f32_bf16 per activation row, then ONE scale / zero update: y += scale * dot + zero * sum(x of the step)
+//                -- the group-scaled sum of w4_gemm_pair.cuh regrouped per step (a step never straddles a group for g >= 64;
+//                g = 32 splits it by 32-k chunk, GPS = 2).  No MFMA: at m <= 4 it would spend 16384 multiplier slots on 512 m
+//                useful products (measured on the stacked kernel: v_dot2 is 6 % faster at m = 1).
+//   split-K    = the 8 waves of a workgroup split k; per pass their partial sums meet in LDS, added in wave order by P * m
+//                threads (deterministic), with the epilogue (bias / residual add, SwiGLU of gate / up row pairs) in that store.
+//   ring       = D steps per lane in flight (registers), running ACROSS passes; refills are unconditional (past the end they
+//                re-read the last step: a conditional refill makes hipcc wait vmcnt(0) at the next use), the last round is
+//                peeled without refills.
+//   tables     = [256 byte values][64 columns] x 4 bytes at LDS address 0 as in the other pair-table kernels (address = byte << 8
+//                | column << 2, one v_perm_b32); a pass uses 32 columns, so the other 32 hold the NEXT pass's table (row-wise
+//                LUT), built from an LDS copy of the range's LUT rows before the pass's only barrier.
+//   activations= all m rows staged once in the w4_gemm_pair.cuh byte order, with the f32 sums of every (super-tile, half,
+//                chunk) next to them; optionally LlamaRMSNorm'ed on the way (NORM, dg_add_rmsnorm's rounding points).
+#pragma once
+
+#ifndef GEMV_TRACE
+#define GEMV_TRACE 0  // developer builds: s_memrealtime stamps of workgroup phases into GemvParams.trace
+#endif
+
+struct GemvParams {
+  const char* x;
+  const char* w;
+  const char* qinfo;
+  const char* lut;
+  char* y;
+  const char* bias;
+  const char* norm_w;
+  int64_t stride_x, stride_w, stride_qinfo, stride_lut, stride_y, stride_bias;
+  int64_t bias_row_stride;
+  int32_t m, wrows, k;
+  int32_t ntiles;    // packed.size(0): 8-row tiles
+  int32_t ksuper;    // packed.size(1): 64-k super-tiles
+  int32_t qtype;
+  int32_t sg_shift;  // log2(super-tiles per quantisation group), g >= 64 (GPS = 1)
+  int32_t P, p_shift;  // weight rows per pass (8, 16, 32) and its log2
+  int32_t unit;      // tiles are dealt to workgroups in units of this many (2 with the SwiGLU epilogue: a gate / up block)
+  int32_t spw;       // k super-tiles per wave
+  int32_t spp;       // steps per pass and wave
+  int32_t x_pitch, xs_pitch;  // bytes per staged activation row / per row of its sums
+  int32_t lds_lut, lds_x, lds_xs, lds_red;
+  float norm_eps;
+  int32_t epilogue;
+  unsigned long long* trace;
+};
+
+// DT = BF16 / F16, M = activation rows (1 ... 4), GPS = groups per super-tile half-step (1: g >= 64, 2: g = 32), D = ring depth,
+// NORM = RMSNorm fused into the staging
+template <typename DT, int M, int GPS, int D, bool NORM>
+__global__ void __launch_bounds__(512, 2) w4_gemv_kernel(const GemvParams p) {
+  constexpr int NW = 8, NT = NW * 64;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.y;
+#if GEMV_TRACE
+  unsigned long long tr[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) tr[i] = 0;
+  tr[0] = __builtin_amdgcn_s_memrealtime();
+#endif
+
+  // ---- this workgroup's tiles, this lane's place in a pass ----
+  const int units = p.ntiles / p.unit;
+  const int t0 = (int)(((int64_t)blockIdx.x * units) / gridDim.x) * p.unit;
+  const int t1 = (int)(((int64_t)(blockIdx.x + 1) * units) / gridDim.x) * p.unit;
+  if (t0 >= t1) return;
+  const int P = p.P, Pm = P - 1, tpp = P >> 3;        // tiles per pass
+  const int passes = (t1 - t0 + tpp - 1) / tpp;
+  const int row_l = lane & Pm;
+  const int sub = lane >> p.p_shift;
+  const int h = sub & 1, ss = sub >> 1;
+  const int SS = 32 >> p.p_shift;                      // super-tiles per step
+  const int s_begin = wave * p.spw;
+  const int s_end = min(s_begin + p.spw, p.ksuper);
+  const int s_last = (s_end > s_begin ? s_end : p.ksuper) - 1;
+  const int spp = p.spp;
+  const int total = passes * spp;
+
+  const char* wb = p.w + (int64_t)b * p.stride_w;
+  const char* qb = p.qinfo + (int64_t)b * p.stride_qinfo;
+  const char* lb = p.lut + (int64_t)b * p.stride_lut;
+
+  // ---- the ring ----
+  struct Slot {
+    u32x4 w;
+    uint32_t q[GPS];
+  };
+  Slot ring[D];
+  // issue pointer: (pass ip, step ii); per-pass lane offsets
+  int ip = 0, ii = 0;
+  uint32_t wlane, qlane;  // byte offsets of this lane's row in super-tile 0 / in a group's scale | zero words
+  auto pass_lane = [&](int pass) {
+    const int tile = min(t0 + pass * tpp + (row_l >> 3), t1 - 1);
+    wlane = (uint32_t)tile * (uint32_t)p.ksuper * 256u + (uint32_t)((row_l & 7) * 32 + h * 16);
+    qlane = (uint32_t)(tile * 8 + (row_l & 7)) * 4u;
+  };
+  pass_lane(0);
+  auto issue = [&](Slot& sl) {
+    const int s = min(s_begin + ii * SS + ss, s_last);
+    sl.w = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wb + (wlane + (uint32_t)s * 256u)));
+    if constexpr (GPS == 1) {
+      sl.q[0] = *reinterpret_cast<const uint32_t*>(qb + ((uint32_t)(s >> p.sg_shift) * (uint32_t)p.wrows * 4u + qlane));
+    } else {
+      sl.q[0] = *reinterpret_cast<const uint32_t*>(qb + ((uint32_t)(2 * s) * (uint32_t)p.wrows * 4u + qlane));
+      sl.q[1] = *reinterpret_cast<const uint32_t*>(qb + ((uint32_t)(2 * s + 1) * (uint32_t)p.wrows * 4u + qlane));
+    }
+    if (++ii == spp) {  // (wave-uniform) the next step belongs to the next pass; past the last pass the last one is re-read
+      ii = 0;
+      if (ip + 1 < passes) pass_lane(++ip);
+      else ii = spp - 1;
+    }
+  };
+
+  // ---- requests, in the order the prologue consumes them: activations, LUT rows, the first D steps ----
+  const int nch = p.k >> 5;
+  const int xtotal = p.m * nch;  // 32-k chunks to stage (host: NORM needs xtotal <= NT)
+  const char* xb = p.x + (int64_t)b * p.stride_x;
+  uint32_t xd[16];
+  auto x_load = [&](int xi) {
+    const int a = xi / nch, ch = xi - a * nch;
+    const u32x4* src = reinterpret_cast<const u32x4*>(xb + ((int64_t)a * p.k + ch * 32) * 2);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const u32x4 v = src[j];
+      xd[4 * j] = v[0]; xd[4 * j + 1] = v[1]; xd[4 * j + 2] = v[2]; xd[4 * j + 3] = v[3];
+    }
+  };
+#pragma unroll
+  for (int j = 0; j < 16; ++j) xd[j] = 0u;
+  if (tid < xtotal) x_load(tid);
+  u32x4 gw[4];
+  if constexpr (NORM) {
+    const int a = tid < xtotal ? tid / nch : 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) gw[j] = reinterpret_cast<const u32x4*>(p.norm_w + (tid < xtotal ? tid - a * nch : 0) * 64)[j];
+  }
+  // LUT: the 16 values of table column c of pass 0 as 8 packed pairs
+  const int c = tid & 31;   // table column this thread builds
+  const int hi = tid >> 5;  // ... for the bytes with this high nibble (16 x 32 = 512 threads)
+  uint32_t lp[8];
+  const bool rowwise = p.qtype == TG_Q_ANY4_ROWWISE;
+  const int wg_rows = (t1 - t0) * 8;
+  if (p.qtype == TG_Q_INT4) {
+#pragma unroll
+    for (int e = 0; e < 16; e += 2) lp[e >> 1] = DT::pack2((float)(e - 8), (float)(e - 7));
+  } else {
+    const int trow = min(t0 + ((c & Pm) >> 3), t1 - 1) * 8 + (c & 7);
+    const char* lsrc = lb + (rowwise ? (int64_t)trow * 32 : 0);
+    const u32x4 l0 = reinterpret_cast<const u32x4*>(lsrc)[0];
+    const u32x4 l1 = reinterpret_cast<const u32x4*>(lsrc)[1];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { lp[j] = l0[j]; lp[4 + j] = l1[j]; }
+  }
+  // the range's LUT rows -> LDS (the tables of the passes after the first are built from there)
+  const bool stage_lut = rowwise && passes > 1;
+  u32x4 lstage = {0, 0, 0, 0};
+  if (stage_lut && tid < wg_rows * 2) lstage = reinterpret_cast<const u32x4*>(lb + (int64_t)t0 * 256)[tid];
+#pragma unroll
+  for (int j = 0; j < D; ++j) {
+    __builtin_amdgcn_sched_barrier(0);
+    issue(ring[j]);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#if GEMV_TRACE
+  tr[1] = __builtin_amdgcn_s_memrealtime();
+#endif
+
+  // ---- stage the activations (byte order of w4_gemm_pair.cuh) and their sums ----
+  const uint32_t lds_x = (uint32_t)p.lds_x, lds_xs = (uint32_t)p.lds_xs, lds_red = (uint32_t)p.lds_red;
+  auto x_store = [&](int xi) {
+    const int a = xi / nch, ch = xi - a * nch;
+    const uint32_t dst = lds_x + (uint32_t)(a * p.x_pitch + ch * 64);
+    float sums[2] = {0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      u32x4 o;
+      o[0] = __builtin_amdgcn_perm(xd[q + 4], xd[q], 0x05040100u);       // x[2q]     x[2q+8]
+      o[1] = __builtin_amdgcn_perm(xd[q + 12], xd[q + 8], 0x05040100u);  // x[2q+16]  x[2q+24]
+      o[2] = __builtin_amdgcn_perm(xd[q + 4], xd[q], 0x07060302u);       // x[2q+1]   x[2q+9]
+      o[3] = __builtin_amdgcn_perm(xd[q + 12], xd[q + 8], 0x07060302u);  // x[2q+17]  x[2q+25]
+      *(lds_u32x4ptr)(dst + (uint32_t)(q * 16)) = o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) sums[q >> 1] = dot2_ones<DT>(o[j], sums[q >> 1]);
+    }
+    // sums of the chunk's halves: [super-tile][half][chunk of the super-tile]
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) *(lds_fptr)(lds_xs + (uint32_t)(a * p.xs_pitch + (((ch >> 1) * 2 + hh) * 2 + (ch & 1)) * 4)) = sums[hh];
+  };
+  if constexpr (NORM) {
+    // LlamaRMSNorm on the way (dg_add_rmsnorm's formula): sum of squares per chunk -> per wave and row -> per row, in wave order
+    float ssq = chunk_sumsq<DT>(xd);
+    // (chunks of one row may straddle waves: every wave publishes one partial per activation row)
+    float part[M];
+    const int arow = tid < xtotal ? tid / nch : -1;
+#pragma unroll
+    for (int a = 0; a < M; ++a) {
+      float v = arow == a ? ssq : 0.f;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) v += __shfl_xor(v, o);
+      part[a] = v;
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int a = 0; a < M; ++a) *(lds_fptr)(lds_red + (uint32_t)((wave * M + a) * 4)) = part[a];
+    }
+    __syncthreads();
+    float tot = 0.f;
+    if (arow >= 0)
+      for (int w8 = 0; w8 < NW; ++w8) tot += *(lds_fptr)(lds_red + (uint32_t)((w8 * M + arow) * 4));
+    if (arow >= 0) chunk_rmsnorm<DT>(xd, rsqrtf(tot * (1.0f / (float)p.k) + p.norm_eps), gw);
+    if (tid < xtotal) x_store(tid);
+    __syncthreads();  // the partials are read before the split-K sums land in the same area
+  } else {
+    if (tid < xtotal) x_store(tid);
+    for (int xi = tid + NT; xi < xtotal; xi += NT) {
+      x_load(xi);
+      x_store(xi);
+    }
+  }
+  if (stage_lut && tid < wg_rows * 2) *(lds_u32x4ptr)((uint32_t)p.lds_lut + (uint32_t)tid * 16u) = lstage;
+  if (stage_lut)
+    for (int i = tid + NT; i < wg_rows * 2; i += NT)
+      *(lds_u32x4ptr)((uint32_t)p.lds_lut + (uint32_t)i * 16u) = reinterpret_cast<const u32x4*>(lb + (int64_t)t0 * 256)[i];
+
+  // ---- pair table of a pass: entry[byte][column] = (lut[byte & 15], lut[byte >> 4]); thread = (column c, high nibble hi) ----
+  auto build_table = [&](int half) {
+    const uint32_t hw = lp[0];
+    uint32_t hsel = hw;
+#pragma unroll
+    for (int j = 1; j < 8; ++j) hsel = (hi >> 1) == j ? lp[j] : hsel;
+    const uint32_t hv = (hi & 1) ? (hsel & 0xffff0000u) : (hsel << 16);
+    const lds_u32ptr tb = (lds_u32ptr)((uint32_t)(hi * 16 * 256 + (half * 32 + c) * 4));
+#pragma unroll
+    for (int lo = 0; lo < 16; ++lo) {
+      const uint32_t lv = (lo & 1) ? (lp[lo >> 1] >> 16) : (lp[lo >> 1] & 0xffffu);
+      tb[lo * 64] = lv | hv;
+    }
+  };
+  build_table(0);
+#if GEMV_TRACE
+  tr[2] = __builtin_amdgcn_s_memrealtime();
+#endif
+  __syncthreads();
+#if GEMV_TRACE
+  tr[3] = __builtin_amdgcn_s_memrealtime();
+#endif
+
+  // ---- main loop ----
+  uint32_t colreg = (uint32_t)((lane & 31) * 4);
+  float yacc[M];
+#pragma unroll
+  for (int a = 0; a < M; ++a) yacc[a] = 0.f;
+  int cp = 0, ci = 0;  // consume pointer: pass, step of the pass
+
+  auto pass_end = [&]() {
+    // the sub-slots of a row sit in lanes row + P i: lane `row` gets the wave's sum
+    float v[M];
+#pragma unroll
+    for (int a = 0; a < M; ++a) {
+      v[a] = yacc[a];
+      yacc[a] = 0.f;
+      v[a] += __shfl_xor(v[a], 32);
+      if (P <= 16) v[a] += __shfl_xor(v[a], 16);
+      if (P <= 8) v[a] += __shfl_xor(v[a], 8);
+    }
+    const uint32_t par = (uint32_t)(cp & 1);
+    if (lane < P) {
+#pragma unroll
+      for (int a = 0; a < M; ++a) *(lds_fptr)(lds_red + (uint32_t)((((par * NW + wave) * M + a) * 32 + lane) * 4)) = v[a];
+    }
+    // the next pass's table goes into the other 32 columns (row-wise LUT only: the others never change)
+    if (rowwise && cp + 1 < passes) {
+      const int lrow = min((cp + 1) * P + (c & Pm), wg_rows - 1);
+      const u32x4 l0 = *(lds_cu32x4ptr)((uint32_t)p.lds_lut + (uint32_t)lrow * 32u);
+      const u32x4 l1 = *(lds_cu32x4ptr)((uint32_t)p.lds_lut + (uint32_t)lrow * 32u + 16u);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { lp[j] = l0[j]; lp[4 + j] = l1[j]; }
+      build_table((cp + 1) & 1);
+      colreg ^= 128u;
+    }
+    __syncthreads();
+    if (tid < P * M) {
+      const int a = tid >> p.p_shift, r = tid & Pm;
+      const int tile = t0 + cp * tpp + (r >> 3);
+      if (tile < t1) {
+        const int row = tile * 8 + (r & 7);
+        float sum = 0.f;
+#pragma unroll
+        for (int w8 = 0; w8 < NW; ++w8) sum += *(lds_fptr)(lds_red + (uint32_t)((((par * NW + w8) * M + a) * 32 + r) * 4));
+        if (p.epilogue == TG_EPI_SWIGLU) {
+          // rows come in blocks of 8 gate + 8 up (a block = two tiles of one pass): lane r + 8 holds the up row of gate row r
+          if ((r & 15) < 8) {
+            float up = 0.f;
+#pragma unroll
+            for (int w8 = 0; w8 < NW; ++w8) up += *(lds_fptr)(lds_red + (uint32_t)((((par * NW + w8) * M + a) * 32 + r + 8) * 4));
+            *reinterpret_cast<uint16_t*>(p.y + (int64_t)b * p.stride_y + ((int64_t)a * (p.wrows >> 1) + ((row >> 4) << 3) + (row & 7)) * 2) = swiglu16<DT>(sum, up);
+          }
+        } else {
+          uint16_t o16 = DT::from_f32(sum);
+          if (p.bias)  // rounded sum + bias, rounded again: the reference module's separate `y + bias` (modules.py:221-222)
+            o16 = DT::from_f32(DT::lo_f32(o16) + DT::lo_f32(*reinterpret_cast<const uint16_t*>(p.bias + (int64_t)b * p.stride_bias + ((int64_t)a * p.bias_row_stride + row) * 2)));
+          *reinterpret_cast<uint16_t*>(p.y + (int64_t)b * p.stride_y + ((int64_t)a * p.wrows + row) * 2) = o16;
+        }
+      }
+    }
+  };
+
+  auto consume = [&](const Slot& sl, bool real) {
+    const int s_l = s_begin + ci * SS + ss;
+    const bool on = real && s_l < s_end;
+    const int s = min(s_l, s_last);
+    const uint32_t xa = lds_x + (uint32_t)(s * 128 + h * 32);
+    const uint32_t xsa = lds_xs + (uint32_t)((s * 2 + h) * 8);
+    float dsum[M][GPS];
+#pragma unroll
+    for (int a = 0; a < M; ++a)
+#pragma unroll
+      for (int g = 0; g < GPS; ++g) dsum[a][g] = 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int jc = u >> 1, qq = u & 1;  // 32-k chunk of the super-tile, quad of the half
+      const uint32_t w = sl.w[qq * 2 + jc];
+      uint32_t e[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) e[j] = *(lds_cu32ptr)(__builtin_amdgcn_perm(w, colreg, 0x0c0c0400u + ((uint32_t)j << 8)));
+#pragma unroll
+      for (int a = 0; a < M; ++a) {
+        const u32x4 xf = *(lds_cu32x4ptr)(xa + (uint32_t)(a * p.x_pitch + jc * 64 + qq * 16));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dsum[a][GPS == 1 ? 0 : jc] = dot2_pair<DT>(e[j], xf[j], dsum[a][GPS == 1 ? 0 : jc]);
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < GPS; ++g) {
+      const float sc = on ? DT::lo_f32(sl.q[g]) : 0.f;
+      const float zz = on ? DT::hi_f32(sl.q[g]) : 0.f;
+#pragma unroll
+      for (int a = 0; a < M; ++a) {
+        const f32x2 xs2 = *(const __attribute__((address_space(3))) f32x2*)(xsa + (uint32_t)(a * p.xs_pitch));
+        const float xs = GPS == 1 ? xs2[0] + xs2[1] : xs2[g];
+        yacc[a] = __builtin_fmaf(zz, xs, __builtin_fmaf(sc, dsum[a][g], yacc[a]));
+      }
+    }
+    if (real) {  // (wave-uniform)
+      if (++ci == spp) {
+        pass_end();
+        ci = 0;
+        ++cp;
+      }
+    }
+  };
+
+  // rounds of D steps; the total is padded to a multiple of D with steps that re-read the last one and add nothing
+  const int total_p = (total + D - 1) / D * D;
+  int n0 = 0;
+  for (; n0 < total_p - D; n0 += D) {
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      consume(ring[j], true);  // (n0 + j < total: only the last round holds padding)
+      issue(ring[j]);
+#if GEMV_TRACE
+      if (n0 == 0 && j == 0) tr[4] = __builtin_amdgcn_s_memrealtime();
+#endif
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < D; ++j) {
+    consume(ring[j], n0 + j < total);
+#if GEMV_TRACE
+    if (n0 == 0 && j == 0) tr[4] = __builtin_amdgcn_s_memrealtime();
+#endif
+  }
+#if GEMV_TRACE
+  tr[5] = __builtin_amdgcn_s_memrealtime();
+  if (tid == 0 && p.trace) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) p.trace[(size_t)blockIdx.x * 8 + i] = tr[i];
+  }
+#endif
+}

@@ -195,11 +195,8 @@ class DecodeLayer(torch.nn.Module):
         self.norm2 = RMSNorm(cfg.hidden, cfg.rms_eps, device, dtype)
         self.register_buffer("k_cache", torch.zeros(bs, self.kvl, cfg.max_seq, d, device=device, dtype=dtype), persistent=False)
         self.register_buffer("v_cache", torch.zeros(bs, self.kvl, cfg.max_seq, d, device=device, dtype=dtype), persistent=False)
-        # forward_fused5: which stages the library fused (None: not tried yet; set by the first step).  RMSNorm goes into the qkv
-        # GEMM only when that is one round of the small-launch kernel's workgroups (<= 4096 rows): for Llama-3-8B's 6144 rows the
-        # fused launch (12.6 us on w4_gemm_pair16_kernel) costs what the stream kernel + the norm launch cost (8.5 + 4.5 us)
-        qkv_rows = (self.hl + 2 * self.kvl) * d
-        self._fuse = {"norm1": None if qkv_rows <= 4096 else False, "norm2": None, "mlp": None}
+        # forward_fused5: which stages the library fused (None: not tried yet; set by the first step)
+        self._fuse = {"norm1": None, "norm2": None, "mlp": None}
 
     def forward(self, h, pos, cos, sin, mask, gather):
         cfg, d, bs = self.cfg, self.cfg.head_dim, h.shape[0]

@@ -90,7 +90,7 @@ def numerics(name: str):
             _tls.numerics = prev
 
 
-_PLANS = {_lib.TG_PLAN_SPLITK: "splitk", _lib.TG_PLAN_STREAM: "stream", _lib.TG_PLAN_PAIR: "pair", _lib.TG_PLAN_PAIR_XR: "pair_xr"}
+_PLANS = {_lib.TG_PLAN_SPLITK: "splitk", _lib.TG_PLAN_STREAM: "stream", _lib.TG_PLAN_PAIR: "pair", _lib.TG_PLAN_PAIR_XR: "pair_xr", _lib.TG_PLAN_GEMV: "gemv"}
 
 
 def gemm_w4_plan(m: int, wrows: int, k: int, group: int, qtype: int, weight_on_right: bool = True, inner_k_tiles: int = 4,

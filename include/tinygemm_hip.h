@@ -197,8 +197,11 @@ TG_API int tg_gemm_w4(const tg_w4_gemm* args, int device, tg_stream_t stream);
  *   TG_PLAN_PAIR    w4_gemm_pair_kernel    per-row tables of LUT pairs, group-scaled numerics (TG_NUM_FAST; mx4 -- converted in
  *                                          registers by v_cvt_scalef32_pk_bf16_fp4, exact -- in both numerics)
  *   TG_PLAN_PAIR_XR w4_gemm_xr_kernel      the same tables and numerics, activations resident in registers (Bint4 weights,
- *                                          2 ... 16 activation rows, k = 4096, stacked launches)  */
-enum { TG_PLAN_SPLITK = 1, TG_PLAN_STREAM = 2, TG_PLAN_PAIR = 3, TG_PLAN_PAIR_XR = 4 };
+ *                                          2 ... 16 activation rows, k = 4096, stacked launches)
+ *   TG_PLAN_GEMV    w4_gemv_kernel         the same tables and numerics for ONE layer per launch with 1 ... 4 activation rows (a
+ *                                          decode step's GEMMs): one workgroup per CU over a contiguous range of weight rows,
+ *                                          v_dot2 contraction, fused norm / residual / SwiGLU stages  */
+enum { TG_PLAN_SPLITK = 1, TG_PLAN_STREAM = 2, TG_PLAN_PAIR = 3, TG_PLAN_PAIR_XR = 4, TG_PLAN_GEMV = 5 };
 enum { TG_LAYOUT_RM = 0, TG_LAYOUT_TC_A = 1 };
 TG_API int tg_gemm_w4_plan(const tg_w4_gemm* args, int device);
 
