@@ -50,7 +50,19 @@ int go_m(int m, int gps, int d, bool norm, const GemvParams& gp, dim3 grid, unsi
     default: return go_g<DT, 4>(gps, d, norm, gp, grid, lds, st);
   }
 }
+#if GEMV_TRACE
+unsigned long long* g_trace = nullptr;  // developer builds only (-DGEMV_TRACE=1): [slots][256 workgroups][8 stamps]
+int g_trace_slots = 0, g_trace_launch = 0;
+#endif
 }  // namespace
+
+#if GEMV_TRACE
+extern "C" TG_API void tg_dev_gemv_trace(unsigned long long* buf, int slots) {
+  g_trace = buf;
+  g_trace_slots = slots;
+  g_trace_launch = 0;
+}
+#endif
 
 int tgx::gemv(int dt, int I, bool qmx, GemmParams& p, int64_t batch, hipStream_t st) {
   if (I != 4 || qmx || p.m > 4 || p.x_tc || p.y_tc || batch != 1) return TG_PAIR_NA;
@@ -77,10 +89,11 @@ int tgx::gemv(int dt, int I, bool qmx, GemmParams& p, int64_t batch, hipStream_t
   gp.spw = (p.ksuper + 7) / 8;
   const int SS = 32 / gp.P;
   gp.spp = (gp.spw + SS - 1) / SS;
-  const int total = passes * gp.spp;
-  const int d = total <= 4 ? 4 : 8;
-  // fused RMSNorm: every chunk of the activation block is one thread's
-  if (p.norm_w && (int64_t)p.m * (p.k / 32) > 512) return TG_PAIR_NA;
+  const int d = gp.spp <= 4 ? 4 : 8;  // ring depth: a pass occupies whole rounds of D slots
+  gp.rounds = (gp.spp + d - 1) / d;
+  gp.ubase = units / wgs;
+  gp.urem = units % wgs;
+  if (p.k > 16384) return TG_PAIR_NA;  // a thread keeps its pieces of the activation block in registers: four rounds of 512 per row
   gp.lds_lut = 65536;
   const bool stage_lut = p.qtype == TG_Q_ANY4_ROWWISE && passes > 1;
   gp.x_pitch = p.k * 2 + (p.m > 1 ? 16 : 0);
@@ -88,10 +101,14 @@ int tgx::gemv(int dt, int I, bool qmx, GemmParams& p, int64_t batch, hipStream_t
   gp.xs_pitch = p.k / 4;
   gp.lds_xs = gp.lds_x + p.m * gp.x_pitch;
   gp.lds_red = gp.lds_xs + p.m * gp.xs_pitch;
-  const unsigned lds = (unsigned)gp.lds_red + (unsigned)(2 * 8 * p.m * 32 * 4);
+  gp.lds_nrm = gp.lds_red + 2 * 8 * p.m * 32 * 4;
+  const unsigned lds = (unsigned)gp.lds_nrm + (unsigned)(8 * p.m * 4);
   if (lds > 160u * 1024u) return TG_PAIR_NA;
   if (p.dry) return TG_PLAN_GEMV;
   const dim3 grid((unsigned)wgs, (unsigned)batch);
+#if GEMV_TRACE
+  if (g_trace && g_trace_slots > 0) gp.trace = g_trace + (size_t)(g_trace_launch++ % g_trace_slots) * 256 * 8;
+#endif
   return dt == TG_BF16 ? go_m<BF16>(p.m, gps, d, p.norm_w != nullptr, gp, grid, lds, st)
                        : go_m<F16>(p.m, gps, d, p.norm_w != nullptr, gp, grid, lds, st);
 }

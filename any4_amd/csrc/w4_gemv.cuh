@@ -24,14 +24,20 @@
 //                useful products (measured on the stacked kernel: v_dot2 is 6 % faster at m = 1).
 //   split-K    = the 8 waves of a workgroup split k; per pass their partial sums meet in LDS, added in wave order by P * m
 //                threads (deterministic), with the epilogue (bias / residual add, SwiGLU of gate / up row pairs) in that store.
-//   ring       = D steps per lane in flight (registers), running ACROSS passes; refills are unconditional (past the end they
-//                re-read the last step: a conditional refill makes hipcc wait vmcnt(0) at the next use), the last round is
-//                peeled without refills.
+//   ring       = D steps per lane in flight (registers), running ACROSS passes (a pass occupies a whole number of rounds of D
+//                slots; slots past its last step re-read that step and are skipped); refills are unconditional (a conditional
+//                refill makes hipcc wait vmcnt(0) at the next use), the launch's last round is peeled without refills.
 //   tables     = [256 byte values][64 columns] x 4 bytes at LDS address 0 as in the other pair-table kernels (address = byte << 8
 //                | column << 2, one v_perm_b32); a pass uses 32 columns, so the other 32 hold the NEXT pass's table (row-wise
 //                LUT), built from an LDS copy of the range's LUT rows before the pass's only barrier.
-//   activations= all m rows staged once in the w4_gemm_pair.cuh byte order, with the f32 sums of every (super-tile, half,
-//                chunk) next to them; optionally LlamaRMSNorm'ed on the way (NORM, dg_add_rmsnorm's rounding points).
+//   activations= all m rows staged once in the w4_gemm_pair.cuh byte order, one 16-byte piece (8 values) per thread, with the
+//                f32 sums of every (super-tile, half, chunk) next to them; optionally LlamaRMSNorm'ed on the way (NORM,
+//                dg_add_rmsnorm's rounding points): every WAVE adds the squares of the whole row itself (k / 512 loads per lane
+//                from L2, one butterfly) -- no barrier, no LDS round trip in front of the staging.
+//   latency    = what a launch of this kind is made of (dev/gemv_trace.py, s_memrealtime stamps inside a decode step): ~1.2 us
+//                from the previous kernel's last wave to this one's first, then the time to ISSUE the first loads, one memory
+//                round trip (~1 us), the steps, the split-K tail.  Hence: no integer division and no dependent scalar load in
+//                front of the first requests, the residual / bias values requested up front, one inlined copy of the pass tail.
 #pragma once
 
 #ifndef GEMV_TRACE
@@ -54,11 +60,13 @@ struct GemvParams {
   int32_t qtype;
   int32_t sg_shift;  // log2(super-tiles per quantisation group), g >= 64 (GPS = 1)
   int32_t P, p_shift;  // weight rows per pass (8, 16, 32) and its log2
-  int32_t unit;      // tiles are dealt to workgroups in units of this many (2 with the SwiGLU epilogue: a gate / up block)
+  int32_t unit;      // tiles are dealt to workgroups in units of this many (2 with the SwiGLU epilogue: a gate / up block):
+  int32_t ubase, urem;  // workgroup b owns ubase + (b < urem) units, starting at unit b * ubase + min(b, urem)
   int32_t spw;       // k super-tiles per wave
   int32_t spp;       // steps per pass and wave
+  int32_t rounds;    // ceil(spp / D): rounds of D ring slots a pass occupies
   int32_t x_pitch, xs_pitch;  // bytes per staged activation row / per row of its sums
-  int32_t lds_lut, lds_x, lds_xs, lds_red;
+  int32_t lds_lut, lds_x, lds_xs, lds_red, lds_nrm;  // LDS byte offsets (lds_nrm: 8 x m f32 partial sums of squares)
   float norm_eps;
   int32_t epilogue;
   unsigned long long* trace;
@@ -80,13 +88,24 @@ __global__ void __launch_bounds__(512, 2) w4_gemv_kernel(const GemvParams p) {
   tr[0] = __builtin_amdgcn_s_memrealtime();
 #endif
 
+  // Every kernel argument into scalar registers NOW: left alone, hipcc loads them where they are first used -- four dependent
+  // scalar-memory round trips (~0.3 us each from the cold argument segment) in front of the first weight request.
+  asm volatile("" ::"s"(p.x), "s"(p.w), "s"(p.qinfo), "s"(p.lut), "s"(p.y), "s"(p.bias), "s"(p.norm_w), "s"(p.stride_x), "s"(p.stride_w),
+               "s"(p.stride_qinfo), "s"(p.stride_lut), "s"(p.stride_y), "s"(p.stride_bias), "s"(p.bias_row_stride));
+  asm volatile("" ::"s"(p.m), "s"(p.wrows), "s"(p.k), "s"(p.ksuper), "s"(p.qtype), "s"(p.sg_shift), "s"(p.P), "s"(p.p_shift), "s"(p.unit),
+               "s"(p.ubase), "s"(p.urem), "s"(p.spw), "s"(p.spp), "s"(p.rounds), "s"(p.x_pitch), "s"(p.xs_pitch), "s"(p.lds_lut),
+               "s"(p.lds_x), "s"(p.lds_xs), "s"(p.lds_red), "s"(p.lds_nrm), "s"(p.norm_eps), "s"(p.epilogue));
+#if GEMV_TRACE
+  tr[6] = __builtin_amdgcn_s_memrealtime();
+#endif
+
   // ---- this workgroup's tiles, this lane's place in a pass ----
-  const int units = p.ntiles / p.unit;
-  const int t0 = (int)(((int64_t)blockIdx.x * units) / gridDim.x) * p.unit;
-  const int t1 = (int)(((int64_t)(blockIdx.x + 1) * units) / gridDim.x) * p.unit;
+  const int bx = blockIdx.x;
+  const int t0 = (bx * p.ubase + min(bx, p.urem)) * p.unit;
+  const int t1 = t0 + (p.ubase + (bx < p.urem ? 1 : 0)) * p.unit;
   if (t0 >= t1) return;
   const int P = p.P, Pm = P - 1, tpp = P >> 3;        // tiles per pass
-  const int passes = (t1 - t0 + tpp - 1) / tpp;
+  const int passes = (t1 - t0 + tpp - 1) >> (p.p_shift - 3);
   const int row_l = lane & Pm;
   const int sub = lane >> p.p_shift;
   const int h = sub & 1, ss = sub >> 1;
@@ -94,12 +113,13 @@ __global__ void __launch_bounds__(512, 2) w4_gemv_kernel(const GemvParams p) {
   const int s_begin = wave * p.spw;
   const int s_end = min(s_begin + p.spw, p.ksuper);
   const int s_last = (s_end > s_begin ? s_end : p.ksuper) - 1;
-  const int spp = p.spp;
-  const int total = passes * spp;
+  const int spp = p.spp;                               // real steps of a pass
+  const int rounds = p.rounds;                         // rounds of D ring slots a pass occupies: ceil(spp / D)
 
   const char* wb = p.w + (int64_t)b * p.stride_w;
   const char* qb = p.qinfo + (int64_t)b * p.stride_qinfo;
   const char* lb = p.lut + (int64_t)b * p.stride_lut;
+  const char* xb = p.x + (int64_t)b * p.stride_x;
 
   // ---- the ring ----
   struct Slot {
@@ -107,7 +127,7 @@ __global__ void __launch_bounds__(512, 2) w4_gemv_kernel(const GemvParams p) {
     uint32_t q[GPS];
   };
   Slot ring[D];
-  // issue pointer: (pass ip, step ii); per-pass lane offsets
+  // issue pointer: pass ip, slot ii of the pass (slots >= spp re-read the pass's last step); per-pass lane offsets
   int ip = 0, ii = 0;
   uint32_t wlane, qlane;  // byte offsets of this lane's row in super-tile 0 / in a group's scale | zero words
   auto pass_lane = [&](int pass) {
@@ -116,8 +136,9 @@ __global__ void __launch_bounds__(512, 2) w4_gemv_kernel(const GemvParams p) {
     qlane = (uint32_t)(tile * 8 + (row_l & 7)) * 4u;
   };
   pass_lane(0);
+  const int slots = rounds * D;
   auto issue = [&](Slot& sl) {
-    const int s = min(s_begin + ii * SS + ss, s_last);
+    const int s = min(s_begin + min(ii, spp - 1) * SS + ss, s_last);
     sl.w = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wb + (wlane + (uint32_t)s * 256u)));
     if constexpr (GPS == 1) {
       sl.q[0] = *reinterpret_cast<const uint32_t*>(qb + ((uint32_t)(s >> p.sg_shift) * (uint32_t)p.wrows * 4u + qlane));
@@ -125,36 +146,45 @@ __global__ void __launch_bounds__(512, 2) w4_gemv_kernel(const GemvParams p) {
       sl.q[0] = *reinterpret_cast<const uint32_t*>(qb + ((uint32_t)(2 * s) * (uint32_t)p.wrows * 4u + qlane));
       sl.q[1] = *reinterpret_cast<const uint32_t*>(qb + ((uint32_t)(2 * s + 1) * (uint32_t)p.wrows * 4u + qlane));
     }
-    if (++ii == spp) {  // (wave-uniform) the next step belongs to the next pass; past the last pass the last one is re-read
+    if (++ii == slots) {  // (wave-uniform) the next slot belongs to the next pass; past the last pass the last slot is re-read
       ii = 0;
       if (ip + 1 < passes) pass_lane(++ip);
-      else ii = spp - 1;
+      else ii = slots - 1;
     }
   };
 
-  // ---- requests, in the order the prologue consumes them: activations, LUT rows, the first D steps ----
-  const int nch = p.k >> 5;
-  const int xtotal = p.m * nch;  // 32-k chunks to stage (host: NORM needs xtotal <= NT)
-  const char* xb = p.x + (int64_t)b * p.stride_x;
-  uint32_t xd[16];
-  auto x_load = [&](int xi) {
-    const int a = xi / nch, ch = xi - a * nch;
-    const u32x4* src = reinterpret_cast<const u32x4*>(xb + ((int64_t)a * p.k + ch * 32) * 2);
+  // ---- requests: this thread's share of the activations, norm weights, LUT rows, bias values -- then, behind a workgroup barrier,
+  // the first D steps of the weight stream (the CU's vector-memory path takes requests in arrival order: 64 KiB of weight
+  // requests of the waves that got there first would sit in front of the last wave's 16 bytes of activations) ----
+  // Activation staging: a 32-k chunk becomes four 16-byte pieces; piece q = the chunk's dwords q, q + 4, q + 8, q + 12
+  // (x[2q], x[2q+1] | +8 | +16 | +24).  k <= 4096: thread t stages piece t of every row (four dword loads); larger k: thread t
+  // stages chunk t (four 16-byte loads).  Lanes without a share re-read the last one: every load of this prologue is
+  // unconditional per lane (a load under a lane mask made hipcc wait vmcnt(0) right behind it).
+  const int npc = p.k >> 3;   // pieces per activation row
+  const int nch = p.k >> 5;   // chunks per activation row (host: <= NT)
+  const bool wide = npc > NT; // (wave-uniform)
+  uint32_t xd[M][16];         // !wide: [0..3] = the piece's four dwords; wide: the chunk's 16 dwords
+  uint32_t gwd[NORM ? 16 : 1];
+  auto stage_load = [&](const char* base, uint32_t (&d)[16]) {
+    if (!wide) {
+      const int pc = min(tid, npc - 1);
+      const char* src = base + (pc >> 2) * 64 + (pc & 3) * 4;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const u32x4 v = src[j];
-      xd[4 * j] = v[0]; xd[4 * j + 1] = v[1]; xd[4 * j + 2] = v[2]; xd[4 * j + 3] = v[3];
+      for (int j = 0; j < 4; ++j) d[j] = *reinterpret_cast<const uint32_t*>(src + j * 16);
+#pragma unroll
+      for (int j = 4; j < 16; ++j) d[j] = 0u;
+    } else {
+      const u32x4* src = reinterpret_cast<const u32x4*>(base + min(tid, nch - 1) * 64);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const u32x4 v = src[j];
+        d[4 * j] = v[0]; d[4 * j + 1] = v[1]; d[4 * j + 2] = v[2]; d[4 * j + 3] = v[3];
+      }
     }
   };
 #pragma unroll
-  for (int j = 0; j < 16; ++j) xd[j] = 0u;
-  if (tid < xtotal) x_load(tid);
-  u32x4 gw[4];
-  if constexpr (NORM) {
-    const int a = tid < xtotal ? tid / nch : 0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) gw[j] = reinterpret_cast<const u32x4*>(p.norm_w + (tid < xtotal ? tid - a * nch : 0) * 64)[j];
-  }
+  for (int a = 0; a < M; ++a) stage_load(xb + (int64_t)a * p.k * 2, xd[a]);
+  if constexpr (NORM) stage_load(p.norm_w, gwd);
   // LUT: the 16 values of table column c of pass 0 as 8 packed pairs
   const int c = tid & 31;   // table column this thread builds
   const int hi = tid >> 5;  // ... for the bytes with this high nibble (16 x 32 = 512 threads)
@@ -175,7 +205,17 @@ __global__ void __launch_bounds__(512, 2) w4_gemv_kernel(const GemvParams p) {
   // the range's LUT rows -> LDS (the tables of the passes after the first are built from there)
   const bool stage_lut = rowwise && passes > 1;
   u32x4 lstage = {0, 0, 0, 0};
-  if (stage_lut && tid < wg_rows * 2) lstage = reinterpret_cast<const u32x4*>(lb + (int64_t)t0 * 256)[tid];
+  if (stage_lut) lstage = reinterpret_cast<const u32x4*>(lb + (int64_t)t0 * 256)[min(tid, wg_rows * 2 - 1)];
+  // the bias / residual values of the first pass's outputs (thread = (activation row, row of the pass), as in pass_end)
+  uint16_t res0 = 0;
+  if (p.bias) {
+    const int a = min(tid >> p.p_shift, M - 1), r = tid & Pm;
+    const int row = min(t0 + (r >> 3), t1 - 1) * 8 + (r & 7);
+    res0 = *reinterpret_cast<const uint16_t*>(p.bias + (int64_t)b * p.stride_bias + ((int64_t)a * p.bias_row_stride + row) * 2);
+  }
+  // the first D steps of the weight stream, behind everything the staging in front of the first barrier waits for (vector
+  // memory returns in order: requested first, the staging would wait for HBM instead of L2) -- on every wave of the workgroup
+  __builtin_amdgcn_s_barrier();
 #pragma unroll
   for (int j = 0; j < D; ++j) {
     __builtin_amdgcn_sched_barrier(0);
@@ -185,57 +225,62 @@ __global__ void __launch_bounds__(512, 2) w4_gemv_kernel(const GemvParams p) {
 #if GEMV_TRACE
   tr[1] = __builtin_amdgcn_s_memrealtime();
 #endif
-
   // ---- stage the activations (byte order of w4_gemm_pair.cuh) and their sums ----
   const uint32_t lds_x = (uint32_t)p.lds_x, lds_xs = (uint32_t)p.lds_xs, lds_red = (uint32_t)p.lds_red;
-  auto x_store = [&](int xi) {
-    const int a = xi / nch, ch = xi - a * nch;
-    const uint32_t dst = lds_x + (uint32_t)(a * p.x_pitch + ch * 64);
-    float sums[2] = {0.f, 0.f};
+  // one piece -> LDS (byte order); returns the sum of its 8 values
+  auto piece_store = [&](int a, int pc, uint32_t d0, uint32_t d1, uint32_t d2, uint32_t d3, bool on) -> float {
+    u32x4 o;
+    o[0] = __builtin_amdgcn_perm(d1, d0, 0x05040100u);  // x[2q]     x[2q+8]
+    o[1] = __builtin_amdgcn_perm(d3, d2, 0x05040100u);  // x[2q+16]  x[2q+24]
+    o[2] = __builtin_amdgcn_perm(d1, d0, 0x07060302u);  // x[2q+1]   x[2q+9]
+    o[3] = __builtin_amdgcn_perm(d3, d2, 0x07060302u);  // x[2q+17]  x[2q+25]
+    float sum = 0.f;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      u32x4 o;
-      o[0] = __builtin_amdgcn_perm(xd[q + 4], xd[q], 0x05040100u);       // x[2q]     x[2q+8]
-      o[1] = __builtin_amdgcn_perm(xd[q + 12], xd[q + 8], 0x05040100u);  // x[2q+16]  x[2q+24]
-      o[2] = __builtin_amdgcn_perm(xd[q + 4], xd[q], 0x07060302u);       // x[2q+1]   x[2q+9]
-      o[3] = __builtin_amdgcn_perm(xd[q + 12], xd[q + 8], 0x07060302u);  // x[2q+17]  x[2q+25]
-      *(lds_u32x4ptr)(dst + (uint32_t)(q * 16)) = o;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) sums[q >> 1] = dot2_ones<DT>(o[j], sums[q >> 1]);
-    }
-    // sums of the chunk's halves: [super-tile][half][chunk of the super-tile]
-#pragma unroll
-    for (int hh = 0; hh < 2; ++hh) *(lds_fptr)(lds_xs + (uint32_t)(a * p.xs_pitch + (((ch >> 1) * 2 + hh) * 2 + (ch & 1)) * 4)) = sums[hh];
+    for (int j = 0; j < 4; ++j) sum = dot2_ones<DT>(o[j], sum);
+    if (on) *(lds_u32x4ptr)(lds_x + (uint32_t)(a * p.x_pitch + pc * 16)) = o;
+    return sum;
   };
-  if constexpr (NORM) {
-    // LlamaRMSNorm on the way (dg_add_rmsnorm's formula): sum of squares per chunk -> per wave and row -> per row, in wave order
-    float ssq = chunk_sumsq<DT>(xd);
-    // (chunks of one row may straddle waves: every wave publishes one partial per activation row)
-    float part[M];
-    const int arow = tid < xtotal ? tid / nch : -1;
+  // sums of a chunk's halves: [super-tile][half][chunk of the super-tile]
+  auto xs_store = [&](int a, int ch, int hh, float sum) {
+    *(lds_fptr)(lds_xs + (uint32_t)(a * p.xs_pitch + (((ch >> 1) * 2 + hh) * 2 + (ch & 1)) * 4)) = sum;
+  };
 #pragma unroll
-    for (int a = 0; a < M; ++a) {
-      float v = arow == a ? ssq : 0.f;
+  for (int a = 0; a < M; ++a) {
+    const bool on = wide ? tid < nch : tid < npc;
+    if constexpr (NORM) {
+      // LlamaRMSNorm as  y = rs * sum_k w_k x'_k,  x'_k = RNE16(x_k g_k),  rs = rsqrt(mean(x^2) + eps)  applied to the f32 sum in the
+      // output store: the launch does not wait for a reduction over the activations before it can stage them.  Squares of this
+      // thread's share -> wave -> one partial per wave and row in LDS, added in wave order by the threads that store the outputs.
+      float v = 0.f;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        if constexpr (std::is_same<DT, BF16>::value)
+          v = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, xd[a][j]), __builtin_bit_cast(bf16x2, xd[a][j]), v, false);
+        else
+          v = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, xd[a][j]), __builtin_bit_cast(f16x2, xd[a][j]), v, false);
+      }
+      v = on ? v : 0.f;
 #pragma unroll
       for (int o = 1; o < 64; o <<= 1) v += __shfl_xor(v, o);
-      part[a] = v;
-    }
-    if (lane == 0) {
+      if (lane == 0) *(lds_fptr)((uint32_t)p.lds_nrm + (uint32_t)((wave * M + a) * 4)) = v;
 #pragma unroll
-      for (int a = 0; a < M; ++a) *(lds_fptr)(lds_red + (uint32_t)((wave * M + a) * 4)) = part[a];
+      for (int j = 0; j < 16; ++j) {
+        const uint32_t xv = xd[a][j], g = gwd[j];
+        xd[a][j] = DT::pack2(DT::lo_f32(xv) * DT::lo_f32(g), DT::hi_f32(xv) * DT::hi_f32(g));
+      }
     }
-    __syncthreads();
-    float tot = 0.f;
-    if (arow >= 0)
-      for (int w8 = 0; w8 < NW; ++w8) tot += *(lds_fptr)(lds_red + (uint32_t)((w8 * M + arow) * 4));
-    if (arow >= 0) chunk_rmsnorm<DT>(xd, rsqrtf(tot * (1.0f / (float)p.k) + p.norm_eps), gw);
-    if (tid < xtotal) x_store(tid);
-    __syncthreads();  // the partials are read before the split-K sums land in the same area
-  } else {
-    if (tid < xtotal) x_store(tid);
-    for (int xi = tid + NT; xi < xtotal; xi += NT) {
-      x_load(xi);
-      x_store(xi);
+    if (!wide) {
+      float sum = piece_store(a, tid, xd[a][0], xd[a][1], xd[a][2], xd[a][3], on);
+      sum += __shfl_xor(sum, 1);  // the two quads of a half sit in adjacent lanes
+      if (on && (tid & 1) == 0) xs_store(a, tid >> 2, (tid >> 1) & 1, sum);
+    } else {
+      float sq[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) sq[q] = piece_store(a, 4 * tid + q, xd[a][q], xd[a][q + 4], xd[a][q + 8], xd[a][q + 12], on);
+      if (on) {
+        xs_store(a, tid, 0, sq[0] + sq[1]);
+        xs_store(a, tid, 1, sq[2] + sq[3]);
+      }
     }
   }
   if (stage_lut && tid < wg_rows * 2) *(lds_u32x4ptr)((uint32_t)p.lds_lut + (uint32_t)tid * 16u) = lstage;
@@ -245,8 +290,7 @@ __global__ void __launch_bounds__(512, 2) w4_gemv_kernel(const GemvParams p) {
 
   // ---- pair table of a pass: entry[byte][column] = (lut[byte & 15], lut[byte >> 4]); thread = (column c, high nibble hi) ----
   auto build_table = [&](int half) {
-    const uint32_t hw = lp[0];
-    uint32_t hsel = hw;
+    uint32_t hsel = lp[0];
 #pragma unroll
     for (int j = 1; j < 8; ++j) hsel = (hi >> 1) == j ? lp[j] : hsel;
     const uint32_t hv = (hi & 1) ? (hsel & 0xffff0000u) : (hsel << 16);
@@ -271,9 +315,8 @@ __global__ void __launch_bounds__(512, 2) w4_gemv_kernel(const GemvParams p) {
   float yacc[M];
 #pragma unroll
   for (int a = 0; a < M; ++a) yacc[a] = 0.f;
-  int cp = 0, ci = 0;  // consume pointer: pass, step of the pass
 
-  auto pass_end = [&]() {
+  auto pass_end = [&](int cp) {
     // the sub-slots of a row sit in lanes row + P i: lane `row` gets the wave's sum
     float v[M];
 #pragma unroll
@@ -308,27 +351,39 @@ __global__ void __launch_bounds__(512, 2) w4_gemv_kernel(const GemvParams p) {
         float sum = 0.f;
 #pragma unroll
         for (int w8 = 0; w8 < NW; ++w8) sum += *(lds_fptr)(lds_red + (uint32_t)((((par * NW + w8) * M + a) * 32 + r) * 4));
+        float rsn = 1.f;
+        if constexpr (NORM) {
+          float tot = 0.f;
+#pragma unroll
+          for (int w8 = 0; w8 < NW; ++w8) tot += *(lds_fptr)((uint32_t)p.lds_nrm + (uint32_t)((w8 * M + a) * 4));
+          rsn = rsqrtf(tot * (1.0f / (float)p.k) + p.norm_eps);
+          sum *= rsn;
+        }
         if (p.epilogue == TG_EPI_SWIGLU) {
           // rows come in blocks of 8 gate + 8 up (a block = two tiles of one pass): lane r + 8 holds the up row of gate row r
           if ((r & 15) < 8) {
             float up = 0.f;
 #pragma unroll
             for (int w8 = 0; w8 < NW; ++w8) up += *(lds_fptr)(lds_red + (uint32_t)((((par * NW + w8) * M + a) * 32 + r + 8) * 4));
+            up *= rsn;
             *reinterpret_cast<uint16_t*>(p.y + (int64_t)b * p.stride_y + ((int64_t)a * (p.wrows >> 1) + ((row >> 4) << 3) + (row & 7)) * 2) = swiglu16<DT>(sum, up);
           }
         } else {
           uint16_t o16 = DT::from_f32(sum);
-          if (p.bias)  // rounded sum + bias, rounded again: the reference module's separate `y + bias` (modules.py:221-222)
-            o16 = DT::from_f32(DT::lo_f32(o16) + DT::lo_f32(*reinterpret_cast<const uint16_t*>(p.bias + (int64_t)b * p.stride_bias + ((int64_t)a * p.bias_row_stride + row) * 2)));
+          if (p.bias) {  // rounded sum + bias, rounded again: the reference module's separate `y + bias` (modules.py:221-222)
+            uint16_t bv = res0;  // (the first pass's were requested with the first loads)
+            if (cp > 0) bv = *reinterpret_cast<const uint16_t*>(p.bias + (int64_t)b * p.stride_bias + ((int64_t)a * p.bias_row_stride + row) * 2);
+            o16 = DT::from_f32(DT::lo_f32(o16) + DT::lo_f32(bv));
+          }
           *reinterpret_cast<uint16_t*>(p.y + (int64_t)b * p.stride_y + ((int64_t)a * p.wrows + row) * 2) = o16;
         }
       }
     }
   };
 
-  auto consume = [&](const Slot& sl, bool real) {
-    const int s_l = s_begin + ci * SS + ss;
-    const bool on = real && s_l < s_end;
+  auto consume = [&](const Slot& sl, int i) {  // step i of the current pass (wave-uniform, < spp)
+    const int s_l = s_begin + i * SS + ss;
+    const bool on = s_l < s_end;
     const int s = min(s_l, s_last);
     const uint32_t xa = lds_x + (uint32_t)(s * 128 + h * 32);
     const uint32_t xsa = lds_xs + (uint32_t)((s * 2 + h) * 8);
@@ -362,40 +417,39 @@ __global__ void __launch_bounds__(512, 2) w4_gemv_kernel(const GemvParams p) {
         yacc[a] = __builtin_fmaf(zz, xs, __builtin_fmaf(sc, dsum[a][g], yacc[a]));
       }
     }
-    if (real) {  // (wave-uniform)
-      if (++ci == spp) {
-        pass_end();
-        ci = 0;
-        ++cp;
-      }
-    }
   };
 
-  // rounds of D steps; the total is padded to a multiple of D with steps that re-read the last one and add nothing
-  const int total_p = (total + D - 1) / D * D;
-  int n0 = 0;
-  for (; n0 < total_p - D; n0 += D) {
+  // a pass = `rounds` rounds of D ring slots (slots >= spp are padding: requested, skipped); every round refills its slots with
+  // the slots D further -- except the launch's last round
+  for (int cp = 0; cp < passes; ++cp) {
+    const bool last = cp + 1 == passes;
+    const int nr = rounds - (last ? 1 : 0);
+    for (int r = 0; r < nr; ++r) {
 #pragma unroll
-    for (int j = 0; j < D; ++j) {
-      consume(ring[j], true);  // (n0 + j < total: only the last round holds padding)
-      issue(ring[j]);
+      for (int j = 0; j < D; ++j) {
+        if (r * D + j < spp) consume(ring[j], r * D + j);
+        issue(ring[j]);
 #if GEMV_TRACE
-      if (n0 == 0 && j == 0) tr[4] = __builtin_amdgcn_s_memrealtime();
+        if (cp == 0 && r == 0 && j == 0) tr[4] = __builtin_amdgcn_s_memrealtime();
 #endif
+      }
     }
-  }
+    if (last) {
 #pragma unroll
-  for (int j = 0; j < D; ++j) {
-    consume(ring[j], n0 + j < total);
+      for (int j = 0; j < D; ++j) {
+        if ((rounds - 1) * D + j < spp) consume(ring[j], (rounds - 1) * D + j);
 #if GEMV_TRACE
-    if (n0 == 0 && j == 0) tr[4] = __builtin_amdgcn_s_memrealtime();
+        if (cp == 0 && rounds == 1 && j == 0) tr[4] = __builtin_amdgcn_s_memrealtime();
 #endif
+      }
+    }
+    pass_end(cp);
   }
 #if GEMV_TRACE
   tr[5] = __builtin_amdgcn_s_memrealtime();
   if (tid == 0 && p.trace) {
 #pragma unroll
-    for (int i = 0; i < 6; ++i) p.trace[(size_t)blockIdx.x * 8 + i] = tr[i];
+    for (int i = 0; i < 7; ++i) p.trace[(size_t)blockIdx.x * 8 + i] = tr[i];
   }
 #endif
 }
