@@ -88,6 +88,8 @@ SYMBOLS = {
                        ctypes.c_int, ctypes.c_int, _vp],
     "dg_rope_attn": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, ctypes.c_int, ctypes.c_int, ctypes.c_int, _i64, ctypes.c_float,
                      ctypes.c_int, ctypes.c_int, _vp],
+    "dg_rope_attn_online": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, ctypes.c_int, ctypes.c_int, ctypes.c_int, _i64, ctypes.c_float,
+                     ctypes.c_int, ctypes.c_int, _vp],
     "dg_rope_attn_split_scratch_bytes": [_i64, ctypes.c_int, ctypes.c_int, ctypes.c_int],
     "dg_rope_attn_split": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, ctypes.c_int, ctypes.c_int, ctypes.c_int, _i64,
                            ctypes.c_float, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp],

@@ -435,6 +435,160 @@ __global__ void __launch_bounds__(256) rope_attn_split_kernel(const uint16_t* __
   if (t == 0) counters[bh] = 0;  // ready for the next launch / graph replay
 }
 
+template <typename DT>
+__device__ __forceinline__ float dot2_16(uint32_t a, uint32_t b, float acc) {
+  if constexpr (std::is_same<DT, BF16>::value)
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, a), __builtin_bit_cast(bf16x2, b), acc, false);
+  else
+    return __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, a), __builtin_bit_cast(f16x2, b), acc, false);
+}
+
+// ---- RoPE + KV-cache write + decode attention, one launch, ONE barrier: block = one query head of one sequence, 8 waves ----
+// What a batch-1 decode step needs from this node is latency, not bandwidth (at a few hundred cached positions the K and V
+// rows of a head are < 100 KiB): rope_attn_kernel above walks five dependent phases with four barriers (11 us per layer in
+// the Llama-3-8B step, profiles/); this one issues EVERY load of the launch -- q / k / v of the new token, the rotary table row,
+// and the K and V rows of up to 256 cached positions -- right behind the read of `pos`, and then computes without another
+// global round trip:
+//   row layout   a K / V row is d / 8 lanes x 16 bytes; a wave-load covers 64 / (d / 8) rows, the block 8 times that per
+//                iteration, NI iterations (256 positions) in flight per chunk.
+//   scores       v_dot2 of the packed rotated q with the packed K piece, summed over the row's lanes with DPP (quad_perm /
+//                row_half_mirror / row_mirror: no LDS traffic), rounded to 16 bits like the matmul of the torch formulation,
+//                times scale.
+//   softmax      per ROW GROUP (the d / 8 lanes that share rows): running max / sum / unnormalised value accumulator over the
+//                group's rows (flash-decoding style; probabilities are not rounded to 16 bits before the value contraction --
+//                as dg_rope_attn_split: the same result within 16-bit rounding); the 32 (64) groups meet ONCE in LDS.
+//   RoPE         rotate_half pairs (j, j + d/2) sit d/16 lanes apart in the row: one lane exchange per value; the same products
+//                and roundings as rope_kv_kernel (the cache rows written are bit-identical to it).
+template <typename DT, int LPR>
+__global__ void __launch_bounds__(512) rope_attn_online_kernel(const uint16_t* __restrict__ qkv, const float* __restrict__ cos,
+                                                               const float* __restrict__ sin, const int64_t* __restrict__ pos_p,
+                                                               uint16_t* __restrict__ k_cache, uint16_t* __restrict__ v_cache,
+                                                               uint16_t* __restrict__ out, int hl, int kvl, int64_t max_seq, float scale) {
+  constexpr int D = LPR * 8, RPW = 64 / LPR, NWV = 8, RPI = NWV * RPW, NI = 256 / RPI, NG = RPI;
+  extern __shared__ float sm[];  // [NG groups][D + 2]: unnormalised accumulator, max, sum
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int g = lane / LPR, i = lane % LPR, grp = wave * RPW + g;
+  const int b = blockIdx.x / hl, h = blockIdx.x % hl, rep = hl / kvl, kv = h / rep;
+  const int64_t pos = *pos_p;
+  if (pos < 0 || pos >= max_seq) return;  // the position lives on the device (graph replays bypass the host check)
+  const int S = (int)pos + 1;
+  const uint16_t* row = qkv + (int64_t)b * (hl + 2 * kvl) * D;
+  const u32x4* K = reinterpret_cast<const u32x4*>(k_cache + ((int64_t)b * kvl + kv) * max_seq * D);
+  const u32x4* V = reinterpret_cast<const u32x4*>(v_cache + ((int64_t)b * kvl + kv) * max_seq * D);
+  // ---- every load of the launch (positions past the end re-read position 0; the new token's row comes from qkv) ----
+  const u32x4 qraw = reinterpret_cast<const u32x4*>(row + h * D)[i];
+  const u32x4 kraw = reinterpret_cast<const u32x4*>(row + (hl + kv) * D)[i];
+  const u32x4 vraw = reinterpret_cast<const u32x4*>(row + (hl + kvl + kv) * D)[i];
+  const f32x4 c0 = reinterpret_cast<const f32x4*>(cos + pos * D)[2 * i], c1 = reinterpret_cast<const f32x4*>(cos + pos * D)[2 * i + 1];
+  const f32x4 s0 = reinterpret_cast<const f32x4*>(sin + pos * D)[2 * i], s1 = reinterpret_cast<const f32x4*>(sin + pos * D)[2 * i + 1];
+  u32x4 kk[NI], vv[NI];
+  auto request = [&](int base) {
+#pragma unroll
+    for (int it = 0; it < NI; ++it) {
+      const int r = base + it * RPI + grp;
+      const int rc = r < S - 1 ? r : 0;
+      kk[it] = K[(int64_t)rc * LPR + i];
+      vv[it] = V[(int64_t)rc * LPR + i];
+    }
+  };
+  request(0);
+  // ---- rotary embedding of q and k (this lane's 8 elements; the partner elements j +- d/2 are LPR/2 lanes away) ----
+  float cf[8], sf[8];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { cf[e] = c0[e]; cf[4 + e] = c1[e]; sf[e] = s0[e]; sf[4 + e] = s1[e]; }
+  const bool lower = i < LPR / 2;
+  auto rotate = [&](const u32x4& raw) -> u32x4 {
+    float x[8], o[8];
+    unpack8<DT>(raw, x);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float partner = __shfl_xor(x[e], LPR / 2, 64);
+      // rope_kv_kernel: o1 = x1 c1 + (-x2) s1 (lower half), o2 = x2 c2 + x1 s2 (upper half); every product and the sum rounded once
+      // (two rounded products and a rounded sum, never an fma: hipcc contracts __fmul_rn / __fadd_rn across a lambda, so the
+      //  products are made opaque)
+      float p1 = x[e] * cf[e], p2 = (lower ? -partner : partner) * sf[e];
+      asm volatile("" : "+v"(p1), "+v"(p2));
+      o[e] = p1 + p2;
+    }
+    return pack8<DT>(o);
+  };
+  const u32x4 qp = rotate(qraw), kn = rotate(kraw);
+  if (h % rep == 0 && grp == 0) {  // one row group of the KV group's first head writes the new token's cache rows
+    reinterpret_cast<u32x4*>(k_cache + (((int64_t)b * kvl + kv) * max_seq + pos) * D)[i] = kn;
+    reinterpret_cast<u32x4*>(v_cache + (((int64_t)b * kvl + kv) * max_seq + pos) * D)[i] = vraw;
+  }
+  auto dpp_add = [](float v, auto ctrl) -> float {
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), decltype(ctrl)::value, 0xf, 0xf, true));
+  };
+  // ---- this group's rows: running max m, sum l, unnormalised accumulator acc[8] (the lane's 8 elements of the value row) ----
+  float m = -INFINITY, l = 0.f, acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int base = 0; base < S; base += NI * RPI) {
+    if (base > 0) request(base);
+    float x[NI];
+    float cm = -INFINITY;
+#pragma unroll
+    for (int it = 0; it < NI; ++it) {
+      const int r = base + it * RPI + grp;
+      const u32x4 kr = r == S - 1 ? kn : kk[it];
+      // (literal indices: with a loop variable hipcc (ROCm 7.2) fed dword 0 of both vectors to all four v_dot2)
+      float d2 = dot2_16<DT>(kr[0], qp[0], 0.f);
+      d2 = dot2_16<DT>(kr[1], qp[1], d2);
+      d2 = dot2_16<DT>(kr[2], qp[2], d2);
+      d2 = dot2_16<DT>(kr[3], qp[3], d2);
+#ifdef DG_ATTN_SHFL
+#pragma unroll
+      for (int o = 1; o < LPR; o <<= 1) d2 += __shfl_xor(d2, o, 64);
+#else
+      d2 = dpp_add(d2, std::integral_constant<int, 0xB1>{});    // quad_perm [1,0,3,2]
+      d2 = dpp_add(d2, std::integral_constant<int, 0x4E>{});    // quad_perm [2,3,0,1]
+      d2 = dpp_add(d2, std::integral_constant<int, 0x141>{});   // row_half_mirror: the other quad of the 8 lanes
+      if constexpr (LPR == 16) d2 = dpp_add(d2, std::integral_constant<int, 0x140>{});  // row_mirror: the other half of the 16 lanes
+#endif
+      x[it] = r < S ? round16<DT>(d2) * scale : -INFINITY;
+#ifdef DG_ATTN_DUMP
+      if (blockIdx.x == 0 && i == 0 && r < S) reinterpret_cast<float*>(v_cache + (((int64_t)kvl - 1) * max_seq + (max_seq - 1)) * D)[r] = x[it];
+#endif
+      cm = fmaxf(cm, x[it]);
+    }
+    const float mn = fmaxf(m, cm);
+    if (mn > -INFINITY) {  // (uniform within the row group; a group without rows so far keeps its zeros)
+      const float alpha = __expf(m - mn);  // exp(-inf) = 0 for the first chunk with rows
+      l *= alpha;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] *= alpha;
+#pragma unroll
+      for (int it = 0; it < NI; ++it) {
+        const int r = base + it * RPI + grp;
+        const float pr = __expf(x[it] - mn);  // 0 for rows past the end
+        l += pr;
+        float vf[8];
+        // (rows past the end re-read position 0, which at S = 1 is the row this launch is writing: never let its bytes in)
+        unpack8<DT>(r == S - 1 ? vraw : r < S ? vv[it] : u32x4{0u, 0u, 0u, 0u}, vf);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = fmaf(pr, vf[e], acc[e]);
+      }
+      m = mn;
+    }
+  }
+  // ---- the groups meet: out[e] = sum_g exp(m_g - M) acc_g[e] / sum_g exp(m_g - M) l_g ----
+  float* mine = sm + grp * (D + 2);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) mine[i * 8 + e] = acc[e];
+  if (i == 0) { mine[D] = m; mine[D + 1] = l; }
+  __syncthreads();
+  if (t < D) {
+    float M = -INFINITY;
+    for (int gg = 0; gg < NG; ++gg) M = fmaxf(M, sm[gg * (D + 2) + D]);
+    float num = 0.f, den = 0.f;
+    for (int gg = 0; gg < NG; ++gg) {
+      const float w = __expf(sm[gg * (D + 2) + D] - M);
+      num = fmaf(w, sm[gg * (D + 2) + t], num);
+      den = fmaf(w, sm[gg * (D + 2) + D + 1], den);
+    }
+    out[((int64_t)b * hl + h) * D + t] = DT::from_f32(num / den);
+  }
+}
+
 // ---- SwiGLU ----------------------------------------------------------------------------------------
 template <typename DT>
 __global__ void __launch_bounds__(256) swiglu_kernel(const u32x4* __restrict__ gu, u32x4* __restrict__ out, int64_t il8, int64_t total8) {
@@ -514,6 +668,29 @@ int dg_rope_attn(const void* qkv, const float* cos, const float* sin, const int6
   auto kern = dtype == TG_BF16 ? rope_attn_kernel<BF16> : rope_attn_kernel<F16>;
   hipLaunchKernelGGL(kern, dim3((unsigned)(bs * hl)), dim3(256), lds, (hipStream_t)stream, (const uint16_t*)qkv, cos, sin, pos,
                      (uint16_t*)k_cache, (uint16_t*)v_cache, (uint16_t*)out, hl, kvl, d, max_seq, scale);
+  return launch_status();
+}
+
+int dg_rope_attn_online(const void* qkv, const float* cos, const float* sin, const int64_t* pos, void* k_cache, void* v_cache,
+                        void* out, int64_t bs, int hl, int kvl, int d, int64_t max_seq, float scale, int dtype, int device,
+                        tg_stream_t stream) {
+  if (!qkv || !cos || !sin || !pos || !k_cache || !v_cache || !out) return TG_E_NULL;
+  if (!(dtype == TG_BF16 || dtype == TG_F16)) return TG_E_DTYPE;
+  if (bs <= 0 || hl <= 0 || kvl <= 0 || hl % kvl != 0 || !(d == 64 || d == 128) || max_seq <= 0 || bs * hl > INT32_MAX) return TG_E_SHAPE;
+  if (!aligned16(qkv) || !aligned16(cos) || !aligned16(sin) || !aligned16(k_cache) || !aligned16(v_cache)) return TG_E_ALIGN;
+  DeviceScope ds(device);
+  if (!ds.ok) return TG_E_DEVICE;
+  const int ng = 8 * (64 / (d / 8));
+  const unsigned lds = (unsigned)(ng * (d + 2) * sizeof(float));
+#define DG_ONLINE(DTT, LPR_)                                                                                                        \
+  hipLaunchKernelGGL((rope_attn_online_kernel<DTT, LPR_>), dim3((unsigned)(bs * hl)), dim3(512), lds, (hipStream_t)stream,          \
+                     (const uint16_t*)qkv, cos, sin, pos, (uint16_t*)k_cache, (uint16_t*)v_cache, (uint16_t*)out, hl, kvl, max_seq, scale)
+  if (dtype == TG_BF16) {
+    if (d == 128) DG_ONLINE(BF16, 16); else DG_ONLINE(BF16, 8);
+  } else {
+    if (d == 128) DG_ONLINE(F16, 16); else DG_ONLINE(F16, 8);
+  }
+#undef DG_ONLINE
   return launch_status();
 }
 

@@ -228,8 +228,8 @@ class DecodeLayer(torch.nn.Module):
             ctx = G.rope_attn_split(self.qkv(y), cos_tab, sin_tab, pos, self.k_cache, self.v_cache, self.hl, self.kvl, d,
                                     1.0 / math.sqrt(d), attn_scratch, attn_split)
         else:
-            ctx = G.rope_attn(self.qkv(y), cos_tab, sin_tab, pos, self.k_cache, self.v_cache, self.hl, self.kvl, d,
-                              1.0 / math.sqrt(d))
+            attn = G.rope_attn_online if d in (64, 128) else G.rope_attn
+            ctx = attn(self.qkv(y), cos_tab, sin_tab, pos, self.k_cache, self.v_cache, self.hl, self.kvl, d, 1.0 / math.sqrt(d))
         h, y = G.add_rmsnorm(h, gather(self.o(gather(ctx))), self.norm2.weight, self.norm2.eps)
         return h, gather(self.down(gather(G.swiglu(self._split_gate_up(self.gate_up(y)).contiguous()))))
 
@@ -275,7 +275,8 @@ class DecodeLayer(torch.nn.Module):
             ctx = G.rope_attn_split(qkv, cos_tab, sin_tab, pos, self.k_cache, self.v_cache, self.hl, self.kvl, d,
                                     1.0 / math.sqrt(d), attn_scratch, attn_split)
         else:
-            ctx = G.rope_attn(qkv, cos_tab, sin_tab, pos, self.k_cache, self.v_cache, self.hl, self.kvl, d, 1.0 / math.sqrt(d))
+            attn = G.rope_attn_online if d in (64, 128) else G.rope_attn
+            ctx = attn(qkv, cos_tab, sin_tab, pos, self.k_cache, self.v_cache, self.hl, self.kvl, d, 1.0 / math.sqrt(d))
         if self._w4(self.o, ctx, residual=h, out=h) is None:       # (a residual add is available in every 4-bit kernel)
             G.add_rmsnorm(h, self.o(ctx), self.norm2.weight, self.norm2.eps, want_norm=False)
         # ---- MLP block: norm2 + SwiGLU inside the gate_up launch; else whichever of the two the library can fuse (a block too

@@ -81,6 +81,21 @@ def rope_attn(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, pos: torc
     return out
 
 
+def rope_attn_online(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, pos: torch.Tensor, k_cache: torch.Tensor,
+                     v_cache: torch.Tensor, hl: int, kvl: int, d: int, scale: float) -> torch.Tensor:
+    """rope_attn built for latency (head_dim 64 / 128): one barrier, every load issued up front, softmax statistics combined
+    flash-decoding style -- the same caches bit for bit, the output within 16-bit rounding of rope_attn's."""
+    _gpu(qkv, cos, sin, pos, k_cache, v_cache)
+    if cos.dtype != torch.float32 or pos.dtype != torch.int64:
+        raise RuntimeError("rope tables must be float32 and pos int64")
+    bs, max_seq = qkv.shape[0], k_cache.shape[2]
+    out = torch.empty((bs, hl * d), dtype=qkv.dtype, device=qkv.device)
+    _lib.check(_lib.load().dg_rope_attn_online(qkv.data_ptr(), cos.data_ptr(), sin.data_ptr(), pos.data_ptr(), k_cache.data_ptr(),
+                                               v_cache.data_ptr(), out.data_ptr(), bs, hl, kvl, d, max_seq, float(scale), _dt(qkv),
+                                               qkv.device.index, _stream(qkv)), "dg_rope_attn_online")
+    return out
+
+
 def rope_attn_split_scratch(bs: int, hl: int, d: int, nsplit: int, device) -> torch.Tensor:
     """Zeroed scratch buffer for rope_attn_split (counters + per-chunk partials); reusable by stream-ordered launches."""
     n = _lib.load().dg_rope_attn_split_scratch_bytes(bs, hl, d, nsplit)

@@ -55,6 +55,14 @@ TG_API int dg_rope_attn(const void* qkv, const float* cos, const float* sin, con
                         void* v_cache, void* out, int64_t bs, int hl, int kvl, int d, int64_t max_seq, float scale,
                         int dtype, int device, tg_stream_t stream);
 
+/* dg_rope_attn for latency (what the decode harness launches at d = 64 / 128): every load of the launch is issued behind the read
+ * of `pos`, scores are reduced with DPP, the softmax statistics are kept per row group and combined once (flash-decoding style,
+ * ONE barrier), so probabilities are normalised after the value contraction: the cache rows written are bit-identical to
+ * dg_rope_kv's, the output agrees with dg_rope_attn within 16-bit rounding.  qkv and the rotary tables 16-byte aligned. */
+TG_API int dg_rope_attn_online(const void* qkv, const float* cos, const float* sin, const int64_t* pos, void* k_cache,
+                               void* v_cache, void* out, int64_t bs, int hl, int kvl, int d, int64_t max_seq, float scale,
+                               int dtype, int device, tg_stream_t stream);
+
 /* dg_rope_attn with the sequence split over `nsplit` blocks per head (flash-decoding style combine by the last block to
  * arrive): fills the GPU at batch 1 and long contexts.  `scratch`: dg_rope_attn_split_scratch_bytes(...) bytes, 16-byte
  * aligned, ZEROED ONCE by the caller before the first launch (the kernel leaves its counters at zero again); launches

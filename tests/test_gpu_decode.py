@@ -122,6 +122,11 @@ def test_glue_kernels_vs_torch(dtype):
         kc3, vc3 = kc.clone(), vc.clone()
         fused = G.rope_attn(qkv, cos, sin, pos, kc3, vc3, hl, kvl, d, scale)
         assert torch.equal(fused, got) and torch.equal(kc3, kc2) and torch.equal(vc3, vc2), p
+        # the latency-built launch (one barrier, flash-decoding style statistics): same caches bit for bit, output within 16-bit rounding
+        kc5, vc5 = kc.clone(), vc.clone()
+        on = G.rope_attn_online(qkv, cos, sin, pos, kc5, vc5, hl, kvl, d, scale)
+        assert torch.equal(kc5, kc2) and torch.equal(vc5, vc2), p
+        assert (on.float() - want.float()).abs().max() <= 4 * ulp * want.float().abs().max(), p
         # split-sequence variant: same caches, output within 16-bit rounding; replayable (counters self-reset)
         for ns in (2, 3, 8):
             scr = G.rope_attn_split_scratch(bs, hl, d, ns, DEV)
@@ -137,6 +142,39 @@ def test_glue_kernels_vs_torch(dtype):
     assert close(G.swiglu(gu), want)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         G.swiglu(gu.cpu())
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_rope_attn_online_llama_heads(dtype):
+    """dg_rope_attn_online at Llama-3-8B's head geometry (32 / 8 heads of 128) against dg_rope_attn: positions inside the first
+    chunk of 256, on its edge, and several chunks in; an UNINITIALISED (NaN-filled) cache beyond the written positions."""
+    from any4_amd import decode_ops as G
+    from any4_amd.decode import DecodeConfig, _rope, _rope_tables
+
+    gen = torch.Generator(device=DEV).manual_seed(1)
+    ulp = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    bs, hl, kvl, d, S = 2, 32, 8, 128, 1024
+    cfg = DecodeConfig(max_seq=S)
+    cos, sin = _rope_tables(cfg, DEV)
+    scale = 1.0 / math.sqrt(d)
+    for p in (0, 1, 135, 255, 256, 257, 700, 1023):
+        kc = torch.full((bs, kvl, S, d), float("nan"), device=DEV, dtype=dtype)
+        vc = torch.full((bs, kvl, S, d), float("nan"), device=DEV, dtype=dtype)
+        kc[:, :, :p] = torch.randn(bs, kvl, p, d, device=DEV, generator=gen).to(dtype)
+        vc[:, :, :p] = torch.randn(bs, kvl, p, d, device=DEV, generator=gen).to(dtype)
+        pos = torch.tensor([p], device=DEV)
+        qkv = torch.randn(bs, (hl + 2 * kvl) * d, device=DEV, generator=gen).to(dtype)
+        k1, v1, k2, v2 = kc.clone(), vc.clone(), kc.clone(), vc.clone()
+        want = G.rope_attn(qkv, cos, sin, pos, k1, v1, hl, kvl, d, scale)
+        got = G.rope_attn_online(qkv, cos, sin, pos, k2, v2, hl, kvl, d, scale)
+        # the rows written: the torch formulation's bits (two rounded products, a rounded sum, one rounding to 16 bits)
+        c, s_ = cos[p].view(1, 1, -1), sin[p].view(1, 1, -1)
+        want_k = _rope(qkv[:, hl * d: (hl + kvl) * d].reshape(bs, kvl, d), c, s_)
+        want_v = qkv[:, (hl + kvl) * d:].reshape(bs, kvl, d)
+        assert torch.equal(k2[:, :, p], want_k) and torch.equal(v2[:, :, p], want_v), p
+        assert torch.equal(k2[:, :, :p], kc[:, :, :p]) and torch.equal(v2[:, :, :p], vc[:, :, :p]), p
+        assert torch.isnan(k2[:, :, p + 1:].float()).all() and torch.isfinite(got.float()).all(), p
+        assert (got.float() - want.float()).abs().max() <= 4 * ulp * want.float().abs().max(), (p, (got.float() - want.float()).abs().max())
 
 
 @pytest.mark.parametrize("max_seq", [32, 4096])  # 4096: the split-sequence attention (8 blocks per head + combine)
