@@ -463,35 +463,55 @@ template <typename DT, int LPR>
 __global__ void __launch_bounds__(512) rope_attn_online_kernel(const uint16_t* __restrict__ qkv, const float* __restrict__ cos,
                                                                const float* __restrict__ sin, const int64_t* __restrict__ pos_p,
                                                                uint16_t* __restrict__ k_cache, uint16_t* __restrict__ v_cache,
-                                                               uint16_t* __restrict__ out, int hl, int kvl, int64_t max_seq, float scale) {
+                                                               uint16_t* __restrict__ out, int hl, int kvl, int64_t max_seq, float scale,
+                                                               unsigned long long* trace) {
   constexpr int D = LPR * 8, RPW = 64 / LPR, NWV = 8, RPI = NWV * RPW, NI = 256 / RPI, NG = RPI;
-  extern __shared__ float sm[];  // [NG groups][D + 2]: unnormalised accumulator, max, sum
+#if GEMV_TRACE
+  unsigned long long tr[8];
+#define DG_STAMP(n) tr[n] = __builtin_amdgcn_s_memrealtime()
+#else
+#define DG_STAMP(n)
+#endif
+  DG_STAMP(0);
+  extern __shared__ float sm[];  // [8 waves][D + 2]: unnormalised accumulator, max, sum
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int g = lane / LPR, i = lane % LPR, grp = wave * RPW + g;
   const int b = blockIdx.x / hl, h = blockIdx.x % hl, rep = hl / kvl, kv = h / rep;
-  const int64_t pos = *pos_p;
-  if (pos < 0 || pos >= max_seq) return;  // the position lives on the device (graph replays bypass the host check)
-  const int S = (int)pos + 1;
   const uint16_t* row = qkv + (int64_t)b * (hl + 2 * kvl) * D;
   const u32x4* K = reinterpret_cast<const u32x4*>(k_cache + ((int64_t)b * kvl + kv) * max_seq * D);
   const u32x4* V = reinterpret_cast<const u32x4*>(v_cache + ((int64_t)b * kvl + kv) * max_seq * D);
+  // the first NSPEC iterations' rows are requested BEFORE the position is known (rows past it are valid memory and masked later):
+  // the read of `pos` is a dependent round trip the K / V requests of a short context need not wait for
+  constexpr int NSPEC = NI < 2 ? NI : 2;
+  u32x4 kk[NI], vv[NI];
+#pragma unroll
+  for (int it = 0; it < NSPEC; ++it) {
+    const int64_t rc = min((int64_t)(it * RPI + grp), max_seq - 1);
+    kk[it] = K[rc * LPR + i];
+    vv[it] = V[rc * LPR + i];
+  }
+  const int64_t pos = *pos_p;
+  if (pos < 0 || pos >= max_seq) return;  // the position lives on the device (graph replays bypass the host check)
+  const int S = (int)pos + 1;
+  DG_STAMP(1);
   // ---- every load of the launch (positions past the end re-read position 0; the new token's row comes from qkv) ----
   const u32x4 qraw = reinterpret_cast<const u32x4*>(row + h * D)[i];
   const u32x4 kraw = reinterpret_cast<const u32x4*>(row + (hl + kv) * D)[i];
   const u32x4 vraw = reinterpret_cast<const u32x4*>(row + (hl + kvl + kv) * D)[i];
   const f32x4 c0 = reinterpret_cast<const f32x4*>(cos + pos * D)[2 * i], c1 = reinterpret_cast<const f32x4*>(cos + pos * D)[2 * i + 1];
   const f32x4 s0 = reinterpret_cast<const f32x4*>(sin + pos * D)[2 * i], s1 = reinterpret_cast<const f32x4*>(sin + pos * D)[2 * i + 1];
-  u32x4 kk[NI], vv[NI];
-  auto request = [&](int base) {
+  auto request = [&](int base, int first) {
 #pragma unroll
     for (int it = 0; it < NI; ++it) {
+      if (it < first || base + it * RPI >= S) continue;  // (wave-uniform) iterations past the last position request nothing
       const int r = base + it * RPI + grp;
       const int rc = r < S - 1 ? r : 0;
       kk[it] = K[(int64_t)rc * LPR + i];
       vv[it] = V[(int64_t)rc * LPR + i];
     }
   };
-  request(0);
+  request(0, NSPEC);
+  DG_STAMP(2);
   // ---- rotary embedding of q and k (this lane's 8 elements; the partner elements j +- d/2 are LPR/2 lanes away) ----
   float cf[8], sf[8];
 #pragma unroll
@@ -513,6 +533,7 @@ __global__ void __launch_bounds__(512) rope_attn_online_kernel(const uint16_t* _
     return pack8<DT>(o);
   };
   const u32x4 qp = rotate(qraw), kn = rotate(kraw);
+  DG_STAMP(3);
   if (h % rep == 0 && grp == 0) {  // one row group of the KV group's first head writes the new token's cache rows
     reinterpret_cast<u32x4*>(k_cache + (((int64_t)b * kvl + kv) * max_seq + pos) * D)[i] = kn;
     reinterpret_cast<u32x4*>(v_cache + (((int64_t)b * kvl + kv) * max_seq + pos) * D)[i] = vraw;
@@ -523,7 +544,7 @@ __global__ void __launch_bounds__(512) rope_attn_online_kernel(const uint16_t* _
   // ---- this group's rows: running max m, sum l, unnormalised accumulator acc[8] (the lane's 8 elements of the value row) ----
   float m = -INFINITY, l = 0.f, acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   for (int base = 0; base < S; base += NI * RPI) {
-    if (base > 0) request(base);
+    if (base > 0) request(base, 0);
     float x[NI];
     float cm = -INFINITY;
 #pragma unroll
@@ -551,6 +572,7 @@ __global__ void __launch_bounds__(512) rope_attn_online_kernel(const uint16_t* _
       cm = fmaxf(cm, x[it]);
     }
     const float mn = fmaxf(m, cm);
+    if (base == 0) { DG_STAMP(4); }
     if (mn > -INFINITY) {  // (uniform within the row group; a group without rows so far keeps its zeros)
       const float alpha = __expf(m - mn);  // exp(-inf) = 0 for the first chunk with rows
       l *= alpha;
@@ -570,25 +592,54 @@ __global__ void __launch_bounds__(512) rope_attn_online_kernel(const uint16_t* _
       m = mn;
     }
   }
-  // ---- the groups meet: out[e] = sum_g exp(m_g - M) acc_g[e] / sum_g exp(m_g - M) l_g ----
-  float* mine = sm + grp * (D + 2);
+  DG_STAMP(5);
+  // ---- the groups meet: out[e] = sum_g exp(m_g - M) acc_g[e] / sum_g exp(m_g - M) l_g.  First the RPW groups of a wave through
+  // lane exchanges (no barrier), then the 8 waves once through LDS ----
 #pragma unroll
-  for (int e = 0; e < 8; ++e) mine[i * 8 + e] = acc[e];
-  if (i == 0) { mine[D] = m; mine[D + 1] = l; }
+  for (int o = LPR; o < 64; o <<= 1) {
+    const float mo = __shfl_xor(m, o, 64), lo = __shfl_xor(l, o, 64);
+    const float mn = fmaxf(m, mo);
+    // (both sides empty: keep the zeros, never exp(-inf - -inf))
+    const float wa = mn > -INFINITY ? __expf(m - mn) : 0.f, wb = mn > -INFINITY ? __expf(mo - mn) : 0.f;
+    l = l * wa + lo * wb;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = acc[e] * wa + __shfl_xor(acc[e], o, 64) * wb;
+    m = mn;
+  }
+  float* mine = sm + wave * (D + 2);
+  if (g == 0) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) mine[i * 8 + e] = acc[e];
+    if (i == 0) { mine[D] = m; mine[D + 1] = l; }
+  }
   __syncthreads();
+  DG_STAMP(6);
   if (t < D) {
     float M = -INFINITY;
-    for (int gg = 0; gg < NG; ++gg) M = fmaxf(M, sm[gg * (D + 2) + D]);
+#pragma unroll
+    for (int w = 0; w < NWV; ++w) M = fmaxf(M, sm[w * (D + 2) + D]);
     float num = 0.f, den = 0.f;
-    for (int gg = 0; gg < NG; ++gg) {
-      const float w = __expf(sm[gg * (D + 2) + D] - M);
-      num = fmaf(w, sm[gg * (D + 2) + t], num);
-      den = fmaf(w, sm[gg * (D + 2) + D + 1], den);
+#pragma unroll
+    for (int w = 0; w < NWV; ++w) {
+      const float wt = __expf(sm[w * (D + 2) + D] - M);
+      num = fmaf(wt, sm[w * (D + 2) + t], num);
+      den = fmaf(wt, sm[w * (D + 2) + D + 1], den);
     }
     out[((int64_t)b * hl + h) * D + t] = DT::from_f32(num / den);
   }
+#if GEMV_TRACE
+  DG_STAMP(7);
+  if (t == 0 && trace) {
+#pragma unroll
+    for (int n = 0; n < 8; ++n) trace[(size_t)blockIdx.x * 8 + n] = tr[n];
+  }
+#endif
+#undef DG_STAMP
 }
 
+#if GEMV_TRACE
+unsigned long long* g_attn_trace = nullptr;
+#endif
 // ---- SwiGLU ----------------------------------------------------------------------------------------
 template <typename DT>
 __global__ void __launch_bounds__(256) swiglu_kernel(const u32x4* __restrict__ gu, u32x4* __restrict__ out, int64_t il8, int64_t total8) {
@@ -671,6 +722,10 @@ int dg_rope_attn(const void* qkv, const float* cos, const float* sin, const int6
   return launch_status();
 }
 
+#if GEMV_TRACE
+TG_API void tg_dev_attn_trace(unsigned long long* buf) { g_attn_trace = buf; }  // developer builds: [blocks][8] stamps of the last launch
+#endif
+
 int dg_rope_attn_online(const void* qkv, const float* cos, const float* sin, const int64_t* pos, void* k_cache, void* v_cache,
                         void* out, int64_t bs, int hl, int kvl, int d, int64_t max_seq, float scale, int dtype, int device,
                         tg_stream_t stream) {
@@ -680,11 +735,14 @@ int dg_rope_attn_online(const void* qkv, const float* cos, const float* sin, con
   if (!aligned16(qkv) || !aligned16(cos) || !aligned16(sin) || !aligned16(k_cache) || !aligned16(v_cache)) return TG_E_ALIGN;
   DeviceScope ds(device);
   if (!ds.ok) return TG_E_DEVICE;
-  const int ng = 8 * (64 / (d / 8));
-  const unsigned lds = (unsigned)(ng * (d + 2) * sizeof(float));
+  const unsigned lds = (unsigned)(8 * (d + 2) * sizeof(float));
 #define DG_ONLINE(DTT, LPR_)                                                                                                        \
   hipLaunchKernelGGL((rope_attn_online_kernel<DTT, LPR_>), dim3((unsigned)(bs * hl)), dim3(512), lds, (hipStream_t)stream,          \
-                     (const uint16_t*)qkv, cos, sin, pos, (uint16_t*)k_cache, (uint16_t*)v_cache, (uint16_t*)out, hl, kvl, max_seq, scale)
+                     (const uint16_t*)qkv, cos, sin, pos, (uint16_t*)k_cache, (uint16_t*)v_cache, (uint16_t*)out, hl, kvl, max_seq, scale, trace)
+  unsigned long long* trace = nullptr;
+#if GEMV_TRACE
+  trace = g_attn_trace;
+#endif
   if (dtype == TG_BF16) {
     if (d == 128) DG_ONLINE(BF16, 16); else DG_ONLINE(BF16, 8);
   } else {

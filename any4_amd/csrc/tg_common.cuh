@@ -12,6 +12,9 @@
 // Kernels and their helpers stay in each unit's anonymous namespace (one device code object per unit, no symbol shared between
 // them); only GemmParams and the tgx:: functions cross unit boundaries.
 #pragma once
+#ifndef GEMV_TRACE
+#define GEMV_TRACE 0  // developer builds (-DGEMV_TRACE=1): s_memrealtime stamps of kernel phases (dev/gemv_trace.py)
+#endif
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>

@@ -96,12 +96,23 @@ def main():
     L.tg_dev_gemv_trace.argtypes = [ctypes.c_void_p, ctypes.c_int]
     L.tg_dev_gemv_trace.restype = None
     L.tg_dev_gemv_trace(buf.data_ptr(), slots)
+    abuf = torch.zeros(64 * 8, dtype=torch.int64, device=dev)
+    L.tg_dev_attn_trace.argtypes = [ctypes.c_void_p]
+    L.tg_dev_attn_trace.restype = None
+    L.tg_dev_attn_trace(abuf.data_ptr())
     stack.capture(warmup=0)
     for i in range(5):
         stack.decode(tok, 140 + i)
     torch.cuda.synchronize()
     t = buf.cpu().numpy().reshape(slots, 256, 8).astype(np.float64) * 0.01  # us
     show(t, 4 * a.layers, ["qkv(+norm)", "o(+res)", "gate_up(+norm,swiglu)", "down(+res)"])
+    at = abuf.cpu().numpy().reshape(64, 8).astype(np.float64)[:32] * 0.01
+    base = at[:, 0].min()
+    qkv_end = t[4 * (a.layers - 1)][:, 5].max()
+    print(f"attention (last layer): first entry {base - qkv_end:+.2f} us after the qkv gemv's last end")
+    for j, nm in enumerate(["entry", "pos known", "loads issued", "rotated", "scores", "values", "barrier", "end"]):
+        v = at[:, j] - base
+        print(f"       {nm:14s} min {v.min():6.2f}  median {np.median(v):6.2f}  max {v.max():6.2f}")
 
 
 if __name__ == "__main__":
