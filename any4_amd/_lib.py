@@ -11,11 +11,12 @@ LIB_PATH = os.path.join(_HERE, "lib", "libtinygemm_hip.so")
 TG_BF16, TG_F16 = 0, 1
 TG_Q_INT4, TG_Q_ANY4_GLOBAL, TG_Q_ANY4_ROWWISE, TG_Q_MX4, TG_Q_INT8 = 0, 1, 2, 3, 4
 TG_NUM_FAST, TG_NUM_REFERENCE = 0, 1
-TG_ABI_VERSION = 5
+TG_ABI_VERSION = 6
 TG_PLAN_SPLITK, TG_PLAN_STREAM, TG_PLAN_PAIR, TG_PLAN_PAIR_XR, TG_PLAN_GEMV = 1, 2, 3, 4, 5
 TG_LAYOUT_RM, TG_LAYOUT_TC_A = 0, 1
 TG_E_LAYOUT = -12
 TG_E_FUSION = -13
+TG_E_STRUCT = -14
 TG_EPI_NONE, TG_EPI_SWIGLU = 0, 1
 
 _i32, _i64, _vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p
@@ -25,6 +26,7 @@ class W4Gemm(ctypes.Structure):
     """struct tg_w4_gemm (include/tinygemm_hip.h)"""
 
     _fields_ = [
+        ("struct_bytes", ctypes.c_uint32), ("struct_reserved", ctypes.c_uint32),
         ("x", _vp), ("w", _vp), ("qinfo", _vp), ("lut", _vp), ("y", _vp),
         ("m", _i64), ("wrows", _i64), ("k", _i64),
         ("group", _i32), ("qtype", _i32), ("dtype", _i32), ("w_on_right", _i32), ("inner_k_tiles", _i32),
@@ -35,6 +37,11 @@ class W4Gemm(ctypes.Structure):
         ("x_layout", _i32), ("y_layout", _i32),
         ("bias_row_stride", _i64), ("norm_weight", _vp), ("norm_eps", ctypes.c_float), ("epilogue", _i32),
     ]
+
+    def __init__(self, *args, **kw):
+        super().__init__(*args, **kw)
+        if "struct_bytes" not in kw:  # ABI 6: the struct says how long it is
+            self.struct_bytes = ctypes.sizeof(W4Gemm)
 
 
 TG_PEER_MAX_WORLD = 16

@@ -26,6 +26,7 @@
 //     two 16-bit floats is exact, so this equals the reference's single-rounding bf16 fma;
 //   * fp32 partial tiles meet in LDS, a fixed-order sum gives a deterministic result.
 
+#include <stddef.h>
 #include "tg_common.cuh"
 
 namespace {
@@ -459,6 +460,7 @@ const char* tg_error_string(int code) {
     case TG_E_DEVICE: return "could not select the requested device";
     case TG_E_SIZE: return "an operand is too large for the kernels' 32-bit byte offsets (activations, packed weights or quantisation info of one problem must stay below 2 GiB; at most 65535 16-row activation tiles)";
     case TG_E_INTERNAL: return "internal error: a kernel that addresses LDS from offset 0 was built with static LDS";
+    case TG_E_STRUCT: return "tg_w4_gemm.struct_bytes must be sizeof(struct tg_w4_gemm) of the header the caller was built with (at least the ABI-1 prefix, at most this library's struct)";
     case TG_E_FUSION: return "no kernel with the requested fused stage (norm_weight / epilogue) for this problem: run that stage as its own launch (include/decode_glue_hip.h)";
     case TG_E_LAYOUT: return "fragment-order activations / outputs (x_layout, y_layout) are not available for this problem: convert with tg_convert_{from,to}_A16 around a row-major call";
     default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown tinygemm error";
@@ -560,9 +562,25 @@ int tg_dequant_int4(const int32_t* in, int64_t count, void* out_bf16, int device
   return launch_status();
 }
 
+// The caller's struct, as long as IT says it is (tg_w4_gemm.struct_bytes), into a zero-filled struct of this library's length:
+// fields the caller's header did not have read as zero = off.  Never reads past struct_bytes.
+static int take_args(const tg_w4_gemm* a, tg_w4_gemm* full) {
+  if (!a) return TG_E_NULL;
+  const size_t prefix = offsetof(tg_w4_gemm, stride_y) + sizeof(a->stride_y);  // ABI 1
+  const size_t n = a->struct_bytes;
+  if (n < prefix || n > sizeof(tg_w4_gemm) || a->struct_reserved != 0) return TG_E_STRUCT;
+  memset(full, 0, sizeof(*full));
+  memcpy(full, a, n);
+  return 0;
+}
+
 // dry: 0 launch, 1 report the kernel family (tg_gemm_w4_plan), 2 report the workspace the fastest kernel wants
-static int gemm_w4_impl(const tg_w4_gemm* a, int device, tg_stream_t stream, int dry, int64_t* ws_need = nullptr) {
-  if (!a || !a->x || !a->w || !a->qinfo || !a->y) return TG_E_NULL;
+static int gemm_w4_impl(const tg_w4_gemm* caller, int device, tg_stream_t stream, int dry, int64_t* ws_need = nullptr) {
+  tg_w4_gemm full;
+  const int src = take_args(caller, &full);
+  if (src != 0) return src;
+  const tg_w4_gemm* a = &full;
+  if (!a->x || !a->w || !a->qinfo || !a->y) return TG_E_NULL;
   if (a->qtype < TG_Q_INT4 || a->qtype > TG_Q_MX4) return TG_E_QTYPE;
   if ((a->qtype == TG_Q_ANY4_GLOBAL || a->qtype == TG_Q_ANY4_ROWWISE) && !a->lut) return TG_E_NULL;
   if (!(a->dtype == TG_BF16 || a->dtype == TG_F16)) return TG_E_DTYPE;
@@ -695,8 +713,12 @@ int tg_convert_to_Aint8(const int32_t* in, int64_t m, int64_t k, int I, int32_t*
   return launch_status();
 }
 
-int tg_gemm_w8(const tg_w4_gemm* a, int device, tg_stream_t stream) {
-  if (!a || !a->x || !a->w || !a->qinfo || !a->y) return TG_E_NULL;
+int tg_gemm_w8(const tg_w4_gemm* caller, int device, tg_stream_t stream) {
+  tg_w4_gemm full;
+  const int src = take_args(caller, &full);
+  if (src != 0) return src;
+  const tg_w4_gemm* a = &full;
+  if (!a->x || !a->w || !a->qinfo || !a->y) return TG_E_NULL;
   if (a->qtype != TG_Q_INT8) return TG_E_QTYPE;
   if (!(a->dtype == TG_BF16 || a->dtype == TG_F16)) return TG_E_DTYPE;
   if (a->m <= 0 || a->wrows <= 0 || a->k <= 0 || a->m > INT32_MAX || a->wrows > INT32_MAX || a->k > INT32_MAX) return TG_E_SHAPE;

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define TG_ABI_VERSION 5
+#define TG_ABI_VERSION 6
 
 #if defined(__GNUC__)
 #define TG_API __attribute__((visibility("default")))
@@ -83,7 +83,8 @@ enum {
   TG_E_SIZE = -10,     /* one problem's operand exceeds the kernels' 32-bit byte offsets   */
   TG_E_INTERNAL = -11, /* build inconsistency (should not happen)                          */
   TG_E_LAYOUT = -12,   /* x_layout / y_layout not available for this problem               */
-  TG_E_FUSION = -13    /* norm_weight / epilogue: no kernel with that fused stage for this problem (issue it as its own launch) */
+  TG_E_FUSION = -13,   /* norm_weight / epilogue: no kernel with that fused stage for this problem (issue it as its own launch) */
+  TG_E_STRUCT = -14    /* tg_w4_gemm.struct_bytes: smaller than the ABI-1 prefix of the struct, or larger than this library's struct */
 };
 
 TG_API int tg_abi_version(void);
@@ -132,6 +133,12 @@ TG_API int tg_dequant_int4(const int32_t* in, int64_t count, void* out_bf16, int
  * which packed layout `w` is in.
  */
 typedef struct tg_w4_gemm {
+  /* ---- ABI version 6: the struct says how long it is.  sizeof(struct tg_w4_gemm) as the CALLER was compiled: the library reads
+   *      exactly that many bytes and takes every later field as zero (= the feature is off), so a binding written against an
+   *      older header keeps working when fields are appended; a value below the ABI-1 prefix (everything up to stride_y) or above
+   *      the library's own struct is rejected with TG_E_STRUCT, never read past.  C: `struct tg_w4_gemm a = {sizeof a};` ---- */
+  uint32_t struct_bytes;
+  uint32_t struct_reserved; /* must be 0 */
   const void* x;     /* activations, RM 16-bit [m][k]                                          */
   const void* w;     /* packed weights: Bint4 if w_on_right else Aint4                         */
   const void* qinfo; /* int4/any4: 16-bit scales_and_zeros [k/group][wrows][2] (scale, zero)   */

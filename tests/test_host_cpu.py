@@ -30,7 +30,7 @@ def test_c_abi_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in include/*.h but not exported"
     assert set(syms) == set(_lib.SYMBOLS), "ctypes binding and header disagree"
-    assert _lib.load().tg_abi_version() == _lib.TG_ABI_VERSION == 5
+    assert _lib.load().tg_abi_version() == _lib.TG_ABI_VERSION == 6
 
 
 def test_peer_gather_preconditions_fail_before_any_launch():
@@ -298,3 +298,52 @@ def test_xr_kernel_routing():
     assert plan(8, 4096, 4096, 128, "any4_rowwise", batch=4) != "pair_xr"  # 256 items: fewer than two per CU
     assert plan(8, 4096, 4096, 128, "any4_rowwise", right=False) != "pair_xr"  # Aint4 weights
     assert plan(17, 4096, 4096, 128, "any4_rowwise") != "pair_xr"
+
+
+def test_integration_md_binding_and_struct_bytes():
+    """The reference-side binding shown in INTEGRATION.md is executed as written (its ctypes struct, against the built library): the
+    struct matches the header's length, a call described by it plans a kernel; a binding written against an OLDER header (struct
+    truncated after y_layout = ABI 3) is accepted with the later fields off; a length below the ABI-1 prefix, above the library's
+    struct, or no length at all is refused with TG_E_STRUCT -- the library never reads past what the caller says it allocated."""
+    import ctypes
+    import re
+
+    from any4_amd import _lib
+
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    m = re.search(r"^class tg_w4_gemm\(ctypes.Structure\):.*?\n\n", text, re.S | re.M)
+    assert m, "INTEGRATION.md lost its tg_w4_gemm binding"
+    ns = {"ctypes": ctypes}
+    exec(m.group(0), ns)  # the snippet, not a copy of it
+    S = ns["tg_w4_gemm"]
+    assert ctypes.sizeof(S) == ctypes.sizeof(_lib.W4Gemm)
+    assert [f[0] for f in S._fields_] == [f[0] for f in _lib.W4Gemm._fields_]
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    L.tg_gemm_w4_plan.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    p = 0x1000  # plan only checks NULL / alignment of the data pointers
+
+    def fill(a):
+        a.x = a.w = a.qinfo = a.lut = a.y = p
+        a.m, a.wrows, a.k, a.group, a.qtype, a.dtype, a.w_on_right, a.inner_k_tiles, a.batch = 1, 4096, 4096, 128, 2, 0, 1, 4, 1
+        return a
+
+    full = fill(S(struct_bytes=ctypes.sizeof(S)))
+    assert L.tg_gemm_w4_plan(ctypes.byref(full), -1) == _lib.TG_PLAN_GEMV
+    # an ABI-3 binding: the same fields up to y_layout, nothing behind them in memory but poison
+    upto = [f[0] for f in S._fields_].index("y_layout") + 1
+    Old = type("tg_w4_gemm_v3", (ctypes.Structure,), {"_fields_": S._fields_[:upto]})
+    n_old = ctypes.sizeof(Old)
+    assert n_old < ctypes.sizeof(S)
+    buf = (ctypes.c_ubyte * (n_old + 64))(*([0xff] * (n_old + 64)))
+    old = fill(Old.from_buffer(buf))
+    old.struct_reserved = old.numerics = old.reserved = old.bias = old.stride_bias = old.workspace = old.workspace_bytes = 0
+    old.x_layout = old.y_layout = 0
+    old.stride_x = old.stride_w = old.stride_qinfo = old.stride_lut = old.stride_y = 0
+    old.struct_bytes = n_old
+    assert L.tg_gemm_w4_plan(ctypes.byref(buf), -1) == _lib.TG_PLAN_GEMV  # 0xff behind the struct: never read (would be TG_E_SHAPE / TG_E_FUSION)
+    for bad in (0, 8, ctypes.sizeof(S) + 8):
+        full.struct_bytes = bad
+        assert L.tg_gemm_w4_plan(ctypes.byref(full), -1) == _lib.TG_E_STRUCT, bad
+    full.struct_bytes = ctypes.sizeof(S)
+    full.struct_reserved = 1
+    assert L.tg_gemm_w4_plan(ctypes.byref(full), -1) == _lib.TG_E_STRUCT
