@@ -16,6 +16,7 @@ if not _BUILD_CLI:
     from . import ops as _ops  # noqa: F401
     from . import functional, modules, utils  # noqa: F401
     from .modules import Any4Linear, Int4Linear, Int8Linear  # noqa: F401
-    from .ops import get_numerics, numerics, set_numerics  # noqa: F401
+    from .ops import get_numerics, get_weight_format, numerics, set_numerics, set_weight_format, weight_format  # noqa: F401
 
-__all__ = ["functional", "modules", "utils", "Any4Linear", "Int4Linear", "Int8Linear", "get_numerics", "set_numerics", "numerics"]
+__all__ = ["functional", "modules", "utils", "Any4Linear", "Int4Linear", "Int8Linear", "get_numerics", "set_numerics", "numerics",
+           "get_weight_format", "set_weight_format", "weight_format"]

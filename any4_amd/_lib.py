@@ -18,6 +18,7 @@ TG_E_LAYOUT = -12
 TG_E_FUSION = -13
 TG_E_STRUCT = -14
 TG_EPI_NONE, TG_EPI_SWIGLU = 0, 1
+TG_WFMT_M16N8K16, TG_WFMT_ROWS = 0, 1
 
 _i32, _i64, _vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p
 
@@ -36,6 +37,7 @@ class W4Gemm(ctypes.Structure):
         ("workspace", _vp), ("workspace_bytes", _i64),
         ("x_layout", _i32), ("y_layout", _i32),
         ("bias_row_stride", _i64), ("norm_weight", _vp), ("norm_eps", ctypes.c_float), ("epilogue", _i32),
+        ("w_format", _i32), ("reserved6", _i32),
     ]
 
     def __init__(self, *args, **kw):
@@ -73,6 +75,7 @@ SYMBOLS = {
     "tg_convert_to_B16": [_vp, _i64, _i64, ctypes.c_int, _vp, ctypes.c_int, _vp],
     "tg_convert_from_B16": [_vp, _i64, _i64, ctypes.c_int, _vp, ctypes.c_int, _vp],
     "tg_dequant_int4": [_vp, _i64, _vp, ctypes.c_int, _vp],
+    "tg_unpack_int4": [_vp, ctypes.c_int, _i64, _i64, ctypes.c_int, _vp, ctypes.c_int, _vp],
     "tg_gemm_w4": [ctypes.POINTER(W4Gemm), ctypes.c_int, _vp],
     "tg_gemm_w4_plan": [ctypes.POINTER(W4Gemm), ctypes.c_int],
     "tg_gemm_w4_workspace_bytes": [ctypes.POINTER(W4Gemm)],

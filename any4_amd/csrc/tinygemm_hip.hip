@@ -208,6 +208,32 @@ __global__ void __launch_bounds__(256) pack_Aint4_kernel(const int32_t* __restri
   }
 }
 
+// ---- unpack: one thread per code; the index arithmetic is the packers' read backwards (TinyGemmConvertA.cu:226-285,
+// TinyGemmConvertB.cu:252-308: pack = v7<<28 | v5<<24 | v3<<20 | v1<<16 | v6<<12 | v4<<8 | v2<<4 | v0) ----
+__global__ void __launch_bounds__(256) unpack_int4_kernel(const uint32_t* __restrict__ packed, int32_t* __restrict__ codes, int layout_a,
+                                                          int64_t rows, int64_t k, int I, int64_t ksuper) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= rows * k) return;
+  const int64_t r = idx / k, kk = idx - r * k;
+  const int64_t kt = kk >> 4;
+  const int kq = (int)(kk & 15);
+  int64_t word;
+  int v;
+  if (layout_a) {  // v = [(m0,k0),(m0,k1),(m1,k0),(m1,k1),(m0,k2),(m0,k3),(m1,k2),(m1,k3)], k0 = 2 (t % 4), k2 = k0 + 8
+    const int rr = (int)(r & 15), m0 = rr & 7, hi = rr >> 3;
+    const int t = 4 * m0 + ((kq & 7) >> 1);
+    v = (kq >> 3) * 4 + hi * 2 + (kq & 1);
+    word = (((r >> 4) * ksuper + kt / I) * 32 + t) * I + kt % I;
+  } else {         // word j of a lane: k-tiles 2j (v0..v3) and 2j + 1 (v4..v7) of the super-tile, k = base + 2 (t % 4) + {0, 1, 8, 9}
+    const int t = 4 * (int)(r & 7) + ((kq & 7) >> 1);
+    const int ktl = (int)(kt % I);
+    v = (ktl & 1) * 4 + (kq & 1) + 2 * (kq >> 3);
+    word = (((r >> 3) * ksuper + kt / I) * 32 + t) * (I / 2) + (ktl >> 1);
+  }
+  const int shift = (v & 1) * 16 + (v >> 1) * 4;
+  codes[idx] = (int32_t)((packed[word] >> shift) & 15u);
+}
+
 // ---- 16-bit fragment-order conversions (pure data movement) ------------------------------------
 // ref TinyGemmConvertA.cu:19-141 / 442-546 and TinyGemmConvertB.cu:20-66 / 136-176
 __global__ void __launch_bounds__(256) to_A16_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out,
@@ -500,6 +526,19 @@ int tg_convert_to_Aint4(const int32_t* in, int64_t m, int64_t k, int I, int32_t*
   return launch_status();
 }
 
+int tg_unpack_int4(const int32_t* packed, int layout_a, int64_t rows, int64_t k, int I, int32_t* codes, int device, tg_stream_t stream) {
+  if (!packed || !codes) return TG_E_NULL;
+  if (layout_a ? !(I == 1 || I == 2 || I == 4) : !(I == 2 || I == 4 || I == 8)) return TG_E_INNER_K;
+  if (rows <= 0 || k <= 0 || rows * k / 256 > INT32_MAX) return TG_E_SHAPE;
+  if (!layout_a && k % (16 * I) != 0) return TG_E_K_DIV;
+  DeviceScope ds(device);
+  if (!ds.ok) return TG_E_DEVICE;
+  const int64_t ksuper = cdiv(k, 16 * I);
+  hipLaunchKernelGGL(unpack_int4_kernel, dim3((unsigned)cdiv(rows * k, 256)), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const uint32_t*>(packed), codes, layout_a, rows, k, I, ksuper);
+  return launch_status();
+}
+
 int tg_convert_to_A16(const void* rm, int64_t m, int64_t k, void* tc, int device, tg_stream_t stream) {
   if (!rm || !tc) return TG_E_NULL;
   if (m <= 0 || k <= 0) return TG_E_SHAPE;
@@ -586,29 +625,36 @@ static int gemm_w4_impl(const tg_w4_gemm* caller, int device, tg_stream_t stream
   if (!(a->dtype == TG_BF16 || a->dtype == TG_F16)) return TG_E_DTYPE;
   if (a->qtype == TG_Q_MX4 && a->dtype != TG_BF16) return TG_E_DTYPE;  // TinyGemm_int4.cu:758,782
   if (a->m <= 0 || a->wrows <= 0 || a->k <= 0 || a->m > INT32_MAX || a->wrows > INT32_MAX || a->k > INT32_MAX) return TG_E_SHAPE;
-  const int I = a->inner_k_tiles;
-  const bool on_right = a->w_on_right != 0;
+  int I = a->inner_k_tiles;
+  bool on_right = a->w_on_right != 0;
   if (on_right ? !(I == 2 || I == 4 || I == 8) : !(I == 1 || I == 2 || I == 4)) return TG_E_INNER_K;
   // TinyGemmImpl.cuh:370-376: kTiles % innerKTiles == 0, k % 32 == 0
   if (a->k % 32 != 0 || a->k % (16 * I) != 0) return TG_E_K_DIV;
   const int g = a->group;
   if (!(g == 32 || g == 64 || g == 128 || g == 256) || a->k % g != 0) return TG_E_GROUP;  // TinyGemm_int4.cu:379-387
+  if (a->wrows % (on_right ? 8 : 16) != 0) return TG_E_SHAPE;
+  if (!(a->w_format == TG_WFMT_M16N8K16 || a->w_format == TG_WFMT_ROWS) || (a->w_format && on_right) || a->reserved6 != 0) return TG_E_SHAPE;
+  if (a->w_format == TG_WFMT_ROWS) {
+    // the A-shaped tensor holds Bint4 words (rows padded to 16): from here on this IS a weights-on-the-right call -- both sides
+    // produce [activation row][weight row] (TinyGemm_int4.cu:450-456)
+    on_right = true;
+    I = a->k % 64 == 0 ? 4 : 2;
+  }
   const int rows_per_tile = on_right ? 8 : 16;
-  if (a->wrows % rows_per_tile != 0) return TG_E_SHAPE;
   if (!aligned16(a->x) || !aligned16(a->w) || (reinterpret_cast<uintptr_t>(a->qinfo) & 3u)) return TG_E_ALIGN;
   if (a->lut && !aligned16(a->lut)) return TG_E_ALIGN;          // LUT rows are read as two 16-byte vectors
   if (a->bias && (reinterpret_cast<uintptr_t>(a->bias) & 7u)) return TG_E_ALIGN;
   if (!(a->numerics == TG_NUM_FAST || a->numerics == TG_NUM_REFERENCE) || a->reserved != 0) return TG_E_SHAPE;
   if (a->workspace && (!aligned16(a->workspace) || a->workspace_bytes < 0)) return TG_E_ALIGN;
   if (!(a->x_layout == TG_LAYOUT_RM || a->x_layout == TG_LAYOUT_TC_A) || !(a->y_layout == TG_LAYOUT_RM || a->y_layout == TG_LAYOUT_TC_A)) return TG_E_LAYOUT;
-  if ((a->x_layout || a->y_layout) && (!a->w_on_right || a->m % 16 != 0 || a->bias)) return TG_E_LAYOUT;
+  if ((a->x_layout || a->y_layout) && (!on_right || a->m % 16 != 0 || a->bias)) return TG_E_LAYOUT;
   if (a->bias_row_stride < 0 || (a->bias_row_stride && !a->bias) || (a->bias_row_stride & 3)) return TG_E_SHAPE;
   if (!(a->epilogue == TG_EPI_NONE || a->epilogue == TG_EPI_SWIGLU)) return TG_E_SHAPE;
   if (a->norm_weight && !aligned16(a->norm_weight)) return TG_E_ALIGN;
   // the fused stages exist in the TG_NUM_FAST pair-table kernels only (row-major operands)
   if ((a->norm_weight || a->epilogue) && (a->numerics != TG_NUM_FAST || a->x_layout || a->y_layout)) return TG_E_FUSION;
   if (a->norm_weight && a->k % 2048 != 0) return TG_E_FUSION;
-  if (a->epilogue == TG_EPI_SWIGLU && (!a->w_on_right || a->bias || a->wrows % 16 != 0)) return TG_E_FUSION;
+  if (a->epilogue == TG_EPI_SWIGLU && (!on_right || a->bias || a->wrows % 16 != 0)) return TG_E_FUSION;
   const int batch = a->batch > 1 ? a->batch : 1;
   if (batch > 1 && ((a->stride_x | a->stride_w | a->stride_lut) & 15)) return TG_E_ALIGN;
   if (batch > 1 && a->bias && (a->stride_bias & 7)) return TG_E_ALIGN;

@@ -40,6 +40,10 @@ class _PackedLinear(torch.nn.Module):
         self.kernel = kernel
         self.w_inner_k = w_inner_k
         self.weight_reshaped = False
+        # packed format of a weights-on-the-left tensor (any4_amd.ops.get_weight_format): recorded by reshape_weight(); None = the
+        # process default.  A state_dict packed by the CUDA implementation holds the reference's words: set "reference" (the slower
+        # kernels take them as they are) or call relayout("native") once.
+        self.weight_format = None
 
     def reshape_weight(self, w_inner_k: int | None = None):
         """Pack `weight` once into the layout `self.kernel` consumes."""
@@ -51,11 +55,29 @@ class _PackedLinear(torch.nn.Module):
         self.weight.data = getattr(_T, packer)(self.weight, w_inner_k)
         self.weight_reshaped = True
         self.w_inner_k = w_inner_k
+        self.weight_format = _ops.get_weight_format() if "Aint4" in packer else None
+
+    def relayout(self, to: str):
+        """Repack an already packed weights-on-the-left tensor ('reference' <-> 'native', lossless; any4_amd.ops.relayout_Aint4)."""
+        packer = self._PACKERS.get(self.kernel, "")
+        if not self.weight_reshaped or "Aint4" not in packer:
+            raise ValueError("relayout() applies to a packed weights-on-the-left (Aint4) tensor")
+        have = self.weight_format or _ops.get_weight_format()
+        if have != to:
+            with _ops.weight_format(have):
+                self.weight.data = _ops.relayout_Aint4(self.weight.data, self.in_features, to)
+            self.weight_format = to
 
     def _gemm(self, x2d: torch.Tensor) -> torch.Tensor:
         raise NotImplementedError
 
     def forward(self, input: torch.Tensor) -> torch.Tensor:
+        if self.weight_format is not None and self.weight_format != _ops.get_weight_format():
+            with _ops.weight_format(self.weight_format):
+                return self._forward(input)
+        return self._forward(input)
+
+    def _forward(self, input: torch.Tensor) -> torch.Tensor:
         lead = input.shape[:-1]
         if self.bias is None:
             y = self._gemm(input.view(-1, input.shape[-1]))

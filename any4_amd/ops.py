@@ -90,11 +90,59 @@ def numerics(name: str):
             _tls.numerics = prev
 
 
+# ---------------------------------------------------------------------------------------------
+# packed format of weights-on-the-left (Aint4) tensors
+# ---------------------------------------------------------------------------------------------
+_WFORMATS = {"native": _lib.TG_WFMT_ROWS, "reference": _lib.TG_WFMT_M16N8K16}
+_wformat = os.environ.get("ANY4_WEIGHT_FORMAT", "native")
+if _wformat not in _WFORMATS:
+    raise ImportError(f"ANY4_WEIGHT_FORMAT must be one of {sorted(_WFORMATS)}, got {_wformat!r}")
+
+
+def get_weight_format() -> str:
+    """What `convert_matrix_to_m16n8k16_Aint4_layout` returns and what the weights-on-the-left GEMM ops expect (the packed tensor
+    is opaque to every caller of the reference: TinyGemm_int4.cu:322-364 only checks its shape).
+    'native' (default): the reference's Aint4 SHAPE [m/16][k/(16 I)][32][I] holding the codes in row-per-lane order (the Bint4
+    word order, rows padded to 16; tg_w4_gemm.w_format = TG_WFMT_ROWS) -- the A-side ops then run the B-side kernels (a packed
+    word holds 8 codes of ONE weight row instead of 4 + 4 of rows r and r + 8).  'reference': the reference's Aint4 words, bit
+    for bit (checkpoints packed by the CUDA implementation; `relayout_Aint4` converts either way, losslessly)."""
+    return getattr(_tls, "wformat", _wformat)
+
+
+def set_weight_format(name: str) -> None:
+    global _wformat
+    if name not in _WFORMATS:
+        raise ValueError(f"weight format must be one of {sorted(_WFORMATS)}")
+    _wformat = name
+
+
+@contextlib.contextmanager
+def weight_format(name: str):
+    """Thread-local override: `with any4_amd.weight_format("reference"): ...`"""
+    if name not in _WFORMATS:
+        raise ValueError(f"weight format must be one of {sorted(_WFORMATS)}")
+    prev = getattr(_tls, "wformat", None)
+    _tls.wformat = name
+    try:
+        yield
+    finally:
+        if prev is None:
+            del _tls.wformat
+        else:
+            _tls.wformat = prev
+
+
+def _rows_inner(k: int) -> int:
+    """innerKTiles of the Bint4 word order inside a native A-shaped tensor (tg_w4_gemm.w_format = TG_WFMT_ROWS)."""
+    return 4 if k % 64 == 0 else 2
+
+
 _PLANS = {_lib.TG_PLAN_SPLITK: "splitk", _lib.TG_PLAN_STREAM: "stream", _lib.TG_PLAN_PAIR: "pair", _lib.TG_PLAN_PAIR_XR: "pair_xr", _lib.TG_PLAN_GEMV: "gemv"}
 
 
 def gemm_w4_plan(m: int, wrows: int, k: int, group: int, qtype: int, weight_on_right: bool = True, inner_k_tiles: int = 4,
-                 dtype=torch.bfloat16, batch: int = 1, numerics: str | None = None, workspace: bool = True, detail: bool = False) -> str:
+                 dtype=torch.bfloat16, batch: int = 1, numerics: str | None = None, workspace: bool = True, detail: bool = False,
+                 weight_format: str | None = None) -> str:
     """Which kernel family tg_gemm_w4 launches for this problem (tg_gemm_w4_plan; nothing is launched, no GPU needed):
     'pair' = pair-table kernels, group-scaled numerics; 'stream' / 'splitk' = reference-numerics kernels.
     `workspace`: the caller provides the scratch tg_gemm_w4_workspace_bytes asks for (the ops of this module do).
@@ -104,7 +152,8 @@ def gemm_w4_plan(m: int, wrows: int, k: int, group: int, qtype: int, weight_on_r
     args = W4Gemm(x=p, w=p, qinfo=p, lut=p, y=p, m=m, wrows=wrows, k=k, group=group, qtype=qtype,
                   dtype=TG_BF16 if dtype == torch.bfloat16 else TG_F16, w_on_right=1 if weight_on_right else 0,
                   inner_k_tiles=inner_k_tiles, batch=batch, stride_x=16, stride_w=16, stride_qinfo=16, stride_lut=16, stride_y=16,
-                  numerics=_NUMERICS[numerics or get_numerics()])
+                  numerics=_NUMERICS[numerics or get_numerics()],
+                  w_format=0 if weight_on_right else _WFORMATS[weight_format or get_weight_format()])
     if workspace:
         need = _L.tg_gemm_w4_workspace_bytes(ctypes.byref(args))
         _lib.check(need if need < 0 else 0, "tg_gemm_w4_workspace_bytes")
@@ -191,10 +240,40 @@ def convert_matrix_to_m16n8k16_Aint4_layout(t: torch.Tensor, innerKTiles: int) -
     _check(t.is_contiguous(), "Aint4 layout: input must be contiguous")
     _check(innerKTiles in (1, 2, 4), "Aint4 layout: innerKTiles must be 1, 2 or 4")
     m, k = t.shape
-    out = torch.empty((_cdiv(m, 16), _cdiv(k, innerKTiles * 16), 32, innerKTiles), dtype=torch.int32, device=t.device)
+    shape = (_cdiv(m, 16), _cdiv(k, innerKTiles * 16), 32, innerKTiles)
+    if get_weight_format() == "native" and k % 32 == 0 and k % (innerKTiles * 16) == 0:
+        # the row-per-lane order (any k a weights-on-the-left GEMM accepts); other k: the reference's words (no GEMM takes them)
+        alloc = torch.zeros if _cdiv(m, 8) % 2 else torch.empty  # an odd number of 8-row tiles: the pad tile is all zero codes
+        out = alloc(shape, dtype=torch.int32, device=t.device)
+        _lib.check(_L.tg_convert_to_Bint4(t.data_ptr(), m, k, _rows_inner(k), out.data_ptr(), _dev(t), _stream(t)),
+                   "convert_matrix_to_m16n8k16_Aint4_layout")
+        return out
+    out = torch.empty(shape, dtype=torch.int32, device=t.device)
     _lib.check(_L.tg_convert_to_Aint4(t.data_ptr(), m, k, innerKTiles, out.data_ptr(), _dev(t), _stream(t)),
                "convert_matrix_to_m16n8k16_Aint4_layout")
     return out
+
+
+def unpack_int4(packed: torch.Tensor, rows: int, k: int, layout: str) -> torch.Tensor:
+    """Packed 4-bit words -> int32 codes [rows][k] (tg_unpack_int4).  layout: 'B' (Bint4 words, innerKTiles = 2 size(3)), 'A' (the
+    reference's Aint4 words, innerKTiles = size(3)) or 'A_native' (an A-shaped tensor in row-per-lane order)."""
+    _check(packed.dim() == 4 and packed.dtype == torch.int32 and packed.is_contiguous(), "unpack_int4: a contiguous 4-D int32 tensor")
+    _check(layout in ("A", "B", "A_native"), "unpack_int4: layout must be 'A', 'B' or 'A_native'")
+    inner = packed.size(3) if layout == "A" else 2 * packed.size(3) if layout == "B" else _rows_inner(k)
+    out = torch.empty((rows, k), dtype=torch.int32, device=packed.device)
+    _lib.check(_L.tg_unpack_int4(packed.data_ptr(), 1 if layout == "A" else 0, rows, k, inner, out.data_ptr(), _dev(packed),
+                                 _stream(packed)), "unpack_int4")
+    return out
+
+
+def relayout_Aint4(packed: torch.Tensor, k: int, to: str) -> torch.Tensor:
+    """Lossless repack of a weights-on-the-left tensor between the reference's Aint4 words ('reference') and the row-per-lane
+    order ('native'), e.g. for a checkpoint packed by the CUDA implementation.  Same shape in, same shape out."""
+    _check(to in _WFORMATS, f"relayout_Aint4: `to` must be one of {sorted(_WFORMATS)}")
+    rows, inner = packed.size(0) * 16, packed.size(3)
+    codes = unpack_int4(packed, rows, k, "A" if to == "native" else "A_native")
+    with weight_format(to):
+        return convert_matrix_to_m16n8k16_Aint4_layout(codes, inner)
 
 
 def convert_matrix_to_m16n8k16_A_layout(t: torch.Tensor, innerKTiles: int) -> torch.Tensor:
@@ -353,15 +432,17 @@ def _w4_rm(A, B, q_group, qinfo, lut, qtype, weight_on_right, opname, frag=False
         y=y.data_ptr(), m=m, wrows=wrows, k=k, group=q_group, qtype=qtype, dtype=_dt(x),
         w_on_right=1 if weight_on_right else 0, inner_k_tiles=inner, batch=1,
         numerics=_NUMERICS[get_numerics()], bias=(bias.data_ptr() if bias is not None else None),
-        x_layout=layout, y_layout=layout,
+        x_layout=layout, y_layout=layout, w_format=0 if weight_on_right else _WFORMATS[get_weight_format()],
     )
     # The planner's answer depends on the problem's shape only: asked once per (shape, layout, numerics), not once per call
     # (m = 1 latency path: one planner pass and no allocation when no scratch is needed).
-    key = (m, wrows, k, q_group, qtype, args.dtype, args.w_on_right, inner, args.numerics, layout, bias is not None)
+    key = (m, wrows, k, q_group, qtype, args.dtype, args.w_on_right, inner, args.numerics, layout, bias is not None, args.w_format,
+           _dev(x))
     ws_bytes = _WS_BYTES.get(key)
     if ws_bytes is None:
         ws_bytes = _L.tg_gemm_w4_workspace_bytes(ctypes.byref(args))
-        if len(_WS_BYTES) < 4096:
+        # (an error code may come from THIS call's pointers -- a misaligned view -- and must not stick to the shape)
+        if len(_WS_BYTES) < 4096 and (ws_bytes >= 0 or ws_bytes == _lib.TG_E_LAYOUT):
             _WS_BYTES[key] = ws_bytes
     if frag and ws_bytes == _lib.TG_E_LAYOUT:
         return None

@@ -91,8 +91,11 @@ def make_batch(L, m, n, k, g, inner, device, seed, qtype="any4_rowwise", on_righ
     return w, x, q, lut, y
 
 
-def make_args(_lib, w, x, q, lut, y, m, n, k, g, qtype, on_right, inner, batch, numerics="fast"):
+def make_args(_lib, w, x, q, lut, y, m, n, k, g, qtype, on_right, inner, batch, numerics="fast", native=False):
+    """native (weights on the left only): the A-shaped tensor holds the row-per-lane word order (tg_w4_gemm.w_format = TG_WFMT_ROWS,
+    what convert_matrix_to_m16n8k16_Aint4_layout returns by default) instead of the reference's Aint4 words."""
     return _lib.W4Gemm(
+        w_format=_lib.TG_WFMT_ROWS if (native and not on_right) else _lib.TG_WFMT_M16N8K16,
         x=x.data_ptr(), w=w.data_ptr(), qinfo=q.data_ptr(), lut=(lut.data_ptr() if lut is not None else None), y=y.data_ptr(),
         m=m, wrows=n, k=k, group=g, qtype=QT[qtype], dtype=_lib.TG_BF16, w_on_right=1 if on_right else 0,
         inner_k_tiles=inner, batch=batch, stride_x=x.stride(0) * 2, stride_w=w.stride(0) * 4,
@@ -113,7 +116,7 @@ def attach_workspace(lib, aa, device):
     return ws
 
 
-def check_layers(w, x, q, lut, y, g, qtype, on_right, inner, plan, layers=(0, 1, -1), rows=256):
+def check_layers(w, x, q, lut, y, g, qtype, on_right, inner, plan, layers=(0, 1, -1), rows=256, native=False):
     """Untimed: `rows` weight rows of a few layers of the launch's output against BOTH CPU oracles.
 
     * pass / fail: the restatement of the arithmetic the kernel that ran implements -- oracle.linear_group_scaled (the derived
@@ -141,12 +144,16 @@ def check_layers(w, x, q, lut, y, g, qtype, on_right, inner, plan, layers=(0, 1,
     differ = total = 0
     steps = 0
     for b in layers:
-        codes = (orc.unpack_Bint4 if on_right else orc.unpack_Aint4)(w[b].cpu().numpy(), n, k)[:rows]
+        if native and not on_right:  # the A-shaped tensor holds Bint4 words (innerKTiles 4 at k % 64 == 0, else 2)
+            ib = 4 if k % 64 == 0 else 2
+            codes = orc.unpack_Bint4(w[b].cpu().numpy().reshape(n // 8, k // (16 * ib), 32, ib // 2), n, k)[:rows]
+        else:
+            codes = (orc.unpack_Bint4 if on_right else orc.unpack_Aint4)(w[b].cpu().numpy(), n, k)[:rows]
         qi = q[b].cpu().numpy()[:rows] if qtype == "mx4" else bits(q[b][:, :rows].contiguous())
         lb = None if lut is None else (bits(lut[b][:rows]) if qtype == "any4_rowwise" else bits(lut[b]))
         xb = bits(x[b])
         r16, r32 = orc.linear(xb, codes, g, oq, qi, lb)                      # the reference's arithmetic
-        y32 = orc.linear_group_scaled(xb, codes, g, oq, qi, lb)[1] if plan == "pair" else r32
+        y32 = orc.linear_group_scaled(xb, codes, g, oq, qi, lb)[1] if plan in ("pair", "gemv") else r32
         fin = np.isfinite(r32) & np.isfinite(y32)
         formula = max(formula, float(np.abs(y32.astype(np.float64) - r32.astype(np.float64))[fin].max()))
         wq = orc.bf16_to_f32(orc.dequant(codes, g, oq, qi, lb)).astype(np.float64)
@@ -179,7 +186,7 @@ def check_layers(w, x, q, lut, y, g, qtype, on_right, inner, plan, layers=(0, 1,
     if not err_ref16 <= max(1e-2 / scale, step):
         raise SystemExit(f"bench.py: {qtype} output is {err_ref16:.3e} from the reference-faithful bf16 result at max|y| = {ymax:.3f}: "
                          f"more than one bf16 step ({step:.3e}) and more than 1e-2 at the fixture's scale")
-    return {"max_abs_err_vs_kernel_formula": own, "kernel_formula": "group_scaled" if plan == "pair" else "reference",
+    return {"max_abs_err_vs_kernel_formula": own, "kernel_formula": "group_scaled" if plan in ("pair", "gemv") else "reference",
             "max_abs_err_vs_reference": err_ref16, "max_abs_err_vs_reference_f32": err_ref32, "max_abs_y": ymax,
             "one_bf16_step_at_max_abs_y": step,
             "max_abs_err_vs_reference_at_fixture_scale": err_ref16 * scale,
@@ -565,17 +572,19 @@ def main():
         # (a) the timed launch's own output against the oracle
         main_check = check_layers(w, x, sz, lut, y, g, "any4_rowwise", True, inner, plan)
 
-        def leg(qtype, mm, nn, kk, gg, on_right, layers, note, numerics="fast"):
-            """One more BASELINE config as a stacked launch of `layers` layers (same protocol: steady clock, HIP events)."""
+        def leg(qtype, mm, nn, kk, gg, on_right, layers, note, numerics="fast", native=True):
+            """One more BASELINE config as a stacked launch of `layers` layers (same protocol: steady clock, HIP events).
+            native: weights on the left in the library's default packed format (row-per-lane order) -- False: the reference's words."""
             ww, xx, qq, ll, yy = make_batch(layers, mm, nn, kk, gg, inner, device, 77, qtype, on_right)
-            aa = make_args(_lib, ww, xx, qq, ll, yy, mm, nn, kk, gg, qtype, on_right, inner, layers, numerics)
+            aa = make_args(_lib, ww, xx, qq, ll, yy, mm, nn, kk, gg, qtype, on_right, inner, layers, numerics, native)
             ws = attach_workspace(lib, aa, device)  # noqa: F841
-            pl = ops.gemm_w4_plan(mm, nn, kk, gg, QT[qtype], on_right, inner, torch.bfloat16, layers, numerics)
-            pld = ops.gemm_w4_plan(mm, nn, kk, gg, QT[qtype], on_right, inner, torch.bfloat16, layers, numerics, detail=True)
+            wf = "native" if native else "reference"
+            pl = ops.gemm_w4_plan(mm, nn, kk, gg, QT[qtype], on_right, inner, torch.bfloat16, layers, numerics, weight_format=wf)
+            pld = ops.gemm_w4_plan(mm, nn, kk, gg, QT[qtype], on_right, inner, torch.bfloat16, layers, numerics, detail=True, weight_format=wf)
             bl = alg_bytes(mm, nn, kk, gg, qtype)
             reps = max(10, int(0.25e6 / (layers * bl / 5e6)))  # ~0.25 s of launches
             us = timed(aa, reps) / layers
-            chk = check_layers(ww, xx, qq, ll, yy, gg, qtype, on_right, inner, pl, layers=(0, -1), rows=128)
+            chk = check_layers(ww, xx, qq, ll, yy, gg, qtype, on_right, inner, pl, layers=(0, -1), rows=128, native=native)
             return {"us_per_layer": round(us, 4), "GBps": round(bl / us / 1e3, 2), "frac": round(bl / us / 1e3 / HBM_PEAK_GBPS, 4),
                     "algorithmic_bytes_per_layer": bl, "layers_per_launch": layers, "kernel_plan": pld, "numerics": numerics,
                     "check": chk, "note": note}
@@ -585,7 +594,8 @@ def main():
         legs = {} if world > 1 else {
             "m8": leg("any4_rowwise", 8, n, k, g, True, L, f"the metric's second point: m=8, n=k={n}, g={g}, Bint4"),
             "m16": leg("any4_rowwise", 16, n, k, g, True, L // 2, f"m=16 (the reference's full 16-row tile, TinyGemmImpl.cuh:53-54), n=k={n}, g={g}, Bint4"),
-            "config3": leg("any4_rowwise", 8, 8192, 8192, 128, False, 128, "BASELINE config 3: m=8, n=k=8192, g=128, weights on the A side (Aint4 innerKTiles=4)"),
+            "config3": leg("any4_rowwise", 8, 8192, 8192, 128, False, 128, "BASELINE config 3: m=8, n=k=8192, g=128, weights on the A side (weightOnRight=False ops), in the packed format convert_matrix_to_m16n8k16_Aint4_layout returns (row-per-lane order, TG_WFMT_ROWS)"),
+            "config3_reference_words": leg("any4_rowwise", 8, 8192, 8192, 128, False, 128, "config 3 on a tensor that holds the reference's own Aint4 words (a checkpoint packed by the CUDA implementation, any4_amd.weight_format('reference'))", native=False),
             "int4": leg("int4", 1, n, k, g, True, L, "BASELINE config 4: uniform int4, m=1"),
             "nf4": leg("any4_global", 1, n, k, g, True, L, "BASELINE config 4: one global 16-entry LUT (the reference's NF4 path), m=1"),
             "mx4": leg("mx4", 1, n, k, 32, True, L, "BASELINE config 4: mx4 (fp4-e2m1 codes, e8m0 exponent per 32), m=1; weights converted by v_cvt_scalef32_pk_bf16_fp4"),
@@ -604,8 +614,8 @@ def main():
             ww, xx, qq, ll, yy = tensors or make_batch(L, m, n, k, g, inner, device, 91, qtype, on_right)
             nl = ww.shape[0]
             sl = lambda t, i: None if t is None else t[i:i + 1]  # noqa: E731
-            singles = [make_args(_lib, ww[i:i + 1], xx[i:i + 1], qq[i:i + 1], sl(ll, i), yy[i:i + 1], m, n, k, g, qtype, on_right, inner, 1)
-                       for i in range(nl)]
+            singles = [make_args(_lib, ww[i:i + 1], xx[i:i + 1], qq[i:i + 1], sl(ll, i), yy[i:i + 1], m, n, k, g, qtype, on_right, inner, 1,
+                                 native=True) for i in range(nl)]
             for sa in singles:
                 launch(sa)
             torch.cuda.synchronize()
@@ -646,7 +656,7 @@ def main():
                     "frac_back_to_back": round(bl / single_us / 1e3 / HBM_PEAK_GBPS, 4),
                     "us_cold_event_pair": round(cold_us, 3), "frac_cold": round(bl / cold_us / 1e3 / HBM_PEAK_GBPS, 4),
                     "us_per_launch_in_hipgraph": round(graph_us, 3), "frac_in_hipgraph": round(bl / graph_us / 1e3 / HBM_PEAK_GBPS, 4),
-                    "kernel_plan": ops.gemm_w4_plan(m, n, k, g, QT[qtype], on_right, inner, torch.bfloat16, 1, "fast")}
+                    "kernel_plan": ops.gemm_w4_plan(m, n, k, g, QT[qtype], on_right, inner, torch.bfloat16, 1, "fast", weight_format="native")}
 
         single_b = single_layer("any4_rowwise", True, (w, x, sz, lut, y)) if world == 1 else {}
         single_a = single_layer("int4", False) if world == 1 else {}

@@ -116,6 +116,12 @@ TG_API int tg_convert_to_B16(const void* rm, int64_t n, int64_t k, int inner_k_t
 TG_API int tg_convert_from_B16(const void* tc, int64_t n, int64_t k, int inner_k_tiles, void* rm, int device,
                         tg_stream_t stream);
 
+/* The inverse of the two int4 packers (no counterpart in the reference: it never unpacks): packed words -> int32 codes [rows][k].
+ * layout_a = 0: Bint4 words [ceil(rows/8)][k/(16 I)][32][I/2], I in {2,4,8}; layout_a = 1: Aint4 words [ceil(rows/16)][ceil(k/(16 I))][32][I],
+ * I in {1,2,4}.  With a packer this is the lossless repack between the reference's Aint4 words and TG_WFMT_ROWS (tg_w4_gemm.w_format). */
+TG_API int tg_unpack_int4(const int32_t* packed, int layout_a, int64_t rows, int64_t k, int inner_k_tiles, int32_t* codes,
+                          int device, tg_stream_t stream);
+
 /* replaces the debug op tinygemm_dequant_int4 (TinyGemmDequantize.cu:36-58):
  * each int32 -> 8 bf16 (nibble - 8) in the order [n0,n4,n1,n5,n2,n6,n3,n7]. */
 TG_API int tg_dequant_int4(const int32_t* in, int64_t count, void* out_bf16, int device, tg_stream_t stream);
@@ -191,9 +197,19 @@ typedef struct tg_w4_gemm {
                            /* y[a][8 B + c] = RNE16(RNE16(silu(g)) * u), g / u = RNE16(acc) of rows 16 B + c / 16 B + 8 + c         */
                            /* (dg_swiglu's formula).  TG_NUM_FAST pair-table kernels, weights on the right, row-major y, no bias;   */
                            /* otherwise TG_E_FUSION.                                                                               */
+  /* ---- ABI version 6 ---- */
+  int32_t w_format;        /* w_on_right = 0 only.  TG_WFMT_M16N8K16 (0): `w` holds the reference's Aint4 words.  TG_WFMT_ROWS (1): the   */
+                           /* tensor has the Aint4 SHAPE [wrows/16][k/(16 I)][32][I] but holds the codes in the row-per-lane order of the */
+                           /* Bint4 layout (rows padded to 16; innerKTiles 4 when k % 64 == 0, else 2) -- what SURVEY 8(b) calls a native */
+                           /* packed layout behind convert_matrix_to_m16n8k16_Aint4_layout: a packed word then holds 8 codes of ONE weight */
+                           /* row instead of 4 + 4 of rows r and r + 8, and the A-side ops run the B-side kernels (the result is          */
+                           /* [activation row][weight row] either way).  tg_convert_to_Bint4 on the [wrows][k] codes produces it,         */
+                           /* tg_unpack_int4 + a packer converts between the two losslessly.                                              */
+  int32_t reserved6;       /* must be 0 */
 } tg_w4_gemm;
 
 enum { TG_EPI_NONE = 0, TG_EPI_SWIGLU = 1 };
+enum { TG_WFMT_M16N8K16 = 0, TG_WFMT_ROWS = 1 };
 
 TG_API int tg_gemm_w4(const tg_w4_gemm* args, int device, tg_stream_t stream);
 

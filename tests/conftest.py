@@ -58,3 +58,14 @@ def reference_numerics():
 
     with any4_amd.numerics("reference"):
         yield
+
+
+@pytest.fixture
+def reference_weight_format():
+    """Weights-on-the-left tensors in the reference's own Aint4 word order (any4_amd.weight_format("reference")): the modules
+    whose tests were written for those words -- bit-exact packer tests, the Aint4 kernels -- run under it; the default
+    (row-per-lane order, TG_WFMT_ROWS) has its own tests in test_gpu_aside.py."""
+    import any4_amd
+
+    with any4_amd.weight_format("reference"):
+        yield

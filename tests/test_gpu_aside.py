@@ -1,0 +1,160 @@
+"""GPU suite (-m gpu): weights on the LEFT (the reference's `..._W_int4TC_x_f16RM` / `weightOnRight=False` ops, Int4Linear's default
+kernel, modules.py:21) in the library's default packed format.
+
+SURVEY 8(b): the packed tensor is opaque to every caller of the reference (TinyGemm_int4.cu:322-364 checks its shape only), so
+`convert_matrix_to_m16n8k16_Aint4_layout` may return a gfx950-native order as long as the GEMM ops accept what it returns and the
+reference's own words stay available as an interchange format with a lossless repack.  Here: the native tensor has the reference's
+Aint4 SHAPE and holds the Bint4 word order (rows padded to 16) -- checked bit for bit against the oracle's Bint4 packer -- the
+repack is checked both ways, and the GEMM through every op flavour is checked against the oracle like the weights-on-the-right
+path (tests/test_gpu_gemv.py, test_gpu_fast.py): the same kernels run it.
+"""
+import numpy as np
+import pytest
+import torch
+
+from tests.test_gpu_fast import QT
+from tests.test_gpu_gemv import check
+from tests.test_gpu_parity import DEV, T, assert_gemm_close, oracle_weights, rand_problem  # noqa: F401  (T is a fixture)
+
+pytestmark = pytest.mark.gpu
+
+
+def native_words(oracle, codes, k):
+    """What the native convert must return, from the oracle's Bint4 packer: rows padded to 16, innerKTiles 4 (k % 64 == 0) or 2."""
+    m = codes.shape[0]
+    pad = -(-m // 16) * 16
+    full = np.zeros((pad, k), np.int32)
+    full[:m] = codes
+    return oracle.pack_Bint4(full, 4 if k % 64 == 0 else 2)
+
+
+@pytest.mark.parametrize("inner", [1, 2, 4])
+@pytest.mark.parametrize("m,k", [(16, 64), (40, 256), (72, 96), (4096, 4096), (8, 32), (129, 1024)])
+def test_native_convert_bit_exact_and_repack(T, oracle, inner, m, k):
+    import any4_amd
+    from any4_amd import ops
+
+    if k % (16 * inner):
+        pytest.skip("k must be a multiple of innerKTiles * 16 for a GEMM-able tensor")
+    codes = torch.randint(0, 16, (m, k), dtype=torch.int32, generator=torch.Generator().manual_seed(m + k))
+    assert any4_amd.get_weight_format() == "native"
+    nat = T.convert_matrix_to_m16n8k16_Aint4_layout(codes.to(DEV), inner)
+    assert tuple(nat.shape) == (-(-m // 16), k // (16 * inner), 32, inner)  # the reference's shape (TinyGemm_int4.cu:340-364)
+    assert np.array_equal(nat.cpu().numpy().reshape(-1), native_words(oracle, codes.numpy(), k).reshape(-1))
+    with any4_amd.weight_format("reference"):
+        ref = T.convert_matrix_to_m16n8k16_Aint4_layout(codes.to(DEV), inner)
+    assert np.array_equal(ref.cpu().numpy(), oracle.pack_Aint4(codes.numpy(), inner))  # the interchange format: the reference's words
+    # unpack (both orders) and the lossless repack, both ways
+    rows = nat.shape[0] * 16
+    want = np.zeros((rows, k), np.int32)
+    want[:m] = codes.numpy()
+    assert np.array_equal(ops.unpack_int4(nat, rows, k, "A_native").cpu().numpy(), want)
+    assert np.array_equal(ops.unpack_int4(ref, rows, k, "A").cpu().numpy(), want)
+    assert torch.equal(ops.relayout_Aint4(ref, k, "native"), nat)
+    assert torch.equal(ops.relayout_Aint4(nat, k, "reference"), ref)
+    wb = T.convert_matrix_to_m16n8k16_Bint4_layout(codes.to(DEV), 4 if k % 64 == 0 else 2)
+    assert np.array_equal(ops.unpack_int4(wb, m, k, "B").cpu().numpy(), codes.numpy())
+
+
+def run_left(T, codes, x, qinfo, lut, g, qtype, inner):
+    d = lambda t: None if t is None else t.to(DEV)
+    w2 = T.convert_matrix_to_m16n8k16_Aint4_layout(d(codes), inner)
+    if qtype == "mx4":
+        return T.tinygemm_y_f16RM_x_f16RM_w_mx4TC(w2, d(x), g, d(qinfo), False)
+    if qtype == "int4":
+        return T.tinygemm_y_f16RM_x_f16RM_w_int4TC(w2, d(x), g, d(qinfo), False)
+    return T.tinygemm_y_f16RM_x_f16RM_w_any4TC(w2, d(x), g, d(qinfo), d(lut), False)
+
+
+def pad_rows(codes, qinfo, lut, qtype):
+    """quantisation info / LUT rows for the 16-row tile padding of the A side (the reference checks them against 16 * size(0))."""
+    n = codes.shape[0]
+    pad = -(-n // 16) * 16 - n
+    if not pad:
+        return qinfo, lut
+    if qtype == "mx4":
+        qinfo = torch.cat([qinfo, torch.full((pad, qinfo.shape[1]), 127, dtype=qinfo.dtype)])
+    else:
+        qinfo = torch.cat([qinfo, torch.zeros(qinfo.shape[0], pad, 2, dtype=qinfo.dtype)], dim=1)
+    if lut is not None and lut.dim() == 2:
+        lut = torch.cat([lut, torch.zeros(pad, 16, dtype=lut.dtype)])
+    return qinfo, lut
+
+
+@pytest.mark.parametrize("case", [
+    # (n, k, m, g, qtype, inner)
+    (4096, 4096, 1, 128, "any4_rowwise", 4),   # Int4Linear / Any4Linear with the weights on the left at batch 1: w4_gemv_kernel
+    (4096, 4096, 1, 128, "int4", 4), (4096, 4096, 3, 64, "any4_global", 2), (6144, 4096, 1, 256, "int4", 1),
+    (200, 512, 2, 32, "any4_rowwise", 4),      # ragged 16-row tile
+    (1024, 4096, 8, 128, "any4_rowwise", 4), (1024, 4096, 16, 128, "int4", 4),   # m > 4: w4_gemm_pair16_kernel
+    (2048, 2048, 7, 32, "mx4", 4), (512, 14336, 1, 128, "any4_rowwise", 4), (264, 96, 5, 32, "int4", 2),  # k % 64 != 0: innerKTiles 2 words
+])
+def test_left_side_gemm_vs_oracle(T, oracle, case):
+    from any4_amd import ops
+
+    n, k, m, g, qtype, inner = case
+    codes, x, qinfo, lut = rand_problem(n, k, g, m, qtype, seed=n + k + m)
+    qp, lp = pad_rows(codes, qinfo, lut, qtype)
+    y = run_left(T, codes, x, qp, lp, g, qtype, inner)
+    plan = ops.gemm_w4_plan(m, -(-n // 16) * 16, k, g, QT[qtype], False, inner)
+    assert plan in ("gemv", "pair"), plan  # a group-scaled kernel of the B side, never the Aint4 fallbacks
+    if qtype == "mx4":
+        assert_gemm_close(y[:, :n], x, oracle_weights(oracle, codes, g, qtype, qinfo, lut))
+    else:
+        rows = None if n <= 2048 else np.unique(np.concatenate([np.arange(0, 96), np.arange(n // 2 - 48, n // 2 + 48), np.arange(n - 96, n)]))
+        check(oracle, y, codes, x, qinfo, lut, g, qtype, rows=rows)
+
+
+def test_left_side_equals_right_side_bits(T):
+    """Same codes, same kernels: the weights-on-the-left op returns the bits of the weights-on-the-right op."""
+    n, k, g = 4096, 4096, 128
+    for m in (1, 4, 8):
+        codes, x, qinfo, lut = rand_problem(n, k, g, m, "any4_rowwise", seed=m)
+        d = lambda t: t.to(DEV)
+        wl = T.convert_matrix_to_m16n8k16_Aint4_layout(d(codes), 4)
+        wr = T.convert_matrix_to_m16n8k16_Bint4_layout(d(codes), 4)
+        assert torch.equal(wl.view(-1), wr.view(-1))
+        yl = T.tinygemm_y_f16RM_x_f16RM_w_any4TC(wl, d(x), g, d(qinfo), d(lut), False)
+        yr = T.tinygemm_y_f16RM_x_f16RM_w_any4TC(d(x), wr, g, d(qinfo), d(lut), True)
+        assert torch.equal(yl.view(torch.int16), yr.view(torch.int16))
+
+
+def test_reference_words_still_served_and_modules_remember_their_format(T, oracle):
+    """A tensor in the reference's Aint4 words (a checkpoint packed by the CUDA implementation) runs under
+    any4_amd.weight_format("reference"); a module records the format it was packed in, relayout() converts it once."""
+    import any4_amd
+    import modules
+
+    n, k, g = 512, 1024, 128
+    codes, x, qinfo, lut = rand_problem(n, k, g, 2, "int4", seed=9)
+    with any4_amd.weight_format("reference"):
+        y_ref = run_left(T, codes, x, qinfo, lut, g, "int4", 4)
+    y_nat = run_left(T, codes, x, qinfo, lut, g, "int4", 4)
+    # two kernel families (the Aint4 words run a reference-numerics kernel at this size, the native ones the group-scaled gemv):
+    # one result within the reference's own weight rounding
+    tol = 0.02 * y_nat.float().abs().max()
+    assert (y_ref.float() - y_nat.float()).abs().max() <= tol
+    lin = modules.Int4Linear(k, n, bias=False, device=DEV, dtype=torch.bfloat16, group_size=g)  # the default kernel: weights on the left
+    assert lin.kernel == "linear_y_f16RM_W_int4TC_x_f16RM"
+    lin.weight.data = codes.to(DEV)
+    lin.scales_and_zeros.data = qinfo.to(DEV)
+    with any4_amd.weight_format("reference"):
+        lin.reshape_weight(4)
+    assert lin.weight_format == "reference" and np.array_equal(lin.weight.cpu().numpy(), oracle.pack_Aint4(codes.numpy(), 4))
+    y1 = lin(x.to(DEV))                       # the module passes its own format whatever the process default is
+    lin.relayout("native")
+    assert lin.weight_format == "native" and np.array_equal(lin.weight.cpu().numpy().reshape(-1), native_words(oracle, codes.numpy(), k).reshape(-1))
+    y2 = lin(x.to(DEV))
+    assert torch.equal(y2, y_nat) and (y1.float() - y2.float()).abs().max() <= tol
+
+
+def test_left_side_tensor_core_layout_ops(T, oracle):
+    """`tinygemm_y_f16TC_x_f16TC_w_int4TC` with the weights on the left (activations / output in B-fragment order) on native words."""
+    n, k, g, m = 256, 512, 64, 5
+    codes, x, qinfo, lut = rand_problem(n, k, g, m, "any4_rowwise", seed=4)
+    d = lambda t: t.to(DEV)
+    w2 = T.convert_matrix_to_m16n8k16_Aint4_layout(d(codes), 2)
+    xb = T.convert_matrix_to_m16n8k16_B_layout(d(x), 1)
+    yb = T.tinygemm_y_f16TC_x_f16TC_w_any4TC(w2, xb, g, d(qinfo), d(lut), False)
+    y = T.convert_matrix_from_m16n8k16_B_layout(yb, m, n)
+    check(oracle, y, codes, x, qinfo, lut, g, "any4_rowwise")

@@ -22,7 +22,7 @@ import torch
 from tests.conftest import bits16, from_bits16, load_golden
 from tests.test_gpu_parity import DEV, T, oracle_weights, rand_problem, run_rm, ulp16  # noqa: F401  (T is a fixture)
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("reference_weight_format")]  # (Aint4 tests here drive the C ABI with the reference's words)
 
 QT = {"int4": 0, "any4_global": 1, "any4_rowwise": 2, "mx4": 3}
 

@@ -22,7 +22,7 @@ import torch
 
 from tests.conftest import bf16_ulp, bits16, from_bits16, load_golden
 
-pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("reference_numerics")]
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("reference_numerics", "reference_weight_format")]
 
 DEV = "cuda:0"
 

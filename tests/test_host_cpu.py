@@ -296,7 +296,12 @@ def test_xr_kernel_routing():
     assert plan(8, 4096, 4096, 128, "any4_rowwise", inner=8) != "pair_xr"
     assert plan(8, 4104, 4096, 128, "any4_rowwise") != "pair_xr"          # rows not a multiple of 64
     assert plan(8, 4096, 4096, 128, "any4_rowwise", batch=4) != "pair_xr"  # 256 items: fewer than two per CU
-    assert plan(8, 4096, 4096, 128, "any4_rowwise", right=False) != "pair_xr"  # Aint4 weights
+    # weights on the left: the reference's Aint4 words stay on their own kernels; the native row-per-lane order IS a B-side call
+    q2 = {'int4': 0, 'any4_global': 1, 'any4_rowwise': 2, 'mx4': 3}
+    assert ops.gemm_w4_plan(8, 4096, 4096, 128, q2["any4_rowwise"], False, 4, batch=64, detail=True, weight_format="reference") != "pair_xr"
+    assert ops.gemm_w4_plan(8, 4096, 4096, 128, q2["any4_rowwise"], False, 4, batch=64, detail=True, weight_format="native") == "pair_xr"
+    assert ops.gemm_w4_plan(1, 4096, 4096, 128, q2["int4"], False, 4, weight_format="native") == "gemv"   # Int4Linear's default kernel at batch 1
+    assert ops.gemm_w4_plan(1, 4096, 4096, 128, q2["int4"], False, 2, weight_format="native") == "gemv"   # (the Aint4 innerKTiles is a shape only)
     assert plan(17, 4096, 4096, 128, "any4_rowwise") != "pair_xr"
 
 

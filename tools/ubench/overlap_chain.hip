@@ -46,7 +46,7 @@ __global__ void __launch_bounds__(512, 4) node_kernel(const P p) {
       unsigned spins = 0;
       while (__hip_atomic_load(p.ctr_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < p.expect) {
         __builtin_amdgcn_s_sleep(2);
-        if (++spins > 2000000u) { *p.err = 1; break; }
+        if (++spins > 20000u) { *p.err = 1; break; }
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
@@ -107,6 +107,29 @@ int main() {
       {"32 MiB boundary-ordered", 32u << 20, 0, 64}, {"32 MiB overlapped", 32u << 20, 1, 64},
       {"64 MiB boundary-ordered", 64u << 20, 0, 64}, {"64 MiB overlapped", 64u << 20, 1, 64},
   };
+  // eager first: two streams, no graph (is it the graph that serialises the two chains?)
+  for (int overlap = 0; overlap < 2; ++overlap) {
+    CHECK(hipMemset(ctr, 0, (N + 2) * 64));
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipEventRecord(e0, s0));
+    if (overlap) { CHECK(hipEventRecord(fork, s0)); CHECK(hipStreamWaitEvent(s1, fork, 0)); }
+    for (int i = 0; i < N; ++i) {
+      P p;
+      p.w = w[i]; p.x_in = x[i & 1]; p.x_out = x[(i + 1) & 1];
+      p.pieces = 4; p.err = err; p.expect = 256; p.lds_pad = 0;
+      p.ctr_in = (overlap && i > 0) ? ctr + (i - 1) * 16 : nullptr;
+      p.ctr_out = overlap ? ctr + i * 16 : nullptr;
+      hipLaunchKernelGGL(node_kernel<4>, dim3(256), dim3(512), 64, (overlap && (i & 1)) ? s1 : s0, p);
+    }
+    if (overlap) { CHECK(hipEventRecord(join, s1)); CHECK(hipStreamWaitEvent(s0, join, 0)); }
+    CHECK(hipEventRecord(e1, s0));
+    CHECK(hipEventSynchronize(e1));
+    float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+    unsigned herr = 0; CHECK(hipMemcpy(&herr, err, 4, hipMemcpyDeviceToHost));
+    printf("eager 8 MiB %-36s %7.2f us per node%s\n", overlap ? "two streams + counters" : "one stream", ms * 1e3 / N, herr ? "   [a spin gave up]" : "");
+    fflush(stdout);
+    CHECK(hipMemset(err, 0, 64));
+  }
   for (const Mode& m : modes) {
     hipGraph_t g; hipGraphExec_t ge;
     CHECK(hipStreamBeginCapture(s0, hipStreamCaptureModeGlobal));
@@ -128,7 +151,7 @@ int main() {
     CHECK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
     for (int it = 0; it < 3; ++it) CHECK(hipGraphLaunch(ge, s0));
     CHECK(hipStreamSynchronize(s0));
-    const int reps = 20;
+    const int reps = 5;
     CHECK(hipEventRecord(e0, s0));
     for (int it = 0; it < reps; ++it) CHECK(hipGraphLaunch(ge, s0));
     CHECK(hipEventRecord(e1, s0));
@@ -137,6 +160,8 @@ int main() {
     unsigned herr = 0; CHECK(hipMemcpy(&herr, err, 4, hipMemcpyDeviceToHost));
     const double us = ms * 1e3 / reps / N;
     printf("%-48s %7.2f us per node   %6.2f TB/s%s\n", m.name, us, m.bytes / us / 1e6, herr ? "   [a spin gave up]" : "");
+    fflush(stdout);
+    CHECK(hipMemset(err, 0, 64));
     CHECK(hipGraphExecDestroy(ge)); CHECK(hipGraphDestroy(g));
   }
   return 0;
