@@ -243,6 +243,16 @@ class DecodeLayer(torch.nn.Module):
         lut = getattr(lin, "lut", None)
         return ops.w4_linear_fused(x, lin.weight, lin.group_size, lin.scales_and_zeros, lut, **kw)
 
+    def launches(self) -> int:
+        """Kernel launches of one decode step of this layer on the fused path (after the first step has settled `_fuse`)."""
+        f = self._fuse
+        n = 5  # qkv GEMM, attention, o GEMM (+ residual), gate_up GEMM, down GEMM (+ residual)
+        n += 0 if f.get("norm1") else 1                      # RMSNorm in front of qkv as its own launch
+        if not f.get("mlp"):
+            n += 0 if f.get("norm2") else 1                  # RMSNorm in front of gate_up
+            n += 0 if f.get("swiglu") else 1                 # SwiGLU behind it
+        return n
+
     def fusable(self) -> bool:
         """The four linears hold Bint4 weights behind the row-major weights-on-the-right kernel (what w4_linear_fused drives)."""
         ok = ("linear_y_f16RM_x_f16RM_W_any4TC", "linear_y_f16RM_x_f16RM_W_int4TC")
@@ -443,6 +453,10 @@ class DecodeStack(torch.nn.Module):
         with torch.cuda.graph(g):
             self._out = self.step()
         self._graph = g
+        if self.fused and self.fuse_gemm_stages and self.world == 1 and all(layer.fusable() for layer in self.layers):
+            self.kernels_per_layer = self.layers[0].launches()
+            # + embedding gather, final norm, LM head
+            self.graph_nodes = sum(layer.launches() for layer in self.layers) + 2 + (1 if self.lm_head is not None else 0)
 
     @torch.no_grad()
     def decode(self, tokens: torch.Tensor, position: int) -> torch.Tensor:

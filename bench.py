@@ -103,6 +103,20 @@ def make_args(_lib, w, x, q, lut, y, m, n, k, g, qtype, on_right, inner, batch, 
         stride_y=y.stride(0) * 2, numerics=_lib.TG_NUM_FAST if numerics == "fast" else _lib.TG_NUM_REFERENCE)
 
 
+def calibrate_x(run, x, y):
+    """Scale the activations IN PLACE by a power of two (exact in bf16: every product, sum and rounding of the GEMM scales with it) so
+    that the largest output lies in (0.95, 1.9]: where north_star's 1e-2 is quoted (the captured fixture: max|y| = 2.2) and one bf16
+    output step is 7.8e-3.  `run` launches the GEMM once; returns the scale."""
+    run()
+    torch.cuda.synchronize()
+    ymax = max(float(torch.nan_to_num(y.float(), nan=0.0, posinf=0.0, neginf=0.0).abs().max().item()), 1e-30)
+    import math
+
+    sc = 2.0 ** math.floor(math.log2(1.9 / ymax))
+    x.mul_(sc)
+    return sc
+
+
 def attach_workspace(lib, aa, device):
     """The scratch tg_gemm_w4_workspace_bytes asks for (m > 1 at k = 4096: the activations are re-arranged once per launch
     for the pair-table kernel).  Allocated once, outside every timed region; the returned tensor keeps it alive."""
@@ -180,15 +194,15 @@ def check_layers(w, x, q, lut, y, g, qtype, on_right, inner, plan, layers=(0, 1,
         steps = max(steps, int(d[top].max()) if top.any() else 0)
     scale = 2.2 / max(ymax, 2.2)
     step = float(np.exp2(np.floor(np.log2(max(ymax, 1e-30))) - 7))  # one bf16 step of the largest output
-    if not formula * scale <= 1e-2:
-        raise SystemExit(f"bench.py: {qtype}: the kernel's arithmetic is {formula:.3e} from the reference's before the output rounding at "
-                         f"max|y| = {ymax:.3f} ({formula * scale:.3e} at the fixture's scale): outside north_star's 1e-2")
-    if not err_ref16 <= max(1e-2 / scale, step):
-        raise SystemExit(f"bench.py: {qtype} output is {err_ref16:.3e} from the reference-faithful bf16 result at max|y| = {ymax:.3f}: "
-                         f"more than one bf16 step ({step:.3e}) and more than 1e-2 at the fixture's scale")
+    # north_star's contract, RAW: the activations of every leg are scaled (calibrate_x: by a power of two, exact in bf16) so that
+    # max|y| lies in (0.95, 1.9] -- the order of the captured fixture's 2.2, below the binade where ONE bf16 step is
+    # already 1.6e-2 -- and there the output must be within 1e-2 max-abs of the reference-faithful bf16 result, no other clause
+    if not (ymax < 2.0 and formula <= 1e-2 and err_ref16 <= 1e-2):
+        raise SystemExit(f"bench.py: {qtype}: max-abs {err_ref16:.3e} from the reference-faithful bf16 result (arithmetic before the output "
+                         f"rounding: {formula:.3e}) at max|y| = {ymax:.3f}: outside north_star's 1e-2 at max|y| < 2")
     return {"max_abs_err_vs_kernel_formula": own, "kernel_formula": "group_scaled" if plan in ("pair", "gemv") else "reference",
             "max_abs_err_vs_reference": err_ref16, "max_abs_err_vs_reference_f32": err_ref32, "max_abs_y": ymax,
-            "one_bf16_step_at_max_abs_y": step,
+            "one_bf16_step_at_max_abs_y": step, "contract": "max_abs_err_vs_reference <= 1e-2 at max|y| < 2 (raw)",
             "max_abs_err_vs_reference_at_fixture_scale": err_ref16 * scale,
             "formula_distance_f32": formula, "formula_distance_f32_at_fixture_scale": formula * scale,
             "frac_outputs_differing_from_reference_bf16": round(differ / max(total, 1), 5), "max_bf16_steps_from_reference_in_top_binade": steps,
@@ -285,7 +299,7 @@ def decode_leg(device, steps=48, warmup=8, start_pos=128, layers=None):
     4-bit linears + the 16-bit LM head + the KV cache read at the timed positions."""
     from any4_amd.decode import Any4Factory, DecodeConfig, DecodeStack
 
-    cfg = DecodeConfig.llama3_8b(max_seq=1024)
+    cfg = DecodeConfig.llama3_8b(max_seq=1024, gate_up_interleave=8)  # (gate / up rows in blocks of 8 + 8: SwiGLU rides in the GEMM's store)
     if layers is not None:
         cfg.layers = layers
     stack = DecodeStack(cfg, Any4Factory(cfg, device, torch.bfloat16, seed=1), device, torch.bfloat16, bs=1)
@@ -391,11 +405,9 @@ def decode_shaped_exchange(lib, _lib, w, x, sz, lut, y, m, n, k, g, inner, devic
     return out
 
 
-def pmc_traffic(L, bytes_per_launch, timeout_s=240):
-    """HBM bytes per launch of the dominant kernel from the PMC counters, measured live: two rocprofv3 passes (FETCH_SIZE and
-    WRITE_SIZE do not fit one pass on gfx950) over `bench.py --roofline-only` in a child process, corrected as
-    MI355X_MICROARCH.md (HBM section) prescribes: FETCH_SIZE counts the 128-byte requests of 16-byte-per-lane streaming reads
-    at 64 bytes -> read bytes = 2 x FETCH_SIZE[KB] x 1024; WRITE_SIZE[KB] x 1024 as reported.  Returns (bytes or None, note)."""
+def pmc_mean(counters, extra, timeout_s=240):
+    """Mean over the GEMM kernel's dispatches of each PMC counter in `counters` -- one rocprofv3 pass per counter (never together
+    with a trace) over `bench.py --roofline-only <extra>` in a child process.  Returns ({counter: mean}, None) or (None, why)."""
     import csv
     import glob
     import shutil
@@ -409,10 +421,10 @@ def pmc_traffic(L, bytes_per_launch, timeout_s=240):
     tmp = tempfile.mkdtemp(prefix="bench_pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp")
     try:
-        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        for ctr in counters:
             d = os.path.join(tmp, ctr)
             cmd = [prof, "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "pmc", "--", sys.executable,
-                   os.path.abspath(__file__), "--roofline-only", "--steps", "3", "--warmup", "2", "--settle-s", "0.02", "--layers", str(L)]
+                   os.path.abspath(__file__), "--roofline-only", "--steps", "3", "--warmup", "2", "--settle-s", "0.02", *extra]
             try:
                 subprocess.run(cmd, cwd="/tmp", env=env, timeout=timeout_s, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
             except (subprocess.SubprocessError, OSError) as e:
@@ -427,10 +439,34 @@ def pmc_traffic(L, bytes_per_launch, timeout_s=240):
             vals[ctr] = sum(rows) / len(rows)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+    return vals, None
+
+
+def pmc_traffic(L, bytes_per_launch, timeout_s=240):
+    """HBM bytes per launch of the dominant kernel from the PMC counters, measured live: two rocprofv3 passes (FETCH_SIZE and
+    WRITE_SIZE do not fit one pass on gfx950) over `bench.py --roofline-only` in a child process, corrected as
+    MI355X_MICROARCH.md (HBM section) prescribes: FETCH_SIZE counts the 128-byte requests of 16-byte-per-lane streaming reads
+    at 64 bytes -> read bytes = 2 x FETCH_SIZE[KB] x 1024; WRITE_SIZE[KB] x 1024 as reported.  Returns (bytes or None, note)."""
+    vals, why = pmc_mean(("FETCH_SIZE", "WRITE_SIZE"), ["--layers", str(L)], timeout_s)
+    if vals is None:
+        return None, why
     rd, wr = 2.0 * vals["FETCH_SIZE"] * 1024.0, vals["WRITE_SIZE"] * 1024.0
     return int(rd + wr), (f"live: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `bench.py --roofline-only --layers {L}`; "
                           f"mean over the kernel's dispatches: FETCH_SIZE {vals['FETCH_SIZE']:.0f} KB x 2 (gfx950 correction for 16-B/lane streaming reads) "
                           f"+ WRITE_SIZE {vals['WRITE_SIZE']:.0f} KB = {(rd + wr) / bytes_per_launch:.4f} x the algorithmic bytes")
+
+
+def pmc_mfma_util():
+    """MfmaUtil (percent of cycles the matrix pipe is busy, rocprofv3's derived counter) of the legs the metric / BASELINE config 3
+    name it for -- north_star: 'MFMA utilisation at m=8/16' -- live, one child pass each; None where a pass failed."""
+    out = {}
+    for name, extra in (("m8", ["--m", "8", "--layers", "256"]), ("m16", ["--m", "16", "--layers", "256"]),
+                        ("config3", ["--m", "8", "--n", "8192", "--k", "8192", "--layers", "64", "--left"])):
+        vals, why = pmc_mean(("MfmaUtil",), extra)
+        out[name] = round(vals["MfmaUtil"], 2) if vals else None
+        if vals is None:
+            out[name + "_note"] = why
+    return out
 
 
 def main():
@@ -447,6 +483,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode", action="store_true", help="skip the Llama-3-8B decode leg (config 5)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 PMC passes that fill roofline.traffic")
+    ap.add_argument("--left", action="store_true", help="weights on the left (weightOnRight=False ops) in the library's default packed format")
     ap.add_argument("--roofline-only", action="store_true",
                     help="skip the informational legs (other configs, single-layer, cpu): every launch of the stacked "
                          "kernel is then a timed-shape launch, which is what the rocprofv3 --stats pass wants")
@@ -471,19 +508,24 @@ def main():
 
     lib = _lib.load()
     L, m, n, k, g, inner = a.layers, a.m, a.n, a.k, a.group, 4
-    w, x, sz, lut, y = make_batch(L, m, n, k, g, inner, device, seed=1234 + rank)
+    on_right = not a.left
+    w, x, sz, lut, y = make_batch(L, m, n, k, g, inner, device, seed=1234 + rank, on_right=on_right)
     if world > 1:
         # replicated activations: every rank sees rank 0's x (as after the previous layer's all-gather)
         dist.broadcast(x, src=0)
         y_all = torch.empty(world, L, m, n, device=device, dtype=torch.bfloat16)
 
-    args = make_args(_lib, w, x, sz, lut, y, m, n, k, g, "any4_rowwise", True, inner, L)
+    args = make_args(_lib, w, x, sz, lut, y, m, n, k, g, "any4_rowwise", on_right, inner, L, native=True)
     args_ws = attach_workspace(lib, args, device)  # noqa: F841  (kept alive)
-    plan = ops.gemm_w4_plan(m, n, k, g, QT["any4_rowwise"], True, inner, torch.bfloat16, L, "fast")
+    plan = ops.gemm_w4_plan(m, n, k, g, QT["any4_rowwise"], on_right, inner, torch.bfloat16, L, "fast", weight_format="native")
     stream = torch.cuda.current_stream()
 
     def launch(aa):
         _lib.check(lib.tg_gemm_w4(ctypes.byref(aa), local_rank, stream.cuda_stream), "tg_gemm_w4")
+
+    x_scale = calibrate_x(lambda: launch(args), x, y)
+    if world > 1:
+        dist.broadcast(x, src=0)
 
     def step():
         launch(args)
@@ -566,11 +608,11 @@ def main():
 
         # marginal rate: slope of launch time over the number of stacked layers -- measured first, while the
         # clock is still in the steady state of the timed region
-        half = make_args(_lib, w, x, sz, lut, y, m, n, k, g, "any4_rowwise", True, inner, L // 2)
+        half = make_args(_lib, w, x, sz, lut, y, m, n, k, g, "any4_rowwise", on_right, inner, L // 2, native=True)
         t_half, t_full = timed(half, 40), timed(args, 40)
         slope_us = (t_full - t_half) / (L - L // 2)
         # (a) the timed launch's own output against the oracle
-        main_check = check_layers(w, x, sz, lut, y, g, "any4_rowwise", True, inner, plan)
+        main_check = check_layers(w, x, sz, lut, y, g, "any4_rowwise", on_right, inner, plan, native=True)
 
         def leg(qtype, mm, nn, kk, gg, on_right, layers, note, numerics="fast", native=True):
             """One more BASELINE config as a stacked launch of `layers` layers (same protocol: steady clock, HIP events).
@@ -578,6 +620,7 @@ def main():
             ww, xx, qq, ll, yy = make_batch(layers, mm, nn, kk, gg, inner, device, 77, qtype, on_right)
             aa = make_args(_lib, ww, xx, qq, ll, yy, mm, nn, kk, gg, qtype, on_right, inner, layers, numerics, native)
             ws = attach_workspace(lib, aa, device)  # noqa: F841
+            xs = calibrate_x(lambda: launch(aa), xx, yy)
             wf = "native" if native else "reference"
             pl = ops.gemm_w4_plan(mm, nn, kk, gg, QT[qtype], on_right, inner, torch.bfloat16, layers, numerics, weight_format=wf)
             pld = ops.gemm_w4_plan(mm, nn, kk, gg, QT[qtype], on_right, inner, torch.bfloat16, layers, numerics, detail=True, weight_format=wf)
@@ -587,7 +630,7 @@ def main():
             chk = check_layers(ww, xx, qq, ll, yy, gg, qtype, on_right, inner, pl, layers=(0, -1), rows=128, native=native)
             return {"us_per_layer": round(us, 4), "GBps": round(bl / us / 1e3, 2), "frac": round(bl / us / 1e3 / HBM_PEAK_GBPS, 4),
                     "algorithmic_bytes_per_layer": bl, "layers_per_launch": layers, "kernel_plan": pld, "numerics": numerics,
-                    "check": chk, "note": note}
+                    "check": chk, "x_scale": xs, "note": note}
 
         # N > 1: the other configs, the single-launch figures, the decode leg and the CPU baselines are N = 1 facts (the driver's
         # N = 1 run carries them): rank 0 does not keep the other ranks waiting in the final barrier for them
@@ -702,6 +745,7 @@ def main():
                             f"one step = {L} independent layers (distinct cold weights) in one stacked launch"
                             + (f"; rows sharded over {world} ranks + RCCL all-gather of y" if world > 1 else ""),
                 "layers_per_step": L, "m": m, "n": n, "k": k, "group": g,
+                "x_scale": x_scale,  # activations = randn * this power of two (calibrate_x): max|y| in (0.95, 1.9]
                 "algorithmic_bytes_per_layer": bytes_layer,
                 "numerics": "TG_NUM_FAST (group-scaled: scale / zero applied per quantisation group to the f32 accumulator; the reference "
                             "rounds every dequantised weight to bf16 first, MatrixLayoutB.cuh:1042-1046 -- see `numerics_check` for the distance "
@@ -746,6 +790,23 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_torch(m, n, k, g)
             out["cpu_baseline_c_oracle"] = cpu_baseline_oracle(m, n, k, g)
+        if world == 1:
+            # the LAST key of the line: what a reader of its tail needs -- the metric's second point (m = 8), the other BASELINE
+            # configs as fractions of the 8 TB/s HBM roofline, MFMA utilisation where the metric asks for it, the decode step
+            fr = lambda name, sub=None: (legs.get(name, {}) if sub is None else legs.get(name, {}).get(sub, {})).get("frac")  # noqa: E731
+            out["legs_summary"] = {
+                "frac_of_hbm_roofline": {"m1": round(achieved / HBM_PEAK_GBPS, 4), "m8": fr("m8"), "m16": fr("m16"), "config3": fr("config3"),
+                                         "config3_reference_words": fr("config3_reference_words"), "int4": fr("int4"), "nf4": fr("nf4"),
+                                         "mx4": fr("mx4"), "reference_numerics_m1": fr("reference_numerics", "m1"),
+                                         "reference_numerics_m8": fr("reference_numerics", "m8")},
+                "mfma_util_percent": None if a.no_pmc else pmc_mfma_util(),
+                "single_layer_us": {"any4_b_side_back_to_back": single_b.get("us_per_launch_back_to_back"),
+                                    "any4_b_side_per_graph_node": single_b.get("us_per_launch_in_hipgraph"),
+                                    "int4_a_side_per_graph_node": single_a.get("us_per_launch_in_hipgraph")},
+                "decode_llama3_8b": None if not decode or "error" in decode else
+                {"ms_per_token": decode["ms_per_token"], "frac_of_hbm_roofline": decode["frac_of_hbm_roofline"],
+                 "kernels_per_layer": decode["kernels_per_layer"]},
+            }
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
