@@ -53,7 +53,11 @@ class PeerWriteGather:
     overwritten by the call after the next one.
     """
 
-    def __init__(self, m_max: int, cols_local: int, group=None, device=None, dtype=torch.bfloat16, timeout_us: int = 2_000_000):
+    def __init__(self, m_max: int, cols_local: int, group=None, device=None, dtype=torch.bfloat16, timeout_us: int = 2_000_000,
+                 graph_timeout_us: int = 50_000):
+        """timeout_us: bound of a call's wait for its peers (eager calls: ranks may be seconds apart after a compile or a load).
+        graph_timeout_us: the bound baked into launches recorded under stream capture -- a replayed decode step runs in lock step,
+        and a dead rank must turn a 2 ms token into tens of milliseconds before poll() raises, not into minutes."""
         from . import _lib
 
         if dtype not in (torch.bfloat16, torch.float16):
@@ -70,6 +74,7 @@ class PeerWriteGather:
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.dev_index = self.device.index
         self.m_max, self.cols_local, self.dtype, self.timeout_us = m_max, cols_local, dtype, timeout_us
+        self.graph_timeout_us = min(graph_timeout_us, timeout_us)
         self.buf_bytes = (m_max * cols_local * self.world * 2 + 255) & ~255
         # control block: flags uint32[16] | seq uint32[16] | status uint32
         self.ctl_bytes = 256
@@ -148,6 +153,7 @@ class PeerWriteGather:
         self._calls += 1
         a = self._args[parity]
         a.src, a.m = y_local.data_ptr(), m
+        a.timeout_us = self.graph_timeout_us if torch.cuda.is_current_stream_capturing() else self.timeout_us
         self._L.check(self.lib.tg_peer_gather_launch(ctypes.byref(a), self.dev_index, torch.cuda.current_stream(self.device).cuda_stream),
                       "tg_peer_gather_launch")
         return self._views[parity][: m * self.world * self.cols_local * 2].view(self.dtype).view(m, self.world * self.cols_local)

@@ -348,3 +348,4 @@ def test_accuracy_loop_with_real_kernels():
     prof.run_profiling(model, lambda m: m(input_ids=ids, use_cache=False), warmup=1, iters=2)
     s = prof.summarize()
     assert len(prof.timings) == 4 and s["attention_time"] > 0 and s["mlp_time"] > 0
+

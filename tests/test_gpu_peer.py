@@ -14,6 +14,17 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+def _place(rank, one_gpu_per_rank):
+    """Device index of a rank: its own GPU when the box has one per rank (the xGMI hop, uncached cross-device stores and RCCL are
+    then really exercised), else GPU 0 for every rank (one-GPU boxes)."""
+    return rank if one_gpu_per_rank else 0
+
+
+PLACEMENTS = [pytest.param(False, id="same_device"),
+              pytest.param(True, id="one_gpu_per_rank",
+                           marks=pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (runs unattended on a multi-GPU box)"))]
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -25,16 +36,17 @@ def _expected(rank, call, m, cols, dtype):
     return torch.randn(m, cols, generator=g).to(dtype)
 
 
-def _worker(rank, world, port, cols, m_max, calls, dtype_name):
+def _worker(rank, world, port, cols, m_max, calls, dtype_name, multi):
     import torch.distributed as dist
 
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    torch.cuda.set_device(0)
+    dev = _place(rank, multi)
+    torch.cuda.set_device(dev)
     dtype = getattr(torch, dtype_name)
     from any4_amd.shard import PeerWriteGather
 
-    pg = PeerWriteGather(m_max, cols, device="cuda:0", dtype=dtype, timeout_us=5_000_000)
+    pg = PeerWriteGather(m_max, cols, device=f"cuda:{dev}", dtype=dtype, timeout_us=5_000_000)
     try:
         for call in range(calls):
             m = 1 + call % m_max
@@ -53,19 +65,22 @@ def _worker(rank, world, port, cols, m_max, calls, dtype_name):
 
 
 @pytest.mark.timeout(180)
+@pytest.mark.parametrize("multi", PLACEMENTS)
 @pytest.mark.parametrize("cols,m_max,dtype_name", [(2048, 8, "bfloat16"), (512, 16, "float16")])
-def test_peer_write_gather_two_processes(cols, m_max, dtype_name):
+def test_peer_write_gather_two_processes(cols, m_max, dtype_name, multi):
     import torch.multiprocessing as mp
 
-    mp.spawn(_worker, args=(2, _free_port(), cols, m_max, 24, dtype_name), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), cols, m_max, 24, dtype_name, multi), nprocs=2, join=True)
 
 
-def _linear_worker(rank, world, port):
+def _linear_worker(rank, world, port, multi, gather="peer"):
     import torch.distributed as dist
 
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    torch.cuda.set_device(0)
+    dev = _place(rank, multi)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl" if gather == "rccl" else "gloo", rank=rank, world_size=world)
+    DEVN = f"cuda:{dev}"
     import tinygemm  # noqa: F401
     from any4_amd.shard import build_row_sharded_any4
 
@@ -74,17 +89,18 @@ def _linear_worker(rank, world, port):
     codes = torch.randint(0, 16, (n, k), dtype=torch.int32, generator=gen)
     lut = torch.randn(n, 16, generator=gen).bfloat16()
     sz = torch.stack([torch.rand(k // g, n, generator=gen) * 0.02 + 0.005, torch.randn(k // g, n, generator=gen) * 0.01], dim=2).bfloat16()
-    full = build_row_sharded_any4(codes, lut, sz, None, g, 0, 1, "cuda:0", torch.bfloat16)  # world 1: the unsharded layer
-    shard = build_row_sharded_any4(codes, lut, sz, None, g, rank, world, "cuda:0", torch.bfloat16)
-    shard.gather = "peer"
+    full = build_row_sharded_any4(codes, lut, sz, None, g, 0, 1, DEVN, torch.bfloat16)  # world 1: the unsharded layer
+    shard = build_row_sharded_any4(codes, lut, sz, None, g, rank, world, DEVN, torch.bfloat16)
+    shard.gather = gather
     try:
         for m in (1, 3, 8):
-            x = torch.randn(m, k, generator=gen).bfloat16().cuda()
+            x = torch.randn(m, k, generator=gen).bfloat16().to(DEVN)
             y = shard(x)  # (a copy by default: RowShardedLinear.alias_output=False)
             y_ref = full.local(x)
             torch.cuda.synchronize()
             assert torch.equal(y.view(torch.int16), y_ref.view(torch.int16)), f"rank {rank} m={m}"
-        shard._peer.check()
+        if shard._peer is not None:
+            shard._peer.check()
     finally:
         if shard._peer is not None:
             shard._peer.close()
@@ -92,19 +108,31 @@ def _linear_worker(rank, world, port):
 
 
 @pytest.mark.timeout(180)
-def test_row_sharded_any4_linear_with_peer_gather():
+@pytest.mark.parametrize("multi", PLACEMENTS)
+def test_row_sharded_any4_linear_with_peer_gather(multi):
     """Two ranks, each with half the weight rows of an Any4Linear, gather through PeerWriteGather: bit-equal to the unsharded layer."""
     import torch.multiprocessing as mp
 
-    mp.spawn(_linear_worker, args=(2, _free_port()), nprocs=2, join=True)
+    mp.spawn(_linear_worker, args=(2, _free_port(), multi), nprocs=2, join=True)
 
 
-def _decode_worker(rank, world, port, results):
+@pytest.mark.timeout(240)
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one GPU per rank (runs unattended on a multi-GPU box)")
+def test_row_sharded_any4_linear_with_rccl_all_gather():
+    """The same layer with the exchange SURVEY 8(e) names first: RCCL all_gather_into_tensor over xGMI, one process per GPU."""
+    import torch.multiprocessing as mp
+
+    mp.spawn(_linear_worker, args=(2, _free_port(), True, "rccl"), nprocs=2, join=True)
+
+
+def _decode_worker(rank, world, port, results, multi):
     import torch.distributed as dist
 
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    torch.cuda.set_device(0)
+    dev = _place(rank, multi)
+    torch.cuda.set_device(dev)
+    DEVN = f"cuda:{dev}"
     from any4_amd.decode import DecodeConfig, DecodeStack, shard_rows
 
     cfg = DecodeConfig(hidden=256, inter=512, layers=2, heads=4, kv_heads=2, head_dim=64, vocab=128, max_seq=32, group_size=128)
@@ -114,15 +142,15 @@ def _decode_worker(rank, world, port, results):
             full_rows = {n: o for n, o, _ in cfg.linear_shapes()}[name]
             gen = torch.Generator().manual_seed(1000 * layer + sum(map(ord, name)))
             wt = torch.randn(full_rows, in_features, generator=gen) / in_features ** 0.5
-            lin = torch.nn.Linear(in_features, rows, bias=False, device="cuda:0", dtype=torch.bfloat16)
-            lin.weight.data = wt[shard_rows(cfg, name, r, w)].contiguous().to("cuda:0", torch.bfloat16)
+            lin = torch.nn.Linear(in_features, rows, bias=False, device=DEVN, dtype=torch.bfloat16)
+            lin.weight.data = wt[shard_rows(cfg, name, r, w)].contiguous().to(DEVN, torch.bfloat16)
             return lin
         return make
 
-    toks = torch.randint(0, cfg.vocab, (5, 2), generator=torch.Generator().manual_seed(3)).cuda()
+    toks = torch.randint(0, cfg.vocab, (5, 2), generator=torch.Generator().manual_seed(3)).to(DEVN)
     try:
-        full = DecodeStack(cfg, factory(0, 1), "cuda:0", torch.bfloat16, bs=2, seed=7)
-        tp = DecodeStack(cfg, factory(rank, world), "cuda:0", torch.bfloat16, bs=2, rank=rank, world=world, seed=7, gather="peer")
+        full = DecodeStack(cfg, factory(0, 1), DEVN, torch.bfloat16, bs=2, seed=7)
+        tp = DecodeStack(cfg, factory(rank, world), DEVN, torch.bfloat16, bs=2, rank=rank, world=world, seed=7, gather="peer")
         ref = torch.stack([full.decode(t, i).float().clone() for i, t in enumerate(toks)])
         eager = torch.stack([tp.decode(t, i).float().clone() for i, t in enumerate(toks)])
         # ... and the same steps replayed from one captured hipGraph (the gather kernels keep their sequence number on the device)
@@ -141,13 +169,14 @@ def _decode_worker(rank, world, port, results):
 
 
 @pytest.mark.timeout(180)
-def test_tensor_parallel_decode_with_peer_gather():
+@pytest.mark.parametrize("multi", PLACEMENTS)
+def test_tensor_parallel_decode_with_peer_gather(multi):
     """TP = 2 decode stack (heads / rows split, 4 exchanges per layer through PeerWriteGather, HIP glue kernels) against the
     unsharded stack, eager and replayed from a hipGraph; both ranks live on the one GPU of the box."""
     import torch.multiprocessing as mp
 
     results = mp.Manager().dict()
-    mp.spawn(_decode_worker, args=(2, _free_port(), results), nprocs=2, join=True)
+    mp.spawn(_decode_worker, args=(2, _free_port(), results, multi), nprocs=2, join=True)
     assert set(results.keys()) == {0, 1}
     for rank, (err_eager, err_graph, calls) in results.items():
         assert err_eager < 3e-2, (rank, err_eager)   # bf16 GEMMs of different shapes (row shards) and summation orders
