@@ -205,6 +205,19 @@ int prepare_lds_kernel() {
 }
 
 
+// compute units of the current device (write-once cache per device index; racing threads store the same value)
+inline int cu_count() {
+  static std::atomic<int> cache[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  int v = cache[dev].load(std::memory_order_relaxed);
+  if (v > 0) return v;
+  if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+  cache[dev].store(v, std::memory_order_relaxed);
+  return v;
+}
+
+
 // Tuning constants of the pair-table launches, each with the measurement that set it.  The shipped library
 // always uses these values; only developer builds (-DTG_DEV / -DTG_DEV_MIN, dev/build_variant.sh) may override one with -D<NAME>=<v>.
 #if !defined(TG_DEV) && !defined(TG_DEV_MIN)

@@ -9,18 +9,6 @@ namespace {
 #define TG_GEMV_MAX_TILES 16384  // 8-row tiles per launch up to which this kernel takes single-problem launches (131072 rows)
 #endif
 
-// compute units of the current device (write-once cache per device index; racing threads store the same value)
-int cu_count() {
-  static std::atomic<int> cache[64];
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
-  int v = cache[dev].load(std::memory_order_relaxed);
-  if (v > 0) return v;
-  if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-  cache[dev].store(v, std::memory_order_relaxed);
-  return v;
-}
-
 template <typename DT, int M, int GPS, int D, bool NORM>
 int go(const GemvParams& gp, dim3 grid, unsigned lds, hipStream_t st) {
   constexpr auto kern = w4_gemv_kernel<DT, M, GPS, D, NORM>;
@@ -51,7 +39,7 @@ int go_m(int m, int gps, int d, bool norm, const GemvParams& gp, dim3 grid, unsi
   }
 }
 #if GEMV_TRACE
-unsigned long long* g_trace = nullptr;  // developer builds only (-DGEMV_TRACE=1): [slots][256 workgroups][8 stamps]
+unsigned long long* g_trace = nullptr;  // developer builds only (-DGEMV_TRACE=1): [slots][512 workgroups][8 stamps]
 int g_trace_slots = 0, g_trace_launch = 0;
 #endif
 }  // namespace
@@ -80,15 +68,21 @@ int tgx::gemv(int dt, int I, bool qmx, GemmParams& p, int64_t batch, hipStream_t
   if (p.ntiles % gp.unit != 0) return TG_PAIR_NA;
   const int units = p.ntiles / gp.unit;
   const int cus = p.dry ? 256 : cu_count();
+  // one workgroup per CU (two per CU were measured on gate_up of Llama-3-8B: the second workgroup of a CU trails the first by 3 us
+  // through its prologue and the launch ends no earlier -- the CU's instruction issue, not latency, bounds the main loop)
   const int wgs = units < cus ? units : cus;
   const int tpw = ((units + wgs - 1) / wgs) * gp.unit;  // tiles of the largest range
   gp.P = tpw <= 1 ? 8 : tpw <= 2 ? 16 : 32;
+  // a step covers SS = 32 / P consecutive super-tiles: they must all lie inside the matrix (the kernel's addressing has no per-lane
+  // clamp), so k = 64 x odd runs 32-row passes whatever the range, k = 128 x odd at least 16-row passes
+  if (p.ksuper % 2 != 0) gp.P = 32;
+  else if (p.ksuper % 4 != 0 && gp.P < 16) gp.P = 16;
   gp.p_shift = gp.P == 8 ? 3 : gp.P == 16 ? 4 : 5;
   const int tpp = gp.P / 8;
   const int passes = (tpw + tpp - 1) / tpp;
-  gp.spw = (p.ksuper + 7) / 8;
   const int SS = 32 / gp.P;
-  gp.spp = (gp.spw + SS - 1) / SS;
+  gp.spw = ((p.ksuper + 7) / 8 + SS - 1) / SS * SS;  // a wave's slice: whole steps
+  gp.spp = gp.spw / SS;
   const int d = gp.spp <= 4 ? 4 : 8;  // ring depth: a pass occupies whole rounds of D slots
   gp.rounds = (gp.spp + d - 1) / d;
   gp.ubase = units / wgs;
@@ -107,7 +101,7 @@ int tgx::gemv(int dt, int I, bool qmx, GemmParams& p, int64_t batch, hipStream_t
   if (p.dry) return TG_PLAN_GEMV;
   const dim3 grid((unsigned)wgs, (unsigned)batch);
 #if GEMV_TRACE
-  if (g_trace && g_trace_slots > 0) gp.trace = g_trace + (size_t)(g_trace_launch++ % g_trace_slots) * 256 * 8;
+  if (g_trace && g_trace_slots > 0) gp.trace = g_trace + (size_t)(g_trace_launch++ % g_trace_slots) * 512 * 8;
 #endif
   return dt == TG_BF16 ? go_m<BF16>(p.m, gps, d, p.norm_w != nullptr, gp, grid, lds, st)
                        : go_m<F16>(p.m, gps, d, p.norm_w != nullptr, gp, grid, lds, st);

@@ -40,18 +40,20 @@ int launch_pair_xr_n(GemmParams& p, int64_t batch, hipStream_t st) {
   xp.bias = p.bias; xp.stride_bias = p.stride_bias; xp.bias_row_stride = p.bias_row_stride;
   xp.y_tc = p.y_tc; xp.y_tiles = (p.wrows + 15) / 16; xp.dry = p.dry;
   if (p.dry) return TG_PLAN_PAIR_XR;
+  const unsigned wgs = (unsigned)cu_count();  // one 8-wave workgroup per compute unit, whatever the part has
+  if (items < 2 * (int64_t)wgs) return TG_PAIR_NA;
 #define TG_XR_LAUNCH(CPG_)                                                  \
   do {                                                                      \
     constexpr auto kern = w4_gemm_xr_kernel<DT, I, NCH, CPG_, (NCH > 16 ? TG_XR_R8K : TG_XR_R)>; \
     const int prc = prepare_lds_kernel<kern>();                             \
-    if (prc != 0) return prc;                                               \
-    hipLaunchKernelGGL(kern, dim3(256), dim3(512), lds, st, xp);            \
+    if (prc != 0) return prc == TG_E_INTERNAL ? prc : TG_PAIR_NA; /* (a part with less LDS: the older kernels take over) */ \
+    hipLaunchKernelGGL(kern, dim3(wgs), dim3(512), lds, st, xp);            \
   } while (0)
   if constexpr (QMX) {
     constexpr auto kern = w4_gemm_xr_kernel<DT, I, NCH, 1, TG_XR_RMX, true>;
     const int prc = prepare_lds_kernel<kern>();
-    if (prc != 0) return prc;
-    hipLaunchKernelGGL(kern, dim3(256), dim3(512), lds, st, xp);
+    if (prc != 0) return prc == TG_E_INTERNAL ? prc : TG_PAIR_NA;
+    hipLaunchKernelGGL(kern, dim3(wgs), dim3(512), lds, st, xp);
   } else {
 #ifdef TG_DEV_MIN
   TG_XR_LAUNCH(4);

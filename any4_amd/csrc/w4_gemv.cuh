@@ -112,7 +112,6 @@ __global__ void __launch_bounds__(512, 2) w4_gemv_kernel(const GemvParams p) {
   const int SS = 32 >> p.p_shift;                      // super-tiles per step
   const int s_begin = wave * p.spw;
   const int s_end = min(s_begin + p.spw, p.ksuper);
-  const int s_last = (s_end > s_begin ? s_end : p.ksuper) - 1;
   const int spp = p.spp;                               // real steps of a pass
   const int rounds = p.rounds;                         // rounds of D ring slots a pass occupies: ceil(spp / D)
 
@@ -129,22 +128,27 @@ __global__ void __launch_bounds__(512, 2) w4_gemv_kernel(const GemvParams p) {
   Slot ring[D];
   // issue pointer: pass ip, slot ii of the pass (slots >= spp re-read the pass's last step); per-pass lane offsets
   int ip = 0, ii = 0;
-  uint32_t wlane, qlane;  // byte offsets of this lane's row in super-tile 0 / in a group's scale | zero words
+  // Addressing: every address of the main loop = (wave-uniform part that moves with the step, scalar registers) + (per-lane
+  // offset fixed for the pass).  The host guarantees ksuper % SS == 0 (it raises P otherwise), so a step's SS super-tiles are
+  // all inside the matrix or all outside: no per-lane clamp, and (su + ss) >> sg == (su >> sg) + (ss >> sg) for the group index.
+  uint32_t wlane, qlane;  // byte offsets of this lane's row and sub-slot in super-tile 0 / in group 0's scale | zero words
+  const uint32_t qrow_bytes = (uint32_t)p.wrows * 4u;
   auto pass_lane = [&](int pass) {
     const int tile = min(t0 + pass * tpp + (row_l >> 3), t1 - 1);
-    wlane = (uint32_t)tile * (uint32_t)p.ksuper * 256u + (uint32_t)((row_l & 7) * 32 + h * 16);
-    qlane = (uint32_t)(tile * 8 + (row_l & 7)) * 4u;
+    wlane = (uint32_t)tile * (uint32_t)p.ksuper * 256u + (uint32_t)((row_l & 7) * 32 + h * 16 + ss * 256);
+    qlane = (uint32_t)(tile * 8 + (row_l & 7)) * 4u + (uint32_t)(GPS == 1 ? (ss >> p.sg_shift) : 2 * ss) * qrow_bytes;
   };
   pass_lane(0);
   const int slots = rounds * D;
+  const int su_max = p.ksuper - SS;
   auto issue = [&](Slot& sl) {
-    const int s = min(s_begin + min(ii, spp - 1) * SS + ss, s_last);
-    sl.w = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wb + (wlane + (uint32_t)s * 256u)));
+    const int su = min(s_begin + min(ii, spp - 1) * SS, su_max);  // (scalar) first super-tile of the step; past the end: the last one
+    sl.w = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wb + (uint32_t)su * 256u + wlane));
     if constexpr (GPS == 1) {
-      sl.q[0] = *reinterpret_cast<const uint32_t*>(qb + ((uint32_t)(s >> p.sg_shift) * (uint32_t)p.wrows * 4u + qlane));
+      sl.q[0] = *reinterpret_cast<const uint32_t*>(qb + (uint32_t)(su >> p.sg_shift) * qrow_bytes + qlane);
     } else {
-      sl.q[0] = *reinterpret_cast<const uint32_t*>(qb + ((uint32_t)(2 * s) * (uint32_t)p.wrows * 4u + qlane));
-      sl.q[1] = *reinterpret_cast<const uint32_t*>(qb + ((uint32_t)(2 * s + 1) * (uint32_t)p.wrows * 4u + qlane));
+      sl.q[0] = *reinterpret_cast<const uint32_t*>(qb + (uint32_t)(2 * su) * qrow_bytes + qlane);
+      sl.q[1] = *reinterpret_cast<const uint32_t*>(qb + (uint32_t)(2 * su + 1) * qrow_bytes + qlane);
     }
     if (++ii == slots) {  // (wave-uniform) the next slot belongs to the next pass; past the last pass the last slot is re-read
       ii = 0;
@@ -381,30 +385,39 @@ __global__ void __launch_bounds__(512, 2) w4_gemv_kernel(const GemvParams p) {
     }
   };
 
+  const uint32_t xlane = lds_x + (uint32_t)(ss * 128 + h * 32), xslane = lds_xs + (uint32_t)((ss * 2 + h) * 8);
   auto consume = [&](const Slot& sl, int i) {  // step i of the current pass (wave-uniform, < spp)
-    const int s_l = s_begin + i * SS + ss;
-    const bool on = s_l < s_end;
-    const int s = min(s_l, s_last);
-    const uint32_t xa = lds_x + (uint32_t)(s * 128 + h * 32);
-    const uint32_t xsa = lds_xs + (uint32_t)((s * 2 + h) * 8);
+    const int su_l = s_begin + i * SS;
+    const bool on = su_l < s_end;          // (wave-uniform: a step is inside the wave's slice or not)
+    const int su = min(su_l, su_max);
+    const uint32_t xa = xlane + (uint32_t)su * 128u;
+    const uint32_t xsa = xslane + (uint32_t)su * 16u;
     float dsum[M][GPS];
 #pragma unroll
     for (int a = 0; a < M; ++a)
 #pragma unroll
       for (int g = 0; g < GPS; ++g) dsum[a][g] = 0.f;
+    // all 16 lookups and the 4 activation pieces per row of the step are requested before the first product: with two waves per
+    // SIMD the LDS latency is otherwise paid once per packed word
+    uint32_t e[4][4];
+    u32x4 xf[M][4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int jc = u >> 1, qq = u & 1;  // 32-k chunk of the super-tile, quad of the half
       const uint32_t w = sl.w[qq * 2 + jc];
-      uint32_t e[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) e[j] = *(lds_cu32ptr)(__builtin_amdgcn_perm(w, colreg, 0x0c0c0400u + ((uint32_t)j << 8)));
+      for (int j = 0; j < 4; ++j) e[u][j] = *(lds_cu32ptr)(__builtin_amdgcn_perm(w, colreg, 0x0c0c0400u + ((uint32_t)j << 8)));
 #pragma unroll
-      for (int a = 0; a < M; ++a) {
-        const u32x4 xf = *(lds_cu32x4ptr)(xa + (uint32_t)(a * p.x_pitch + jc * 64 + qq * 16));
+      for (int a = 0; a < M; ++a) xf[a][u] = *(lds_cu32x4ptr)(xa + (uint32_t)(a * p.x_pitch + jc * 64 + qq * 16));
+    }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) dsum[a][GPS == 1 ? 0 : jc] = dot2_pair<DT>(e[j], xf[j], dsum[a][GPS == 1 ? 0 : jc]);
-      }
+    for (int u = 0; u < 4; ++u) {
+      const int jc = u >> 1;
+#pragma unroll
+      for (int a = 0; a < M; ++a)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dsum[a][GPS == 1 ? 0 : jc] = dot2_pair<DT>(e[u][j], xf[a][u][j], dsum[a][GPS == 1 ? 0 : jc]);
     }
 #pragma unroll
     for (int g = 0; g < GPS; ++g) {

@@ -472,22 +472,39 @@ def w4_linear_fused(x, w, q_group, qinfo, lut=None, *, residual=None, norm_weigh
     inner, wrows = w.size(3) * 2, w.size(0) * 8
     m, k = x.shape
     _check(w.size(1) * inner * 16 == k, "weights: k super-tiles do not match the activations' k")
+    _check(m > 0, "activations must have at least one row")
+    _check(inner in (2, 4, 8), "Bint4 weights: innermost dim must be 1, 2 or 4")
+    _check(q_group in (32, 64, 128, 256) and k % q_group == 0, "qGroupSize must be 32, 64, 128 or 256 and divide k")
+    _check(w.device == x.device, "weights must be on the activations' device")
+    # the operand shapes the kernels index by (a mismatched tensor would be read out of bounds, not rejected): the checks of _w4_rm
     qtype = TG_Q_INT4
     if lut is not None:
-        _check(lut.dtype == x.dtype and lut.is_contiguous(), "LUT dtype must match the activations")
+        _check(lut.dtype == x.dtype and lut.is_contiguous() and lut.device == x.device, "LUT must be contiguous, of the activations' dtype, on their device")
+        _check((lut.dim() == 1 and lut.size(0) == 16) or (lut.dim() == 2 and lut.size(0) == wrows and lut.size(1) == 16),
+               "int4DequantValues must be [16] or [weight rows (tile padded)][16]")
         qtype = TG_Q_ANY4_GLOBAL if lut.dim() == 1 else TG_Q_ANY4_ROWWISE
+        if lut.data_ptr() % 16:
+            lut = lut.clone()
     elif qinfo.dtype == torch.uint8:
         qtype = TG_Q_MX4
     _check(qinfo.is_contiguous() and qinfo.device == x.device, "quantization info must be contiguous on the activations' device")
+    if qtype == TG_Q_MX4:
+        _check(x.dtype == torch.bfloat16, "mx4 supports bfloat16 activations only")
+        _check(qinfo.dim() == 2 and qinfo.size(0) == wrows and qinfo.size(1) == k // q_group, "mx4Exponents must be [weight rows (tile padded)][k / qGroupSize]")
+    else:
+        _check(qinfo.dim() == 3 and qinfo.dtype == x.dtype and tuple(qinfo.shape) == (k // q_group, wrows, 2),
+               "qScaleAndZeros must be [k / qGroupSize][weight rows (tile padded)][2] of the activations' dtype")
     ycols = wrows // 2 if swiglu else wrows
     if out is None:
         out = torch.empty((m, ycols), dtype=x.dtype, device=x.device)
-    _check(out.shape == (m, ycols) and out.dtype == x.dtype and out.is_contiguous(), "out must be a contiguous [m][n] tensor of the activations' dtype")
+    _check(out.shape == (m, ycols) and out.dtype == x.dtype and out.is_contiguous() and out.device == x.device,
+           "out must be a contiguous [m][n] tensor of the activations' dtype on their device")
     if residual is not None:
         _check(residual.dtype == x.dtype and residual.dim() == 2 and residual.shape[0] == m and residual.shape[1] >= wrows
-               and residual.stride(1) == 1, "residual must be [m][>= n] with unit inner stride")
+               and residual.stride(1) == 1 and residual.device == x.device, "residual must be [m][>= n] with unit inner stride on the activations' device")
     if norm_weight is not None:
-        _check(norm_weight.dtype == x.dtype and norm_weight.numel() == k and norm_weight.is_contiguous(), "norm_weight must be [k] of the activations' dtype")
+        _check(norm_weight.dtype == x.dtype and norm_weight.numel() == k and norm_weight.is_contiguous() and norm_weight.device == x.device,
+               "norm_weight must be [k] of the activations' dtype on their device")
     args = W4Gemm(
         x=x.data_ptr(), w=w.data_ptr(), qinfo=qinfo.data_ptr(), lut=(lut.data_ptr() if lut is not None else None), y=out.data_ptr(),
         m=m, wrows=wrows, k=k, group=q_group, qtype=qtype, dtype=_dt(x), w_on_right=1, inner_k_tiles=inner, batch=1,

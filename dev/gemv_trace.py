@@ -36,7 +36,8 @@ def show(t, nslots, names):
         print(line)
         for nm, j in zip(STAMPS, ORDER):
             v = ts[:, j] - base
-            print(f"       {nm:18s} min {v.min():6.2f}  median {np.median(v):6.2f}  max {v.max():6.2f}")
+            print(f"       {nm:18s} min {v.min():6.2f}  median {np.median(v):6.2f}  max {v.max():6.2f}" +
+                  (f"   (workgroups 0-255: median {np.median(v[:256]):6.2f}; 256-511: median {np.median(v[256:]):6.2f})" if len(v) > 256 else ""))
         prev_end = ts[:, 5].max()
 
 
@@ -51,7 +52,7 @@ def repeat(n):
     sz = torch.rand(K // 128, N, 2, device=dev).bfloat16()
     lut = torch.randn(N, 16, device=dev).bfloat16()
     x = torch.randn(1, K, device=dev).bfloat16()
-    buf = torch.zeros(n * 256 * 8, dtype=torch.int64, device=dev)
+    buf = torch.zeros(n * 512 * 8, dtype=torch.int64, device=dev)
     for w in ws[:2]:
         ops.w4_linear_fused(x, w, 128, sz, lut)
     torch.cuda.synchronize()
@@ -68,7 +69,7 @@ def repeat(n):
     for _ in range(5):
         g.replay()
     torch.cuda.synchronize()
-    t = buf.cpu().numpy().reshape(n, 256, 8).astype(np.float64) * 0.01
+    t = buf.cpu().numpy().reshape(n, 512, 8).astype(np.float64) * 0.01
     show(t, n, ["4096x4096"])
 
 
@@ -88,7 +89,7 @@ def main():
     cfg.layers = a.layers
     cfg.gate_up_interleave = 8
     slots = 4 * a.layers + 8
-    buf = torch.zeros(slots * 256 * 8, dtype=torch.int64, device=dev)
+    buf = torch.zeros(slots * 512 * 8, dtype=torch.int64, device=dev)
     stack = DecodeStack(cfg, Any4Factory(cfg, dev, torch.bfloat16, seed=1), dev, torch.bfloat16, bs=1, lm_head=False)
     tok = torch.randint(0, cfg.vocab, (1,), device=dev)
     for i in range(3):
@@ -104,7 +105,7 @@ def main():
     for i in range(5):
         stack.decode(tok, 140 + i)
     torch.cuda.synchronize()
-    t = buf.cpu().numpy().reshape(slots, 256, 8).astype(np.float64) * 0.01  # us
+    t = buf.cpu().numpy().reshape(slots, 512, 8).astype(np.float64) * 0.01  # us
     show(t, 4 * a.layers, ["qkv(+norm)", "o(+res)", "gate_up(+norm,swiglu)", "down(+res)"])
     at = abuf.cpu().numpy().reshape(64, 8).astype(np.float64)[:32] * 0.01
     base = at[:, 0].min()
