@@ -478,17 +478,19 @@ __global__ void __launch_bounds__(512) rope_attn_online_kernel(const uint16_t* _
   const int g = lane / LPR, i = lane % LPR, grp = wave * RPW + g;
   const int b = blockIdx.x / hl, h = blockIdx.x % hl, rep = hl / kvl, kv = h / rep;
   const uint16_t* row = qkv + (int64_t)b * (hl + 2 * kvl) * D;
-  const u32x4* K = reinterpret_cast<const u32x4*>(k_cache + ((int64_t)b * kvl + kv) * max_seq * D);
-  const u32x4* V = reinterpret_cast<const u32x4*>(v_cache + ((int64_t)b * kvl + kv) * max_seq * D);
+  // (row r, piece i) of this head's K / V at byte ((r * LPR + i) << 4): a 32-bit offset on a scalar base (host: max_seq * d * 2 < 4 GiB)
+  const char* K = reinterpret_cast<const char*>(k_cache + ((int64_t)b * kvl + kv) * max_seq * D);
+  const char* V = reinterpret_cast<const char*>(v_cache + ((int64_t)b * kvl + kv) * max_seq * D);
+  auto piece = [&](const char* base, int r) -> u32x4 { return *reinterpret_cast<const u32x4*>(base + (((uint32_t)r * LPR + (uint32_t)i) << 4)); };
   // the first NSPEC iterations' rows are requested BEFORE the position is known (rows past it are valid memory and masked later):
   // the read of `pos` is a dependent round trip the K / V requests of a short context need not wait for
   constexpr int NSPEC = NI < 2 ? NI : 2;
   u32x4 kk[NI], vv[NI];
 #pragma unroll
   for (int it = 0; it < NSPEC; ++it) {
-    const int64_t rc = min((int64_t)(it * RPI + grp), max_seq - 1);
-    kk[it] = K[rc * LPR + i];
-    vv[it] = V[rc * LPR + i];
+    const int rc = min(it * RPI + grp, (int)max_seq - 1);
+    kk[it] = piece(K, rc);
+    vv[it] = piece(V, rc);
   }
   const int64_t pos = *pos_p;
   if (pos < 0 || pos >= max_seq) return;  // the position lives on the device (graph replays bypass the host check)
@@ -506,8 +508,8 @@ __global__ void __launch_bounds__(512) rope_attn_online_kernel(const uint16_t* _
       if (it < first || base + it * RPI >= S) continue;  // (wave-uniform) iterations past the last position request nothing
       const int r = base + it * RPI + grp;
       const int rc = r < S - 1 ? r : 0;
-      kk[it] = K[(int64_t)rc * LPR + i];
-      vv[it] = V[(int64_t)rc * LPR + i];
+      kk[it] = piece(K, rc);
+      vv[it] = piece(V, rc);
     }
   };
   request(0, NSPEC);
@@ -731,7 +733,9 @@ int dg_rope_attn_online(const void* qkv, const float* cos, const float* sin, con
                         tg_stream_t stream) {
   if (!qkv || !cos || !sin || !pos || !k_cache || !v_cache || !out) return TG_E_NULL;
   if (!(dtype == TG_BF16 || dtype == TG_F16)) return TG_E_DTYPE;
-  if (bs <= 0 || hl <= 0 || kvl <= 0 || hl % kvl != 0 || !(d == 64 || d == 128) || max_seq <= 0 || bs * hl > INT32_MAX) return TG_E_SHAPE;
+  if (bs <= 0 || hl <= 0 || kvl <= 0 || hl % kvl != 0 || !(d == 64 || d == 128) || max_seq <= 0 || bs * hl > INT32_MAX ||
+      max_seq * d * 2 >= ((int64_t)1 << 32))
+    return TG_E_SHAPE;
   if (!aligned16(qkv) || !aligned16(cos) || !aligned16(sin) || !aligned16(k_cache) || !aligned16(v_cache)) return TG_E_ALIGN;
   DeviceScope ds(device);
   if (!ds.ok) return TG_E_DEVICE;

@@ -70,17 +70,29 @@ int launch_xprep(const PairParams& pp, int I, int ma, int64_t batch, hipStream_t
 template <typename DT, int I, int GPS, bool QMX, int NSG>
 int launch_pair_m(PairParams& pp, unsigned lds, hipStream_t st, bool xg, int m, int mregs, bool norm) {
   const bool m1 = m == 1 && TG_PAIR_MR1 == 1 && (QMX || GPS <= TG_PAIR_MR1_GPS);  // (mx4: no per-group state, the specialisation fits at any GPS)
-  if (xg) return m1 ? launch_pair_k<DT, I, GPS, 1, QMX, NSG, true>(pp, lds, st) : launch_pair_k<DT, I, GPS, 4, QMX, NSG, true>(pp, lds, st);
-  if (norm) {
+  // Not instantiated (round 4: every one of them compiled with 70 ... 1100 bytes of scratch per lane, and a scratch reload drains
+  // the weight ring behind vmcnt(0)): the 32-activation-row accumulator sets (m > 8 on staged activations), innerKTiles 8 beyond the
+  // m = 1 kernel of int4 / any4, the fused norm with several groups per super-tile.  Those calls take the next kernel family
+  // (16x16x32 tiles with workspace activations, w4_gemm_pair16_kernel, or the reference-numerics kernels).
+  if (mregs != 4) return TG_PAIR_NA;
+  if constexpr (I == 8) {
     if constexpr (QMX) return TG_PAIR_NA;
     else {
-      if (mregs != 4) return TG_PAIR_NA;
+      if (!m1 || norm) return TG_PAIR_NA;
+      return xg ? launch_pair_k<DT, I, GPS, 1, false, NSG, true>(pp, lds, st) : launch_pair_k<DT, I, GPS, 1, false, NSG>(pp, lds, st);
+    }
+  } else {
+  if (xg) return m1 ? launch_pair_k<DT, I, GPS, 1, QMX, NSG, true>(pp, lds, st) : launch_pair_k<DT, I, GPS, 4, QMX, NSG, true>(pp, lds, st);
+  if (norm) {
+    if constexpr (QMX || GPS > 1) return TG_PAIR_NA;
+    else {
       return m1 ? launch_pair_k<DT, I, GPS, 1, false, NSG, false, false, true>(pp, lds, st)
                 : launch_pair_k<DT, I, GPS, 4, false, NSG, false, false, true>(pp, lds, st);
     }
   }
   if (m1) return launch_pair_k<DT, I, GPS, 1, QMX, NSG>(pp, lds, st);
-  return mregs == 4 ? launch_pair_k<DT, I, GPS, 4, QMX, NSG>(pp, lds, st) : launch_pair_k<DT, I, GPS, 16, QMX, NSG>(pp, lds, st);
+  return launch_pair_k<DT, I, GPS, 4, QMX, NSG>(pp, lds, st);
+  }
 }
 
 template <typename DT, int I, bool QMX>
@@ -365,6 +377,7 @@ int TG_TU_SUF(pair_a)(int I, bool qmx, GemmParams& p, int64_t batch, hipStream_t
   return I == 1 ? pair_a_q<TG_TU_DT, 1>(qmx, p, batch, st) : I == 2 ? pair_a_q<TG_TU_DT, 2>(qmx, p, batch, st) : pair_a_q<TG_TU_DT, 4>(qmx, p, batch, st);
 }
 int TG_TU_SUF(pair_b16)(int I, bool qmx, GemmParams& p, int64_t batch, hipStream_t st) {
-  return I == 2 ? pair_b16_q<TG_TU_DT, 2>(qmx, p, batch, st) : I == 4 ? pair_b16_q<TG_TU_DT, 4>(qmx, p, batch, st) : pair_b16_q<TG_TU_DT, 8>(qmx, p, batch, st);
+  // (innerKTiles 8 on the 16x16x32 tiles compiled with > 100 bytes of scratch per lane: not instantiated)
+  return I == 2 ? pair_b16_q<TG_TU_DT, 2>(qmx, p, batch, st) : I == 4 ? pair_b16_q<TG_TU_DT, 4>(qmx, p, batch, st) : (int)TG_PAIR_NA;
 }
 }  // namespace tgx

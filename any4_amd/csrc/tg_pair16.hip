@@ -83,7 +83,9 @@ int p16_q(bool qmx, const GemmParams& p, int64_t batch, hipStream_t st) {
 }
 template <typename DT>
 int p16_i(int I, bool qmx, const GemmParams& p, int64_t batch, hipStream_t st) {
-  return I == 2 ? p16_q<DT, 2>(qmx, p, batch, st) : I == 4 ? p16_q<DT, 4>(qmx, p, batch, st) : p16_q<DT, 8>(qmx, p, batch, st);
+  // (innerKTiles 8: every instantiation compiled with 76 ... 308 bytes of scratch per lane at the 128-VGPR budget of a 1024-thread
+  //  workgroup -- not instantiated; those layers take the streaming kernels)
+  return I == 2 ? p16_q<DT, 2>(qmx, p, batch, st) : I == 4 ? p16_q<DT, 4>(qmx, p, batch, st) : (int)TG_PAIR_NA;
 }
 }  // namespace
 int tgx::pair16(int dt, int I, bool qmx, const GemmParams& p, int64_t batch, hipStream_t st) {

@@ -43,7 +43,8 @@ def assert_fast_close(oracle, y_hip, codes, x, qinfo, lut, g, qtype, dtype=torch
 
     pad = 8 if on_right else 16
     plan = ops.gemm_w4_plan(x.shape[0], -(-codes.shape[0] // pad) * pad, x.shape[1], g, QT[qtype], on_right, inner, dtype, batch, "fast")
-    assert (plan in ("pair", "gemv")) == expect_pair, f"kernel plan {plan!r}, expected {'pair / gemv' if expect_pair else 'a reference kernel'}"
+    if expect_pair is not None:  # (None: whichever family the library routes this shape to -- the tolerance follows the plan)
+        assert (plan in ("pair", "gemv")) == expect_pair, f"kernel plan {plan!r}, expected {'pair / gemv' if expect_pair else 'a reference kernel'}"
     w = from_bits16(oracle_weights(oracle, codes, g, qtype, qinfo, lut, dtype), dtype).double()
     x64 = x.double()
     y_ref = (x64 @ w.t()).numpy()
@@ -154,7 +155,9 @@ def test_pair_kernel_vs_oracle(T, oracle, qtype, inner, g):
             continue
         codes, x, qinfo, lut = rand_problem(n, k, g, m, qtype, seed=n + k + inner)
         y, copies = run_fast(T, codes, x, qinfo, lut, g, qtype, inner)
-        assert_fast_close(oracle, y, codes, x, qinfo, lut, g, qtype, inner=inner, batch=copies)
+        # innerKTiles 2 / 4: always a pair-table kernel; innerKTiles 8: only the m = 1 kernels of int4 / any4 at g >= 128 are
+        # instantiated (the others compiled with 70 ... 1100 bytes of scratch per lane and were dropped in round 4)
+        assert_fast_close(oracle, y, codes, x, qinfo, lut, g, qtype, inner=inner, batch=copies, expect_pair=True if inner < 8 else None)
 
 
 @pytest.mark.parametrize("m", [1, 2, 3, 4, 5, 7, 8])
@@ -196,8 +199,9 @@ def test_pair_kernel_9_to_16_rows(T, oracle, case):
     n, k, m, g, inner, qtype = case
     codes, x, qinfo, lut = rand_problem(n, k, g, m, qtype, seed=n + k + m)
     y, copies = run_fast(T, codes, x, qinfo, lut, g, qtype, inner, min_items=768)
-    assert ops.gemm_w4_plan(m, -(-n // 8) * 8, k, g, QT[qtype], True, inner, batch=copies) == "pair"
-    assert_fast_close(oracle, y, codes, x, qinfo, lut, g, qtype, inner=inner, batch=copies)
+    if inner < 8:  # (innerKTiles 8 on the 16x16x32 tiles is not instantiated: scratch; those shapes take the reference-numerics kernels)
+        assert ops.gemm_w4_plan(m, -(-n // 8) * 8, k, g, QT[qtype], True, inner, batch=copies) == "pair"
+    assert_fast_close(oracle, y, codes, x, qinfo, lut, g, qtype, inner=inner, batch=copies, expect_pair=True if inner < 8 else None)
 
 
 def _run_xr(T, codes, x, qinfo, lut, g, qtype, copies, bias=None, residual=False, tc=False):
@@ -376,7 +380,8 @@ def test_pair16_single_launch(T, oracle, qtype, inner, g):
         codes, x, qinfo, lut = rand_problem(n, k, g, m, qtype, seed=n + k + inner + 7)
         y, copies = run_fast(T, codes, x, qinfo, lut, g, qtype, inner, min_items=1)
         assert copies == 1
-        assert_fast_close(oracle, y, codes, x, qinfo, lut, g, qtype, inner=inner, batch=1)
+        # (innerKTiles 8 has no single-launch pair-table kernel since round 4 -- scratch --: the streaming kernels take it)
+        assert_fast_close(oracle, y, codes, x, qinfo, lut, g, qtype, inner=inner, batch=1, expect_pair=True if inner < 8 else None)
 
 
 def test_pair16_fp16_bias_and_batch(T, oracle):
@@ -498,8 +503,9 @@ def test_tc_ops_native_fragment_order(T, oracle, qtype, case, monkeypatch):
     want = T.convert_matrix_to_m16n8k16_A_layout(y_rm, 1)
     def boom(*a, **k):
         raise AssertionError("converter launched: the fragment-order path is not native")
-    monkeypatch.setattr(ops, "convert_matrix_from_m16n8k16_A_layout", boom)
-    monkeypatch.setattr(ops, "convert_matrix_to_m16n8k16_A_layout", boom)
+    if inner < 8:  # (innerKTiles 8 has no pair-table kernel for 16 rows: that op converts around a row-major call)
+        monkeypatch.setattr(ops, "convert_matrix_from_m16n8k16_A_layout", boom)
+        monkeypatch.setattr(ops, "convert_matrix_to_m16n8k16_A_layout", boom)
     if qtype == "mx4":
         got = T.tinygemm_y_f16TC_x_f16TC_w_mx4TC(xa, w2, g, d(qi), True)
     elif qtype == "int4":
