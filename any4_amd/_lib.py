@@ -10,7 +10,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libtinygemm_hip.so")
 
 TG_BF16, TG_F16 = 0, 1
 TG_Q_INT4, TG_Q_ANY4_GLOBAL, TG_Q_ANY4_ROWWISE, TG_Q_MX4, TG_Q_INT8 = 0, 1, 2, 3, 4
-TG_NUM_FAST, TG_NUM_REFERENCE = 0, 1
+TG_NUM_FAST, TG_NUM_REFERENCE, TG_NUM_FAST_MFMA = 0, 1, 2
 TG_ABI_VERSION = 6
 TG_PLAN_SPLITK, TG_PLAN_STREAM, TG_PLAN_PAIR, TG_PLAN_PAIR_XR, TG_PLAN_GEMV = 1, 2, 3, 4, 5
 TG_LAYOUT_RM, TG_LAYOUT_TC_A = 0, 1

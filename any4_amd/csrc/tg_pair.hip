@@ -10,7 +10,7 @@
 #endif
 namespace {
 #include "w4_gemm_pair.cuh"
-template <typename DT, int I, int GPS, int MR, bool QMX, int NSG, bool XG = false, int LA = 0, bool NORM = false>
+template <typename DT, int I, int GPS, int MR, bool QMX, int NSG, bool XG = false, int LA = 0, bool NORM = false, int ABLV = TG_PAIR_ABL>
 int launch_pair_k(PairParams& pp, unsigned lds, hipStream_t st) {
 #ifdef TG_DEV_MIN  // developer builds: only the headline instantiation (fast A/B builds)
 #ifndef TG_DEV_GPS
@@ -34,7 +34,7 @@ int launch_pair_k(PairParams& pp, unsigned lds, hipStream_t st) {
   // 128-VGPR budget without spills (ring depth measured irrelevant between 2 and 4)
   // (mx4 on the 32x32x16 tiles converts its weights in registers and has no per-group state in the slots: the usual depth)
   constexpr int RING = (QMX && LA == 0) ? TG_PAIR_R : (MR == 1 && NSG == 4 && LA == 0) ? 4 : GPS > 1 ? (LA ? TG_PAIR_RA1 : 1) : LA == 1 ? TG_PAIR_RA : LA == 2 ? TG_PAIR_RB16 : TG_PAIR_R;
-  constexpr auto kern = w4_gemm_pair_kernel<DT, I, GPS, MR, QMX, RING, NSG, TG_PAIR_ABL, XG, LA, NORM>;
+  constexpr auto kern = w4_gemm_pair_kernel<DT, I, GPS, MR, QMX, RING, NSG, ABLV, XG, LA, NORM>;
   if (pp.dry) return TG_PLAN_PAIR;
   const int prc = prepare_lds_kernel<kern>();
   if (prc != 0) return prc;
@@ -188,6 +188,12 @@ int launch_pair(GemmParams& p, int64_t batch, hipStream_t st) {
     // (a group of ONE super-tile, g = 64 at I = 4, also keeps the run-time test: its fixed-boundary build spills 27 registers,
     //  m = 8 50 % against 59 %)
     const bool fixed = TG_PAIR_NSG2 && (TG_PAIR_NSG2_M1 || !(p.m == 1 && TG_PAIR_MR1 == 1));
+    // TG_NUM_FAST_MFMA: the headline shape's m = 1 kernel with the 32x32x16 MFMA as its contraction (north_star: "dequantized
+    // in-register and fed to bf16 MFMA") instead of the per-lane v_dot2 the default takes -- one instantiation, g = 128 at innerKTiles 4
+    if constexpr (I == 4 && !QMX) {
+      if (p.numerics == TG_NUM_FAST_MFMA && p.m == 1 && !xg && !p.norm_w && fixed && nsg == TG_PAIR_R)
+        return launch_pair_k<DT, I, 1, 1, false, TG_PAIR_R, false, 0, false, 100>(pp, lds, st);
+    }
     if (fixed && nsg == TG_PAIR_R) return TG_PAIR_M(1, TG_PAIR_R);
     // m = 1, a group of ONE super-tile (g = 64 at innerKTiles 4): fixed boundaries too since the dot2 contraction freed the registers
     // (with the MFMA this build spilled 27; 77 -> 81 %), and a group of FOUR super-tiles (g = 256) as one round of a ring of four

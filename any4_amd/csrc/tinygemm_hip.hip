@@ -427,11 +427,11 @@ int launch_w4(int dt, bool LAYOUT_A, int canon, bool QMX, GemmParams& p, int64_t
   // TG_NUM_FAST, weights on the B side: the pair-table kernel (group-scaled numerics) whenever its LDS plan fits
   // (mx4 in BOTH numerics: its dequantised weights, fp4 * 2^(e - 127), are exact 16-bit values however they are formed, so the
   //  pair-table kernels -- which convert them with v_cvt_scalef32_pk_bf16_fp4 -- ARE the reference arithmetic for it)
-  if (p.numerics == TG_NUM_FAST || QMX) {
+  if (p.numerics == TG_NUM_FAST || p.numerics == TG_NUM_FAST_MFMA || QMX) {
     int rc;
     if (!LAYOUT_A) {
       // one layer per launch with up to 4 activation rows (a decode step's GEMMs): its own kernel (w4_gemv.cuh)
-      rc = tgx::gemv(dt, 2 * WPL, QMX, p, batch, st);
+      rc = p.numerics == TG_NUM_FAST_MFMA ? (int)TG_PAIR_NA : tgx::gemv(dt, 2 * WPL, QMX, p, batch, st);  // (w4_gemv contracts with v_dot2)
       if (rc != TG_PAIR_NA) return rc;
       rc = tgx::pair_xr(dt, 2 * WPL, QMX, p, batch, st);
       if (rc != TG_PAIR_NA) return rc;
@@ -644,7 +644,7 @@ static int gemm_w4_impl(const tg_w4_gemm* caller, int device, tg_stream_t stream
   if (!aligned16(a->x) || !aligned16(a->w) || (reinterpret_cast<uintptr_t>(a->qinfo) & 3u)) return TG_E_ALIGN;
   if (a->lut && !aligned16(a->lut)) return TG_E_ALIGN;          // LUT rows are read as two 16-byte vectors
   if (a->bias && (reinterpret_cast<uintptr_t>(a->bias) & 7u)) return TG_E_ALIGN;
-  if (!(a->numerics == TG_NUM_FAST || a->numerics == TG_NUM_REFERENCE) || a->reserved != 0) return TG_E_SHAPE;
+  if (!(a->numerics == TG_NUM_FAST || a->numerics == TG_NUM_REFERENCE || a->numerics == TG_NUM_FAST_MFMA) || a->reserved != 0) return TG_E_SHAPE;
   if (a->workspace && (!aligned16(a->workspace) || a->workspace_bytes < 0)) return TG_E_ALIGN;
   if (!(a->x_layout == TG_LAYOUT_RM || a->x_layout == TG_LAYOUT_TC_A) || !(a->y_layout == TG_LAYOUT_RM || a->y_layout == TG_LAYOUT_TC_A)) return TG_E_LAYOUT;
   if ((a->x_layout || a->y_layout) && (!on_right || a->m % 16 != 0 || a->bias)) return TG_E_LAYOUT;
@@ -652,7 +652,7 @@ static int gemm_w4_impl(const tg_w4_gemm* caller, int device, tg_stream_t stream
   if (!(a->epilogue == TG_EPI_NONE || a->epilogue == TG_EPI_SWIGLU)) return TG_E_SHAPE;
   if (a->norm_weight && !aligned16(a->norm_weight)) return TG_E_ALIGN;
   // the fused stages exist in the TG_NUM_FAST pair-table kernels only (row-major operands)
-  if ((a->norm_weight || a->epilogue) && (a->numerics != TG_NUM_FAST || a->x_layout || a->y_layout)) return TG_E_FUSION;
+  if ((a->norm_weight || a->epilogue) && (a->numerics == TG_NUM_REFERENCE || a->x_layout || a->y_layout)) return TG_E_FUSION;
   if (a->norm_weight && a->k % 2048 != 0) return TG_E_FUSION;
   if (a->epilogue == TG_EPI_SWIGLU && (!on_right || a->bias || a->wrows % 16 != 0)) return TG_E_FUSION;
   const int batch = a->batch > 1 ? a->batch : 1;

@@ -246,7 +246,8 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
   // multiplier slots on 512 useful products and, under the 1400 W cap, clock -- 4 v_dot2 per word instead: 76.3 -> 80.6 % on the
   // headline shape, int4 82.6 -> 84.4 %, global LUT 79.4 -> 84.0 % same-box.  Only with fixed group boundaries (NSG > 0): the
   // run-time group test around it compiles to 128 VGPRs + 200-500 bytes of scratch.
-  constexpr bool DOT = TG_PAIR_M1_DOT && MR == 1 && !T16 && (QMX || NSG > 0);  // (mx4 has no group updates: any NSG)
+  // ABL == 100 (the one non-zero value in the shipped library: tg_w4_gemm.numerics = TG_NUM_FAST_MFMA) keeps the MFMA at m = 1
+  constexpr bool DOT = TG_PAIR_M1_DOT && ABL != 100 && MR == 1 && !T16 && (QMX || NSG > 0);  // (mx4 has no group updates: any NSG)
   constexpr bool MXC = QMX;  // mx4: weights converted by v_cvt_scalef32_pk_bf16_fp4 (mx4_cvt_word), no table, no group updates
   static_assert(!NORM || (!XG && !T16 && !QMX), "fused RMSNorm: the workgroup stages the whole activation block itself");
   constexpr int WAVES = 8;

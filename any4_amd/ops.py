@@ -52,7 +52,7 @@ _F16_TYPES = (torch.bfloat16, torch.float16)
 # ---------------------------------------------------------------------------------------------
 # call-side state the reference's op schemas have no argument for: GEMM numerics and a fused bias
 # ---------------------------------------------------------------------------------------------
-_NUMERICS = {"fast": _lib.TG_NUM_FAST, "reference": _lib.TG_NUM_REFERENCE}
+_NUMERICS = {"fast": _lib.TG_NUM_FAST, "reference": _lib.TG_NUM_REFERENCE, "fast_mfma": _lib.TG_NUM_FAST_MFMA}
 _numerics = os.environ.get("ANY4_NUMERICS", "fast")
 if _numerics not in _NUMERICS:
     raise ImportError(f"ANY4_NUMERICS must be one of {sorted(_NUMERICS)}, got {_numerics!r}")
@@ -62,7 +62,8 @@ _tls = threading.local()
 def get_numerics() -> str:
     """'fast' (default): the 4-bit GEMMs may apply scale / zero per quantisation group to the f32 accumulator instead of to
     every weight (include/tinygemm_hip.h, TG_NUM_FAST: no per-weight rounding, results within the reference's own weight
-    rounding).  'reference': bit-identical dequantised weights (w = RNE16(fma(lut, scale, zero))), as the reference kernels."""
+    rounding).  'reference': bit-identical dequantised weights (w = RNE16(fma(lut, scale, zero))), as the reference kernels.
+    'fast_mfma': 'fast' with the m = 1 contraction of stacked launches on the MFMA instead of v_dot2 (TG_NUM_FAST_MFMA)."""
     return getattr(_tls, "numerics", _numerics)
 
 
@@ -412,7 +413,7 @@ def _w4_rm(A, B, q_group, qinfo, lut, qtype, weight_on_right, opname, frag=False
     if lut is not None and lut.data_ptr() % 16:
         lut = lut.clone()
     if frag:
-        if m == 0 or get_numerics() != "fast":
+        if m == 0 or get_numerics() == "reference":
             return None
         # zero-filled when the last 16-column tile is half used (wrows = 8 * odd): the kernel writes wrows columns
         alloc = torch.zeros if wrows % 16 else torch.empty

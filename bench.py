@@ -100,7 +100,7 @@ def make_args(_lib, w, x, q, lut, y, m, n, k, g, qtype, on_right, inner, batch, 
         m=m, wrows=n, k=k, group=g, qtype=QT[qtype], dtype=_lib.TG_BF16, w_on_right=1 if on_right else 0,
         inner_k_tiles=inner, batch=batch, stride_x=x.stride(0) * 2, stride_w=w.stride(0) * 4,
         stride_qinfo=q.stride(0) * q.element_size(), stride_lut=(lut.stride(0) * 2 if lut is not None else 0),
-        stride_y=y.stride(0) * 2, numerics=_lib.TG_NUM_FAST if numerics == "fast" else _lib.TG_NUM_REFERENCE)
+        stride_y=y.stride(0) * 2, numerics={"fast": _lib.TG_NUM_FAST, "reference": _lib.TG_NUM_REFERENCE, "fast_mfma": _lib.TG_NUM_FAST_MFMA}[numerics])
 
 
 def calibrate_x(run, x, y):
@@ -639,6 +639,7 @@ def main():
             "m16": leg("any4_rowwise", 16, n, k, g, True, L // 2, f"m=16 (the reference's full 16-row tile, TinyGemmImpl.cuh:53-54), n=k={n}, g={g}, Bint4"),
             "config3": leg("any4_rowwise", 8, 8192, 8192, 128, False, 128, "BASELINE config 3: m=8, n=k=8192, g=128, weights on the A side (weightOnRight=False ops), in the packed format convert_matrix_to_m16n8k16_Aint4_layout returns (row-per-lane order, TG_WFMT_ROWS)"),
             "config3_reference_words": leg("any4_rowwise", 8, 8192, 8192, 128, False, 128, "config 3 on a tensor that holds the reference's own Aint4 words (a checkpoint packed by the CUDA implementation, any4_amd.weight_format('reference'))", native=False),
+            "m1_mfma": leg("any4_rowwise", 1, n, k, g, True, L, "the headline workload with the m = 1 contraction on the 32x32x16 MFMA (TG_NUM_FAST_MFMA: north_star's 'fed to bf16 MFMA') instead of the per-lane v_dot2 the default takes", "fast_mfma"),
             "int4": leg("int4", 1, n, k, g, True, L, "BASELINE config 4: uniform int4, m=1"),
             "nf4": leg("any4_global", 1, n, k, g, True, L, "BASELINE config 4: one global 16-entry LUT (the reference's NF4 path), m=1"),
             "mx4": leg("mx4", 1, n, k, 32, True, L, "BASELINE config 4: mx4 (fp4-e2m1 codes, e8m0 exponent per 32), m=1; weights converted by v_cvt_scalef32_pk_bf16_fp4"),
@@ -795,7 +796,7 @@ def main():
             # configs as fractions of the 8 TB/s HBM roofline, MFMA utilisation where the metric asks for it, the decode step
             fr = lambda name, sub=None: (legs.get(name, {}) if sub is None else legs.get(name, {}).get(sub, {})).get("frac")  # noqa: E731
             out["legs_summary"] = {
-                "frac_of_hbm_roofline": {"m1": round(achieved / HBM_PEAK_GBPS, 4), "m8": fr("m8"), "m16": fr("m16"), "config3": fr("config3"),
+                "frac_of_hbm_roofline": {"m1": round(achieved / HBM_PEAK_GBPS, 4), "m1_mfma_contraction": fr("m1_mfma"), "m8": fr("m8"), "m16": fr("m16"), "config3": fr("config3"),
                                          "config3_reference_words": fr("config3_reference_words"), "int4": fr("int4"), "nf4": fr("nf4"),
                                          "mx4": fr("mx4"), "reference_numerics_m1": fr("reference_numerics", "m1"),
                                          "reference_numerics_m8": fr("reference_numerics", "m8")},

@@ -555,6 +555,47 @@ def _stacked_launch(layers, m, n, k, g, qtype, numerics, seed=0, on_right=True):
     return w, x, q, lut, y
 
 
+@pytest.mark.parametrize("qtype", ["any4_rowwise", "int4", "any4_global"])
+def test_m1_dot2_contraction_pinned_to_the_mfma_contraction(oracle, qtype):
+    """The default m = 1 kernel contracts with per-lane v_dot2_f32_bf16 (round 3); TG_NUM_FAST_MFMA runs the same kernel with the
+    32x32x16 MFMA.  Same table, same group scaling, another adder tree: both within the fast-numerics tolerance of the oracle, and
+    of each other within one output ulp + twice the f32 accumulation slack -- with ordinary activations and with activations that
+    contain bf16 DENORMALS and signed zeros (v_dot2 and the MFMA do not promise the same denormal handling: the products of a
+    denormal activation with O(1) table values stay far below the slack either way, which is what this pins)."""
+    from any4_amd import _lib
+
+    layers, m, n, k, g = 8, 1, 4096, 4096, 128
+    for denorm in (False, True):
+        w, x, q, lut, y_dot = _stacked_launch(layers, m, n, k, g, qtype, _lib.TG_NUM_FAST, seed=5)
+        if denorm:
+            xi = x.view(torch.int16)
+            xi[:, :, ::7] &= 0x807f       # exponent 0: denormals and signed zeros
+            x = xi.view(torch.bfloat16)
+        args = dict(layers=layers, m=m, n=n, k=k, g=g, qtype=qtype)
+        y = {}
+        for name, num in (("dot", _lib.TG_NUM_FAST), ("mfma", _lib.TG_NUM_FAST_MFMA)):
+            yy = torch.full((layers, m, n), float("nan"), device=DEV, dtype=torch.bfloat16)
+            L = _lib.load()
+            a = _lib.W4Gemm(x=x.data_ptr(), w=w.data_ptr(), qinfo=q.data_ptr(), lut=(lut.data_ptr() if lut is not None else None),
+                            y=yy.data_ptr(), m=m, wrows=n, k=k, group=g, qtype=QT[qtype], dtype=_lib.TG_BF16, w_on_right=1, inner_k_tiles=4,
+                            batch=layers, stride_x=x.stride(0) * 2, stride_w=w.stride(0) * 4, stride_qinfo=q.stride(0) * 2,
+                            stride_lut=(lut.stride(0) * 2 if lut is not None else 0), stride_y=yy.stride(0) * 2, numerics=num)
+            assert L.tg_gemm_w4_plan(ctypes.byref(a), 0) == _lib.TG_PLAN_PAIR
+            _lib.check(L.tg_gemm_w4(ctypes.byref(a), 0, torch.cuda.current_stream().cuda_stream), name)
+            torch.cuda.synchronize()
+            y[name] = yy
+        for b in (0, layers - 1):
+            codes = torch.from_numpy(oracle.unpack_Bint4(w[b].cpu().numpy(), n, k))[:256]
+            lb = None if lut is None else (lut[b][:256].cpu() if qtype == "any4_rowwise" else lut[b].cpu())
+            qb = q[b][:, :256].contiguous().cpu()
+            for name in ("dot", "mfma"):
+                assert_fast_close(oracle, y[name][b][:, :256], codes, x[b].cpu(), qb, lb, g, qtype, batch=layers)
+            wq = from_bits16(oracle_weights(oracle, codes, g, qtype, qb, lb), torch.bfloat16).double()
+            S = (x[b].cpu().double().abs() @ wq.abs().t()).numpy()
+            d, e = y["dot"][b][:, :256].double().cpu().numpy(), y["mfma"][b][:, :256].double().cpu().numpy()
+            assert (np.abs(d - e) <= ulp16(e, torch.bfloat16) * (1 + 2.0 ** -7) + 8e-6 * S).all(), (qtype, denorm, np.abs(d - e).max())
+
+
 @pytest.mark.parametrize("qtype,g", [("any4_rowwise", 128), ("int4", 128), ("any4_global", 128), ("mx4", 32)])
 @pytest.mark.parametrize("m", [1, 8, 16])
 @pytest.mark.parametrize("numerics", ["fast", "reference"])
