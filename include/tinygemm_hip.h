@@ -195,7 +195,10 @@ typedef struct tg_w4_gemm {
   const void* norm_weight; /* non-NULL: LlamaRMSNorm of the activations inside the launch's activation staging, 16-bit [k]:         */
                            /* x'[a][j] = RNE16(RNE16(x[a][j] * rsqrt(mean_j(x[a][j]^2) + norm_eps)) * norm_weight[j])               */
                            /* (dg_add_rmsnorm's formula).  TG_NUM_FAST pair-table kernels, row-major x, k % 2048 == 0, the          */
-                           /* activation block staged whole on chip; otherwise TG_E_FUSION.                                        */
+                           /* activation block staged whole on chip; otherwise TG_E_FUSION.  Launches that w4_gemv_kernel takes    */
+                           /* (m <= 4, one problem; tg_gemm_w4_plan = TG_PLAN_GEMV) apply the row's factor to the f32 sum instead:  */
+                           /* y[a][row] = RNE16(rsqrt(mean_j(x[a][j]^2) + norm_eps) * sum_j RNE16(x[a][j] * norm_weight[j]) w[row][j]) */
+                           /* -- one rounding of the activation where the separate kernel has two; within 2^-8 sum|x' w| of it.     */
   float norm_eps;
   int32_t epilogue;        /* TG_EPI_NONE or TG_EPI_SWIGLU: the weight rows come in blocks of 16 = 8 "gate" rows followed by the 8  */
                            /* matching "up" rows, and y is [m][wrows / 2]:                                                         */
