@@ -3,6 +3,9 @@
 namespace {
 #include "w4_gemm_pair.cuh"   // shared device helpers (tc_a_index, dot2, chunk_rmsnorm, swiglu16, PairParams); its kernel is not instantiated here
 #include "w4_gemm_pair16.cuh"
+#ifndef TG_P16_XREG_MIN_M
+#define TG_P16_XREG_MIN_M 5  // activation rows from which the A operands are arranged in registers instead of staged through LDS
+#endif
 // Small launches of Bint4 weights (one layer per call): w4_gemm_pair16_kernel, 16 weight rows per workgroup, the whole k-slice
 // of a wave requested up front.  Taken when the launch is too small for the persistent kernel (or its LDS plan does not fit)
 // and the activations (m <= 16 rows) fit in LDS next to the table.
@@ -33,6 +36,13 @@ int launch_pair16(const GemmParams& p, int64_t batch, hipStream_t st) {
   // activation rows that do not fit next to the table are staged one part of k at a time (whole groups per part)
   unsigned lds = 0;
   int phases = 1;
+  // XREG (w4_gemm_pair16.cuh): no LDS for activations, one pass whatever m x k is; one workgroup per CU (two rounds at most)
+  const bool xreg = p.m >= TG_P16_XREG_MIN_M && !p.x_tc && !p.norm_w && wgs <= 512 && p.ksuper % nsg == 0;
+  if (xreg) {
+    pp.x_pitch = 0;
+    pp.lds_xs = pp.lds_x;
+    lds = 65536u;
+  } else
   for (; phases <= (wgs <= 512 && !p.norm_w ? 8 : 1); phases *= 2) {  // (the fused norm needs a row's whole k in one part)
     if (p.ksuper % (phases * nsg) != 0 || p.ngroups % phases != 0) return TG_PAIR_NA;
     const int kp = p.k / phases;
@@ -42,6 +52,7 @@ int launch_pair16(const GemmParams& p, int64_t batch, hipStream_t st) {
     if (lds <= lds_limit) break;
   }
   if (lds > lds_limit) return TG_PAIR_NA;
+  if (xreg) phases = 1;
   pp.phases = phases;
   pp.ksuper_p = p.ksuper / phases;
   pp.spw = ((pp.ksuper_p / nsg + 15) / 16) * nsg;
@@ -52,19 +63,21 @@ int launch_pair16(const GemmParams& p, int64_t batch, hipStream_t st) {
   pp.x_tc = p.x_tc; pp.y_tc = p.y_tc; pp.y_tiles = (p.wrows + 15) / 16;
   if (p.dry) return TG_PLAN_PAIR;
   const dim3 grid((unsigned)((p.wrows + 15) / 16), (unsigned)batch);
-#define TG_P16K(CPG_, NORM_)                                                 \
-  do {                                                                      \
-    constexpr auto kern = w4_gemm_pair16_kernel<DT, I, QMX, CPG_, 1, NORM_>; \
-    const int prc = prepare_lds_kernel<kern>();                             \
-    if (prc != 0) return prc;                                               \
-    hipLaunchKernelGGL(kern, grid, dim3(1024), lds, st, pp);                \
+#define TG_P16K(CPG_, NORM_, XREG_, CH_)                                                \
+  do {                                                                                  \
+    constexpr auto kern = w4_gemm_pair16_kernel<DT, I, QMX, CPG_, 1, NORM_, XREG_, CH_>; \
+    const int prc = prepare_lds_kernel<kern>();                                         \
+    if (prc != 0) return prc;                                                           \
+    hipLaunchKernelGGL(kern, grid, dim3(1024), lds, st, pp);                            \
   } while (0)
-#define TG_P16(CPG_)                                 \
-  do {                                               \
-    if constexpr (!QMX) {                            \
-      if (p.norm_w) { TG_P16K(CPG_, true); break; }  \
-    }                                                \
-    TG_P16K(CPG_, false);                            \
+#define TG_P16(CPG_)                                              \
+  do {                                                            \
+    if constexpr (!QMX) {                                         \
+      if (p.norm_w) { TG_P16K(CPG_, true, false, 4); break; }     \
+    }                                                             \
+    if (xreg && pp.spw <= 4) { TG_P16K(CPG_, false, true, 4); break; }  /* the whole slice in one block */ \
+    if (xreg) { TG_P16K(CPG_, false, true, 2); break; }           \
+    TG_P16K(CPG_, false, false, 4);                               \
   } while (0)
   if constexpr (QMX) TG_P16(1);  // mx4: group = 32
   else if (g == 32) TG_P16(1);

@@ -21,7 +21,20 @@
 //                the 128-VGPR budget of a 1024-thread workgroup; m = 1 launches of more than one round go to the stream kernel.
 //   long k     = a slice of more than CH super-tiles per wave (k = 14336: 14) is walked in blocks of CH with the NEXT block's
 //                words requested before the current one is consumed (two register sets).
+//   XREG       = 5 ... 16 activation rows: the A operands never pass through LDS.  A wave only needs the activations of ITS k-slice:
+//                lane (row i = lane & 15, quarter e = lane >> 4) loads the 16 bytes e of row i's 64-byte chunk (a wave-load = 16 rows
+//                x 64 contiguous bytes, L2 hits after the first workgroup), a 4 x 4 dword transpose across the four lane quarters
+//                (two v_permlane32_swap + two v_permlane16_swap) gives lane (i, q) the dwords q, q + 4, q + 8, q + 12 of the chunk,
+//                four v_perm_b32 put them into the packed words' byte order: 8 vector ops per chunk instead of a trip through LDS --
+//                and no LDS for activations at all, so 16 rows x any k run in ONE pass (the LDS path stages 16 x 4096 in two parts
+//                with two workgroup barriers each; 16 x 14336 in eight).  Rows >= m load row m - 1 again (same addresses: no extra
+//                traffic); their accumulator rows are never stored.  The per-group activation sums of the zero-point term come
+//                from the matrix core as well: one more MFMA per chunk against an all-ones B operand leaves sum_k x[4 q + r][k] in
+//                the accumulator layout of the lane that needs it (no shuffles, no LDS).
 #pragma once
+#ifndef P16_XSCHED
+#define P16_XSCHED 2
+#endif
 #ifndef P16_ABL
 #define P16_ABL 0  // developer ablations (0 in the product)
 #endif
@@ -56,16 +69,24 @@ struct Pair16Params {
 // I   = innerKTiles of the Bint4 layout (2, 4, 8): I / 2 words per lane and super-tile (one per 32-k chunk)
 // CPG = 32-k chunks per quantisation group (1, 2, 4, 8): a full block of CH super-tiles then has its group boundaries at fixed
 //       places of the unrolled code (no branches between the steps)
-template <typename DT, int I, bool QMX, int CPG, int TPW = 1, bool NORM = false>
+// XREG / CH: see the header; CH = super-tiles requested at once (4: k = 4096 at I = 4 is the whole slice; XREG with longer slices: 2,
+//       two register sets of words and activation fragments)
+template <typename DT, int I, bool QMX, int CPG, int TPW = 1, bool NORM = false, bool XREG = false, int CH = 4>
 __global__ void __launch_bounds__(1024) w4_gemm_pair16_kernel(const Pair16Params p) {
   static_assert(!NORM || !QMX, "fused RMSNorm borrows the activation-sum area");
+  static_assert(!XREG || (TPW == 1 && !NORM), "register-resident activations: one tile per workgroup, no fused norm");
   constexpr int WAVES = 16;
   constexpr int NT = WAVES * 64;
   constexpr int CPS = I / 2;  // 32-k chunks (= words per lane) of a super-tile
-  constexpr int CH = 4;       // super-tiles requested at once (k = 4096, I = 4: the whole slice)
   constexpr bool STATIC_G = (CH * CPS) % CPG == 0;
   const uint32_t lds_x = (uint32_t)p.lds_x, lds_xs = (uint32_t)p.lds_xs;
 
+  if constexpr (XREG) {
+    // every kernel argument the prologue needs, touched here: the compiler otherwise fetches them where they are first used --
+    // several dependent scalar-memory round trips in front of the first vector load (w4_gemv.cuh)
+    asm volatile("" ::"s"(p.x), "s"(p.w), "s"(p.qinfo), "s"(p.lut), "s"(p.m), "s"(p.wrows), "s"(p.k), "s"(p.ksuper), "s"(p.spw),
+                 "s"(p.stride_x), "s"(p.stride_w), "s"(p.stride_qinfo), "s"(p.stride_lut), "s"(p.gshift), "s"(p.ngroups), "s"(p.qtype));
+  }
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -127,7 +148,8 @@ __global__ void __launch_bounds__(1024) w4_gemm_pair16_kernel(const Pair16Params
       xd[4 * j] = v[0]; xd[4 * j + 1] = v[1]; xd[4 * j + 2] = v[2]; xd[4 * j + 3] = v[3];
     }
   };
-  if (tid < xtotal) x_load(tid, 0);
+  if constexpr (!XREG)
+    if (tid < xtotal) x_load(tid, 0);
 
   // weights of this lane: row n of each of the workgroup's TPW 16-row tiles, quad q
   int wrow[TPW];
@@ -141,7 +163,43 @@ __global__ void __launch_bounds__(1024) w4_gemm_pair16_kernel(const Pair16Params
   const char* qb = p.qinfo + (int64_t)b * p.stride_qinfo;
   // two register sets where they fit without spills (one tile per workgroup, groups of >= 128): set B is only used when a
   // wave's slice is longer than one block of CH super-tiles (see the main loop)
-  constexpr bool PIPE = TPW == 1 && CPG >= 4;
+  constexpr bool PIPE = TPW == 1 && (XREG ? CH < 4 : CPG >= 4);  // (XREG with CH = 4: the host only sends slices of one block)
+  // XREG: this lane's activation fragments of a block, one per 32-k chunk (as loaded: the 16 bytes (lane >> 4) of row lane & 15's
+  // chunk; after x_arrange: the A operand of the chunk)
+  constexpr int NXF = XREG ? CH * CPS : 1;
+  u32x4 xfA[NXF], xfB[PIPE ? NXF : 1];
+  // address = (wave-uniform chunk base, SGPRs) + (per-lane 32-bit offset: the host checks m k 2 < 4 GiB): the saddr form, no 64-bit
+  // vector address per load
+  uint32_t xoff = (uint32_t)((min(n, p.m - 1) * p.k + 8 * q) * 2);
+  auto x_request = [&](u32x4 (&xf)[NXF], int l0) {
+    if constexpr (XREG) {
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        const int s = l0 + j < nl ? s_begin + l0 + j : 0;  // (past the slice: a cached request, never consumed -- as w_request)
+#pragma unroll
+        for (int jc = 0; jc < CPS; ++jc) {
+          asm volatile("" : "+v"(xoff));  // (opaque at its use: the zero-extension stays next to the load, w4_gemm_pair.cuh `pin`)
+          xf[j * CPS + jc] = *reinterpret_cast<const u32x4*>(xb + (uint32_t)__builtin_amdgcn_readfirstlane((s * CPS + jc) * 64) + xoff);
+        }
+      }
+    }
+  };
+  auto x_arrange = [&](u32x4 (&xf)[NXF]) {
+    if constexpr (XREG) {
+#pragma unroll
+      for (int c = 0; c < NXF; ++c) {
+        // dword j of quarter e -> dword e of quarter j (a 4 x 4 transpose over the lane bits 4, 5): lane (i, q) then holds
+        // d[e] = (x[2 q + 8 e], x[2 q + 8 e + 1]) of the chunk
+        const auto s02 = __builtin_amdgcn_permlane32_swap(xf[c][0], xf[c][2], false, false);
+        const auto s13 = __builtin_amdgcn_permlane32_swap(xf[c][1], xf[c][3], false, false);
+        const auto t01 = __builtin_amdgcn_permlane16_swap(s02[0], s13[0], false, false);
+        const auto t23 = __builtin_amdgcn_permlane16_swap(s02[1], s13[1], false, false);
+        const uint32_t d0 = t01[0], d1 = t01[1], d2 = t23[0], d3 = t23[1];
+        xf[c] = u32x4{__builtin_amdgcn_perm(d1, d0, 0x05040100u), __builtin_amdgcn_perm(d3, d2, 0x05040100u),
+                      __builtin_amdgcn_perm(d1, d0, 0x07060302u), __builtin_amdgcn_perm(d3, d2, 0x07060302u)};
+      }
+    }
+  };
   uint32_t wregA[TPW][CH][CPS], wregB[PIPE ? TPW : 1][PIPE ? CH : 1][PIPE ? CPS : 1];
   uint32_t qregA[TPW][CH][CPS], qregB[PIPE ? TPW : 1][PIPE ? CH : 1][PIPE ? CPS : 1];  // scale | zero word (or mx4 exponent byte) of the group of every chunk
   // Requests the block of CH super-tiles at slice position l0.  Positions past the slice are still requested (the number of loads
@@ -176,7 +234,7 @@ __global__ void __launch_bounds__(1024) w4_gemm_pair16_kernel(const Pair16Params
       }
     }
   };
-  if (P16_ABL != 1) w_request(wregA, qregA, 0);
+  if (P16_ABL != 1) { w_request(wregA, qregA, 0); x_request(xfA, 0); }
   else {
 #pragma unroll
     for (int t = 0; t < TPW; ++t)
@@ -252,7 +310,7 @@ __global__ void __launch_bounds__(1024) w4_gemm_pair16_kernel(const Pair16Params
         if ((idx & 15) >= p.m) *(lds_fptr)(lds_xs + (uint32_t)(idx * 4)) = 0.f;
     if (tid == 0) *(lds_u32x4ptr)(lds_x + (uint32_t)(p.m * p.x_pitch)) = u32x4{0, 0, 0, 0};  // zero piece for padding rows
   };
-  x_stage(0, true);
+  if constexpr (!XREG) x_stage(0, true);
   // (mx4: no table -- the weights are converted in registers by v_cvt_scalef32_pk_bf16_fp4, w4_gemm_pair.cuh: mx4_cvt_word)
 #pragma unroll
   for (int t = 0; t < (QMX ? 0 : TPW); ++t) {
@@ -300,6 +358,9 @@ __global__ void __launch_bounds__(1024) w4_gemm_pair16_kernel(const Pair16Params
     for (int r = 0; r < 4; ++r) yacc[t][r] = 0.f;
   }
   f32x4 xsv = {0.f, 0.f, 0.f, 0.f};
+  f32x4_t xsacc = zero4;  // XREG: the group's activation sums, rows 4 q + r (an MFMA against ones)
+  const uint32_t one2 = DT::pack2(1.f, 1.f);
+  const u32x4 ones = {one2, one2, one2, one2};
 
   if (P16_ABL == 2) {  // loads consumed, nothing computed
 #pragma unroll
@@ -311,8 +372,10 @@ __global__ void __launch_bounds__(1024) w4_gemm_pair16_kernel(const Pair16Params
   }
   int chunk_ph = 0;  // first chunk of the current phase: LDS holds chunks / groups relative to it
   // one 32-k chunk of every tile: 4 lookups + one MFMA per tile, the X fragment read once
-  auto step = [&](const uint32_t (&wreg)[TPW][CH][CPS], const uint32_t (&qreg)[TPW][CH][CPS], int j, int jc, int chunk, bool gfirst, bool glast) {
-    const u32x4 xf = *(lds_cu32x4ptr)(xrow + ((uint32_t)((chunk - chunk_ph) * 64) & xmask));
+  auto step = [&](const uint32_t (&wreg)[TPW][CH][CPS], const uint32_t (&qreg)[TPW][CH][CPS], const u32x4 (&xfr)[NXF], int j, int jc, int chunk, bool gfirst, bool glast) {
+    u32x4 xf;
+    if constexpr (XREG) xf = xfr[j * CPS + jc];
+    else xf = *(lds_cu32x4ptr)(xrow + ((uint32_t)((chunk - chunk_ph) * 64) & xmask));
     u32x4 bf[TPW];
     if constexpr (QMX) {  // the group's scale inside the conversion: accumulators run through the whole slice, nothing per group
 #pragma unroll
@@ -344,10 +407,14 @@ __global__ void __launch_bounds__(1024) w4_gemm_pair16_kernel(const Pair16Params
           gz[t] = DT::hi_f32(qv);
         }
       }
-      if constexpr (!QMX) xsv = *(lds_cf32x4ptr)(xs_lane + (uint32_t)(((((chunk - chunk_ph) * 32) >> p.gshift) * 16) * 4));
+      if constexpr (!QMX && !XREG) xsv = *(lds_cf32x4ptr)(xs_lane + (uint32_t)(((((chunk - chunk_ph) * 32) >> p.gshift) * 16) * 4));
     }
 #pragma unroll
     for (int t = 0; t < TPW; ++t) acc[t] = mfma16<DT>(xf, bf[t], gfirst ? zero4 : acc[t]);
+    if constexpr (XREG && !QMX) {
+      xsacc = mfma16<DT>(xf, ones, gfirst ? zero4 : xsacc);
+      if (glast) xsv = f32x4{xsacc[0], xsacc[1], xsacc[2], xsacc[3]};
+    }
     if (glast) {
 #pragma unroll
       for (int t = 0; t < TPW; ++t)
@@ -359,13 +426,19 @@ __global__ void __launch_bounds__(1024) w4_gemm_pair16_kernel(const Pair16Params
     }
   };
   // the block of CH super-tiles at slice position l0 (its words are in wreg / qreg)
-  auto consume_block = [&](const uint32_t (&wreg)[TPW][CH][CPS], const uint32_t (&qreg)[TPW][CH][CPS], int l0) {
+  auto consume_block = [&](const uint32_t (&wreg)[TPW][CH][CPS], const uint32_t (&qreg)[TPW][CH][CPS], const u32x4 (&xfr)[NXF], int l0) {
     if (STATIC_G && l0 + CH <= nl) {
       // a whole block: the slice starts on a group boundary and CH CPS is a multiple of CPG, so step u starts a group iff
       // u % CPG == 0 -- straight-line code
       const int chunk0 = (s_begin + l0) * CPS;
 #pragma unroll
-      for (int u = 0; u < CH * CPS; ++u) step(wreg, qreg, u / CPS, u % CPS, chunk0 + u, u % CPG == 0, u % CPG == CPG - 1);
+      for (int u = 0; u < CH * CPS; ++u) {
+        step(wreg, qreg, xfr, u / CPS, u % CPS, chunk0 + u, u % CPG == 0, u % CPG == CPG - 1);
+        // XREG: the fragments occupy 4 registers per chunk -- keep the scheduler from hoisting every chunk's lookups to the top of the
+        // block (4 more each); two chunks' lookups in flight per wave, four waves per SIMD hide the rest
+        if constexpr (XREG && P16_XSCHED > 0)
+          if (u % P16_XSCHED == P16_XSCHED - 1) __builtin_amdgcn_sched_barrier(0);
+      }
       return;
     }
 #pragma unroll
@@ -375,13 +448,13 @@ __global__ void __launch_bounds__(1024) w4_gemm_pair16_kernel(const Pair16Params
 #pragma unroll
         for (int jc = 0; jc < CPS; ++jc) {
           const int chunk = s * CPS + jc;
-          step(wreg, qreg, j, jc, chunk, (chunk & p.gch_mask) == 0, (chunk & p.gch_mask) == p.gch_mask);
+          step(wreg, qreg, xfr, j, jc, chunk, (chunk & p.gch_mask) == 0, (chunk & p.gch_mask) == p.gch_mask);
         }
       }
     }
   };
-  for (int ph = 0; ph < p.phases; ++ph) {
-    if (ph > 0) {
+  for (int ph = 0; ph < (XREG ? 1 : p.phases); ++ph) {
+    if (!XREG && ph > 0) {
       // the next part of k: its first weights are requested before the activations are re-staged (two barriers: every wave is
       // done with the previous part's activations / the new ones are visible)
       s_begin = ph * p.ksuper_p + wave * p.spw;
@@ -392,22 +465,28 @@ __global__ void __launch_bounds__(1024) w4_gemm_pair16_kernel(const Pair16Params
     }
     chunk_ph = ph * p.ksuper_p * CPS;
     if (P16_ABL == 2) continue;
-    if (nl <= CH) {  // (wave-uniform) the whole slice was requested up front
-      if (nl > 0) consume_block(wregA, qregA, 0);
+    if (nl <= CH || (XREG && CH == 4)) {  // (wave-uniform) the whole slice was requested up front (XREG, CH = 4: always -- the host's choice)
+      x_arrange(xfA);
+      if (nl > 0) consume_block(wregA, qregA, xfA, 0);
       continue;
     }
     if constexpr (PIPE) {
       // long slices: two blocks per turn, the next block always requested before the current one is consumed
       for (int l0 = 0; l0 < nl; l0 += 2 * CH) {
         w_request(wregB, qregB, l0 + CH);
-        consume_block(wregA, qregA, l0);
+        x_request(xfB, l0 + CH);
+        x_arrange(xfA);
+        consume_block(wregA, qregA, xfA, l0);
         w_request(wregA, qregA, l0 + 2 * CH);
-        if (l0 + CH < nl) consume_block(wregB, qregB, l0 + CH);
+        x_request(xfA, l0 + 2 * CH);
+        x_arrange(xfB);
+        if (l0 + CH < nl) consume_block(wregB, qregB, xfB, l0 + CH);
       }
     } else {
       for (int l0 = 0; l0 < nl; l0 += CH) {
-        if (l0 > 0) w_request(wregA, qregA, l0);
-        consume_block(wregA, qregA, l0);
+        if (l0 > 0) { w_request(wregA, qregA, l0); x_request(xfA, l0); }
+        x_arrange(xfA);
+        consume_block(wregA, qregA, xfA, l0);
       }
     }
   }  // phases

@@ -384,6 +384,48 @@ def test_pair16_single_launch(T, oracle, qtype, inner, g):
         assert_fast_close(oracle, y, codes, x, qinfo, lut, g, qtype, inner=inner, batch=1, expect_pair=True if inner < 8 else None)
 
 
+@pytest.mark.parametrize("qtype,g", [("any4_rowwise", 128), ("any4_rowwise", 32), ("any4_global", 64), ("int4", 256), ("mx4", 32)])
+@pytest.mark.parametrize("shape", [
+    # (n, k, m)            what it exercises in the register-resident-activation path of w4_gemm_pair16_kernel (m >= 5, one launch per layer)
+    (4096, 4096, 16),      # the whole slice in one block (four super-tiles per wave): one launch where the LDS path staged k in two parts
+    (4096, 4096, 5), (200, 4096, 11),   # rows >= m load row m - 1 again; a ragged last 16-row tile
+    (48, 1024, 16), (136, 2048, 8),     # slices of one / two super-tiles (shorter than a block)
+    (64, 8192, 9), (32, 14336, 16),     # long slices: blocks of two super-tiles, two register sets; a ragged last block (14 = 7 x 2)
+    (16, 6144, 7),                      # 96 super-tiles over 16 waves: six each
+])
+def test_pair16_register_resident_activations(T, oracle, qtype, g, shape):
+    n, k, m = shape
+    for dtype in (torch.bfloat16, torch.float16):
+        if qtype == "mx4" and dtype == torch.float16:
+            continue  # mx4 is bf16-only (TinyGemm_int4.cu:758)
+        codes, x, qinfo, lut = rand_problem(n, k, g, m, qtype, dtype=dtype, seed=n + k + m)
+        y, copies = run_fast(T, codes, x, qinfo, lut, g, qtype, 4, min_items=1)
+        assert copies == 1
+        rows = slice(None) if n <= 256 else torch.cat([torch.arange(0, 64), torch.arange(n // 2 - 32, n // 2 + 32), torch.arange(n - 64, n)])
+        q = qinfo[rows] if qtype == "mx4" else qinfo[:, rows].contiguous()
+        lt = lut if lut is None or lut.dim() == 1 else lut[rows].contiguous()
+        # same plan for the sliced problem? the tolerance follows the FULL problem's plan: check it here
+        from any4_amd import ops
+        assert ops.gemm_w4_plan(m, n, k, g, QT[qtype], True, 4, dtype, 1, "fast") == "pair"
+        yy = y[:, rows] if n > 256 else y
+        _check_rows(oracle, yy, codes[rows], x, q, lt, g, qtype, dtype)
+
+
+def _check_rows(oracle, y_hip, codes, x, qinfo, lut, g, qtype, dtype):
+    """assert_fast_close's two tolerances on a subset of the weight rows (the plan was checked by the caller)."""
+    w = from_bits16(oracle_weights(oracle, codes, g, qtype, qinfo, lut, dtype), dtype).double()
+    x64 = x.double()
+    y_ref = (x64 @ w.t()).numpy()
+    S = (x64.abs() @ w.abs().t()).numpy()
+    y_gs = gs_reference(oracle, codes, x, qinfo, lut, g, qtype, dtype)
+    got = y_hip.detach().double().cpu().numpy()[:, :codes.shape[0]]
+    tol = 0.5 * ulp16(y_gs, dtype) * (1 + 2.0 ** -7) + 4e-6 * S + 1e-37
+    bad = np.abs(got - y_gs) > tol
+    assert not bad.any(), f"vs group-scaled oracle: {bad.sum()} / {bad.size} outside tolerance; worst {np.abs(got - y_gs).max()} at {np.argwhere(bad)[:4]}"
+    eps16 = 2.0 ** -9 if dtype == torch.bfloat16 else 2.0 ** -12
+    assert not (np.abs(got - y_ref) > 0.5 * ulp16(y_ref, dtype) * (1 + 2.0 ** -7) + (4e-6 + eps16) * S + 1e-37).any()
+
+
 def test_pair16_fp16_bias_and_batch(T, oracle):
     codes, x, qinfo, lut = rand_problem(96, 1024, 128, 5, "any4_rowwise", dtype=torch.float16, seed=21)
     bias = torch.randn(96).half()
