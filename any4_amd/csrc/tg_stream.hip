@@ -12,6 +12,12 @@ namespace {
 #ifndef STREAM_MINW
 #define STREAM_MINW 4
 #endif
+// Bint4, TG_STREAM_LK_MIN <= m <= 15: the lookup block with the X fragment read under an EXEC mask (w4_gemm_stream.cuh, LK).  Same-box
+// A/B at 4096^2, reference numerics: m = 8 46.9 -> 50.1 % of the roofline; m = 4 50.9 -> 49.8 and m = 1 55.6 -> 54.9 (the block's
+// lgkmcnt(0) costs more than the few lanes' reads save); m = 16 reads with every lane either way.
+#ifndef TG_STREAM_LK_MIN
+#define TG_STREAM_LK_MIN 6
+#endif
 // ---- streaming kernel launch ---------------------------------------------------------------------
 // LDS per workgroup: lookup tables (4 KiB per wave and row set) + two X slabs (+ split-K tiles).
 template <bool LAYOUT_A>
@@ -47,13 +53,20 @@ int launch_stream_sw(StreamParams& sp, int sk, int64_t coltiles, int64_t batch, 
   const unsigned lds = stream_lds_bytes<LAYOUT_A>(SW, mrows, sk, privx);
   const int tpb = SW / sk;
   dim3 grid((unsigned)((sp.rowtiles + tpb - 1) / tpb), (unsigned)coltiles, (unsigned)batch);
-#define TG_LAUNCH_STREAM(XL)                                                                              \
+#define TG_LAUNCH_STREAM_LK(XL, LK_)                                                                      \
   do {                                                                                                    \
-    constexpr auto kern = w4_gemm_stream_kernel<DT, LAYOUT_A, WPL, QMX, SW, STREAM_MINW, XL, privx>;      \
+    constexpr auto kern = w4_gemm_stream_kernel<DT, LAYOUT_A, WPL, QMX, SW, STREAM_MINW, XL, privx, 0, false, LK_>; \
     if (sp.dry) return TG_PLAN_STREAM;                                                                    \
     const int prc = prepare_lds_kernel<kern>();                                                           \
     if (prc != 0) return prc;                                                                             \
     hipLaunchKernelGGL(kern, grid, dim3(SW * 64), lds, st, sp);                                           \
+  } while (0)
+#define TG_LAUNCH_STREAM(XL)                                                                              \
+  do {                                                                                                    \
+    if constexpr (!LAYOUT_A && !privx) {                                                                  \
+      if (sp.m >= TG_STREAM_LK_MIN && sp.m <= 15) { TG_LAUNCH_STREAM_LK(XL, 1); break; }                  \
+    }                                                                                                     \
+    TG_LAUNCH_STREAM_LK(XL, 0);                                                                           \
   } while (0)
   if constexpr (privx && SW > 1) {
     if (xl != 1) return TG_E_SHAPE;  // private slabs with split-K are only instantiated for one piece per lane (m = 1)
@@ -67,6 +80,7 @@ int launch_stream_sw(StreamParams& sp, int sk, int64_t coltiles, int64_t batch, 
     else TG_LAUNCH_STREAM(4);
   }
 #undef TG_LAUNCH_STREAM
+#undef TG_LAUNCH_STREAM_LK
   return launch_status();
 }
 
@@ -78,11 +92,20 @@ int launch_stream_xres(StreamParams& sp, int64_t coltiles, int64_t batch, unsign
   int tpw = 4;
   while (tpw > 1 && ((sp.rowtiles + 16 * tpw - 1) / (16 * tpw)) * coltiles * batch < 512) tpw >>= 1;
   sp.tiles_per_wave = tpw;
-  constexpr auto kern = w4_gemm_stream_kernel<DT, LAYOUT_A, WPL, QMX, 16, STREAM_MINW, 1, false, 0, true>;
   if (sp.dry) return TG_PLAN_STREAM;
+  dim3 grid((unsigned)((sp.rowtiles + 16 * tpw - 1) / (16 * tpw)), (unsigned)coltiles, (unsigned)batch);
+  if constexpr (!LAYOUT_A) {
+    if (sp.m >= TG_STREAM_LK_MIN && sp.m <= 15) {
+      constexpr auto kern = w4_gemm_stream_kernel<DT, LAYOUT_A, WPL, QMX, 16, STREAM_MINW, 1, false, 0, true, 1>;
+      const int prc = prepare_lds_kernel<kern>();
+      if (prc != 0) return prc;
+      hipLaunchKernelGGL(kern, grid, dim3(16 * 64), lds, st, sp);
+      return launch_status();
+    }
+  }
+  constexpr auto kern = w4_gemm_stream_kernel<DT, LAYOUT_A, WPL, QMX, 16, STREAM_MINW, 1, false, 0, true, 0>;
   const int prc = prepare_lds_kernel<kern>();
   if (prc != 0) return prc;
-  dim3 grid((unsigned)((sp.rowtiles + 16 * tpw - 1) / (16 * tpw)), (unsigned)coltiles, (unsigned)batch);
   hipLaunchKernelGGL(kern, grid, dim3(16 * 64), lds, st, sp);
   return launch_status();
 }

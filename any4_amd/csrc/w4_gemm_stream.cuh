@@ -64,8 +64,13 @@ struct StreamParams {
 
 // WPL = packed words per (k super-tile, lane-row) entry: Bint4: I/2, Aint4: I
 // XL  = 16-byte X pieces staged per thread and unit (host picks the smallest that covers the slab)
-template <typename DT, bool LAYOUT_A, int WPL, bool QMX, int WAVES, int MINW, int XL, bool PRIVX, int ABL = 0, bool XRES = false>
+// LK  = 1 (Bint4): the lookups of one MFMA step as ONE block of hand-written LDS instructions (do_chunk) in which the X fragment
+//       is read under an EXEC mask of the lanes whose MFMA column is a real activation row (m = 1: 4 of 64 lanes; the others keep
+//       the zeros their fragment registers were initialised with): a 16-byte LDS read of all 64 lanes costs eight LDS cycles,
+//       a third of this kernel's LDS time at m = 1 (SQ_LDS_IDX_ACTIVE: 2.8 cycles per wave and weight, of which 2 are the lookups).
+template <typename DT, bool LAYOUT_A, int WPL, bool QMX, int WAVES, int MINW, int XL, bool PRIVX, int ABL = 0, bool XRES = false, int LK = 0>
 __global__ void __launch_bounds__(WAVES * 64, MINW) w4_gemm_stream_kernel(const StreamParams p) {
+  static_assert(LK == 0 || !LAYOUT_A, "the hand-written lookup block exists for Bint4 weights");
   constexpr int CHUNK = LAYOUT_A ? 16 : 32;  // k per chunk (one packed word per q)
   constexpr int UNIT = 4 * CHUNK;            // k per unit = 64 packed bytes per lane
   constexpr int NMMA = LAYOUT_A ? 2 : 4;     // MFMAs per chunk
@@ -237,6 +242,9 @@ __global__ void __launch_bounds__(WAVES * 64, MINW) w4_gemm_stream_kernel(const 
   };
 
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  // LK: the X fragment registers (zero in the lanes whose MFMA column is padding, for good) and the lanes that read them
+  u32x4 xz = {0u, 0u, 0u, 0u};
+  const uint64_t xexec = (uint64_t)((1u << mrows) - 1u) * 0x0001000100010001ull;
 
   constexpr bool ONE = WAVES == 1;  // single-wave workgroup: table at LDS offset 0, no table-select bits
   const uint32_t tabbase = ONE ? 0u : (uint32_t)wave * 4096u;
@@ -295,6 +303,46 @@ __global__ void __launch_bounds__(WAVES * 64, MINW) w4_gemm_stream_kernel(const 
           wa[q] = ONE ? (w & 0x0f0f0f0fu) : ((w & 0x0f0f0f0fu) | kmask);                 // bytes: v0 v4 v1 v5
           wb4[q] = ONE ? ((w >> 4) & 0x0f0f0f0fu) : (((w >> 4) & 0x0f0f0f0fu) | kmask);  // bytes: v2 v6 v3 v7
         }
+        if constexpr (LK) {
+#pragma unroll
+          for (int h = 0; h < 4; ++h) {
+            uint32_t al[4], ah[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const uint32_t src = (h & 1) ? wb4[q] : wa[q];
+              al[q] = __builtin_amdgcn_perm(src, lane4, 0x0c0c0400u + ((uint32_t)(h >> 1) << 8));
+              ah[q] = __builtin_amdgcn_perm(src, lane4, 0x0c0c0400u + ((uint32_t)((h >> 1) + 2) << 8));
+            }
+            uint32_t a0, a1, a2, a3, t0, t1, t2, t3;
+            uint64_t sv;
+            // (LDS returns in order and the block ends with lgkmcnt(0): nothing it issued is outstanding when the compiler's own
+            //  bookkeeping resumes; the data of a read arrives >= 64 cycles after its issue, long after the previous MFMA has
+            //  read the operand registers it overwrites.  The d16 load forms would make the merges unnecessary, but with SRAM ECC
+            //  enabled (this part) they clear the other half of the register instead of preserving it.)
+            asm volatile(
+                "ds_read_u16 %0, %10 offset:2\n\t"
+                "ds_read_b32 %4, %11\n\t"
+                "ds_read_u16 %1, %12 offset:2\n\t"
+                "ds_read_b32 %5, %13\n\t"
+                "ds_read_u16 %2, %14 offset:2\n\t"
+                "ds_read_b32 %6, %15\n\t"
+                "ds_read_u16 %3, %16 offset:2\n\t"
+                "ds_read_b32 %7, %17\n\t"
+                "s_mov_b64 %9, exec\n\t"
+                "s_mov_b64 exec, %19\n\t"
+                "ds_read_b128 %8, %18\n\t"
+                "s_mov_b64 exec, %9\n\t"
+                "s_waitcnt lgkmcnt(0)\n\t"
+                "v_or_b32 %0, %0, %4\n\t"
+                "v_or_b32 %1, %1, %5\n\t"
+                "v_or_b32 %2, %2, %6\n\t"
+                "v_or_b32 %3, %3, %7"
+                : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "+v"(xz), "=&s"(sv)
+                : "v"(al[0]), "v"(ah[0]), "v"(al[1]), "v"(ah[1]), "v"(al[2]), "v"(ah[2]), "v"(al[3]), "v"(ah[3]), "v"(xa + 16u * h), "s"(xexec)
+                : "memory");
+            acc = DT::mfma(u32x4{a0, a1, a2, a3}, xz, acc);
+          }
+        } else
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
           u32x4 a;
