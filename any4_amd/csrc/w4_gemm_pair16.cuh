@@ -411,7 +411,7 @@ __global__ void __launch_bounds__(1024) w4_gemm_pair16_kernel(const Pair16Params
     }
 #pragma unroll
     for (int t = 0; t < TPW; ++t) acc[t] = mfma16<DT>(xf, bf[t], gfirst ? zero4 : acc[t]);
-    if constexpr (XREG && !QMX) {
+    if constexpr (XREG && !QMX && P16_ABL != 5) {  // (ablation 5: no activation sums)
       xsacc = mfma16<DT>(xf, ones, gfirst ? zero4 : xsacc);
       if (glast) xsv = f32x4{xsacc[0], xsacc[1], xsacc[2], xsacc[3]};
     }
@@ -466,7 +466,7 @@ __global__ void __launch_bounds__(1024) w4_gemm_pair16_kernel(const Pair16Params
     chunk_ph = ph * p.ksuper_p * CPS;
     if (P16_ABL == 2) continue;
     if (nl <= CH || (XREG && CH == 4)) {  // (wave-uniform) the whole slice was requested up front (XREG, CH = 4: always -- the host's choice)
-      x_arrange(xfA);
+      if (P16_ABL != 6) x_arrange(xfA);  // (ablation 6: fragments used as loaded)
       if (nl > 0) consume_block(wregA, qregA, xfA, 0);
       continue;
     }
