@@ -9,6 +9,10 @@ namespace {
 // Small launches of Bint4 weights (one layer per call): w4_gemm_pair16_kernel, 16 weight rows per workgroup, the whole k-slice
 // of a wave requested up front.  Taken when the launch is too small for the persistent kernel (or its LDS plan does not fit)
 // and the activations (m <= 16 rows) fit in LDS next to the table.
+#if GEMV_TRACE
+unsigned long long* g_p16_trace = nullptr;  // developer builds only (-DGEMV_TRACE=1): [slots][512 workgroups][8 stamps]
+int g_p16_slots = 0, g_p16_launch = 0;
+#endif
 template <typename DT, int I, bool QMX>
 int launch_pair16(const GemmParams& p, int64_t batch, hipStream_t st) {
   if constexpr (QMX && !std::is_same<DT, BF16>::value) return TG_E_DTYPE;  // mx4 is bf16-only (TinyGemm_int4.cu:758)
@@ -63,6 +67,9 @@ int launch_pair16(const GemmParams& p, int64_t batch, hipStream_t st) {
   pp.x_tc = p.x_tc; pp.y_tc = p.y_tc; pp.y_tiles = (p.wrows + 15) / 16;
   if (p.dry) return TG_PLAN_PAIR;
   const dim3 grid((unsigned)((p.wrows + 15) / 16), (unsigned)batch);
+#if GEMV_TRACE
+  pp.trace = (g_p16_trace && g_p16_slots > 0 && grid.x <= 512) ? g_p16_trace + (size_t)(g_p16_launch++ % g_p16_slots) * 512 * 8 : nullptr;
+#endif
 #define TG_P16K(CPG_, NORM_, XREG_, CH_)                                                \
   do {                                                                                  \
     constexpr auto kern = w4_gemm_pair16_kernel<DT, I, QMX, CPG_, 1, NORM_, XREG_, CH_>; \
@@ -101,6 +108,13 @@ int p16_i(int I, bool qmx, const GemmParams& p, int64_t batch, hipStream_t st) {
   return I == 2 ? p16_q<DT, 2>(qmx, p, batch, st) : I == 4 ? p16_q<DT, 4>(qmx, p, batch, st) : (int)TG_PAIR_NA;
 }
 }  // namespace
+#if GEMV_TRACE
+extern "C" TG_API void tg_dev_p16_trace(unsigned long long* buf, int slots) {
+  g_p16_trace = buf;
+  g_p16_slots = slots;
+  g_p16_launch = 0;
+}
+#endif
 int tgx::pair16(int dt, int I, bool qmx, const GemmParams& p, int64_t batch, hipStream_t st) {
   return dt == TG_BF16 ? p16_i<BF16>(I, qmx, p, batch, st) : p16_i<F16>(I, qmx, p, batch, st);
 }

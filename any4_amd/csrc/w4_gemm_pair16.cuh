@@ -64,7 +64,15 @@ struct Pair16Params {
   int32_t epilogue;         // TG_EPI_SWIGLU: rows in blocks of 8 gate + 8 up, y is [m][wrows / 2]
   int32_t x_tc, y_tc;  // 1: activations / output in A-fragment order (tc_a_index, w4_gemm_pair.cuh)
   int32_t y_tiles;     // ceil(wrows / 16)
+#if GEMV_TRACE
+  unsigned long long* trace;  // developer builds (-DGEMV_TRACE=1): [workgroup][8] s_memrealtime stamps
+#endif
 };
+#if GEMV_TRACE
+#define P16_STAMP(i) do { if (p.trace && tid == 0) tr[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define P16_STAMP(i) do { } while (0)
+#endif
 
 // I   = innerKTiles of the Bint4 layout (2, 4, 8): I / 2 words per lane and super-tile (one per 32-k chunk)
 // CPG = 32-k chunks per quantisation group (1, 2, 4, 8): a full block of CH super-tiles then has its group boundaries at fixed
@@ -88,6 +96,10 @@ __global__ void __launch_bounds__(1024) w4_gemm_pair16_kernel(const Pair16Params
                  "s"(p.stride_x), "s"(p.stride_w), "s"(p.stride_qinfo), "s"(p.stride_lut), "s"(p.gshift), "s"(p.ngroups), "s"(p.qtype));
   }
   const int tid = threadIdx.x;
+#if GEMV_TRACE
+  unsigned long long tr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  P16_STAMP(0);
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n = lane & 15, q = lane >> 4;
@@ -310,6 +322,7 @@ __global__ void __launch_bounds__(1024) w4_gemm_pair16_kernel(const Pair16Params
         if ((idx & 15) >= p.m) *(lds_fptr)(lds_xs + (uint32_t)(idx * 4)) = 0.f;
     if (tid == 0) *(lds_u32x4ptr)(lds_x + (uint32_t)(p.m * p.x_pitch)) = u32x4{0, 0, 0, 0};  // zero piece for padding rows
   };
+  P16_STAMP(1);
   if constexpr (!XREG) x_stage(0, true);
   // (mx4: no table -- the weights are converted in registers by v_cvt_scalef32_pk_bf16_fp4, w4_gemm_pair.cuh: mx4_cvt_word)
 #pragma unroll
@@ -333,7 +346,9 @@ __global__ void __launch_bounds__(1024) w4_gemm_pair16_kernel(const Pair16Params
       ((lds_u32ptr)base)[a * 64] = e;  // (one LDS pointer + constant offsets: immediate offset fields, no address arithmetic per store)
     }
   }
+  P16_STAMP(2);
   __syncthreads();
+  P16_STAMP(3);
 
   // ---- main loop ----
   const bool a_on = n < p.m;  // (as the A operand's row index: lane (i = n, q))
@@ -467,6 +482,10 @@ __global__ void __launch_bounds__(1024) w4_gemm_pair16_kernel(const Pair16Params
     if (P16_ABL == 2) continue;
     if (nl <= CH || (XREG && CH == 4)) {  // (wave-uniform) the whole slice was requested up front (XREG, CH = 4: always -- the host's choice)
       if (P16_ABL != 6) x_arrange(xfA);  // (ablation 6: fragments used as loaded)
+#if GEMV_TRACE
+      asm volatile("" ::"v"(xfA[0]), "v"(xfA[NXF - 1]));
+#endif
+      P16_STAMP(4);
       if (nl > 0) consume_block(wregA, qregA, xfA, 0);
       continue;
     }
@@ -498,12 +517,23 @@ __global__ void __launch_bounds__(1024) w4_gemm_pair16_kernel(const Pair16Params
       for (int r = 0; r < 4; ++r) yacc[t][r] = acc[t][r];
   }
   // ---- split-K tail: partial sums of the 16 waves meet in the (now unused) table's LDS, added in wave order ----
+#if GEMV_TRACE
+  asm volatile("" ::"v"(yacc[0][0]), "v"(yacc[0][3]));
+#endif
+  P16_STAMP(5);
   __syncthreads();
 #pragma unroll
   for (int t = 0; t < TPW; ++t)
 #pragma unroll
     for (int r = 0; r < 4; ++r) *(lds_fptr)((uint32_t)((((t * WAVES + wave) * 4 + r) * 64 + lane) * 4)) = yacc[t][r];
   __syncthreads();
+  P16_STAMP(6);
+#if GEMV_TRACE
+  if (p.trace && tid == 0) {
+#pragma unroll
+    for (int i = 0; i < 7; ++i) p.trace[(size_t)blockIdx.x * 8 + i] = tr[i];
+  }
+#endif
   if (tid < 256 * TPW) {
     const int t = tid >> 8, r = (tid >> 6) & 3, l = tid & 63;
     const int a = 4 * (l >> 4) + r, row = row0 + 16 * t + (l & 15);

@@ -41,6 +41,61 @@ def show(t, nslots, names):
         prev_end = ts[:, 5].max()
 
 
+P16_STAMPS = ["entry", "loads issued", "table built", "barrier passed", "fragments arranged", "main loop done", "partial sums visible"]
+
+
+def show_p16(t, nslots):
+    prev_end = None
+    for s in range(nslots):
+        ts = t[s]
+        on = ts[:, 0] > 0
+        if not on.any():
+            continue
+        ts = ts[on]
+        base = ts[:, 0].min()
+        line = f"[{s:2d}] pair16 wgs {on.sum():3d}"
+        if prev_end is not None:
+            line += f"  first entry {base - prev_end:+6.2f} us after the previous launch's last stamp"
+        print(line)
+        for j, nm in enumerate(P16_STAMPS):
+            v = ts[:, j] - base
+            print(f"       {nm:22s} min {v.min():6.2f}  median {np.median(v):6.2f}  max {v.max():6.2f}")
+        prev_end = ts[:, 6].max()
+
+
+def repeat_p16(n, m):
+    """n launches of one 4096 x 4096 layer with m (5 ... 16) activation rows from a graph: w4_gemm_pair16_kernel's stamps."""
+    from any4_amd import _lib, ops
+    import tinygemm  # noqa: F401
+
+    L = _lib.load()
+    dev = torch.device("cuda:0")
+    N = K = 4096
+    ws = [torch.randint(-2 ** 31, 2 ** 31 - 1, (N // 8, K // 64, 32, 2), dtype=torch.int64, device=dev).to(torch.int32) for _ in range(n)]
+    sz = torch.rand(K // 128, N, 2, device=dev).bfloat16()
+    lut = torch.randn(N, 16, device=dev).bfloat16()
+    x = torch.randn(m, K, device=dev).bfloat16()
+    buf = torch.zeros(n * 512 * 8, dtype=torch.int64, device=dev)
+    for w in ws[:2]:
+        ops.w4_linear_fused(x, w, 128, sz, lut)
+    torch.cuda.synchronize()
+    L.tg_dev_p16_trace.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    L.tg_dev_p16_trace.restype = None
+    L.tg_dev_p16_trace(buf.data_ptr(), n)
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(g):
+            y = x
+            for w in ws:
+                y = ops.w4_linear_fused(y, w, 128, sz, lut)
+    for _ in range(5):
+        g.replay()
+    torch.cuda.synchronize()
+    t = buf.cpu().numpy().reshape(n, 512, 8).astype(np.float64) * 0.01
+    show_p16(t, n)
+
+
 def repeat(n):
     from any4_amd import _lib, ops
     import tinygemm  # noqa: F401
@@ -77,7 +132,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--layers", type=int, default=3)
     ap.add_argument("--repeat", type=int, default=0, help="instead of a decode step: this many launches of ONE 4096 x 4096 layer shape back to back (distinct weights), from a graph")
+    ap.add_argument("--m", type=int, default=1, help="with --repeat: activation rows (5 ... 16: the stamps of w4_gemm_pair16_kernel)")
     a = ap.parse_args()
+    if a.repeat and a.m > 4:
+        return repeat_p16(a.repeat, a.m)
     if a.repeat:
         return repeat(a.repeat)
     from any4_amd import _lib
