@@ -5,7 +5,14 @@ namespace {
 #include "w4_gemm_xr.cuh"
 // Bint4 weights, stacked launches, TG_XR_MIN_M ... 16 activation rows, k = 4096: w4_gemm_xr_kernel (one 8-wave workgroup per CU, the
 // activations of a wave's k-slice resident in its registers, 64-row work items, two tables).  No workspace, no pre-pass.
-template <typename DT, int I, bool QMX, int NCH>
+#ifndef TG_XR_WV16
+#define TG_XR_WV16 0  // 1 (developer builds): k = 4096, not mx4, on sixteen k-slices per workgroup (w4_gemm_xr.cuh, WV) -- four waves per
+                      // SIMD instead of two, measured EQUAL at m = 8 (71.5 vs 71.3 %) and slower at m = 16 (67.1 vs 69.0 %): not shipped
+#endif
+#ifndef TG_XR_R16
+#define TG_XR_R16 2   // ring depth of the sixteen-slice variant (a slice is four super-tiles)
+#endif
+template <typename DT, int I, bool QMX, int NCH, int WV = 8>
 int launch_pair_xr_n(GemmParams& p, int64_t batch, hipStream_t st) {
   if constexpr (I != 4 || (QMX && (NCH != 16 || !std::is_same<DT, BF16>::value))) return TG_PAIR_NA;  // (mx4: bf16, k = 4096)
   else {
@@ -44,10 +51,10 @@ int launch_pair_xr_n(GemmParams& p, int64_t batch, hipStream_t st) {
   if (items < 2 * (int64_t)wgs) return TG_PAIR_NA;
 #define TG_XR_LAUNCH(CPG_)                                                  \
   do {                                                                      \
-    constexpr auto kern = w4_gemm_xr_kernel<DT, I, NCH, CPG_, (NCH > 16 ? TG_XR_R8K : TG_XR_R)>; \
+    constexpr auto kern = w4_gemm_xr_kernel<DT, I, NCH, CPG_, (WV == 16 ? TG_XR_R16 : NCH > 16 ? TG_XR_R8K : TG_XR_R), false, WV>; \
     const int prc = prepare_lds_kernel<kern>();                             \
     if (prc != 0) return prc == TG_E_INTERNAL ? prc : TG_PAIR_NA; /* (a part with less LDS: the older kernels take over) */ \
-    hipLaunchKernelGGL(kern, dim3(wgs), dim3(512), lds, st, xp);            \
+    hipLaunchKernelGGL(kern, dim3(wgs), dim3(WV * 64), lds, st, xp);        \
   } while (0)
   if constexpr (QMX) {
     constexpr auto kern = w4_gemm_xr_kernel<DT, I, NCH, 1, TG_XR_RMX, true>;
@@ -74,6 +81,9 @@ int launch_pair_xr_n(GemmParams& p, int64_t batch, hipStream_t st) {
 
 template <typename DT, int I, bool QMX>
 int launch_pair_xr(GemmParams& p, int64_t batch, hipStream_t st) {
+  if constexpr (!QMX && TG_XR_WV16) {
+    if (p.k == 4096 && (1 << p.gshift) <= 256) return launch_pair_xr_n<DT, I, QMX, 8, 16>(p, batch, st);
+  }
   if (p.k == 4096) return launch_pair_xr_n<DT, I, QMX, 16>(p, batch, st);
   // k = 8192: 128 registers of activations per lane leave room for two super-tiles in flight only -- faster than the 16x16x32
   // workspace kernel it replaces at 9 ... 16 rows (8192^2, m = 16: 62 vs 47-51 %), slower than the 32x32x16 one below that

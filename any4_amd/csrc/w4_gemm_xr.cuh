@@ -73,9 +73,13 @@ struct XrParams {
 //       scale 2^(e - 127) inside the conversion: no table, no lookups, no per-group accumulator updates; the word pair of a lane is
 //       swapped BEFORE the conversion (one v_permlane16_swap per stage); the e8m0 exponents of a lane's four rows over its k-slice
 //       are one 16-byte load per row and item, requested one item ahead.  CPG is 1 (a group is one 32-k chunk).
-template <typename DT, int I, int NCH, int CPG, int R, bool QMX = false>
-__global__ void __launch_bounds__(512, 2) w4_gemm_xr_kernel(const XrParams p) {
-  constexpr int WAVES = 8;
+// WV  = waves per workgroup = k-slices (8: two waves per SIMD with 256 registers each; 16: four per SIMD with 128 -- a slice is half
+//       as long, so the activation registers are 32 instead of 64 and the ring two super-tiles deep: the same bytes in flight per CU,
+//       twice the waves to hide LDS and MFMA latency behind)
+template <typename DT, int I, int NCH, int CPG, int R, bool QMX = false, int WV = 8>
+__global__ void __launch_bounds__(WV * 64, WV == 8 ? 2 : 1) w4_gemm_xr_kernel(const XrParams p) {
+  constexpr int WAVES = WV;
+  static_assert(WV == 8 || (WV == 16 && !QMX), "8 or 16 k-slices (mx4: 8)");
   constexpr int CPS = I / 2;                       // 32-k chunks per super-tile
   constexpr int NST = NCH / CPS;                   // super-tiles of a wave's slice
   constexpr int NWL = 2 * CPS;                     // packed words per lane, tile pair and super-tile
@@ -175,7 +179,7 @@ __global__ void __launch_bounds__(512, 2) w4_gemm_xr_kernel(const XrParams p) {
     const char* lsrc = p.lut + (int64_t)e.b * p.stride_lut + (p.qtype == TG_Q_ANY4_ROWWISE ? (int64_t)lrow * 32 : 0);
     lpa = reinterpret_cast<const u32x4*>(lsrc)[0];
     lpb = reinterpret_cast<const u32x4*>(lsrc)[1];
-    lhw = reinterpret_cast<const uint32_t*>(lsrc)[wave];
+    lhw = reinterpret_cast<const uint32_t*>(lsrc)[WAVES == 8 ? wave : wave >> 1];
   };
   // mx4: the 16 exponent bytes of row 16 t + (lane & 15) over this wave's slice, tile t = 0 ... 3, current and next item
   u32x4 ecur[4], enext[4];
@@ -201,10 +205,17 @@ __global__ void __launch_bounds__(512, 2) w4_gemm_xr_kernel(const XrParams p) {
       if (e < 8) lpa[(e >> 1) & 3] = v;
       else lpb[(e >> 1) & 3] = v;
     }
-    lhw = DT::pack2((float)(2 * wave - 8), (float)(2 * wave - 7));
+    lhw = DT::pack2((float)(2 * (WAVES == 8 ? wave : wave >> 1) - 8), (float)(2 * (WAVES == 8 ? wave : wave >> 1) - 7));
   }
   // table build: thread = (column, high nibbles 2 wave and 2 wave + 1); step a = low nibble a: entries (lut[a], lut[2 wave (+1)])
   auto build_step = [&](uint32_t buf, int a, uint32_t hw) {
+    if constexpr (WAVES == 16) {  // thread = (column, high nibble `wave`): one entry per step
+      const uint32_t hsel = (wave & 1) ? 0x07060000u : 0x05040000u;
+      const uint32_t e = __builtin_amdgcn_perm(hw, lpe(a >> 1), hsel | ((a & 1) ? 0x0302u : 0x0100u));
+      const lds_u32ptr tb = (lds_u32ptr)(buf * TABLE + (uint32_t)(wave * 16 * 256 + tcol * 4));
+      tb[a * 64] = e;
+      return;
+    }
     const uint32_t e0 = __builtin_amdgcn_perm(hw, lpe(a >> 1), (a & 1) ? 0x05040302u : 0x05040100u);
     const uint32_t e1 = __builtin_amdgcn_perm(hw, lpe(a >> 1), (a & 1) ? 0x07060302u : 0x07060100u);
     const lds_u32ptr tb = (lds_u32ptr)(buf * TABLE + (uint32_t)(wave * 2 * 16 * 256 + tcol * 4));
@@ -329,7 +340,8 @@ __global__ void __launch_bounds__(512, 2) w4_gemm_xr_kernel(const XrParams p) {
         else { pv[st & 1][j] = *(lds_cu32ptr)(av); pw[st & 1][j] = *(lds_cu32ptr)(aw); }
       }
     };
-    if constexpr (!QMX) look(0);
+    constexpr bool AHEAD = WAVES == 8;  // (sixteen waves: four per SIMD hide the lookup latency; one stage's registers less)
+    if constexpr (!QMX && AHEAD) look(0);
     xr_static_for<NSTG>([&](auto ST) {
       constexpr int st = decltype(ST)::value;
       constexpr int ci = st >> 1, u = st & 1, l = ci / CPS, c = ci % CPS;
@@ -350,7 +362,11 @@ __global__ void __launch_bounds__(512, 2) w4_gemm_xr_kernel(const XrParams p) {
       }
       const bool gfirst = ci % CPG == 0;
       const int gi = ci / CPG;
-      if (st + 1 < NSTG) look(st + 1);
+      if constexpr (AHEAD) {
+        if (st + 1 < NSTG) look(st + 1);
+      } else {
+        look(st);
+      }
       __builtin_amdgcn_sched_barrier(0);
       if (gfirst) {
         if (ci > 0) finalize_pair(u, gi - 1);  // the previous group of this pair's tiles, behind the next stage's lookups
@@ -430,6 +446,32 @@ __global__ void __launch_bounds__(512, 2) w4_gemm_xr_kernel(const XrParams p) {
       const int a = r + 4 * (l >> 4);
       const uint32_t pa = lds_red + (uint32_t)(((t0 * 4 + r) * 64 + l) * 4);
       f32x2 v0, v1, v2, v3, w0, w1, w2, w3;
+      if constexpr (WAVES == 16) {
+        // 1024 threads, ONE output each (tile t0 = q0 >> 2 covers all four tiles): its sixteen partial sums, 4096 bytes apart
+        asm volatile(
+            "ds_read2st64_b32 %0, %8 offset1:16\n\t"
+            "ds_read2st64_b32 %1, %8 offset0:32 offset1:48\n\t"
+            "ds_read2st64_b32 %2, %8 offset0:64 offset1:80\n\t"
+            "ds_read2st64_b32 %3, %8 offset0:96 offset1:112\n\t"
+            "ds_read2st64_b32 %4, %8 offset0:128 offset1:144\n\t"
+            "ds_read2st64_b32 %5, %8 offset0:160 offset1:176\n\t"
+            "ds_read2st64_b32 %6, %8 offset0:192 offset1:208\n\t"
+            "ds_read2st64_b32 %7, %8 offset0:224 offset1:240\n\t"
+            "s_waitcnt lgkmcnt(0)"
+            : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3), "=&v"(w0), "=&v"(w1), "=&v"(w2), "=&v"(w3)
+            : "v"(pa)
+            : "memory");
+        float sum = ((((((v0[0] + v0[1]) + v1[0]) + v1[1]) + v2[0]) + v2[1]) + v3[0]) + v3[1];
+        sum = ((((((((sum + w0[0]) + w0[1]) + w1[0]) + w1[1]) + w2[0]) + w2[1]) + w3[0]) + w3[1]);
+        char* yb = p.y + (int64_t)cur.b * p.stride_y;
+        const int row = row0 + 16 * t0 + (l & 15);
+        if (a < p.m && (XR_ABL != 7 || sum == 123.456f)) {
+          uint16_t o16 = DT::from_f32(sum);
+          if (p.bias)
+            o16 = DT::from_f32(DT::lo_f32(o16) + DT::lo_f32(*reinterpret_cast<const uint16_t*>(p.bias + (int64_t)cur.b * p.stride_bias + ((int64_t)a * p.bias_row_stride + row) * 2)));
+          *reinterpret_cast<uint16_t*>(yb + (p.y_tc ? tc_a_index(a, row, p.y_tiles) : (int64_t)a * p.wrows + row) * 2) = o16;
+        }
+      } else {
       asm volatile(
           "ds_read2st64_b32 %0, %8 offset1:16\n\t"
           "ds_read2st64_b32 %1, %8 offset0:32 offset1:48\n\t"
@@ -457,6 +499,7 @@ __global__ void __launch_bounds__(512, 2) w4_gemm_xr_kernel(const XrParams p) {
           *reinterpret_cast<uint16_t*>(yb + (p.y_tc ? tc_a_index(a, row, p.y_tiles) : (int64_t)a * p.wrows + row) * 2) = o16;
         }
       }
+      }  // WAVES == 8
     }
     if constexpr (XR_ABL != 8)  // (ablation 8: without this barrier -- a race, timing only)
     __syncthreads();  // the partial sums are consumed before the next item's build steps write into this buffer
