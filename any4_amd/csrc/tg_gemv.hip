@@ -72,7 +72,14 @@ int tgx::gemv(int dt, int I, bool qmx, GemmParams& p, int64_t batch, hipStream_t
   // through its prologue and the launch ends no earlier -- the CU's instruction issue, not latency, bounds the main loop)
   const int wgs = units < cus ? units : cus;
   const int tpw = ((units + wgs - 1) / wgs) * gp.unit;  // tiles of the largest range
-  gp.P = tpw <= 1 ? 8 : tpw <= 2 ? 16 : 32;
+  // rows per pass of ranges longer than two tiles: 16 (two super-tiles of k per ring step), not 32 -- a range is rarely a multiple of
+  // four tiles (Llama-3-8B: gate_up 14, q/k/v 3) and the padding tiles of its last pass cost what real ones do.  Same box, per graph
+  // node, 32 -> 16: 28672 x 4096 17.6 -> 16.2-16.6 us, 8192 rows 7.6 -> 6.4, 10240 11.2 -> 8.9, 12288 10.8 -> 8.4, 32768 (a multiple
+  // of four tiles) 16.5 -> 16.7; 8-row passes 22.5 us at 28672 rows; the decode step 1.667 -> 1.600 ms (profiles/r04_ab_gemv_pass_rows.txt)
+#ifndef TG_GEMV_P_BIG
+#define TG_GEMV_P_BIG 16
+#endif
+  gp.P = tpw <= 1 ? 8 : tpw <= 2 ? 16 : TG_GEMV_P_BIG;
   // a step covers SS = 32 / P consecutive super-tiles: they must all lie inside the matrix (the kernel's addressing has no per-lane
   // clamp), so k = 64 x odd runs 32-row passes whatever the range, k = 128 x odd at least 16-row passes
   if (p.ksuper % 2 != 0) gp.P = 32;
