@@ -9,9 +9,9 @@ namespace {
 #define TG_GEMV_MAX_TILES 16384  // 8-row tiles per launch up to which this kernel takes single-problem launches (131072 rows)
 #endif
 
-template <typename DT, int M, int GPS, int D, bool NORM>
+template <typename DT, int M, int GPS, int D, bool NORM, bool MF = false>
 int go(const GemvParams& gp, dim3 grid, unsigned lds, hipStream_t st) {
-  constexpr auto kern = w4_gemv_kernel<DT, M, GPS, D, NORM>;
+  constexpr auto kern = w4_gemv_kernel<DT, M, GPS, D, NORM, MF>;
   const int prc = prepare_lds_kernel<kern>();
   if (prc != 0) return prc == TG_E_INTERNAL ? prc : TG_PAIR_NA;  // (a part with less LDS: the older kernels take over)
   hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, gp);
@@ -28,6 +28,23 @@ int go_d(int d, bool norm, const GemvParams& gp, dim3 grid, unsigned lds, hipStr
 template <typename DT, int M>
 int go_g(int gps, int d, bool norm, const GemvParams& gp, dim3 grid, unsigned lds, hipStream_t st) {
   return gps == 1 ? go_d<DT, M, 1>(d, norm, gp, grid, lds, st) : go_d<DT, M, 2>(d, norm, gp, grid, lds, st);
+}
+// the matrix-core contraction (w4_gemv.cuh, MF): 3 ... 8 rows, one group per step, ring of four (k <= 4096: four steps per pass)
+template <typename DT, int M>
+int go_mf(int d, bool norm, const GemvParams& gp, dim3 grid, unsigned lds, hipStream_t st) {
+  if (d != 4) return TG_PAIR_NA;
+  return norm ? go<DT, M, 1, 4, true, true>(gp, grid, lds, st) : go<DT, M, 1, 4, false, true>(gp, grid, lds, st);
+}
+template <typename DT>
+int go_mf_m(int m, int d, bool norm, const GemvParams& gp, dim3 grid, unsigned lds, hipStream_t st) {
+  switch (m) {
+    case 3: return go_mf<DT, 3>(d, norm, gp, grid, lds, st);
+    case 4: return go_mf<DT, 4>(d, norm, gp, grid, lds, st);
+    case 5: return go_mf<DT, 5>(d, norm, gp, grid, lds, st);
+    case 6: return go_mf<DT, 6>(d, norm, gp, grid, lds, st);
+    case 7: return go_mf<DT, 7>(d, norm, gp, grid, lds, st);
+    default: return go_mf<DT, 8>(d, norm, gp, grid, lds, st);
+  }
 }
 template <typename DT>
 int go_m(int m, int gps, int d, bool norm, const GemvParams& gp, dim3 grid, unsigned lds, hipStream_t st) {
@@ -53,7 +70,13 @@ extern "C" TG_API void tg_dev_gemv_trace(unsigned long long* buf, int slots) {
 #endif
 
 int tgx::gemv(int dt, int I, bool qmx, GemmParams& p, int64_t batch, hipStream_t st) {
-  if (I != 4 || qmx || p.m > 4 || p.x_tc || p.y_tc || batch != 1) return TG_PAIR_NA;
+#ifndef TG_GEMV_MF_MIN_M
+#define TG_GEMV_MF_MIN_M 3  // activation rows from which the contraction runs on the matrix core (where its conditions hold)
+#endif
+  const int g0 = 1 << p.gshift;
+  // matrix-core contraction: 16-row passes of two super-tiles per step inside ONE group, a piece per thread in the staging
+  const bool mf = p.m >= TG_GEMV_MF_MIN_M && p.m <= 8 && (g0 == 128 || g0 == 256) && p.k <= 4096 && p.ksuper % 2 == 0;
+  if (I != 4 || qmx || (p.m > 4 && !mf) || p.x_tc || p.y_tc || batch != 1) return TG_PAIR_NA;
   if (p.ksuper * 64 != p.k || p.ntiles * 8 != p.wrows || p.ntiles > TG_GEMV_MAX_TILES) return TG_PAIR_NA;
   const int g = 1 << p.gshift;
   const int gps = g == 32 ? 2 : 1;
@@ -79,7 +102,7 @@ int tgx::gemv(int dt, int I, bool qmx, GemmParams& p, int64_t batch, hipStream_t
 #ifndef TG_GEMV_P_BIG
 #define TG_GEMV_P_BIG 16
 #endif
-  gp.P = tpw <= 1 ? 8 : tpw <= 2 ? 16 : TG_GEMV_P_BIG;
+  gp.P = mf ? 16 : tpw <= 1 ? 8 : tpw <= 2 ? 16 : TG_GEMV_P_BIG;
   // a step covers SS = 32 / P consecutive super-tiles: they must all lie inside the matrix (the kernel's addressing has no per-lane
   // clamp), so k = 64 x odd runs 32-row passes whatever the range, k = 128 x odd at least 16-row passes
   if (p.ksuper % 2 != 0) gp.P = 32;
@@ -110,6 +133,8 @@ int tgx::gemv(int dt, int I, bool qmx, GemmParams& p, int64_t batch, hipStream_t
 #if GEMV_TRACE
   if (g_trace && g_trace_slots > 0) gp.trace = g_trace + (size_t)(g_trace_launch++ % g_trace_slots) * 512 * 8;
 #endif
+  if (mf) return dt == TG_BF16 ? go_mf_m<BF16>(p.m, d, p.norm_w != nullptr, gp, grid, lds, st)
+                               : go_mf_m<F16>(p.m, d, p.norm_w != nullptr, gp, grid, lds, st);
   return dt == TG_BF16 ? go_m<BF16>(p.m, gps, d, p.norm_w != nullptr, gp, grid, lds, st)
                        : go_m<F16>(p.m, gps, d, p.norm_w != nullptr, gp, grid, lds, st);
 }

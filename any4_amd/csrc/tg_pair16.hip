@@ -41,7 +41,7 @@ int launch_pair16(const GemmParams& p, int64_t batch, hipStream_t st) {
   unsigned lds = 0;
   int phases = 1;
   // XREG (w4_gemm_pair16.cuh): no LDS for activations, one pass whatever m x k is; one workgroup per CU (two rounds at most)
-  const bool xreg = p.m >= TG_P16_XREG_MIN_M && !p.x_tc && !p.norm_w && wgs <= 512 && p.ksuper % nsg == 0;
+  const bool xreg = p.m >= TG_P16_XREG_MIN_M && !p.norm_w && wgs <= 512 && p.ksuper % nsg == 0;
   if (xreg) {
     pp.x_pitch = 0;
     pp.lds_xs = pp.lds_x;
@@ -70,9 +70,10 @@ int launch_pair16(const GemmParams& p, int64_t batch, hipStream_t st) {
 #if GEMV_TRACE
   pp.trace = (g_p16_trace && g_p16_slots > 0 && grid.x <= 512) ? g_p16_trace + (size_t)(g_p16_launch++ % g_p16_slots) * 512 * 8 : nullptr;
 #endif
-#define TG_P16K(CPG_, NORM_, XREG_, CH_)                                                \
+#define TG_P16K(CPG_, NORM_, XREG_, CH_) do { if (XREG_ && p.x_tc) TG_P16KX(CPG_, NORM_, XREG_, CH_, XREG_); else TG_P16KX(CPG_, NORM_, XREG_, CH_, false); } while (0)
+#define TG_P16KX(CPG_, NORM_, XREG_, CH_, XTC_)                                         \
   do {                                                                                  \
-    constexpr auto kern = w4_gemm_pair16_kernel<DT, I, QMX, CPG_, 1, NORM_, XREG_, CH_>; \
+    constexpr auto kern = w4_gemm_pair16_kernel<DT, I, QMX, CPG_, 1, NORM_, XREG_, CH_, XTC_>; \
     const int prc = prepare_lds_kernel<kern>();                                         \
     if (prc != 0) return prc;                                                           \
     hipLaunchKernelGGL(kern, grid, dim3(1024), lds, st, pp);                            \
@@ -92,6 +93,7 @@ int launch_pair16(const GemmParams& p, int64_t batch, hipStream_t st) {
   else if (g == 128) TG_P16(4);
   else TG_P16(8);
 #undef TG_P16K
+#undef TG_P16KX
 #undef TG_P16
   return launch_status();
   }

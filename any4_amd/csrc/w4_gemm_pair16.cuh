@@ -79,7 +79,9 @@ struct Pair16Params {
 //       places of the unrolled code (no branches between the steps)
 // XREG / CH: see the header; CH = super-tiles requested at once (4: k = 4096 at I = 4 is the whole slice; XREG with longer slices: 2,
 //       two register sets of words and activation fragments)
-template <typename DT, int I, bool QMX, int CPG, int TPW = 1, bool NORM = false, bool XREG = false, int CH = 4>
+// XTC  = XREG with the activations in A-fragment order (tg_w4_gemm.x_layout, the `f16TC` ops): the four dwords of a lane's piece come
+//        from four places of the fragment tensor (tc_a_index) -- four 4-byte loads instead of one 16-byte load, the same registers after
+template <typename DT, int I, bool QMX, int CPG, int TPW = 1, bool NORM = false, bool XREG = false, int CH = 4, bool XTC = false>
 __global__ void __launch_bounds__(1024) w4_gemm_pair16_kernel(const Pair16Params p) {
   static_assert(!NORM || !QMX, "fused RMSNorm borrows the activation-sum area");
   static_assert(!XREG || (TPW == 1 && !NORM), "register-resident activations: one tile per workgroup, no fused norm");
@@ -190,6 +192,12 @@ __global__ void __launch_bounds__(1024) w4_gemm_pair16_kernel(const Pair16Params
         const int s = l0 + j < nl ? s_begin + l0 + j : 0;  // (past the slice: a cached request, never consumed -- as w_request)
 #pragma unroll
         for (int jc = 0; jc < CPS; ++jc) {
+          if constexpr (XTC) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              xf[j * CPS + jc][e] = *reinterpret_cast<const uint32_t*>(xb + tc_a_index(min(n, p.m - 1), (s * CPS + jc) * 32 + 8 * q + 2 * e, p.k >> 4) * 2);
+            continue;
+          }
           asm volatile("" : "+v"(xoff));  // (opaque at its use: the zero-extension stays next to the load, w4_gemm_pair.cuh `pin`)
           xf[j * CPS + jc] = *reinterpret_cast<const u32x4*>(xb + (uint32_t)__builtin_amdgcn_readfirstlane((s * CPS + jc) * 64) + xoff);
         }

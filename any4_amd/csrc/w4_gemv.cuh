@@ -72,10 +72,18 @@ struct GemvParams {
   unsigned long long* trace;
 };
 
-// DT = BF16 / F16, M = activation rows (1 ... 4), GPS = groups per super-tile half-step (1: g >= 64, 2: g = 32), D = ring depth,
+// DT = BF16 / F16, M = activation rows (1 ... 4; MF: 3 ... 8), GPS = groups per super-tile half-step (1: g >= 64, 2: g = 32), D = ring depth,
 // NORM = RMSNorm fused into the staging
-template <typename DT, int M, int GPS, int D, bool NORM>
+// MF  = the contraction on the matrix core (3 ... 8 rows: four v_dot2 per packed word and ROW make the vector ALU the bound -- gate_up of
+//       Llama-3-8B at 4 rows: 30.8 us against 17.9 at one).  16-row passes only (P = 16, the host's choice): lane (n = lane & 15, sub =
+//       lane >> 4) holds the words of weight row n at the k-subset `sub` of the step (super-tile sub >> 1, quads 2 (sub & 1) + qq) -- one B
+//       operand of v_mfma_f32_16x16x32 per looked-up word; the A operand of the same lane is the matching 16-byte piece of activation
+//       row lane & 15 (rows >= M read row M - 1: their accumulator rows are never stored), so ONE LDS read per word serves all rows.
+//       D[a][n]: lane (n, sub) holds rows 4 sub + r.  A step (two super-tiles) lies inside one quantisation group (g >= 128, the host
+//       checks): one scale / zero update per step, the step's activation sums [step][16 rows] come from the staging.
+template <typename DT, int M, int GPS, int D, bool NORM, bool MF = false>
 __global__ void __launch_bounds__(512, 2) w4_gemv_kernel(const GemvParams p) {
+  static_assert(!MF || GPS == 1, "matrix-core contraction: groups of at least two super-tiles");
   constexpr int NW = 8, NT = NW * 64;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -273,7 +281,14 @@ __global__ void __launch_bounds__(512, 2) w4_gemv_kernel(const GemvParams p) {
         xd[a][j] = DT::pack2(DT::lo_f32(xv) * DT::lo_f32(g), DT::hi_f32(xv) * DT::hi_f32(g));
       }
     }
-    if (!wide) {
+    if (MF) {
+      // (host: !wide) the sums of a STEP's 128 k (the zero-point term is added per step): its 16 pieces are 16 consecutive threads
+      float sum = piece_store(a, tid, xd[a][0], xd[a][1], xd[a][2], xd[a][3], on);
+      sum = on ? sum : 0.f;
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) sum += __shfl_xor(sum, o);
+      if (on && (tid & 15) == 0) *(lds_fptr)(lds_xs + (uint32_t)((tid >> 4) * 64 + a * 4)) = sum;
+    } else if (!wide) {
       float sum = piece_store(a, tid, xd[a][0], xd[a][1], xd[a][2], xd[a][3], on);
       sum += __shfl_xor(sum, 1);  // the two quads of a half sit in adjacent lanes
       if (on && (tid & 1) == 0) xs_store(a, tid >> 2, (tid >> 1) & 1, sum);
@@ -316,11 +331,21 @@ __global__ void __launch_bounds__(512, 2) w4_gemv_kernel(const GemvParams p) {
 
   // ---- main loop ----
   uint32_t colreg = (uint32_t)((lane & 31) * 4);
-  float yacc[M];
+  float yacc[MF ? 4 : M];  // MF: rows 4 (lane >> 4) + r of weight row lane & 15
 #pragma unroll
-  for (int a = 0; a < M; ++a) yacc[a] = 0.f;
+  for (int a = 0; a < (MF ? 4 : M); ++a) yacc[a] = 0.f;
 
   auto pass_end = [&](int cp) {
+    const uint32_t par = (uint32_t)(cp & 1);
+    if constexpr (MF) {
+      // the matrix core has summed the k-subsets of the four lane quarters already: lane (n, sub) stores rows 4 sub + r
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int a = 4 * (lane >> 4) + r;
+        if (a < M) *(lds_fptr)(lds_red + (uint32_t)((((par * NW + wave) * M + a) * 32 + (lane & 15)) * 4)) = yacc[r];
+        yacc[r] = 0.f;
+      }
+    } else {
     // the sub-slots of a row sit in lanes row + P i: lane `row` gets the wave's sum
     float v[M];
 #pragma unroll
@@ -331,10 +356,10 @@ __global__ void __launch_bounds__(512, 2) w4_gemv_kernel(const GemvParams p) {
       if (P <= 16) v[a] += __shfl_xor(v[a], 16);
       if (P <= 8) v[a] += __shfl_xor(v[a], 8);
     }
-    const uint32_t par = (uint32_t)(cp & 1);
     if (lane < P) {
 #pragma unroll
       for (int a = 0; a < M; ++a) *(lds_fptr)(lds_red + (uint32_t)((((par * NW + wave) * M + a) * 32 + lane) * 4)) = v[a];
+    }
     }
     // the next pass's table goes into the other 32 columns (row-wise LUT only: the others never change)
     if (rowwise && cp + 1 < passes) {
@@ -392,6 +417,28 @@ __global__ void __launch_bounds__(512, 2) w4_gemv_kernel(const GemvParams p) {
     const int su = min(su_l, su_max);
     const uint32_t xa = xlane + (uint32_t)su * 128u;
     const uint32_t xsa = xslane + (uint32_t)su * 16u;
+    if constexpr (MF) {
+      const uint32_t xr = xa + (uint32_t)(min(lane & 15, M - 1) * p.x_pitch);
+      f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+      u32x4 e4[4], xf4[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int jc = u >> 1, qq = u & 1;
+        const uint32_t w = sl.w[qq * 2 + jc];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) e4[u][j] = *(lds_cu32ptr)(__builtin_amdgcn_perm(w, colreg, 0x0c0c0400u + ((uint32_t)j << 8)));
+        xf4[u] = *(lds_cu32x4ptr)(xr + (uint32_t)(jc * 64 + qq * 16));
+      }
+      const f32x4 gs4 = *(lds_cf32x4ptr)(lds_xs + (uint32_t)((su >> 1) * 64 + (lane >> 4) * 16));
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc = mfma16<DT>(xf4[u], e4[u], acc);
+      const float sc = on ? DT::lo_f32(sl.q[0]) : 0.f;
+      const float zz = on ? DT::hi_f32(sl.q[0]) : 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) yacc[r] = __builtin_fmaf(zz, gs4[r], __builtin_fmaf(sc, acc[r], yacc[r]));
+      return;
+    }
     float dsum[M][GPS];
 #pragma unroll
     for (int a = 0; a < M; ++a)

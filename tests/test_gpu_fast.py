@@ -406,7 +406,9 @@ def test_pair16_register_resident_activations(T, oracle, qtype, g, shape):
         lt = lut if lut is None or lut.dim() == 1 else lut[rows].contiguous()
         # same plan for the sliced problem? the tolerance follows the FULL problem's plan: check it here
         from any4_amd import ops
-        assert ops.gemm_w4_plan(m, n, k, g, QT[qtype], True, 4, dtype, 1, "fast") == "pair"
+        # (5 ... 8 rows at k <= 4096 with groups of 128 / 256 go to w4_gemv_kernel's matrix-core contraction since it exists; every
+        #  other shape of this list -- more rows, longer k, groups of 32 / 64, mx4 -- is this kernel's)
+        assert ops.gemm_w4_plan(m, n, k, g, QT[qtype], True, 4, dtype, 1, "fast") == ("gemv" if m <= 8 and k <= 4096 and g >= 128 and qtype != "mx4" else "pair")
         yy = y[:, rows] if n > 256 else y
         _check_rows(oracle, yy, codes[rows], x, q, lt, g, qtype, dtype)
 

@@ -89,6 +89,38 @@ def test_gemv_fp16_and_every_m(T, oracle, m, g):
         check(oracle, y, codes, x, qinfo, lut, g, qtype, dtype=torch.float16)
 
 
+@pytest.mark.parametrize("case", [
+    # (n, k, m, g, qtype)  3 ... 8 rows with a group of >= 128 at k <= 4096: the contraction runs on the matrix core (16-row passes)
+    (4096, 4096, 4, 128, "any4_rowwise"),   # two tiles per workgroup, one pass
+    (4096, 4096, 8, 128, "any4_rowwise"),   # rows 4 ... 7 come from the second lane quarter
+    (6144, 4096, 3, 256, "any4_global"),    # three tiles: the second pass is half empty
+    (28672, 4096, 5, 128, "any4_rowwise"),  # gate_up of Llama-3-8B: seven passes, the LUT rows staged through LDS
+    (2056, 512, 7, 128, "int4"),            # 257 tiles: ranges of one and two tiles; one super-tile per wave
+    (72, 256, 6, 128, "any4_rowwise"),      # k = 256: waves 2 ... 7 hold no step
+    (1024, 2048, 8, 256, "int4"), (200, 1024, 3, 128, "any4_rowwise"),
+])
+def test_gemv_matrix_core_contraction_vs_oracle(T, oracle, case):
+    n, k, m, g, qtype = case
+    for dtype in (torch.bfloat16, torch.float16):
+        assert plan(m, n, k, g, qtype, dtype) == "gemv"
+        codes, x, qinfo, lut = rand_problem(n, k, g, m, qtype, dtype=dtype, seed=n + k + m)
+        y = run_rm(T, codes, x, qinfo, lut, g, qtype, True, 4)
+        rows = None
+        if n > 2048:
+            rows = np.unique(np.concatenate([np.arange(0, 160), np.arange(n // 2 - 80, n // 2 + 80), np.arange(n - 160, n)]))
+        check(oracle, y, codes, x, qinfo, lut, g, qtype, dtype=dtype, rows=rows)
+
+
+def test_gemv_matrix_core_rows_agree_with_the_dot2_rows(T):
+    """The same activation row inside a 1-row launch (v_dot2 contraction) and as row 5 of a 6-row launch (matrix core): one output
+    step apart at most (another adder tree over the same products)."""
+    codes, x, qinfo, lut = rand_problem(4096, 4096, 128, 6, "any4_rowwise", seed=8)
+    y6 = run_rm(T, codes, x, qinfo, lut, 128, "any4_rowwise", True, 4)
+    y1 = run_rm(T, codes, x[5:6].contiguous(), qinfo, lut, 128, "any4_rowwise", True, 4)
+    step = torch.exp2(torch.floor(torch.log2(y1.float().abs().clamp_min(1e-30))) - 7)
+    assert ((y6[5:6].float() - y1.float()).abs() <= step).all()
+
+
 def test_gemv_identity_within_one_ulp(T):
     """The reference's identity known-answer test (test_tinygemm_any4.py:14-37): w = eye(k) quantised, LUT = 8 - arange(16),
     scales negated.  Reference numerics reproduce x bit for bit (test_gpu_parity.py); the group-scaled default multiplies by
