@@ -302,6 +302,13 @@ def test_xr_kernel_routing():
     assert ops.gemm_w4_plan(8, 4096, 4096, 128, q2["any4_rowwise"], False, 4, batch=64, detail=True, weight_format="native") == "pair_xr"
     assert ops.gemm_w4_plan(1, 4096, 4096, 128, q2["int4"], False, 4, weight_format="native") == "gemv"   # Int4Linear's default kernel at batch 1
     assert ops.gemm_w4_plan(1, 4096, 4096, 128, q2["int4"], False, 2, weight_format="native") == "gemv"   # (the Aint4 innerKTiles is a shape only)
+    # one layer per launch with 3 ... 8 rows, k <= 4096, groups of 128 / 256: the gemv kernel's matrix-core contraction; otherwise pair16
+    assert ops.gemm_w4_plan(8, 4096, 4096, 128, q2["any4_rowwise"], True, 4) == "gemv"
+    assert ops.gemm_w4_plan(5, 28672, 4096, 256, q2["int4"], True, 4) == "gemv"
+    assert ops.gemm_w4_plan(8, 4096, 4096, 64, q2["any4_rowwise"], True, 4) == "pair"
+    assert ops.gemm_w4_plan(8, 4096, 14336, 128, q2["any4_rowwise"], True, 4) == "pair"
+    assert ops.gemm_w4_plan(9, 4096, 4096, 128, q2["any4_rowwise"], True, 4) == "pair"
+    assert ops.gemm_w4_plan(4, 4096, 4096, 32, q2["any4_rowwise"], True, 4) == "gemv"   # (the v_dot2 contraction: any group size)
     assert plan(17, 4096, 4096, 128, "any4_rowwise") != "pair_xr"
 
 
