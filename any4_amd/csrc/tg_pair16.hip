@@ -41,7 +41,8 @@ int launch_pair16(const GemmParams& p, int64_t batch, hipStream_t st) {
   unsigned lds = 0;
   int phases = 1;
   // XREG (w4_gemm_pair16.cuh): no LDS for activations, one pass whatever m x k is; one workgroup per CU (two rounds at most)
-  const bool xreg = p.m >= TG_P16_XREG_MIN_M && !p.norm_w && wgs <= 512 && p.ksuper % nsg == 0;
+  bool xreg = p.m >= TG_P16_XREG_MIN_M && !p.norm_w && wgs <= 512 && p.ksuper % nsg == 0;
+  if (xreg && g == 32 && I == 4 && ((p.ksuper / nsg + 15) / 16) * nsg > 4) xreg = false;  // (see TG_P16: that instantiation spills)
   if (xreg) {
     pp.x_pitch = 0;
     pp.lds_xs = pp.lds_x;
@@ -84,7 +85,10 @@ int launch_pair16(const GemmParams& p, int64_t batch, hipStream_t st) {
       if (p.norm_w) { TG_P16K(CPG_, true, false, 4); break; }     \
     }                                                             \
     if (xreg && pp.spw <= 4) { TG_P16K(CPG_, false, true, 4); break; }  /* the whole slice in one block */ \
-    if (xreg) { TG_P16K(CPG_, false, true, 2); break; }           \
+    /* (groups of 32 at innerKTiles 4 with slices longer than a block: 84 ... 128 bytes of scratch -- not instantiated, the LDS path) */ \
+    if constexpr (!(CPG_ == 1 && I == 4)) {                       \
+      if (xreg) { TG_P16K(CPG_, false, true, 2); break; }         \
+    }                                                             \
     TG_P16K(CPG_, false, false, 4);                               \
   } while (0)
   if constexpr (QMX) TG_P16(1);  // mx4: group = 32

@@ -227,7 +227,14 @@ __global__ void __launch_bounds__(512, 2) w4_gemv_kernel(const GemvParams p) {
   }
   // the first D steps of the weight stream, behind everything the staging in front of the first barrier waits for (vector
   // memory returns in order: requested first, the staging would wait for HBM instead of L2) -- on every wave of the workgroup
+#ifndef TG_GEMV_ASM_BARRIER
+#define TG_GEMV_ASM_BARRIER 1
+#endif
+#if TG_GEMV_ASM_BARRIER
+  asm volatile("s_barrier" ::: "memory");  // (spelled out: in front of the builtin hipcc waits vmcnt(0) -- the staging loads would have to RETURN before the first weight request)
+#else
   __builtin_amdgcn_s_barrier();
+#endif
 #pragma unroll
   for (int j = 0; j < D; ++j) {
     __builtin_amdgcn_sched_barrier(0);
