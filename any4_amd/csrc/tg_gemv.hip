@@ -5,6 +5,12 @@ namespace {
 #include "w4_gemm_pair.cuh"   // shared device helpers (dot2, chunk_rmsnorm, swiglu16); its kernel is not instantiated here
 #include "w4_gemv.cuh"
 
+#ifndef TG_GEMV_MF_MIN_M
+#define TG_GEMV_MF_MIN_M 1  // activation rows from which the contraction runs on the matrix core where its conditions hold (k <= 4096, groups
+                            // of 128 / 256).  Same box, per graph node, v_dot2 -> matrix core: m = 1: 4096^2 5.10 -> 4.92 us, 28672 x 4096
+                            // 15.4 -> 14.85, the decode step 622 -> 630 tokens/s; m = 2: 5.8 -> 5.1, 19.3 -> 14.9, decode at batch 2
+                            // 1054 -> 1173 tokens/s (the kernel's bound was vector-ALU issue; profiles/r04_ab_gemv_mf_min_m.txt)
+#endif
 #ifndef TG_GEMV_MAX_TILES
 #define TG_GEMV_MAX_TILES 16384  // 8-row tiles per launch up to which this kernel takes single-problem launches (131072 rows)
 #endif
@@ -38,6 +44,12 @@ int go_mf(int d, bool norm, const GemvParams& gp, dim3 grid, unsigned lds, hipSt
 template <typename DT>
 int go_mf_m(int m, int d, bool norm, const GemvParams& gp, dim3 grid, unsigned lds, hipStream_t st) {
   switch (m) {
+#if TG_GEMV_MF_MIN_M <= 1
+    case 1: return go_mf<DT, 1>(d, norm, gp, grid, lds, st);
+#endif
+#if TG_GEMV_MF_MIN_M <= 2
+    case 2: return go_mf<DT, 2>(d, norm, gp, grid, lds, st);
+#endif
     case 3: return go_mf<DT, 3>(d, norm, gp, grid, lds, st);
     case 4: return go_mf<DT, 4>(d, norm, gp, grid, lds, st);
     case 5: return go_mf<DT, 5>(d, norm, gp, grid, lds, st);
@@ -70,9 +82,6 @@ extern "C" TG_API void tg_dev_gemv_trace(unsigned long long* buf, int slots) {
 #endif
 
 int tgx::gemv(int dt, int I, bool qmx, GemmParams& p, int64_t batch, hipStream_t st) {
-#ifndef TG_GEMV_MF_MIN_M
-#define TG_GEMV_MF_MIN_M 3  // activation rows from which the contraction runs on the matrix core (where its conditions hold)
-#endif
   const int g0 = 1 << p.gshift;
   // matrix-core contraction: 16-row passes of two super-tiles per step inside ONE group, a piece per thread in the staging
   const bool mf = p.m >= TG_GEMV_MF_MIN_M && p.m <= 8 && (g0 == 128 || g0 == 256) && p.k <= 4096 && p.ksuper % 2 == 0;
@@ -124,7 +133,8 @@ int tgx::gemv(int dt, int I, bool qmx, GemmParams& p, int64_t batch, hipStream_t
   gp.lds_x = gp.lds_lut + (stage_lut ? tpw * 8 * 32 : 0);
   gp.xs_pitch = p.k / 4;
   gp.lds_xs = gp.lds_x + p.m * gp.x_pitch;
-  gp.lds_red = gp.lds_xs + p.m * gp.xs_pitch;
+  // (matrix-core contraction: the sums are [step of 128 k][16 rows] f32 instead -- more than one row's k / 4 bytes)
+  gp.lds_red = gp.lds_xs + (mf && (p.k / 128) * 64 > p.m * gp.xs_pitch ? (p.k / 128) * 64 : p.m * gp.xs_pitch);
   gp.lds_nrm = gp.lds_red + 2 * 8 * p.m * 32 * 4;
   const unsigned lds = (unsigned)gp.lds_nrm + (unsigned)(8 * p.m * 4);
   if (lds > 160u * 1024u) return TG_PAIR_NA;

@@ -111,14 +111,18 @@ def test_gemv_matrix_core_contraction_vs_oracle(T, oracle, case):
         check(oracle, y, codes, x, qinfo, lut, g, qtype, dtype=dtype, rows=rows)
 
 
-def test_gemv_matrix_core_rows_agree_with_the_dot2_rows(T):
-    """The same activation row inside a 1-row launch (v_dot2 contraction) and as row 5 of a 6-row launch (matrix core): one output
-    step apart at most (another adder tree over the same products)."""
+def test_gemv_matrix_core_row_does_not_depend_on_the_batch(T):
+    """The same activation row alone and as row 5 of a 6-row launch (another lane quarter and accumulator register of the matrix
+    core), and against the v_dot2 contraction (groups of 64 keep it: same codes and LUT, scales repeated): one output step at most."""
     codes, x, qinfo, lut = rand_problem(4096, 4096, 128, 6, "any4_rowwise", seed=8)
     y6 = run_rm(T, codes, x, qinfo, lut, 128, "any4_rowwise", True, 4)
     y1 = run_rm(T, codes, x[5:6].contiguous(), qinfo, lut, 128, "any4_rowwise", True, 4)
     step = torch.exp2(torch.floor(torch.log2(y1.float().abs().clamp_min(1e-30))) - 7)
     assert ((y6[5:6].float() - y1.float()).abs() <= step).all()
+    q64 = qinfo.repeat_interleave(2, dim=0).contiguous()       # groups of 64 with the same scale | zero: the same weights
+    assert plan(1, 4096, 4096, 64, "any4_rowwise") == "gemv"
+    yd = run_rm(T, codes, x[5:6].contiguous(), q64, lut, 64, "any4_rowwise", True, 4)
+    assert ((yd.float() - y1.float()).abs() <= step).all()
 
 
 def test_gemv_identity_within_one_ulp(T):
