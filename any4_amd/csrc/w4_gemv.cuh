@@ -288,8 +288,17 @@ __global__ void __launch_bounds__(512, 2) w4_gemv_kernel(const GemvParams p) {
         xd[a][j] = DT::pack2(DT::lo_f32(xv) * DT::lo_f32(g), DT::hi_f32(xv) * DT::hi_f32(g));
       }
     }
-    if (MF) {
-      // (host: !wide) the sums of a STEP's 128 k (the zero-point term is added per step): its 16 pieces are 16 consecutive threads
+    if (MF && M <= 2 && wide) {  // (host: long k only with one or two rows)
+      // a thread stages a 32-k chunk; a STEP's 128 k are four consecutive threads
+      float sum = 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) sum += piece_store(a, 4 * tid + q, xd[a][q], xd[a][q + 4], xd[a][q + 8], xd[a][q + 12], on);
+      sum = on ? sum : 0.f;
+      sum += __shfl_xor(sum, 1);
+      sum += __shfl_xor(sum, 2);
+      if (on && (tid & 3) == 0) *(lds_fptr)(lds_xs + (uint32_t)((tid >> 2) * 64 + a * 4)) = sum;
+    } else if (MF) {
+      // the sums of a STEP's 128 k (the zero-point term is added per step): its 16 pieces are 16 consecutive threads
       float sum = piece_store(a, tid, xd[a][0], xd[a][1], xd[a][2], xd[a][3], on);
       sum = on ? sum : 0.f;
 #pragma unroll
