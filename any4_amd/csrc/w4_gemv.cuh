@@ -1,4 +1,4 @@
-// w4_gemv.cuh -- the W4A16 kernel for ONE layer per launch with 1 ... 4 activation rows: what a batch-1 decode step issues
+// w4_gemv.cuh -- the W4A16 kernel for ONE layer per launch with 1 ... 4 (matrix-core contraction: ... 8) activation rows: what a batch-1 decode step issues
 // four times per decoder layer (BASELINE config 5; the reference times it through HuggingFace's LlamaDecoderLayer,
 // benchmark.py:113-215) and what Any4Linear.forward / Int4Linear.forward issue at batch 1 (modules.py:207-227, 56-80).
 //
@@ -11,8 +11,8 @@
 //   grid       = one 8-wave workgroup per CU, each owns a CONTIGUOUS range of 8-row tiles of the packed layout and the whole k:
 //                every CU streams from the first cycle whatever the layer's row count (4096 rows = 2 tiles per CU, 6144 = 3,
 //                28672 = 14), nothing is persistent, nothing is reduced across workgroups.
-//   pass       = P = 8, 16 or 32 weight rows of the range at a time (the smallest P that holds the whole range, else 32 and
-//                several passes).  lane = (row of the pass, sub-slot); a sub-slot is (k super-tile offset, half of the
+//   pass       = P = 8, 16 or 32 weight rows of the range at a time (8 / 16 for ranges of one / two tiles, 16 and several passes for
+//                longer ones; 32 only where k forces it: tg_gemv.hip).  lane = (row of the pass, sub-slot); a sub-slot is (k super-tile offset, half of the
 //                super-tile's lane-quads): P = 32 -> 2 sub-slots (the halves), P = 16 -> 4 (2 super-tiles), P = 8 -> 8 (4).
 //                A wave-load is therefore always whole 256-byte super-tile blocks of the packed layout, and the lanes of a
 //                32-lane LDS access group always use 32 distinct table columns (column = lane & 31): conflict-free lookups.
@@ -20,8 +20,9 @@
 //                (v_perm_b32 address + ds_read_b32), 4 activation pieces per activation row (ds_read_b128, broadcast), 16
 //                v_dot2_f32_bf16 per activation row, then ONE scale / zero update: y += scale * dot + zero * sum(x of the step)
 //                -- the group-scaled sum of w4_gemm_pair.cuh regrouped per step (a step never straddles a group for g >= 64;
-//                g = 32 splits it by 32-k chunk, GPS = 2).  No MFMA: at m <= 4 it would spend 16384 multiplier slots on 512 m
-//                useful products (measured on the stacked kernel: v_dot2 is 6 % faster at m = 1).
+//                g = 32 splits it by 32-k chunk, GPS = 2).  This is the contraction of groups of 32 / 64 and of what the matrix-core
+//                variant (MF, below) declines; on the power-capped STACKED kernel v_dot2 is 6 % faster than the 32x32x16 MFMA at
+//                m = 1 -- in this latency-bound launch the 16x16x32 MFMA of MF measured faster from one row on.
 //   split-K    = the 8 waves of a workgroup split k; per pass their partial sums meet in LDS, added in wave order by P * m
 //                threads (deterministic), with the epilogue (bias / residual add, SwiGLU of gate / up row pairs) in that store.
 //   ring       = D steps per lane in flight (registers), running ACROSS passes (a pass occupies a whole number of rounds of D
@@ -74,8 +75,8 @@ struct GemvParams {
 
 // DT = BF16 / F16, M = activation rows (1 ... 4; MF: 3 ... 8), GPS = groups per super-tile half-step (1: g >= 64, 2: g = 32), D = ring depth,
 // NORM = RMSNorm fused into the staging
-// MF  = the contraction on the matrix core (3 ... 8 rows: four v_dot2 per packed word and ROW make the vector ALU the bound -- gate_up of
-//       Llama-3-8B at 4 rows: 30.8 us against 17.9 at one).  16-row passes only (P = 16, the host's choice): lane (n = lane & 15, sub =
+// MF  = the contraction on the matrix core (built for 3 ... 8 rows, where four v_dot2 per packed word and ROW make the vector ALU the bound
+//       -- gate_up of Llama-3-8B at 4 rows: 30.8 us against 17.9 at one --, measured faster from ONE row on: tg_gemv.hip, TG_GEMV_MF_MIN_M).  16-row passes only (P = 16, the host's choice): lane (n = lane & 15, sub =
 //       lane >> 4) holds the words of weight row n at the k-subset `sub` of the step (super-tile sub >> 1, quads 2 (sub & 1) + qq) -- one B
 //       operand of v_mfma_f32_16x16x32 per looked-up word; the A operand of the same lane is the matching 16-byte piece of activation
 //       row lane & 15 (rows >= M read row M - 1: their accumulator rows are never stored), so ONE LDS read per word serves all rows.
