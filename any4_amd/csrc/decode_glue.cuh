@@ -484,7 +484,13 @@ __global__ void __launch_bounds__(512) rope_attn_online_kernel(const uint16_t* _
   auto piece = [&](const char* base, int r) -> u32x4 { return *reinterpret_cast<const u32x4*>(base + (((uint32_t)r * LPR + (uint32_t)i) << 4)); };
   // the first NSPEC iterations' rows are requested BEFORE the position is known (rows past it are valid memory and masked later):
   // the read of `pos` is a dependent round trip the K / V requests of a short context need not wait for
-  constexpr int NSPEC = NI < 2 ? NI : 2;
+  // (all of the first chunk: same box, Llama-3-8B decode, 2 -> 8 iterations: 620 -> 620 tokens/s at position 136, 544 -> 553 at 900,
+  //  481 -> 494 at 1900.  Requesting the NEXT chunk before the current one is consumed -- a second register set, 211 VGPRs -- measured
+  //  SLOWER than this: 550 / 480 tokens/s at 900 / 1900; profiles/r04_ab_attention_speculation.txt)
+#ifndef DG_ATTN_NSPEC
+#define DG_ATTN_NSPEC 8
+#endif
+  constexpr int NSPEC = NI < DG_ATTN_NSPEC ? NI : DG_ATTN_NSPEC;
   u32x4 kk[NI], vv[NI];
 #pragma unroll
   for (int it = 0; it < NSPEC; ++it) {
