@@ -464,8 +464,15 @@ __global__ void __launch_bounds__(512) rope_attn_online_kernel(const uint16_t* _
                                                                const float* __restrict__ sin, const int64_t* __restrict__ pos_p,
                                                                uint16_t* __restrict__ k_cache, uint16_t* __restrict__ v_cache,
                                                                uint16_t* __restrict__ out, int hl, int kvl, int64_t max_seq, float scale,
-                                                               unsigned long long* trace) {
+                                                               unsigned long long* trace, float* part, int* counters) {
+  // gridDim.y = NS > 1: split over the sequence.  Block (head, c) takes the 32-row iterations c, c + NS, c + 2 NS, ... of the context
+  // (a partition that does not depend on the position: the speculative requests below stay possible), writes its (max, sum,
+  // unnormalised output) to `part`, and the last block of a head to arrive (self-resetting counter: replayable in a graph) combines
+  // the NS partials.  One block per head walks a long context at one CU's pace (~50 GB/s: 19 us per layer at 1900 positions).
   constexpr int D = LPR * 8, RPW = 64 / LPR, NWV = 8, RPI = NWV * RPW, NI = 256 / RPI, NG = RPI;
+  const int NS = gridDim.y, cblk = blockIdx.y;
+  // first row of the block's local iteration jl
+  auto row0_of = [&](int jl) -> int { return (jl * NS + cblk) * RPI; };
 #if GEMV_TRACE
   unsigned long long tr[8];
 #define DG_STAMP(n) tr[n] = __builtin_amdgcn_s_memrealtime()
@@ -494,7 +501,7 @@ __global__ void __launch_bounds__(512) rope_attn_online_kernel(const uint16_t* _
   u32x4 kk[NI], vv[NI];
 #pragma unroll
   for (int it = 0; it < NSPEC; ++it) {
-    const int rc = min(it * RPI + grp, (int)max_seq - 1);
+    const int rc = min(row0_of(it) + grp, (int)max_seq - 1);
     kk[it] = piece(K, rc);
     vv[it] = piece(V, rc);
   }
@@ -511,8 +518,8 @@ __global__ void __launch_bounds__(512) rope_attn_online_kernel(const uint16_t* _
   auto request = [&](int base, int first) {
 #pragma unroll
     for (int it = 0; it < NI; ++it) {
-      if (it < first || base + it * RPI >= S) continue;  // (wave-uniform) iterations past the last position request nothing
-      const int r = base + it * RPI + grp;
+      if (it < first || row0_of(base / RPI + it) >= S) continue;  // (wave-uniform) iterations past the last position request nothing
+      const int r = row0_of(base / RPI + it) + grp;
       const int rc = r < S - 1 ? r : 0;
       kk[it] = piece(K, rc);
       vv[it] = piece(V, rc);
@@ -542,7 +549,7 @@ __global__ void __launch_bounds__(512) rope_attn_online_kernel(const uint16_t* _
   };
   const u32x4 qp = rotate(qraw), kn = rotate(kraw);
   DG_STAMP(3);
-  if (h % rep == 0 && grp == 0) {  // one row group of the KV group's first head writes the new token's cache rows
+  if (h % rep == 0 && grp == 0 && cblk == 0) {  // one row group of the KV group's first head writes the new token's cache rows
     reinterpret_cast<u32x4*>(k_cache + (((int64_t)b * kvl + kv) * max_seq + pos) * D)[i] = kn;
     reinterpret_cast<u32x4*>(v_cache + (((int64_t)b * kvl + kv) * max_seq + pos) * D)[i] = vraw;
   }
@@ -551,13 +558,13 @@ __global__ void __launch_bounds__(512) rope_attn_online_kernel(const uint16_t* _
   };
   // ---- this group's rows: running max m, sum l, unnormalised accumulator acc[8] (the lane's 8 elements of the value row) ----
   float m = -INFINITY, l = 0.f, acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  for (int base = 0; base < S; base += NI * RPI) {
+  for (int base = 0; row0_of(base / RPI) < S; base += NI * RPI) {  // (base counts the block's own rows: local iteration base / RPI)
     if (base > 0) request(base, 0);
     float x[NI];
     float cm = -INFINITY;
 #pragma unroll
     for (int it = 0; it < NI; ++it) {
-      const int r = base + it * RPI + grp;
+      const int r = row0_of(base / RPI + it) + grp;
       const u32x4 kr = r == S - 1 ? kn : kk[it];
       // (literal indices: with a loop variable hipcc (ROCm 7.2) fed dword 0 of both vectors to all four v_dot2)
       float d2 = dot2_16<DT>(kr[0], qp[0], 0.f);
@@ -588,7 +595,7 @@ __global__ void __launch_bounds__(512) rope_attn_online_kernel(const uint16_t* _
       for (int e = 0; e < 8; ++e) acc[e] *= alpha;
 #pragma unroll
       for (int it = 0; it < NI; ++it) {
-        const int r = base + it * RPI + grp;
+        const int r = row0_of(base / RPI + it) + grp;
         const float pr = __expf(x[it] - mn);  // 0 for rows past the end
         l += pr;
         float vf[8];
@@ -622,18 +629,54 @@ __global__ void __launch_bounds__(512) rope_attn_online_kernel(const uint16_t* _
   }
   __syncthreads();
   DG_STAMP(6);
+  float Mb = -INFINITY, num = 0.f, den = 0.f;
   if (t < D) {
-    float M = -INFINITY;
 #pragma unroll
-    for (int w = 0; w < NWV; ++w) M = fmaxf(M, sm[w * (D + 2) + D]);
-    float num = 0.f, den = 0.f;
+    for (int w = 0; w < NWV; ++w) Mb = fmaxf(Mb, sm[w * (D + 2) + D]);
+    if (Mb > -INFINITY) {  // (a block of a split launch may have no rows)
 #pragma unroll
-    for (int w = 0; w < NWV; ++w) {
-      const float wt = __expf(sm[w * (D + 2) + D] - M);
-      num = fmaf(wt, sm[w * (D + 2) + t], num);
-      den = fmaf(wt, sm[w * (D + 2) + D + 1], den);
+      for (int w = 0; w < NWV; ++w) {
+        const float wt = __expf(sm[w * (D + 2) + D] - Mb);
+        num = fmaf(wt, sm[w * (D + 2) + t], num);
+        den = fmaf(wt, sm[w * (D + 2) + D + 1], den);
+      }
     }
-    out[((int64_t)b * hl + h) * D + t] = DT::from_f32(num / den);
+    if (NS == 1) out[((int64_t)b * hl + h) * D + t] = DT::from_f32(num / den);
+  }
+  if (NS > 1) {  // (uniform over the launch)
+    const int bh = blockIdx.x;
+    float* mine = part + ((int64_t)bh * NS + cblk) * (D + 2);
+    // No device-scope fence here: __threadfence() writes back and invalidates the XCD's whole L2 and costs ~12 us per block on this
+    // 8-XCD part (measured: NS = 2 / 4 / 8 made the decode step 20 / 30 / 45 % slower at ANY context length).  Instead every value that
+    // crosses blocks is written and read with agent-scope atomics (write-through stores, cache-bypassing loads), a thread's stores
+    // are complete (vmcnt(0), the workgroup barrier's release) before thread 0 increments the head's counter, and the counter itself
+    // is an agent-scope atomic: the last block to arrive sees every partial.
+    if (t < D) __hip_atomic_store(mine + 2 + t, num, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t == 0) {
+      __hip_atomic_store(mine, Mb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(mine + 1, den, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    __shared__ int s_last;
+    if (t == 0) s_last = __hip_atomic_fetch_add(&counters[bh], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == NS - 1;
+    __syncthreads();
+    if (s_last) {
+      if (t < D) {
+        const float* base = part + (int64_t)bh * NS * (D + 2);
+        float M = -INFINITY;
+        for (int c2 = 0; c2 < NS; ++c2) M = fmaxf(M, __hip_atomic_load(base + c2 * (D + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        float L = 0.f, o = 0.f;
+        for (int c2 = 0; c2 < NS; ++c2) {
+          const float mi = __hip_atomic_load(base + c2 * (D + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const float w = mi == -INFINITY ? 0.f : __expf(mi - M);
+          L += w * __hip_atomic_load(base + c2 * (D + 2) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          o += w * __hip_atomic_load(base + c2 * (D + 2) + 2 + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        out[((int64_t)b * hl + h) * D + t] = DT::from_f32(o / L);
+      }
+      if (t == 0) __hip_atomic_store(&counters[bh], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch / graph replay
+    }
   }
 #if GEMV_TRACE
   DG_STAMP(7);
@@ -748,7 +791,8 @@ int dg_rope_attn_online(const void* qkv, const float* cos, const float* sin, con
   const unsigned lds = (unsigned)(8 * (d + 2) * sizeof(float));
 #define DG_ONLINE(DTT, LPR_)                                                                                                        \
   hipLaunchKernelGGL((rope_attn_online_kernel<DTT, LPR_>), dim3((unsigned)(bs * hl)), dim3(512), lds, (hipStream_t)stream,          \
-                     (const uint16_t*)qkv, cos, sin, pos, (uint16_t*)k_cache, (uint16_t*)v_cache, (uint16_t*)out, hl, kvl, max_seq, scale, trace)
+                     (const uint16_t*)qkv, cos, sin, pos, (uint16_t*)k_cache, (uint16_t*)v_cache, (uint16_t*)out, hl, kvl, max_seq, scale, trace, \
+                     (float*)nullptr, (int*)nullptr)
   unsigned long long* trace = nullptr;
 #if GEMV_TRACE
   trace = g_attn_trace;
@@ -777,9 +821,24 @@ int dg_rope_attn_split(const void* qkv, const float* cos, const float* sin, cons
   const int64_t cs = (max_seq + nsplit - 1) / nsplit;
   const int64_t sc_floats = cs > (256 / (d / 8)) * (int64_t)d ? cs : (256 / (d / 8)) * (int64_t)d;
   const unsigned lds = (unsigned)((772 + sc_floats) * sizeof(float));
-  if (lds > 64u * 1024u) return TG_E_SHAPE;
   int* counters = reinterpret_cast<int*>(scratch);
   float* part = reinterpret_cast<float*>(reinterpret_cast<char*>(scratch) + ((bs * hl * 4 + 15) / 16) * 16);
+  if ((d == 64 || d == 128) && max_seq * d * 2 < ((int64_t)1 << 32) && aligned16(qkv) && aligned16(cos) && aligned16(sin)) {
+    // the one-barrier kernel, split over the sequence (same scratch layout: counters, then [head][chunk][max, sum, d outputs])
+    const unsigned lds1 = (unsigned)(8 * (d + 2) * sizeof(float));
+    const dim3 grid((unsigned)(bs * hl), (unsigned)nsplit);
+#define DG_ONLINE_SPLIT(DTT, LPR_)                                                                                                   \
+  hipLaunchKernelGGL((rope_attn_online_kernel<DTT, LPR_>), grid, dim3(512), lds1, (hipStream_t)stream, (const uint16_t*)qkv, cos, sin, \
+                     pos, (uint16_t*)k_cache, (uint16_t*)v_cache, (uint16_t*)out, hl, kvl, max_seq, scale, (unsigned long long*)nullptr, part, counters)
+    if (dtype == TG_BF16) {
+      if (d == 128) DG_ONLINE_SPLIT(BF16, 16); else DG_ONLINE_SPLIT(BF16, 8);
+    } else {
+      if (d == 128) DG_ONLINE_SPLIT(F16, 16); else DG_ONLINE_SPLIT(F16, 8);
+    }
+#undef DG_ONLINE_SPLIT
+    return launch_status();
+  }
+  if (lds > 64u * 1024u) return TG_E_SHAPE;
   auto kern = dtype == TG_BF16 ? rope_attn_split_kernel<BF16> : rope_attn_split_kernel<F16>;
   hipLaunchKernelGGL(kern, dim3((unsigned)(bs * hl), (unsigned)nsplit), dim3(256), lds, (hipStream_t)stream, (const uint16_t*)qkv,
                      cos, sin, pos, (uint16_t*)k_cache, (uint16_t*)v_cache, (uint16_t*)out, part, counters, hl, kvl, d, max_seq, scale);

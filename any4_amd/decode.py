@@ -22,6 +22,7 @@ Launch structure, chosen for the hardware rather than copied from HF:
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass
 from typing import Callable, Optional
 
@@ -374,8 +375,14 @@ class DecodeStack(torch.nn.Module):
             from . import decode_ops as G
 
             hl = cfg.heads // world
-            # (the cross-block combine needs device-scope fences, ~15 us on the 8-XCD part: it only pays for long caches)
-            self._attn_split = max(1, min(8, 256 // max(1, bs * hl))) if cfg.max_seq > 2048 else 1
+            # One block per head walks the cache at one CU's pace (Llama-3-8B, tokens/s at positions 136 / 500 / 900 / 1900: 624 / 583 /
+            # 553 / 483); split 4 ways: 579 / 579 / 577 / 554, 8 ways: 537 / 535 / 537 / 539 (the cross-block combine costs ~1 us per
+            # block of a head; profiles/r04_ab_attention_split.txt).  The grid is fixed when the step is captured, so the cache's
+            # capacity decides: up to 1024 positions one block, up to 4096 four, beyond that eight.
+            want = 1 if cfg.max_seq <= 1024 else 4 if cfg.max_seq <= 4096 else 8
+            self._attn_split = max(1, min(want, 256 // max(1, bs * hl)))
+            if os.environ.get("ANY4_ATTN_SPLIT"):  # developer override (A/B of the threshold above)
+                self._attn_split = max(1, int(os.environ["ANY4_ATTN_SPLIT"]))
             if self._attn_split > 1:
                 self._attn_scratch = G.rope_attn_split_scratch(bs, hl, cfg.head_dim, self._attn_split, device)
 

@@ -64,7 +64,9 @@ TG_API int dg_rope_attn_online(const void* qkv, const float* cos, const float* s
                                int dtype, int device, tg_stream_t stream);
 
 /* dg_rope_attn with the sequence split over `nsplit` blocks per head (flash-decoding style combine by the last block to
- * arrive): fills the GPU at batch 1 and long contexts.  `scratch`: dg_rope_attn_split_scratch_bytes(...) bytes, 16-byte
+ * arrive): fills the GPU at batch 1 and long contexts.  With d = 64 / 128 (and 16-byte aligned qkv / tables) it is
+ * dg_rope_attn_online's one-barrier kernel with gridDim.y = nsplit: block c of a head takes the 32-row iterations c, c + nsplit,
+ * ... of the context; what crosses blocks goes through agent-scope atomics, not through a device-scope fence.  `scratch`: dg_rope_attn_split_scratch_bytes(...) bytes, 16-byte
  * aligned, ZEROED ONCE by the caller before the first launch (the kernel leaves its counters at zero again); launches
  * sharing a scratch buffer must be stream-ordered.  Probabilities are normalised after the value contraction, so results
  * agree with dg_rope_attn within 16-bit rounding, not bit for bit.  max_seq / nsplit <= ~15000. */

@@ -175,6 +175,39 @@ def test_rope_attn_online_llama_heads(dtype):
         assert torch.equal(k2[:, :, :p], kc[:, :, :p]) and torch.equal(v2[:, :, :p], vc[:, :, :p]), p
         assert torch.isnan(k2[:, :, p + 1:].float()).all() and torch.isfinite(got.float()).all(), p
         assert (got.float() - want.float()).abs().max() <= 4 * ulp * want.float().abs().max(), (p, (got.float() - want.float()).abs().max())
+        # the same kernel split over the sequence (blocks take every NS-th 32-row iteration; the last block of a head to arrive combines):
+        # blocks without rows, the new token's row in any block, twice through the same scratch (the counters reset themselves)
+        for ns in (2, 5, 8):
+            scr = G.rope_attn_split_scratch(bs, hl, d, ns, DEV)
+            for _ in range(2):
+                k3, v3 = kc.clone(), vc.clone()
+                sp = G.rope_attn_split(qkv, cos, sin, pos, k3, v3, hl, kvl, d, scale, scr, ns)
+                assert torch.equal(k3[:, :, :p + 1], k2[:, :, :p + 1]) and torch.equal(v3[:, :, :p + 1], v2[:, :, :p + 1]), (p, ns)
+                assert torch.isnan(k3[:, :, p + 1:].float()).all() and torch.isfinite(sp.float()).all(), (p, ns)
+                assert (sp.float() - want.float()).abs().max() <= 4 * ulp * want.float().abs().max(), (p, ns)
+
+
+def test_rope_attn_split_many_back_to_back_launches():
+    """The split launch's cross-block hand-over uses no device-scope fence (agent-scope atomics for everything that crosses blocks, a
+    self-resetting counter): 300 launches back to back on one stream with fresh inputs each -- a stale partial or an early combine
+    would show as a result of another launch."""
+    from any4_amd import decode_ops as G
+    from any4_amd.decode import DecodeConfig, _rope_tables
+
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    bs, hl, kvl, d, S, p, ns = 1, 32, 8, 128, 2048, 1500, 4
+    cos, sin = _rope_tables(DecodeConfig(max_seq=S), DEV)
+    scale = 1.0 / math.sqrt(d)
+    kc = torch.randn(bs, kvl, S, d, device=DEV, generator=gen).bfloat16()
+    vc = torch.randn(bs, kvl, S, d, device=DEV, generator=gen).bfloat16()
+    pos = torch.tensor([p], device=DEV)
+    scr = G.rope_attn_split_scratch(bs, hl, d, ns, DEV)
+    qs = [torch.randn(bs, (hl + 2 * kvl) * d, device=DEV, generator=gen).bfloat16() for _ in range(300)]
+    outs = [G.rope_attn_split(q, cos, sin, pos, kc, vc, hl, kvl, d, scale, scr, ns) for q in qs]   # no sync in between
+    torch.cuda.synchronize()
+    for q, o in zip(qs[::7], outs[::7]):
+        want = G.rope_attn_online(q, cos, sin, pos, kc, vc, hl, kvl, d, scale)
+        assert (o.float() - want.float()).abs().max() <= 2.0 ** -6 * want.float().abs().max()
 
 
 @pytest.mark.parametrize("max_seq", [32, 4096])  # 4096: the split-sequence attention (8 blocks per head + combine)
@@ -188,7 +221,7 @@ def test_decode_graph_replay_equals_eager(max_seq):
     assert graph._graph is not None
     toks = torch.randint(0, cfg.vocab, (5, 2), generator=torch.Generator().manual_seed(2)).to(DEV)
     # capture's warm-up steps wrote position 0 of the cache with token 0; decoding from position 0 overwrites it
-    assert (eager._attn_split > 1) == (max_seq > 2048)
+    assert (eager._attn_split > 1) == (max_seq > 1024)
     for i, t in enumerate(toks):
         a, b = eager.decode(t, i), graph.decode(t, i).clone()
         if max_seq <= 2048:
