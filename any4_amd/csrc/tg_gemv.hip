@@ -38,8 +38,8 @@ int go_g(int gps, int d, bool norm, const GemvParams& gp, dim3 grid, unsigned ld
 // the matrix-core contraction (w4_gemv.cuh, MF): 3 ... 8 rows, one group per step, ring of four (k <= 4096: four steps per pass)
 template <typename DT, int M>
 int go_mf(int d, bool norm, const GemvParams& gp, dim3 grid, unsigned lds, hipStream_t st) {
-  if (d == 8) {  // (k > 4096: slices of more than four steps; one or two rows -- the activation block has to fit next to the table)
-    if constexpr (M <= 2) return norm ? go<DT, M, 1, 8, true, true>(gp, grid, lds, st) : go<DT, M, 1, 8, false, true>(gp, grid, lds, st);
+  if (d == 8) {  // (k > 4096: slices of more than four steps; up to four rows -- the activation block has to fit next to the table)
+    if constexpr (M <= 4) return norm ? go<DT, M, 1, 8, true, true>(gp, grid, lds, st) : go<DT, M, 1, 8, false, true>(gp, grid, lds, st);
     else return TG_PAIR_NA;
   }
   return norm ? go<DT, M, 1, 4, true, true>(gp, grid, lds, st) : go<DT, M, 1, 4, false, true>(gp, grid, lds, st);
@@ -87,7 +87,7 @@ extern "C" TG_API void tg_dev_gemv_trace(unsigned long long* buf, int slots) {
 int tgx::gemv(int dt, int I, bool qmx, GemmParams& p, int64_t batch, hipStream_t st) {
   const int g0 = 1 << p.gshift;
   // matrix-core contraction: 16-row passes of two super-tiles per step inside ONE group, a piece per thread in the staging
-  const bool mf = p.m >= TG_GEMV_MF_MIN_M && p.m <= 8 && (g0 == 128 || g0 == 256) && (p.k <= 4096 || p.m <= 2) && p.ksuper % 2 == 0;
+  const bool mf = p.m >= TG_GEMV_MF_MIN_M && p.m <= 8 && (g0 == 128 || g0 == 256) && (p.k <= 4096 || p.m <= 4) && p.ksuper % 2 == 0;
   if (I != 4 || qmx || (p.m > 4 && !mf) || p.x_tc || p.y_tc || batch != 1) return TG_PAIR_NA;
   if (p.ksuper * 64 != p.k || p.ntiles * 8 != p.wrows || p.ntiles > TG_GEMV_MAX_TILES) return TG_PAIR_NA;
   const int g = 1 << p.gshift;

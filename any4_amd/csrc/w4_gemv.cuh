@@ -289,7 +289,7 @@ __global__ void __launch_bounds__(512, 2) w4_gemv_kernel(const GemvParams p) {
         xd[a][j] = DT::pack2(DT::lo_f32(xv) * DT::lo_f32(g), DT::hi_f32(xv) * DT::hi_f32(g));
       }
     }
-    if (MF && M <= 2 && wide) {  // (host: long k only with one or two rows)
+    if (MF && M <= 4 && wide) {  // (host: long k only with up to four rows)
       // a thread stages a 32-k chunk; a STEP's 128 k are four consecutive threads
       float sum = 0.f;
 #pragma unroll

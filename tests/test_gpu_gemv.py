@@ -99,6 +99,7 @@ def test_gemv_fp16_and_every_m(T, oracle, m, g):
     (72, 256, 6, 128, "any4_rowwise"),      # k = 256: waves 2 ... 7 hold no step
     (1024, 2048, 8, 256, "int4"), (200, 1024, 3, 128, "any4_rowwise"),
     (4096, 14336, 1, 128, "any4_rowwise"), (512, 8192, 2, 256, "int4"),   # long k: a chunk per thread in the staging, ring of eight
+    (8192, 8192, 4, 128, "any4_rowwise"), (1024, 12288, 3, 128, "any4_rowwise"),
 ])
 def test_gemv_matrix_core_contraction_vs_oracle(T, oracle, case):
     n, k, m, g, qtype = case
