@@ -34,3 +34,7 @@ cp $(find /tmp/dec_prof -name 'dec_kernel_stats.csv' | head -1) gpurun_out/${RN}
 python tools/decode_timeline.py "$(find /tmp/dec_prof -name 'dec_kernel_trace.csv' | head -1)" --last 10 > gpurun_out/${RN}_decode_timeline.txt 2>&1
 tail -2 gpurun_out/${RN}_decode_bench.log | cut -c1-300; cat gpurun_out/${RN}_decode_timeline.txt
 variants/graph_chain > gpurun_out/${RN}_ubench_graph_chain.txt 2>&1; timeout 60 variants/overlap_chain > gpurun_out/${RN}_ubench_overlap_chain.txt 2>&1
+# (hipcc --offload-arch=gfx950 -O3 -o variants/<name> tools/ubench/<name>.hip beforehand: the binaries are git-ignored but travel)
+[ -x variants/grid_barrier ] && timeout 120 variants/grid_barrier > gpurun_out/${RN}_ubench_grid_barrier.txt 2>&1
+# the reference's module-level protocol (microbenchmark.py)
+(for k in 4096 8192; do for q in "anyq" "intq" "anyq --quantize-args per_row=False"; do echo "##### K=$k --quantize $q"; timeout 600 python tools/microbenchmark.py --input-dim $k --output-dim $k --quantize $q 2>&1 | grep -v "amdgpu.ids\|ROCTracer" | tail -5; done; done) > gpurun_out/${RN}_microbenchmark.txt 2>&1
