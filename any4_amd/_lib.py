@@ -104,6 +104,7 @@ SYMBOLS = {
     "dg_rope_attn_split": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, ctypes.c_int, ctypes.c_int, ctypes.c_int, _i64,
                            ctypes.c_float, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp],
     "dg_swiglu": [_vp, _vp, _i64, _i64, ctypes.c_int, ctypes.c_int, _vp],
+    "dg_linear16": [_vp, _vp, _vp, _i64, _i64, _i64, ctypes.c_int, ctypes.c_int, _vp],
 }
 
 _lib = None

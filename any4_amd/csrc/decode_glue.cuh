@@ -688,6 +688,56 @@ __global__ void __launch_bounds__(512) rope_attn_online_kernel(const uint16_t* _
 #undef DG_STAMP
 }
 
+// ---- y[a][row] = RNE16(sum_k x[a][k] w[row][k]) for ROW-MAJOR 16-bit weights [n][k] and 1 ... 4 activation rows: the LM head of the
+// decode step (the reference leaves it an nn.Linear, quantize.py:34-36; 1.05 GB at Llama-3-8B's vocabulary -- hipBLASLt streams it at
+// 5.8 TB/s, this kernel's only job is to stream it faster).  A wave owns a weight row at a time: lane l holds the 16-byte pieces
+// l, l + 64, ... of the row (every wave-load is 1 KiB contiguous) and the same pieces of the activation rows in registers for the
+// whole launch; NR rows per wave are in flight. k = 512 KP (KP pieces per lane); f32 accumulation in one fixed order per row. ----
+template <typename DT, int M, int KP, int NR>
+__global__ void __launch_bounds__(512) linear16_gemv_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w,
+                                                            uint16_t* __restrict__ y, int64_t n, int64_t rows_per_wave) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wv = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 6);
+  const int64_t r0 = wv * rows_per_wave, r1 = min(r0 + rows_per_wave, n);
+  if (r0 >= r1) return;
+  constexpr int K = KP * 512;
+  u32x4 xr[M][KP];
+#pragma unroll
+  for (int a = 0; a < M; ++a)
+#pragma unroll
+    for (int j = 0; j < KP; ++j) xr[a][j] = reinterpret_cast<const u32x4*>(x + (int64_t)a * K)[lane + 64 * j];
+  for (int64_t r = r0; r < r1; r += NR) {
+    u32x4 wr[NR][KP];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      const int64_t rr = min(r + i, r1 - 1);  // (rows past the range re-read its last row: every load unconditional)
+#pragma unroll
+      for (int j = 0; j < KP; ++j) wr[i][j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(w + rr * K) + lane + 64 * j);
+    }
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      float acc[M];
+#pragma unroll
+      for (int a = 0; a < M; ++a) {
+        acc[a] = 0.f;
+#pragma unroll
+        for (int j = 0; j < KP; ++j) {
+          acc[a] = dot2_16<DT>(wr[i][j][0], xr[a][j][0], acc[a]);
+          acc[a] = dot2_16<DT>(wr[i][j][1], xr[a][j][1], acc[a]);
+          acc[a] = dot2_16<DT>(wr[i][j][2], xr[a][j][2], acc[a]);
+          acc[a] = dot2_16<DT>(wr[i][j][3], xr[a][j][3], acc[a]);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc[a] += __shfl_xor(acc[a], o, 64);
+      }
+      if (lane == 0 && r + i < r1) {
+#pragma unroll
+        for (int a = 0; a < M; ++a) y[(int64_t)a * n + r + i] = DT::from_f32(acc[a]);
+      }
+    }
+  }
+}
+
 #if GEMV_TRACE
 unsigned long long* g_attn_trace = nullptr;
 #endif
@@ -847,6 +897,37 @@ int dg_rope_attn_split(const void* qkv, const float* cos, const float* sin, cons
 
 int64_t dg_rope_attn_split_scratch_bytes(int64_t bs, int hl, int d, int nsplit) {
   return ((bs * hl * 4 + 15) / 16) * 16 + bs * hl * (int64_t)nsplit * (d + 2) * 4;
+}
+
+int dg_linear16(const void* x, const void* w, void* y, int64_t m, int64_t n, int64_t k, int dtype, int device, tg_stream_t stream) {
+  if (!x || !w || !y) return TG_E_NULL;
+  if (!(dtype == TG_BF16 || dtype == TG_F16)) return TG_E_DTYPE;
+  if (m < 1 || m > 4 || n <= 0 || !(k == 2048 || k == 4096 || k == 8192) || (k == 8192 && m > 2)) return TG_E_SHAPE;  // (what is instantiated: the caller falls back to its GEMM)
+  if (!aligned16(x) || !aligned16(w)) return TG_E_ALIGN;
+  DeviceScope ds(device);
+  if (!ds.ok) return TG_E_DEVICE;
+  // persistent waves: 256 CUs x 2 workgroups x 8 waves, contiguous row ranges
+  const int64_t waves = 2 * 8 * (int64_t)cu_count();
+  const int64_t rpw = (n + waves - 1) / waves;
+  const unsigned blocks = (unsigned)((n + rpw * 8 - 1) / (rpw * 8));
+#define DG_L16(DTT, M_, KP_, NR_)                                                                                              \
+  hipLaunchKernelGGL((linear16_gemv_kernel<DTT, M_, KP_, NR_>), dim3(blocks), dim3(512), 0, (hipStream_t)stream, (const uint16_t*)x, \
+                     (const uint16_t*)w, (uint16_t*)y, n, rpw)
+#define DG_L16_M(DTT, KP_, NR_)                                                          \
+  do {                                                                                   \
+    if (m == 1) DG_L16(DTT, 1, KP_, NR_); else if (m == 2) DG_L16(DTT, 2, KP_, NR_);      \
+    else if (m == 3) DG_L16(DTT, 3, KP_, NR_); else DG_L16(DTT, 4, KP_, NR_);             \
+  } while (0)
+#define DG_L16_K(DTT)                                                                    \
+  do {                                                                                   \
+    if (k == 2048) DG_L16_M(DTT, 4, 4); else if (k == 4096) DG_L16_M(DTT, 8, 2);           \
+    else if (m == 1) DG_L16(DTT, 1, 16, 1); else DG_L16(DTT, 2, 16, 1);  /* (k = 8192: one or two rows fit the registers) */ \
+  } while (0)
+  if (dtype == TG_BF16) DG_L16_K(BF16); else DG_L16_K(F16);
+#undef DG_L16_K
+#undef DG_L16_M
+#undef DG_L16
+  return launch_status();
 }
 
 int dg_swiglu(const void* gu, void* out, int64_t bs, int64_t il, int dtype, int device, tg_stream_t stream) {

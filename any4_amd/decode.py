@@ -437,7 +437,11 @@ class DecodeStack(torch.nn.Module):
                 for layer in self.layers:
                     h, delta = layer.forward_fused(h, delta, pos, self.cos, self.sin, self._gather, self._attn_scratch, self._attn_split)
             _, y = G.add_rmsnorm(h, delta, self.norm.weight, self.norm.eps)
-            return self.lm_head(y) if self.lm_head is not None else y
+            if self.lm_head is None:
+                return y
+            # the un-quantised LM head (quantize.py:34-36 skips it): a streaming GEMV for up to four rows, else torch's GEMM
+            logits = G.linear16(y, self.lm_head.weight) if self.lm_head.bias is None else None
+            return logits if logits is not None else self.lm_head(y)
         cos = self.cos.index_select(0, pos).view(1, 1, -1)
         sin = self.sin.index_select(0, pos).view(1, 1, -1)
         mask = (self.arange > pos).view(1, 1, 1, -1)

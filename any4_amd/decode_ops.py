@@ -124,3 +124,18 @@ def swiglu(gu: torch.Tensor) -> torch.Tensor:
     out = torch.empty((bs, il), dtype=gu.dtype, device=gu.device)
     _lib.check(_lib.load().dg_swiglu(gu.data_ptr(), out.data_ptr(), bs, il, _dt(gu), gu.device.index, _stream(gu)), "dg_swiglu")
     return out
+
+
+def linear16(x: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
+    """y = x @ weight.T for a ROW-MAJOR 16-bit weight [n][k] (an nn.Linear's) and 1 ... 4 rows of x: the decode step's LM head.
+    Returns None when the library has no instantiation for the shape (the caller keeps its GEMM)."""
+    _gpu(x)
+    m, k = x.shape
+    n = weight.shape[0]
+    if not (1 <= m <= (2 if k == 8192 else 4) and k in (2048, 4096, 8192) and weight.dtype == x.dtype and weight.is_contiguous() and x.is_contiguous()
+            and weight.shape[1] == k and x.data_ptr() % 16 == 0 and weight.data_ptr() % 16 == 0):
+        return None
+    y = torch.empty((m, n), dtype=x.dtype, device=x.device)
+    _lib.check(_lib.load().dg_linear16(x.data_ptr(), weight.data_ptr(), y.data_ptr(), m, n, k, _dt(x), x.device.index, _stream(x)), "dg_linear16")
+    return y
+

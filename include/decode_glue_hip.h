@@ -78,6 +78,11 @@ TG_API int dg_rope_attn_split(const void* qkv, const float* cos, const float* si
 /* out[b][j] = to16(silu(gu[b][j])) * gu[b][il + j], j < il; gu [bs][2 il]; il % 8 == 0. */
 TG_API int dg_swiglu(const void* gu, void* out, int64_t bs, int64_t il, int dtype, int device, tg_stream_t stream);
 
+/* y[m][n] = RNE16(x[m][k] . w[n][k]^T), ROW-MAJOR 16-bit weights (an nn.Linear's), f32 accumulation: the LM head of the decode step,
+ * which the reference leaves un-quantised (quantize.py:34-36).  m = 1 ... 4 at k = 2048 / 4096, 1 ... 2 at k = 8192 (TG_E_SHAPE otherwise: the caller
+ * keeps its GEMM); x and w 16-byte aligned. */
+TG_API int dg_linear16(const void* x, const void* w, void* y, int64_t m, int64_t n, int64_t k, int dtype, int device, tg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -187,6 +187,25 @@ def test_rope_attn_online_llama_heads(dtype):
                 assert (sp.float() - want.float()).abs().max() <= 4 * ulp * want.float().abs().max(), (p, ns)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_linear16_gemv_vs_torch(dtype):
+    """dg_linear16 (the decode step's un-quantised LM head: row-major 16-bit weights, 1 ... 4 rows) against an f64 product: one 16-bit
+    rounding (half a spacing = 2^-8 |y| for bf16, 2^-11 |y| for fp16, at most) of a sum with f32 accumulation; ragged row counts (not a
+    multiple of the waves), every k."""
+    from any4_amd import decode_ops as G
+
+    gen = torch.Generator(device=DEV).manual_seed(5)
+    ulp = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    for (m, n, k) in [(1, 128256, 4096), (3, 1000, 2048), (4, 32000, 4096), (2, 5003, 8192), (1, 7, 4096)]:
+        x = torch.randn(m, k, device=DEV, generator=gen).to(dtype)
+        w = (torch.randn(n, k, device=DEV, generator=gen) * 0.02).to(dtype)
+        y = G.linear16(x, w)
+        assert y is not None and y.shape == (m, n)
+        want = x.double() @ w.double().t()
+        assert ((y.double() - want).abs() <= ulp * want.abs() * 1.01 + 8e-6 * (x.double().abs() @ w.double().abs().t())).all(), (m, n, k)
+    assert G.linear16(torch.randn(2, 1024, device=DEV).to(dtype), torch.randn(8, 1024, device=DEV).to(dtype)) is None   # no instantiation: the caller's GEMM
+
+
 def test_rope_attn_split_many_back_to_back_launches():
     """The split launch's cross-block hand-over uses no device-scope fence (agent-scope atomics for everything that crosses blocks, a
     self-resetting counter): 300 launches back to back on one stream with fresh inputs each -- a stale partial or an early combine
