@@ -25,7 +25,12 @@ def _gpu(*ts):
             raise RuntimeError("decode glue kernels need contiguous tensors on a ROCm device (there is no CPU fallback)")
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream(t):
+    if _raw_stream is not None:
+        return _raw_stream(t.device.index if t.device.index is not None else torch.cuda.current_device())
     return torch.cuda.current_stream(t.device).cuda_stream
 
 

@@ -874,3 +874,46 @@ def test_default_numerics_row_does_not_depend_on_batch_shape(T, oracle, qtype, g
         assert not bad.any(), f"m = {m}: row 0 is {np.abs(rows[m] - y_gs).max():.3e} from the group-scaled sum"
     for m in (2, 8, 9, 16, 33):
         assert (np.abs(rows[m] - rows[1]) <= 2 * tol).all(), f"row 0 at m = {m} against m = 1"
+
+
+def test_module_launch_plan_is_the_full_path_and_follows_its_inputs():
+    """Any4Linear / Int4Linear.forward re-issue a recorded launch (ops.LaunchPlan) for a repeated (module, activation shape): the same
+    bits as the fully validated path, for fresh inputs, and the plan is dropped when anything it depends on changes -- a parameter
+    re-assigned, another numerics setting, another shape, a non-contiguous input."""
+    import any4_amd
+    import modules
+    from any4_amd import ops
+
+    n, k, g = 1024, 2048, 128
+    gen = torch.Generator().manual_seed(2)
+    for cls, kw in ((modules.Any4Linear, {}), (modules.Int4Linear, {})):
+        lin = cls(k, n, bias=False, device=DEV, dtype=torch.bfloat16, group_size=g, **kw)
+        codes, x, qinfo, lut = rand_problem(n, k, g, 3, "any4_rowwise", seed=4)
+        lin.weight.data = codes.to(DEV)
+        lin.scales_and_zeros.data = qinfo.to(DEV)
+        if hasattr(lin, "lut") and lin.lut is not None:
+            lin.lut.data = lut.to(DEV)
+        lin.reshape_weight()
+        full = lambda xx: lin._gemm(xx)                      # the fully validated path (no plan)
+        xs = [torch.randn(3, k, generator=gen).bfloat16().to(DEV) for _ in range(4)]
+        ys = [lin(xx) for xx in xs]                          # first call records, the others run the plan
+        assert lin.__dict__["_plan"][1] is not None
+        for xx, yy in zip(xs, ys):
+            assert torch.equal(yy, full(xx))
+        # another shape, a 3-D input, a non-contiguous input
+        x1 = torch.randn(2, 5, k, generator=gen).bfloat16().to(DEV)
+        assert torch.equal(lin(x1), full(x1.view(-1, k)).view(2, 5, n))
+        xt = torch.randn(k, 3, generator=gen).bfloat16().to(DEV).t()
+        with pytest.raises(RuntimeError, match="contiguous"):      # (as in the reference: TinyGemm_int4.cu checks is_contiguous)
+            lin(xt)
+        # a re-assigned parameter: the old plan must not be used
+        q2 = (qinfo * 2).to(DEV)
+        lin.scales_and_zeros.data = q2
+        y_new = lin(xs[0])
+        assert torch.equal(y_new, full(xs[0])) and not torch.equal(y_new, ys[0])
+        # another numerics setting
+        with any4_amd.numerics("reference"):
+            y_ref = lin(xs[0])
+            assert torch.equal(y_ref, full(xs[0]))
+        assert torch.equal(lin(xs[0]), y_new)
+
