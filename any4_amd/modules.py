@@ -77,6 +77,12 @@ class _PackedLinear(torch.nn.Module):
                 return self._forward(input)
         return self._forward(input)
 
+    def __getstate__(self):
+        # (the recorded launch plan holds raw device pointers in a ctypes struct: never copied or pickled with the module)
+        state = self.__dict__.copy()
+        state.pop("_plan", None)
+        return state
+
     def _plan_key(self, x2d):
         p = self._parameters
         ptr = lambda t: None if t is None else t.data_ptr()

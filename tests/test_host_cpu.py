@@ -359,3 +359,21 @@ def test_integration_md_binding_and_struct_bytes():
     full.struct_bytes = ctypes.sizeof(S)
     full.struct_reserved = 1
     assert L.tg_gemm_w4_plan(ctypes.byref(full), -1) == _lib.TG_E_STRUCT
+
+
+def test_module_copies_drop_the_launch_plan():
+    """copy.deepcopy / pickle of a quantized module must not carry (or choke on) the recorded launch plan's ctypes struct."""
+    import copy
+    import ctypes
+    import pickle
+
+    import modules
+    from any4_amd import _lib
+
+    lin = modules.Int4Linear(64, 32, bias=False, dtype=torch.bfloat16, group_size=32)
+    lin.__dict__["_plan"] = (("key",), _lib.W4Gemm(x=ctypes.c_void_p(1234).value))
+    twin = copy.deepcopy(lin)
+    assert "_plan" not in twin.__dict__ and torch.equal(twin.weight, lin.weight)
+    again = pickle.loads(pickle.dumps(lin))
+    assert "_plan" not in again.__dict__ and "_plan" in lin.__dict__
+
