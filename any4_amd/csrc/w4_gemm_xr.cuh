@@ -378,6 +378,11 @@ __global__ void __launch_bounds__(WV * 64, WV == 8 ? 2 : 1) w4_gemm_xr_kernel(co
         u32x4 b0, b1;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
+          if constexpr (XR_ABL == 9) {  // ablation: no lane swaps (wrong operands: timing only)
+            b0[j] = pv[st & 1][j];
+            b1[j] = pw[st & 1][j];
+            continue;
+          }
           const auto sw = __builtin_amdgcn_permlane16_swap(pv[st & 1][j], pw[st & 1][j], false, false);
           b0[j] = sw[0];
           b1[j] = sw[1];
@@ -472,33 +477,36 @@ __global__ void __launch_bounds__(WV * 64, WV == 8 ? 2 : 1) w4_gemm_xr_kernel(co
           *reinterpret_cast<uint16_t*>(yb + (p.y_tc ? tc_a_index(a, row, p.y_tiles) : (int64_t)a * p.wrows + row) * 2) = o16;
         }
       } else {
-      asm volatile(
-          "ds_read2st64_b32 %0, %8 offset1:16\n\t"
-          "ds_read2st64_b32 %1, %8 offset0:32 offset1:48\n\t"
-          "ds_read2st64_b32 %2, %8 offset0:64 offset1:80\n\t"
-          "ds_read2st64_b32 %3, %8 offset0:96 offset1:112\n\t"
-          "ds_read2st64_b32 %4, %9 offset1:16\n\t"
-          "ds_read2st64_b32 %5, %9 offset0:32 offset1:48\n\t"
-          "ds_read2st64_b32 %6, %9 offset0:64 offset1:80\n\t"
-          "ds_read2st64_b32 %7, %9 offset0:96 offset1:112\n\t"
-          "s_waitcnt lgkmcnt(0)"
-          : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3), "=&v"(w0), "=&v"(w1), "=&v"(w2), "=&v"(w3)
-          : "v"(pa), "v"(pa + 2u * 4u * 64u * 4u)
-          : "memory");
-      float sums[2];
-      sums[0] = ((((((v0[0] + v0[1]) + v1[0]) + v1[1]) + v2[0]) + v2[1]) + v3[0]) + v3[1];
-      sums[1] = ((((((w0[0] + w0[1]) + w1[0]) + w1[1]) + w2[0]) + w2[1]) + w3[0]) + w3[1];
-      char* yb = p.y + (int64_t)cur.b * p.stride_y;
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        const int row = row0 + 16 * (t0 + 2 * e) + (l & 15);
-        if (a < p.m && (XR_ABL != 7 || sums[e] == 123.456f)) {  // (ablation 7: no output stores)
-          uint16_t o16 = DT::from_f32(sums[e]);
-          if (p.bias)  // rounded sum + bias, rounded again: bit-identical to the reference module's separate `y + bias`
-            o16 = DT::from_f32(DT::lo_f32(o16) + DT::lo_f32(*reinterpret_cast<const uint16_t*>(p.bias + (int64_t)cur.b * p.stride_bias + ((int64_t)a * p.bias_row_stride + row) * 2)));
-          *reinterpret_cast<uint16_t*>(yb + (p.y_tc ? tc_a_index(a, row, p.y_tiles) : (int64_t)a * p.wrows + row) * 2) = o16;
+        // 512 threads, TWO ADJACENT weight rows of one activation row each: thread = (tile t2, register r2, lane quarter kb2, row pair
+        // n2).  The partial sums of rows 2 n2, 2 n2 + 1 sit in adjacent lanes = adjacent dwords: one 8-byte LDS read per wave's
+        // partials (four ds_read2st64_b64 instead of eight ds_read2st64_b32), added in wave order as before (the same bits), and ONE
+        // 4-byte store of the pair instead of two 2-byte stores (same-box ablation: the output stores alone were 8 % of the item)
+        const int n2 = tid_t & 7, kb2 = (tid_t >> 3) & 3, r2 = (tid_t >> 5) & 3, t2 = tid_t >> 7;
+        const int a2 = r2 + 4 * kb2;
+        const uint32_t pa2 = lds_red + (uint32_t)(((t2 * 4 + r2) * 64 + 2 * n2 + 16 * kb2) * 4);
+        f32x4 q0v, q1v, q2v, q3v;  // (wave w: [0], [1] = the two rows; wave w + 1: [2], [3])
+        asm volatile(
+            "ds_read2st64_b64 %0, %4 offset1:8\n\t"
+            "ds_read2st64_b64 %1, %4 offset0:16 offset1:24\n\t"
+            "ds_read2st64_b64 %2, %4 offset0:32 offset1:40\n\t"
+            "ds_read2st64_b64 %3, %4 offset0:48 offset1:56\n\t"
+            "s_waitcnt lgkmcnt(0)"
+            : "=&v"(q0v), "=&v"(q1v), "=&v"(q2v), "=&v"(q3v)
+            : "v"(pa2)
+            : "memory");
+        const float sa = ((((((q0v[0] + q0v[2]) + q1v[0]) + q1v[2]) + q2v[0]) + q2v[2]) + q3v[0]) + q3v[2];
+        const float sb = ((((((q0v[1] + q0v[3]) + q1v[1]) + q1v[3]) + q2v[1]) + q2v[3]) + q3v[1]) + q3v[3];
+        char* yb = p.y + (int64_t)cur.b * p.stride_y;
+        const int row = row0 + 16 * t2 + 2 * n2;  // (even; the host guarantees wrows % 64 == 0)
+        if (a2 < p.m && (XR_ABL != 7 || sa == 123.456f)) {  // (ablation 7: no output stores)
+          uint16_t oa = DT::from_f32(sa), ob = DT::from_f32(sb);
+          if (p.bias) {  // rounded sum + bias, rounded again: bit-identical to the reference module's separate `y + bias`
+            const uint32_t bv = *reinterpret_cast<const uint32_t*>(p.bias + (int64_t)cur.b * p.stride_bias + ((int64_t)a2 * p.bias_row_stride + row) * 2);
+            oa = DT::from_f32(DT::lo_f32(oa) + DT::lo_f32(bv));
+            ob = DT::from_f32(DT::lo_f32(ob) + DT::hi_f32(bv));
+          }
+          *reinterpret_cast<uint32_t*>(yb + (p.y_tc ? tc_a_index(a2, row, p.y_tiles) : (int64_t)a2 * p.wrows + row) * 2) = (uint32_t)oa | ((uint32_t)ob << 16);
         }
-      }
       }  // WAVES == 8
     }
     if constexpr (XR_ABL != 8)  // (ablation 8: without this barrier -- a race, timing only)
