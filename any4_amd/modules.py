@@ -40,10 +40,6 @@ class _PackedLinear(torch.nn.Module):
         self.kernel = kernel
         self.w_inner_k = w_inner_k
         self.weight_reshaped = False
-        # packed format of a weights-on-the-left tensor (any4_amd.ops.get_weight_format): recorded by reshape_weight(); None = the
-        # process default.  A state_dict packed by the CUDA implementation holds the reference's words: set "reference" (the slower
-        # kernels take them as they are) or call relayout("native") once.
-        self.weight_format = None
 
     def reshape_weight(self, w_inner_k: int | None = None):
         """Pack `weight` once into the layout `self.kernel` consumes."""
@@ -55,26 +51,67 @@ class _PackedLinear(torch.nn.Module):
         self.weight.data = getattr(_T, packer)(self.weight, w_inner_k)
         self.weight_reshaped = True
         self.w_inner_k = w_inner_k
-        self.weight_format = _ops.get_weight_format() if "Aint4" in packer else None
+
+    @property
+    def weight_format(self):
+        """'native' / 'reference' for a packed weights-on-the-left tensor (read off the tensor's own shape, any4_amd.ops.aside_format:
+        the two packed formats differ in shape, so the tag travels with the tensor through state_dict, pickling and other
+        processes), None otherwise."""
+        if not self.weight_reshaped or "Aint4" not in self._PACKERS.get(self.kernel, "") or self.weight.dim() != 4:
+            return None
+        return _ops.aside_format(self.weight, self.in_features)
 
     def relayout(self, to: str):
-        """Repack an already packed weights-on-the-left tensor ('reference' <-> 'native', lossless; any4_amd.ops.relayout_Aint4)."""
-        packer = self._PACKERS.get(self.kernel, "")
-        if not self.weight_reshaped or "Aint4" not in packer:
+        """Repack an already packed weights-on-the-left tensor ('reference' <-> 'native', lossless; any4_amd.ops.relayout_Aint4),
+        e.g. once after loading a checkpoint packed by the CUDA implementation."""
+        if self.weight_format is None:
             raise ValueError("relayout() applies to a packed weights-on-the-left (Aint4) tensor")
-        have = self.weight_format or _ops.get_weight_format()
-        if have != to:
-            with _ops.weight_format(have):
-                self.weight.data = _ops.relayout_Aint4(self.weight.data, self.in_features, to)
-            self.weight_format = to
+        self.weight.data = _ops.relayout_Aint4(self.weight.data, self.in_features, to, self.w_inner_k)
+
+    # ---- checkpoints: what the reference keeps in plain attributes (modules.py:38-41: kernel, w_inner_k, weight_reshaped) decides
+    # how the `weight` tensor of a state_dict has to be read, so for a PACKED module it travels with it (eval.py:180-210 saves /
+    # loads state_dicts).  An unpacked module's state_dict has exactly the reference's keys.
+    _TAG = torch.nn.modules.module._EXTRA_STATE_KEY_SUFFIX
+
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        super()._save_to_state_dict(destination, prefix, keep_vars)
+        if self.weight_reshaped:
+            destination[prefix + self._TAG] = {"kernel": self.kernel, "w_inner_k": int(self.w_inner_k), "weight_reshaped": True}
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        w = state_dict.get(prefix + "weight")
+        tag = state_dict.get(prefix + self._TAG)
+        if tag is not None and tag.get("weight_reshaped") and tag.get("kernel", self.kernel) != self.kernel \
+                and self._PACKERS.get(tag["kernel"]) != self._PACKERS.get(self.kernel):
+            # a tensor packed for the other operand side cannot be multiplied by this kernel: refuse instead of mis-computing
+            raise RuntimeError(f"checkpoint weight was packed for kernel {tag['kernel']!r}, this module runs {self.kernel!r}")
+        if w is not None and w.dim() != self.weight.dim():
+            # a packed checkpoint into an unpacked module (or the reverse): take the checkpoint's shape
+            self.weight.data = torch.empty(w.shape, dtype=self.weight.dtype, device=self.weight.device)
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs)
+        if prefix + self._TAG in unexpected_keys:
+            unexpected_keys.remove(prefix + self._TAG)
+        if w is not None:
+            packed = w.dim() == 4
+            self.weight_reshaped = packed
+            if tag is not None:
+                self.w_inner_k = int(tag.get("w_inner_k", self.w_inner_k))
+            elif packed:
+                # a state_dict of the reference implementation (no tag): the tensor's innermost size says the innerKTiles
+                # (TinyGemm_int4.cu:322-364), and a weights-on-the-left tensor says its format by its shape (ops.aside_format)
+                packer = self._PACKERS.get(self.kernel, "")
+                if "Bint4" in packer:
+                    self.w_inner_k = w.size(3) * 2
+                elif "Aint8" in packer:
+                    self.w_inner_k = w.size(3) // 2
+                elif "Bint8" in packer or _ops.aside_format(w, self.in_features) == "reference":
+                    self.w_inner_k = w.size(3)
+        self.__dict__.pop("_plan", None)
 
     def _gemm(self, x2d: torch.Tensor) -> torch.Tensor:
         raise NotImplementedError
 
     def forward(self, input: torch.Tensor) -> torch.Tensor:
-        if self.weight_format is not None and self.weight_format != _ops.get_weight_format():
-            with _ops.weight_format(self.weight_format):
-                return self._forward(input)
         return self._forward(input)
 
     def __getstate__(self):
@@ -83,11 +120,13 @@ class _PackedLinear(torch.nn.Module):
         state.pop("_plan", None)
         return state
 
+    _PLAN_PARAMS = ("weight", "scales_and_zeros", "exponents", "lut")
+
     def _plan_key(self, x2d):
         p = self._parameters
-        ptr = lambda t: None if t is None else t.data_ptr()
-        return (x2d.shape, x2d.dtype, x2d.device, self.kernel, ptr(p["weight"]), ptr(p.get("scales_and_zeros")), ptr(p.get("exponents")),
-                ptr(p.get("lut")), _ops.get_numerics(), _ops.get_weight_format())
+        # (pointer AND version of every parameter: an in-place update -- load_state_dict, copy_ -- drops the plan as well)
+        tag = tuple((t.data_ptr(), t._version, t.shape) for t in (p.get(n) for n in self._PLAN_PARAMS) if t is not None)
+        return (x2d.shape, x2d.dtype, x2d.device, self.kernel, self.group_size, self.w_inner_k, tag, _ops.get_numerics())
 
     def _forward(self, input: torch.Tensor) -> torch.Tensor:
         lead = input.shape[:-1]
@@ -99,7 +138,7 @@ class _PackedLinear(torch.nn.Module):
                 key = self._plan_key(x2d)
                 plan = self.__dict__.get("_plan")
                 if plan is None or plan[0] != key:
-                    y, lp = _ops.record_plan(self._gemm, x2d, key)
+                    y, lp = _ops.record_plan(self._gemm, x2d, key, [self._parameters.get(n) for n in self._PLAN_PARAMS])
                     self.__dict__["_plan"] = (key, lp)   # (lp None: this kernel flavour has no single-launch plan -- remembered too)
                     return y.view(*lead, y.shape[-1])
                 if plan[1] is not None:

@@ -101,12 +101,14 @@ if _wformat not in _WFORMATS:
 
 
 def get_weight_format() -> str:
-    """What `convert_matrix_to_m16n8k16_Aint4_layout` returns and what the weights-on-the-left GEMM ops expect (the packed tensor
-    is opaque to every caller of the reference: TinyGemm_int4.cu:322-364 only checks its shape).
-    'native' (default): the reference's Aint4 SHAPE [m/16][k/(16 I)][32][I] holding the codes in row-per-lane order (the Bint4
-    word order, rows padded to 16; tg_w4_gemm.w_format = TG_WFMT_ROWS) -- the A-side ops then run the B-side kernels (a packed
-    word holds 8 codes of ONE weight row instead of 4 + 4 of rows r and r + 8).  'reference': the reference's Aint4 words, bit
-    for bit (checkpoints packed by the CUDA implementation; `relayout_Aint4` converts either way, losslessly)."""
+    """What `convert_matrix_to_m16n8k16_Aint4_layout` PRODUCES (the packed tensor is opaque to every caller of the reference:
+    TinyGemm_int4.cu:322-364 only checks its shape).  What a GEMM op CONSUMES is decided by the tensor itself, never
+    by this setting: the two formats have different shapes (`aside_format`), so a tensor packed under either setting, in any
+    process, by this library or by the CUDA implementation, is multiplied correctly or rejected -- and `state_dict` carries it.
+    'native' (default): the Bint4 tensor of the weight rows padded to 16, [2 ceil(m/16)][k/(16 J)][32][J/2] with J = 4 (k % 64
+    == 0) or 2 -- row-per-lane order, a packed word holds 8 codes of ONE weight row instead of 4 + 4 of rows r and r + 8; the
+    A-side ops then run the B-side kernels (tg_w4_gemm.w_format = TG_WFMT_ROWS).  'reference': the reference's Aint4 tensor
+    [ceil(m/16)][k/(16 I)][32][I], bit for bit (`relayout_Aint4` converts either way, losslessly)."""
     return getattr(_tls, "wformat", _wformat)
 
 
@@ -134,8 +136,20 @@ def weight_format(name: str):
 
 
 def _rows_inner(k: int) -> int:
-    """innerKTiles of the Bint4 word order inside a native A-shaped tensor (tg_w4_gemm.w_format = TG_WFMT_ROWS)."""
+    """innerKTiles of the Bint4 word order of a native weights-on-the-left tensor (tg_w4_gemm.w_format = TG_WFMT_ROWS)."""
     return 4 if k % 64 == 0 else 2
+
+
+def aside_format(w: torch.Tensor, k: int) -> str:
+    """Which packed format a weights-on-the-left tensor holds, from its shape and the activations' k alone.  The reference's
+    Aint4 tensor [m/16][k/(16 I)][32][I] covers size(1) * size(3) * 16 = k; the native tensor (a Bint4 tensor,
+    [m/8][k/(16 J)][32][J/2]) covers size(1) * size(3) * 32 = k: no tensor satisfies both for one k."""
+    span = w.size(1) * w.size(3) * 16
+    if span == k:
+        return "reference"
+    _check(span * 2 == k and w.size(0) % 2 == 0 and w.size(3) * 2 == _rows_inner(k),
+           "weights: k super-tiles do not match the activations' k")
+    return "native"
 
 
 _PLANS = {_lib.TG_PLAN_SPLITK: "splitk", _lib.TG_PLAN_STREAM: "stream", _lib.TG_PLAN_PAIR: "pair", _lib.TG_PLAN_PAIR_XR: "pair_xr", _lib.TG_PLAN_GEMV: "gemv"}
@@ -246,40 +260,48 @@ def convert_matrix_to_m16n8k16_Aint4_layout(t: torch.Tensor, innerKTiles: int) -
     _check(t.is_contiguous(), "Aint4 layout: input must be contiguous")
     _check(innerKTiles in (1, 2, 4), "Aint4 layout: innerKTiles must be 1, 2 or 4")
     m, k = t.shape
-    shape = (_cdiv(m, 16), _cdiv(k, innerKTiles * 16), 32, innerKTiles)
     if get_weight_format() == "native" and k % 32 == 0 and k % (innerKTiles * 16) == 0:
-        # the row-per-lane order (any k a weights-on-the-left GEMM accepts); other k: the reference's words (no GEMM takes them)
+        # the row-per-lane order (any k a weights-on-the-left GEMM accepts); other k: the reference's words (no GEMM takes them).
+        # The tensor says what it is by its shape (aside_format): the Bint4 tensor of the rows padded to 16.
+        j = _rows_inner(k)
         alloc = torch.zeros if _cdiv(m, 8) % 2 else torch.empty  # an odd number of 8-row tiles: the pad tile is all zero codes
-        out = alloc(shape, dtype=torch.int32, device=t.device)
-        _lib.check(_L.tg_convert_to_Bint4(t.data_ptr(), m, k, _rows_inner(k), out.data_ptr(), _dev(t), _stream(t)),
+        out = alloc((2 * _cdiv(m, 16), k // (16 * j), 32, j // 2), dtype=torch.int32, device=t.device)
+        _lib.check(_L.tg_convert_to_Bint4(t.data_ptr(), m, k, j, out.data_ptr(), _dev(t), _stream(t)),
                    "convert_matrix_to_m16n8k16_Aint4_layout")
         return out
-    out = torch.empty(shape, dtype=torch.int32, device=t.device)
+    out = torch.empty((_cdiv(m, 16), _cdiv(k, innerKTiles * 16), 32, innerKTiles), dtype=torch.int32, device=t.device)
     _lib.check(_L.tg_convert_to_Aint4(t.data_ptr(), m, k, innerKTiles, out.data_ptr(), _dev(t), _stream(t)),
                "convert_matrix_to_m16n8k16_Aint4_layout")
     return out
 
 
 def unpack_int4(packed: torch.Tensor, rows: int, k: int, layout: str) -> torch.Tensor:
-    """Packed 4-bit words -> int32 codes [rows][k] (tg_unpack_int4).  layout: 'B' (Bint4 words, innerKTiles = 2 size(3)), 'A' (the
-    reference's Aint4 words, innerKTiles = size(3)) or 'A_native' (an A-shaped tensor in row-per-lane order)."""
+    """Packed 4-bit words -> int32 codes [rows][k] (tg_unpack_int4).  layout: 'B' (Bint4 words, innerKTiles = 2 size(3); a native
+    weights-on-the-left tensor is one) or 'A' (the reference's Aint4 words, innerKTiles = size(3))."""
     _check(packed.dim() == 4 and packed.dtype == torch.int32 and packed.is_contiguous(), "unpack_int4: a contiguous 4-D int32 tensor")
-    _check(layout in ("A", "B", "A_native"), "unpack_int4: layout must be 'A', 'B' or 'A_native'")
-    inner = packed.size(3) if layout == "A" else 2 * packed.size(3) if layout == "B" else _rows_inner(k)
+    _check(layout in ("A", "B"), "unpack_int4: layout must be 'A' or 'B'")
+    inner = packed.size(3) if layout == "A" else 2 * packed.size(3)
     out = torch.empty((rows, k), dtype=torch.int32, device=packed.device)
     _lib.check(_L.tg_unpack_int4(packed.data_ptr(), 1 if layout == "A" else 0, rows, k, inner, out.data_ptr(), _dev(packed),
                                  _stream(packed)), "unpack_int4")
     return out
 
 
-def relayout_Aint4(packed: torch.Tensor, k: int, to: str) -> torch.Tensor:
+def relayout_Aint4(packed: torch.Tensor, k: int, to: str, inner_k_tiles: int | None = None) -> torch.Tensor:
     """Lossless repack of a weights-on-the-left tensor between the reference's Aint4 words ('reference') and the row-per-lane
-    order ('native'), e.g. for a checkpoint packed by the CUDA implementation.  Same shape in, same shape out."""
+    order ('native'), e.g. for a checkpoint packed by the CUDA implementation.  The tensor's own shape says which it holds
+    (aside_format); already in `to`: returned as it is.  inner_k_tiles: the Aint4 innerKTiles of a 'reference' result (default 4
+    when k % 64 == 0, else 2)."""
     _check(to in _WFORMATS, f"relayout_Aint4: `to` must be one of {sorted(_WFORMATS)}")
-    rows, inner = packed.size(0) * 16, packed.size(3)
-    codes = unpack_int4(packed, rows, k, "A" if to == "native" else "A_native")
+    _check(packed.dim() == 4 and packed.dtype == torch.int32 and packed.is_contiguous() and packed.size(2) == 32,
+           "relayout_Aint4: a contiguous 4-D int32 weights-on-the-left tensor")
+    have = aside_format(packed, k)
+    if have == to:
+        return packed
+    rows = packed.size(0) * (16 if have == "reference" else 8)
+    codes = unpack_int4(packed, rows, k, "A" if have == "reference" else "B")
     with weight_format(to):
-        return convert_matrix_to_m16n8k16_Aint4_layout(codes, inner)
+        return convert_matrix_to_m16n8k16_Aint4_layout(codes, inner_k_tiles or _rows_inner(k))
 
 
 def convert_matrix_to_m16n8k16_A_layout(t: torch.Tensor, innerKTiles: int) -> torch.Tensor:
@@ -384,6 +406,10 @@ def _w4_rm(A, B, q_group, qinfo, lut, qtype, weight_on_right, opname, frag=False
         wrows = w.size(0) * 16
     m, k = x.shape
     k_tiles = _cdiv(k, 16)
+    w_format = _lib.TG_WFMT_M16N8K16
+    if not weight_on_right and w.size(1) != _cdiv(k_tiles, inner) and aside_format(w, k) == "native":
+        # the tensor is the Bint4 tensor of the 16-row-padded weights (what the convert op returns by default): its shape says so
+        w_format, inner, wrows = _lib.TG_WFMT_ROWS, w.size(3) * 2, w.size(0) * 8
     _check(w.size(1) == _cdiv(k_tiles, inner), "weights: k super-tiles do not match the activations' k")
     _check(w.size(2) == 32, "weights: dim 2 must be 32")
     _check(x.dtype in _F16_TYPES, "activation dtype must be bfloat16 or float16")
@@ -438,7 +464,7 @@ def _w4_rm(A, B, q_group, qinfo, lut, qtype, weight_on_right, opname, frag=False
         y=y.data_ptr(), m=m, wrows=wrows, k=k, group=q_group, qtype=qtype, dtype=_dt(x),
         w_on_right=1 if weight_on_right else 0, inner_k_tiles=inner, batch=1,
         numerics=_NUMERICS[get_numerics()], bias=(bias.data_ptr() if bias is not None else None),
-        x_layout=layout, y_layout=layout, w_format=0 if weight_on_right else _WFORMATS[get_weight_format()],
+        x_layout=layout, y_layout=layout, w_format=w_format,
     )
     # The planner's answer depends on the problem's shape only: asked once per (shape, layout, numerics), not once per call
     # (m = 1 latency path: one planner pass and no allocation when no scratch is needed).
@@ -458,13 +484,12 @@ def _w4_rm(A, B, q_group, qinfo, lut, qtype, weight_on_right, opname, frag=False
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
         args.workspace, args.workspace_bytes = ws.data_ptr(), ws_bytes
     _lib.check(_L.tg_gemm_w4(ctypes.byref(args), _dev(x), _stream(x)), opname)
-    if _PLAN_SINK is not None and not frag and ws_bytes == 0:
+    sink = getattr(_tls, "plan_sink", None)
+    if sink is not None and not frag and ws_bytes == 0:
         # a caller (modules._PackedLinear) keeps the validated argument struct to re-issue the same launch with new x / y pointers
-        _PLAN_SINK.append((W4Gemm.from_buffer_copy(args), x, (w, qinfo, lut, bias), opname))
+        sink.append((W4Gemm.from_buffer_copy(args), x, (w, qinfo, lut, bias), opname))
     return y
 
-
-_PLAN_SINK = None  # a list while modules._PackedLinear records a launch plan (single-threaded use: set and cleared around one call)
 
 
 class LaunchPlan:
@@ -472,17 +497,33 @@ class LaunchPlan:
     `forward` of Any4Linear / Int4Linear spends ~20 us in Python (35 precondition checks, the op dispatcher, building the argument
     struct) around a 5 us kernel; the checks only depend on the parameters and the activations' shape / dtype / device, which the
     plan's key pins.  Anything else (another shape, a re-assigned parameter, another numerics / weight-format setting, a
-    non-contiguous or misaligned input) takes the full path again."""
+    non-contiguous or misaligned input) takes the full path again.
 
-    __slots__ = ("args", "key", "m", "n", "dtype", "device", "dev_index", "opname", "keep")
+    Re-entrant like the reference's host functions (TinyGemm_int4.cu:41-42: no state, the current stream of the calling thread):
+    the recorded struct is a template that is never written after construction; every host thread fills in x / y in ITS OWN copy
+    (made once per thread), so two threads running the same module on two streams cannot see each other's pointers.  A plan is
+    only recorded for launches without a workspace (nothing but x and y differs between calls)."""
+
+    __slots__ = ("args", "key", "m", "n", "dtype", "device", "dev_index", "opname", "keep", "_per_thread")
 
     def __init__(self, args, x, keep, opname, key):
         self.args, self.key, self.opname, self.keep = args, key, opname, keep  # (keep: the tensors the struct points at stay alive)
         self.m, self.n, self.dtype, self.device, self.dev_index = x.shape[0], args.wrows, x.dtype, x.device, _dev(x)
+        self._per_thread = {}   # thread id -> that thread's private copy of the struct (dict get / set are atomic under the GIL)
+
+    def thread_args(self):
+        """The calling thread's private copy of the argument struct (live threads never share an ident)."""
+        tid = threading.get_ident()
+        a = self._per_thread.get(tid)
+        if a is None:
+            if len(self._per_thread) >= 64:      # (threads come and go: do not grow without bound)
+                self._per_thread.clear()
+            a = self._per_thread[tid] = W4Gemm.from_buffer_copy(self.args)
+        return a
 
     def run(self, x):
         y = torch.empty((self.m, self.n), dtype=self.dtype, device=self.device)
-        a = self.args
+        a = self.thread_args()
         a.x, a.y = x.data_ptr(), y.data_ptr()
         rc = _L.tg_gemm_w4(ctypes.byref(a), self.dev_index, _raw_stream(self.dev_index) if _raw_stream is not None else torch.cuda.current_stream(self.device).cuda_stream)
         if rc:
@@ -490,17 +531,22 @@ class LaunchPlan:
         return y
 
 
-def record_plan(fn, x, key):
-    """Runs fn(x) (a functional of this module that ends in ONE row-major 4-bit GEMM) and returns (y, LaunchPlan or None)."""
-    global _PLAN_SINK
-    _PLAN_SINK = sink = []
+def record_plan(fn, x, key, params=()):
+    """Runs fn(x) (a functional of this module that ends in ONE row-major 4-bit GEMM) and returns (y, LaunchPlan or None).
+    `params`: the module's own parameter tensors -- a plan is only kept when the recorded struct points at THEM (not at a
+    contiguous / re-aligned copy the op made, which a later in-place update of the parameter would not reach)."""
+    prev = getattr(_tls, "plan_sink", None)
+    _tls.plan_sink = sink = []       # thread-local: another thread's launches never land in this recording
     try:
         y = fn(x)
     finally:
-        _PLAN_SINK = None
+        _tls.plan_sink = prev
     if len(sink) != 1 or sink[0][1].data_ptr() != x.data_ptr() or tuple(y.shape) != (x.shape[0], sink[0][0].wrows):
         return y, None
     args, _, keep, opname = sink[0]
+    own = {t.data_ptr() for t in params if t is not None}
+    if params and any(p is not None and p not in own for p in (args.w, args.qinfo, args.lut)):
+        return y, None
     return y, LaunchPlan(args, x, keep, opname, key)
 
 
@@ -604,7 +650,8 @@ def _w4_tc_impl(A, B, q_group, qinfo, lut, qtype, weight_on_right, opname):
     _check(B.size(3) in (4, 8), "activations (B layout) must have innermost dim 4 or 8")
     b_inner = B.size(3) // 4
     k_tiles_a, k_tiles_b = A.size(1) * A.size(3), B.size(1) * b_inner
-    _check(k_tiles_a == k_tiles_b, "A and B disagree on k")
+    # (the reference's Aint4 tensor covers k_tiles_a k-tiles, the native one -- a Bint4 tensor, `aside_format` -- twice that)
+    _check(k_tiles_a == k_tiles_b or (2 * k_tiles_a == k_tiles_b and A.size(3) * 2 == _rows_inner(k_tiles_b * 16)), "A and B disagree on k")
     n_pad, k = B.size(0) * 8, k_tiles_b * 16
     x = convert_matrix_from_m16n8k16_B_layout(B, n_pad, k)
     y = _w4_rm(A, x, q_group, qinfo, lut, qtype, False, opname)          # [n_pad][m_pad]

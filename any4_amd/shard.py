@@ -54,10 +54,13 @@ class PeerWriteGather:
     """
 
     def __init__(self, m_max: int, cols_local: int, group=None, device=None, dtype=torch.bfloat16, timeout_us: int = 2_000_000,
-                 graph_timeout_us: int = 50_000):
+                 graph_timeout_us: int = 500_000):
         """timeout_us: bound of a call's wait for its peers (eager calls: ranks may be seconds apart after a compile or a load).
-        graph_timeout_us: the bound baked into launches recorded under stream capture -- a replayed decode step runs in lock step,
-        and a dead rank must turn a 2 ms token into tens of milliseconds before poll() raises, not into minutes."""
+        graph_timeout_us: the bound baked into launches recorded under stream capture.  Replays are started by independent host
+        processes, so the bound has to cover the SKEW between the ranks' graph launches (a GC pause, sampling or tokenisation on
+        one rank), not just the step: half a second by default -- a dead rank then turns a 2 ms token into 0.5 s before poll()
+        raises, never into minutes.  A serving loop that keeps its ranks in lock step (a host barrier per step) may pass less;
+        the caller must keep the launch skew below this value."""
         from . import _lib
 
         if dtype not in (torch.bfloat16, torch.float16):

@@ -21,9 +21,14 @@
  *   B16      m16n8k16 "B" fragment order  [ceil(n/8)][ceil(k/(16 I))][32][4 I]   16-bit, I in {1,2}
  *   Aint4    packed 4-bit, weights on the left   [ceil(m/16)][ceil(k/(16 I))][32][I]   int32, I in {1,2,4}
  *   Bint4    packed 4-bit, weights on the right  [ceil(n/8)][k/(16 I)][32][I/2]       int32, I in {2,4,8}
- * The packed int4 words are bit-identical to the reference's
- * (TinyGemmConvertA.cu:226-285, TinyGemmConvertB.cu:252-308), so a state_dict packed by
- * either implementation loads in the other.
+ * tg_convert_to_{A,B}int4 produce words bit-identical to the reference's (TinyGemmConvertA.cu:226-285,
+ * TinyGemmConvertB.cu:252-308) and tg_gemm_w4 consumes them: a weight packed by the CUDA implementation runs here as it
+ * is, on either operand side.  For weights on the LEFT this library additionally accepts -- and its Python convert op
+ * produces by default -- a second packed format, TG_WFMT_ROWS (tg_w4_gemm.w_format): the Bint4 tensor of the weight rows
+ * padded to 16.  The CUDA implementation cannot read that one; at this boundary the caller names the format in the
+ * argument struct, and the Python layer reads it off the tensor's shape (the two formats never share a shape for one k:
+ * any4_amd/ops.py aside_format), so a checkpoint of either format is multiplied correctly or rejected, never misread.
+ * tg_unpack_int4 + a packer converts between the two losslessly.
  */
 #ifndef TINYGEMM_HIP_H_
 #define TINYGEMM_HIP_H_
@@ -206,9 +211,9 @@ typedef struct tg_w4_gemm {
                            /* (dg_swiglu's formula).  TG_NUM_FAST pair-table kernels, weights on the right, row-major y, no bias;   */
                            /* otherwise TG_E_FUSION.                                                                               */
   /* ---- ABI version 6 ---- */
-  int32_t w_format;        /* w_on_right = 0 only.  TG_WFMT_M16N8K16 (0): `w` holds the reference's Aint4 words.  TG_WFMT_ROWS (1): the   */
-                           /* tensor has the Aint4 SHAPE [wrows/16][k/(16 I)][32][I] but holds the codes in the row-per-lane order of the */
-                           /* Bint4 layout (rows padded to 16; innerKTiles 4 when k % 64 == 0, else 2) -- what SURVEY 8(b) calls a native */
+  int32_t w_format;        /* w_on_right = 0 only.  TG_WFMT_M16N8K16 (0): `w` holds the reference's Aint4 words.  TG_WFMT_ROWS (1): `w`  */
+                           /* is the Bint4 tensor [wrows/8][k/(16 J)][32][J/2] of the weight rows (padded to 16; J = 4 when k % 64 == 0,  */
+                           /* else 2; inner_k_tiles is then only range-checked) -- what SURVEY 8(b) calls a native                        */
                            /* packed layout behind convert_matrix_to_m16n8k16_Aint4_layout: a packed word then holds 8 codes of ONE weight */
                            /* row instead of 4 + 4 of rows r and r + 8, and the A-side ops run the B-side kernels (the result is          */
                            /* [activation row][weight row] either way).  tg_convert_to_Bint4 on the [wrows][k] codes produces it,         */

@@ -3,9 +3,9 @@ kernel, modules.py:21) in the library's default packed format.
 
 SURVEY 8(b): the packed tensor is opaque to every caller of the reference (TinyGemm_int4.cu:322-364 checks its shape only), so
 `convert_matrix_to_m16n8k16_Aint4_layout` may return a gfx950-native order as long as the GEMM ops accept what it returns and the
-reference's own words stay available as an interchange format with a lossless repack.  Here: the native tensor has the reference's
-Aint4 SHAPE and holds the Bint4 word order (rows padded to 16) -- checked bit for bit against the oracle's Bint4 packer -- the
-repack is checked both ways, and the GEMM through every op flavour is checked against the oracle like the weights-on-the-right
+reference's own words stay available as an interchange format with a lossless repack.  Here: the native tensor IS the Bint4 tensor
+of the weight rows padded to 16 -- checked bit for bit against the oracle's Bint4 packer; its shape differs from the reference's Aint4
+shape for every k, so a GEMM op / module / state_dict reads the format off the tensor (ops.aside_format) -- the repack is checked both ways, and the GEMM through every op flavour is checked against the oracle like the weights-on-the-right
 path (tests/test_gpu_gemv.py, test_gpu_fast.py): the same kernels run it.
 """
 import numpy as np
@@ -39,19 +39,23 @@ def test_native_convert_bit_exact_and_repack(T, oracle, inner, m, k):
     codes = torch.randint(0, 16, (m, k), dtype=torch.int32, generator=torch.Generator().manual_seed(m + k))
     assert any4_amd.get_weight_format() == "native"
     nat = T.convert_matrix_to_m16n8k16_Aint4_layout(codes.to(DEV), inner)
-    assert tuple(nat.shape) == (-(-m // 16), k // (16 * inner), 32, inner)  # the reference's shape (TinyGemm_int4.cu:340-364)
+    j = 4 if k % 64 == 0 else 2
+    assert tuple(nat.shape) == (2 * -(-m // 16), k // (16 * j), 32, j // 2)  # the Bint4 tensor of the 16-row-padded codes
+    assert ops.aside_format(nat, k) == "native"
     assert np.array_equal(nat.cpu().numpy().reshape(-1), native_words(oracle, codes.numpy(), k).reshape(-1))
     with any4_amd.weight_format("reference"):
         ref = T.convert_matrix_to_m16n8k16_Aint4_layout(codes.to(DEV), inner)
     assert np.array_equal(ref.cpu().numpy(), oracle.pack_Aint4(codes.numpy(), inner))  # the interchange format: the reference's words
+    assert tuple(ref.shape) == (-(-m // 16), k // (16 * inner), 32, inner) and ops.aside_format(ref, k) == "reference"  # TinyGemm_int4.cu:340-364
     # unpack (both orders) and the lossless repack, both ways
-    rows = nat.shape[0] * 16
+    rows = ref.shape[0] * 16
     want = np.zeros((rows, k), np.int32)
     want[:m] = codes.numpy()
-    assert np.array_equal(ops.unpack_int4(nat, rows, k, "A_native").cpu().numpy(), want)
+    assert np.array_equal(ops.unpack_int4(nat, rows, k, "B").cpu().numpy(), want)
     assert np.array_equal(ops.unpack_int4(ref, rows, k, "A").cpu().numpy(), want)
     assert torch.equal(ops.relayout_Aint4(ref, k, "native"), nat)
-    assert torch.equal(ops.relayout_Aint4(nat, k, "reference"), ref)
+    assert torch.equal(ops.relayout_Aint4(nat, k, "reference", inner), ref)
+    assert ops.relayout_Aint4(nat, k, "native") is nat and ops.relayout_Aint4(ref, k, "reference") is ref
     wb = T.convert_matrix_to_m16n8k16_Bint4_layout(codes.to(DEV), 4 if k % 64 == 0 else 2)
     assert np.array_equal(ops.unpack_int4(wb, m, k, "B").cpu().numpy(), codes.numpy())
 
@@ -120,16 +124,21 @@ def test_left_side_equals_right_side_bits(T):
 
 
 def test_reference_words_still_served_and_modules_remember_their_format(T, oracle):
-    """A tensor in the reference's Aint4 words (a checkpoint packed by the CUDA implementation) runs under
-    any4_amd.weight_format("reference"); a module records the format it was packed in, relayout() converts it once."""
+    """A tensor in the reference's Aint4 words (a checkpoint packed by the CUDA implementation) runs whatever the process default
+    is: the GEMM ops read the format off the tensor; relayout() converts a module's tensor once."""
     import any4_amd
     import modules
 
     n, k, g = 512, 1024, 128
     codes, x, qinfo, lut = rand_problem(n, k, g, 2, "int4", seed=9)
     with any4_amd.weight_format("reference"):
-        y_ref = run_left(T, codes, x, qinfo, lut, g, "int4", 4)
+        w_ref = T.convert_matrix_to_m16n8k16_Aint4_layout(codes.to(DEV), 4)
+    # consumed OUTSIDE the context, under the 'native' process default: the tensor says what it is
+    y_ref = T.tinygemm_y_f16RM_x_f16RM_w_int4TC(w_ref, x.to(DEV), g, qinfo.to(DEV), False)
     y_nat = run_left(T, codes, x, qinfo, lut, g, "int4", 4)
+    with any4_amd.weight_format("reference"):   # ... and a native tensor under the 'reference' default
+        w_nat = T.convert_matrix_to_m16n8k16_Bint4_layout(codes.to(DEV), 4)
+        assert torch.equal(T.tinygemm_y_f16RM_x_f16RM_w_int4TC(w_nat, x.to(DEV), g, qinfo.to(DEV), False), y_nat)
     # two kernel families (the Aint4 words run a reference-numerics kernel at this size, the native ones the group-scaled gemv):
     # one result within the reference's own weight rounding
     tol = 0.02 * y_nat.float().abs().max()
@@ -141,7 +150,7 @@ def test_reference_words_still_served_and_modules_remember_their_format(T, oracl
     with any4_amd.weight_format("reference"):
         lin.reshape_weight(4)
     assert lin.weight_format == "reference" and np.array_equal(lin.weight.cpu().numpy(), oracle.pack_Aint4(codes.numpy(), 4))
-    y1 = lin(x.to(DEV))                       # the module passes its own format whatever the process default is
+    y1 = lin(x.to(DEV))                       # whatever the process default is
     lin.relayout("native")
     assert lin.weight_format == "native" and np.array_equal(lin.weight.cpu().numpy().reshape(-1), native_words(oracle, codes.numpy(), k).reshape(-1))
     y2 = lin(x.to(DEV))
@@ -158,3 +167,89 @@ def test_left_side_tensor_core_layout_ops(T, oracle):
     yb = T.tinygemm_y_f16TC_x_f16TC_w_any4TC(w2, xb, g, d(qinfo), d(lut), False)
     y = T.convert_matrix_from_m16n8k16_B_layout(yb, m, n)
     check(oracle, y, codes, x, qinfo, lut, g, "any4_rowwise")
+
+
+@pytest.mark.parametrize("fmt", ["native", "reference"])
+@pytest.mark.parametrize("cls", ["Int4Linear", "Any4Linear"])
+def test_state_dict_round_trip_into_a_fresh_module(T, fmt, cls):
+    """eval.py:180-210 saves / loads state_dicts of quantised models.  A packed weights-on-the-left module -> state_dict -> a FRESH
+    module (unpacked shape, no attributes set) under the OTHER process default gives the same bits: weight_reshaped / w_inner_k
+    travel in the extra state, the packed format in the tensor's shape."""
+    import io
+
+    import any4_amd
+    import modules
+
+    n, k, g = 512, 1024, 128
+    codes, x, qinfo, lut = rand_problem(n, k, g, 2, "any4_rowwise" if cls == "Any4Linear" else "int4", seed=11)
+    kernel = "linear_y_f16RM_W_any4TC_x_f16RM" if cls == "Any4Linear" else "linear_y_f16RM_W_int4TC_x_f16RM"
+
+    def fresh():
+        return getattr(modules, cls)(k, n, bias=False, device=DEV, dtype=torch.bfloat16, group_size=g, kernel=kernel)
+
+    src = fresh()
+    src.weight.data, src.scales_and_zeros.data = codes.to(DEV), qinfo.to(DEV)
+    if cls == "Any4Linear":
+        src.lut.data = lut.to(DEV)
+    with any4_amd.weight_format(fmt):
+        src.reshape_weight(2 if fmt == "reference" else 4)
+    assert src.weight_format == fmt
+    want = src(x.to(DEV))
+    buf = io.BytesIO()
+    torch.save(src.state_dict(), buf)
+    buf.seek(0)
+    sd = torch.load(buf)
+    other = "reference" if fmt == "native" else "native"
+    with any4_amd.weight_format(other):
+        dst = fresh()
+        assert not dst.weight_reshaped
+        dst.load_state_dict(sd)                      # strict
+        assert dst.weight_reshaped and dst.weight_format == fmt and dst.w_inner_k == src.w_inner_k
+        assert torch.equal(dst(x.to(DEV)), want)
+    # a state_dict WITHOUT the tag (what the reference implementation writes: eval.py:195): rank and shape of `weight` decide
+    bare = {k_: v for k_, v in sd.items() if not k_.endswith("_extra_state")}
+    dst2 = fresh()
+    dst2.load_state_dict(bare)                       # strict, no "missing key"
+    assert dst2.weight_reshaped and dst2.weight_format == fmt and torch.equal(dst2(x.to(DEV)), want)
+    # a tensor packed for the other operand side is refused, not mis-multiplied
+    wrong = getattr(modules, cls)(k, n, bias=False, device=DEV, dtype=torch.bfloat16, group_size=g,
+                                  kernel="linear_y_f16RM_x_f16RM_W_any4TC" if cls == "Any4Linear" else "linear_y_f16RM_x_f16RM_W_int4TC")
+    with pytest.raises(RuntimeError, match="packed for kernel"):
+        wrong.load_state_dict(sd)
+
+
+def test_same_module_from_two_threads_on_two_streams(T):
+    """The reference's host functions are stateless and re-entrant (TinyGemm_int4.cu:41-42).  Two host threads, each on its own
+    stream, run the SAME module (one recorded launch plan) on different activations many times: every result is its own."""
+    import threading
+
+    import modules
+
+    n, k, g = 4096, 4096, 128
+    codes, x, qinfo, lut = rand_problem(n, k, g, 1, "any4_rowwise", seed=3)
+    lin = modules.Any4Linear(k, n, bias=False, device=DEV, dtype=torch.bfloat16, group_size=g)
+    lin.weight.data, lin.scales_and_zeros.data, lin.lut.data = codes.to(DEV), qinfo.to(DEV), lut.to(DEV)
+    lin.reshape_weight()
+    xs = [(x * s).to(DEV) for s in (1.0, -2.0)]
+    want = [lin(xi).clone() for xi in xs]           # (also records the plan)
+    assert lin.__dict__["_plan"][1] is not None
+    torch.cuda.synchronize()
+    bad, go = [], threading.Barrier(2)
+
+    def work(i):
+        st = torch.cuda.Stream()
+        go.wait()
+        with torch.cuda.stream(st):
+            for _ in range(2000):
+                y = lin(xs[i])
+                if _ % 100 == 0 and not torch.equal(y, want[i]):
+                    bad.append(i)
+            st.synchronize()
+            if not torch.equal(lin(xs[i]), want[i]):
+                bad.append(i)
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not bad
+    assert len(lin.__dict__["_plan"][1]._per_thread) >= 2   # every thread filled in its own copy of the argument struct

@@ -5,10 +5,12 @@ compared with the SAME stack on 16-bit `nn.Linear`s holding the oracle's dequant
 replay and a k-means-free random `Any4Factory` stack are exercised."""
 import math
 
+import numpy as np
 import pytest
 import torch
 
 from tests.conftest import bits16, from_bits16
+from tests.test_gpu_parity import T  # noqa: F401  (fixture: torch.ops.tinygemm)
 
 pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("reference_numerics")]
 DEV = "cuda:0"
@@ -293,6 +295,57 @@ def test_kmeans_on_gpu_matches_cpu():
     assert torch.allclose(sse(a_g, c_g), sse(a_c, c_c), rtol=2e-3)
     codes, lut, sz = Q.anyq_quantize_tensor(w.to(torch.bfloat16), device=DEV)   # CPU checkpoint, clustered on the GPU
     assert codes.device.type == "cpu" and lut.device.type == "cpu" and lut.dtype == torch.bfloat16
+
+
+def test_quantizer_on_the_gpu_against_the_reference_fixture(T, oracle):
+    """N1 pinned on the GPU to the REFERENCE's output, not to itself: the W of the captured fixture (tests/golden/make_golden.py:
+    torch.manual_seed(1234), randn(1024, 1024) * 0.02 -> bf16, quantized there by the imported reference's
+    quantize.anyq_quantize_tensor, quantize.py:523-610) is quantized here by any4_amd.quantize.anyq_quantize_tensor ON cuda:0.
+    Scales / zeros bit-equal to the reference's; reconstruction error within 1.02 x of the reference's codes + LUT (sklearn parity
+    is statistical); the result, packed and multiplied by the HIP kernel, within north_star's 1e-2 of the reference's
+    own captured y (max|y| = 2.2).  And the reference's exact-recovery property (test_anyq.py:31-49) on the GPU."""
+    from any4_amd import quantize as Q
+    from tests.conftest import bits16, from_bits16, load_golden
+
+    d = load_golden("any4_n1024_k1024_g128_seed1234.npz")
+    torch.manual_seed(1234)
+    W = (torch.randn(1024, 1024) * 0.02).to(torch.bfloat16)
+    c8 = d["codes_nib"]
+    ref_codes = np.empty((1024, 1024), np.int32)
+    ref_codes[:, 0::2], ref_codes[:, 1::2] = c8 & 15, c8 >> 4
+    ref_lut, ref_sz = from_bits16(d["lut_bits"], torch.bfloat16), from_bits16(d["sz_bits"], torch.bfloat16)
+    ref_deq = Q.anyq_dequantize_tensor(torch.from_numpy(ref_codes), ref_lut, ref_sz, n_bit=4, q_group_size=128, per_row=True)
+
+    codes, lut, sz = Q.anyq_quantize_tensor(W.to(DEV), n_bit=4, q_group_size=128, per_row=True)
+    assert codes.is_cuda and lut.is_cuda and sz.is_cuda and codes.dtype == torch.int32 and lut.dtype == torch.bfloat16
+    assert int(codes.min()) >= 0 and int(codes.max()) <= 15 and lut.shape == (1024, 16) and sz.shape == (8, 1024, 2)
+    assert np.array_equal(bits16(sz.cpu()), d["sz_bits"])                       # the reference's grouping, bit for bit
+    mine = Q.anyq_dequantize_tensor(codes, lut, sz, n_bit=4, q_group_size=128, per_row=True).cpu()
+    mse = lambda a: ((a.float() - W.float()) ** 2).mean().item()
+    assert mse(mine) <= 1.02 * mse(ref_deq), (mse(mine), mse(ref_deq))
+    # through the product path: pack, multiply on the HIP kernel (lut - 8 is what the module receives, quantize.py:893), compare
+    # with the y the reference itself computed from ITS quantization of the same W
+    x = from_bits16(d["x_bits"], torch.bfloat16)
+    w2 = T.convert_matrix_to_m16n8k16_Bint4_layout(codes, 4)
+    y = T.tinygemm_y_f16RM_x_f16RM_w_any4TC(x.to(DEV), w2, 128, sz, (lut.float() - 8).to(torch.bfloat16), True)
+    y_ref = from_bits16(d["y_bits"], torch.bfloat16).float()
+    assert float(y_ref.abs().max()) < 2.3
+    # two different (equally good) codebooks of one W: the outputs differ by the quantization noise of either, which at this k
+    # and |x| ~ 1 is a few 1e-2 -- bounded here by the noise the reference's own quantization has against the dense product
+    dense = (x.float() @ W.float().t())
+    noise_ref = (y_ref - dense).abs().max().item()
+    assert (y.float().cpu() - dense).abs().max().item() <= 1.5 * noise_ref
+    # the kernel itself on the GPU-made tensors: within 1e-2 of the CPU dequant-matmul of the same tensors
+    y_cpu = (x.float() @ mine.float().t())
+    assert (y.float().cpu() - y_cpu).abs().max().item() <= 1e-2 * max(1.0, float(y_cpu.abs().max()) / 2.2)
+
+    # exact recovery of <= 16 distinct values per row (test_anyq.py:31-49), clustered on the GPU
+    for per_row, g in ((True, 32), (False, 64)):
+        torch.manual_seed(g)
+        vals = torch.linspace(-8, 7, 16)
+        w16 = vals[torch.stack([torch.randperm(16) for _ in range(64 * 64 // 16)]).view(64, 64)].to(DEV)
+        c, l, s_ = Q.anyq_quantize_tensor(w16, n_bit=4, q_group_size=g, per_row=per_row)
+        assert c.is_cuda and torch.equal(Q.anyq_dequantize_tensor(c, l, s_, q_group_size=g, per_row=per_row), w16)
 
 
 def test_quantize_model_decode_stack():

@@ -377,3 +377,108 @@ def test_module_copies_drop_the_launch_plan():
     again = pickle.loads(pickle.dumps(lin))
     assert "_plan" not in again.__dict__ and "_plan" in lin.__dict__
 
+
+
+def test_weights_on_the_left_format_is_read_off_the_tensor():
+    """ops.aside_format: the reference's Aint4 tensor [m/16][k/(16 I)][32][I] and the native one (the Bint4 tensor of the rows
+    padded to 16) never have the same shape for one k, so no setting is needed to consume either."""
+    from any4_amd import ops
+
+    for m in (16, 40, 4096):
+        for k in (32, 64, 96, 256, 4096, 14336):
+            j = 4 if k % 64 == 0 else 2
+            nat = torch.empty((2 * -(-m // 16), k // (16 * j), 32, j // 2), dtype=torch.int32)
+            assert ops.aside_format(nat, k) == "native"
+            for inner in (1, 2, 4):
+                if k % (16 * inner) == 0:
+                    ref = torch.empty((-(-m // 16), k // (16 * inner), 32, inner), dtype=torch.int32)
+                    assert ops.aside_format(ref, k) == "reference"
+                    assert ref.shape != nat.shape
+    with pytest.raises(RuntimeError, match="do not match"):
+        ops.aside_format(torch.empty((2, 5, 32, 2), dtype=torch.int32), 4096)
+    with pytest.raises(RuntimeError, match="do not match"):   # odd number of 8-row tiles: not a native tensor
+        ops.aside_format(torch.empty((3, 64, 32, 2), dtype=torch.int32), 4096)
+
+
+def test_state_dict_carries_what_decides_how_weight_is_read():
+    """eval.py:180-210 (save / load of state_dicts).  The reference keeps kernel / w_inner_k / weight_reshaped in plain attributes
+    (modules.py:38-41); here they travel in the module's extra state, a fresh module takes a packed tensor's shape, a state_dict
+    without the tag (the reference implementation's) is read by rank and shape, and a tensor packed for the other operand side is
+    refused."""
+    import modules
+
+    k, n, g = 256, 64, 64
+    src = modules.Int4Linear(k, n, bias=False, dtype=torch.bfloat16, group_size=g)          # default kernel: weights on the left
+    assert src.weight_format is None
+    for fmt, shape, inner in (("native", (2 * n // 16, k // 64, 32, 2), 4), ("reference", (n // 16, k // 32, 32, 2), 2)):
+        src.weight.data = torch.randint(0, 2 ** 31 - 1, shape, dtype=torch.int32)
+        src.weight_reshaped, src.w_inner_k = True, inner
+        assert src.weight_format == fmt
+        sd = src.state_dict()
+        assert sd["_extra_state"] == {"kernel": src.kernel, "w_inner_k": inner, "weight_reshaped": True}
+        dst = modules.Int4Linear(k, n, bias=False, dtype=torch.bfloat16, group_size=g)
+        dst.__dict__["_plan"] = ("stale",)
+        dst.load_state_dict(sd)
+        assert dst.weight_reshaped and dst.w_inner_k == inner and dst.weight_format == fmt and torch.equal(dst.weight, src.weight)
+        assert "_plan" not in dst.__dict__
+        bare = {key: v for key, v in sd.items() if key != "_extra_state"}
+        dst2 = modules.Int4Linear(k, n, bias=False, dtype=torch.bfloat16, group_size=g)
+        dst2.load_state_dict(bare)
+        assert dst2.weight_reshaped and dst2.weight_format == fmt and (fmt == "native" or dst2.w_inner_k == inner)
+        wrong = modules.Int4Linear(k, n, bias=False, dtype=torch.bfloat16, group_size=g, kernel="linear_y_f16RM_x_f16RM_W_int4TC")
+        with pytest.raises(RuntimeError, match="packed for kernel"):
+            wrong.load_state_dict(sd)
+        assert set(modules.Int4Linear(k, n, bias=False, dtype=torch.bfloat16, group_size=g).state_dict()) == {"weight", "scales_and_zeros"}
+    # an unpacked checkpoint into a packed module: back to unpacked
+    plain = modules.Int4Linear(k, n, bias=False, dtype=torch.bfloat16, group_size=g)
+    dst.load_state_dict(plain.state_dict())
+    assert not dst.weight_reshaped and dst.weight.shape == (n, k)
+    # inside a parent module (prefix handling), B side, any4
+    parent = torch.nn.Sequential(modules.Any4Linear(k, n, bias=True, dtype=torch.bfloat16, group_size=g))
+    parent[0].weight.data = torch.zeros((n // 8, k // 64, 32, 2), dtype=torch.int32)
+    parent[0].weight_reshaped = True
+    twin = torch.nn.Sequential(modules.Any4Linear(k, n, bias=True, dtype=torch.bfloat16, group_size=g))
+    twin.load_state_dict({key: v for key, v in parent.state_dict().items() if not key.endswith("_extra_state")})
+    assert twin[0].weight_reshaped and twin[0].w_inner_k == 4 and twin[0].weight.shape == (n // 8, k // 64, 32, 2)
+
+
+def test_launch_plan_is_per_thread_and_plan_sink_thread_local():
+    """LaunchPlan.run fills x / y into a per-thread copy of the recorded struct (the recorded one is never written), and a plan
+    being recorded on one thread does not see another thread's launches."""
+    import threading
+
+    from any4_amd import _lib, ops
+
+    tmpl = _lib.W4Gemm(x=1, y=2, wrows=8)
+    x = torch.empty((1, 32), dtype=torch.bfloat16)
+    lp = ops.LaunchPlan.__new__(ops.LaunchPlan)
+    lp.args, lp._per_thread = tmpl, {}
+    seen, both = {}, threading.Barrier(2)
+
+    def copy_for_thread(i):
+        both.wait()                 # both threads alive at once (a finished thread's ident may be reused, harmlessly)
+        a = lp.thread_args()
+        a.x = 100 + i
+        seen[i] = a
+        assert lp.thread_args() is a
+        both.wait()
+
+    th = [threading.Thread(target=copy_for_thread, args=(i,)) for i in range(2)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert seen[0] is not seen[1] and (seen[0].x, seen[1].x) == (100, 101) and tmpl.x == 1
+    # the sink of record_plan lives in thread-local storage
+    got = []
+
+    def other():
+        got.append(getattr(ops._tls, "plan_sink", "unset"))
+
+    def fn(_):
+        t = threading.Thread(target=other)
+        t.start()
+        t.join()
+        got.append(getattr(ops._tls, "plan_sink", "unset"))
+        return torch.empty((1, 8))
+
+    y, plan = ops.record_plan(fn, x, ("key",))
+    assert got[0] == "unset" and got[1] == [] and plan is None and getattr(ops._tls, "plan_sink", None) is None
