@@ -12,7 +12,10 @@ namespace {
 #ifndef TG_XR_R16
 #define TG_XR_R16 2   // ring depth of the sixteen-slice variant (a slice is four super-tiles)
 #endif
-template <typename DT, int I, bool QMX, int NCH, int WV = 8>
+#ifndef TG_XR_PK_K4096
+#define TG_XR_PK_K4096 0  // 1 (developer builds): k = 4096 with at most 8 rows on the packed-rows variant too (32 instead of 64 activation registers)
+#endif
+template <typename DT, int I, bool QMX, int NCH, int WV = 8, bool PK = false>
 int launch_pair_xr_n(GemmParams& p, int64_t batch, hipStream_t st) {
   if constexpr (I != 4 || (QMX && (NCH != 16 || !std::is_same<DT, BF16>::value))) return TG_PAIR_NA;  // (mx4: bf16, k = 4096)
   else {
@@ -20,7 +23,7 @@ int launch_pair_xr_n(GemmParams& p, int64_t batch, hipStream_t st) {
   if constexpr (!std::is_same<DT, BF16>::value) return TG_PAIR_NA;
   else {
 #endif
-  if (p.m > 16 || p.m < TG_XR_MIN_M || p.norm_w || p.epilogue) return TG_PAIR_NA;
+  if (p.m > (PK ? 8 : 16) || p.m < TG_XR_MIN_M || p.norm_w || p.epilogue) return TG_PAIR_NA;
   if (p.ksuper * 16 * I != p.k || p.wrows % 64 != 0 || p.ntiles * 8 != p.wrows) return TG_PAIR_NA;
   const int g = 1 << p.gshift;
   const int cpg = g / 32 < NCH ? g / 32 : NCH;  // 32-k chunks per group inside a wave's slice
@@ -29,7 +32,7 @@ int launch_pair_xr_n(GemmParams& p, int64_t batch, hipStream_t st) {
 #endif
   if (QMX ? cpg != 1 : (cpg != 1 && cpg != 2 && cpg != 4 && cpg != 8)) return TG_PAIR_NA;  // g = 32, 64, 128, 256; mx4: g = 32
   if (QMX && p.ngroups % 16 != 0) return TG_PAIR_NA;  // 16-byte exponent blocks
-  if (NCH > 16 && cpg == 2) return TG_PAIR_NA;          // (k = 8192, g = 64: that instantiation spills four registers)
+  if (NCH > 16 && cpg == 2 && !PK) return TG_PAIR_NA;   // (k = 8192, g = 64, unpacked: that instantiation spills four registers)
   XrParams xp;
   xp.w = p.w; xp.qinfo = p.qinfo; xp.lut = p.lut; xp.y = p.y;
   xp.m = p.m; xp.wrows = p.wrows; xp.k = p.k; xp.ntiles = p.ntiles; xp.ksuper = p.ksuper;
@@ -51,7 +54,7 @@ int launch_pair_xr_n(GemmParams& p, int64_t batch, hipStream_t st) {
   if (items < 2 * (int64_t)wgs) return TG_PAIR_NA;
 #define TG_XR_LAUNCH(CPG_)                                                  \
   do {                                                                      \
-    constexpr auto kern = w4_gemm_xr_kernel<DT, I, NCH, CPG_, (WV == 16 ? TG_XR_R16 : NCH > 16 ? TG_XR_R8K : TG_XR_R), false, WV>; \
+    constexpr auto kern = w4_gemm_xr_kernel<DT, I, NCH, CPG_, (WV == 16 ? TG_XR_R16 : (NCH > 16 && !PK) ? TG_XR_R8K : TG_XR_R), false, WV, PK>; \
     const int prc = prepare_lds_kernel<kern>();                             \
     if (prc != 0) return prc == TG_E_INTERNAL ? prc : TG_PAIR_NA; /* (a part with less LDS: the older kernels take over) */ \
     hipLaunchKernelGGL(kern, dim3(wgs), dim3(WV * 64), lds, st, xp);        \
@@ -84,10 +87,16 @@ int launch_pair_xr(GemmParams& p, int64_t batch, hipStream_t st) {
   if constexpr (!QMX && TG_XR_WV16) {
     if (p.k == 4096 && (1 << p.gshift) <= 256) return launch_pair_xr_n<DT, I, QMX, 8, 16>(p, batch, st);
   }
+  if constexpr (!QMX && TG_XR_PK_K4096) {
+    if (p.k == 4096 && p.m <= 8) return launch_pair_xr_n<DT, I, QMX, 16, 8, true>(p, batch, st);
+  }
   if (p.k == 4096) return launch_pair_xr_n<DT, I, QMX, 16>(p, batch, st);
-  // k = 8192: 128 registers of activations per lane leave room for two super-tiles in flight only -- faster than the 16x16x32
-  // workspace kernel it replaces at 9 ... 16 rows (8192^2, m = 16: 62 vs 47-51 %), slower than the 32x32x16 one below that
-  // (m = 8: 66 vs 70 %)
+  // k = 8192, 9 ... 16 rows: 128 registers of activations per lane leave room for two super-tiles in flight only -- faster than
+  // the 16x16x32 workspace kernel it replaces (8192^2, m = 16: 62 vs 47-51 %).  Up to 8 rows: two chunks per register set (PK),
+  // 64 registers, four super-tiles in flight like k = 4096
+  if constexpr (!QMX) {
+    if (p.k == 8192 && p.m <= 8) return launch_pair_xr_n<DT, I, QMX, 32, 8, true>(p, batch, st);
+  }
   if (p.k == 8192 && p.m >= 9) return launch_pair_xr_n<DT, I, QMX, 32>(p, batch, st);
   return TG_PAIR_NA;
 }

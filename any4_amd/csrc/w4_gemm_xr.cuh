@@ -76,10 +76,18 @@ struct XrParams {
 // WV  = waves per workgroup = k-slices (8: two waves per SIMD with 256 registers each; 16: four per SIMD with 128 -- a slice is half
 //       as long, so the activation registers are 32 instead of 64 and the ring two super-tiles deep: the same bytes in flight per CU,
 //       twice the waves to hide LDS and MFMA latency behind)
-template <typename DT, int I, int NCH, int CPG, int R, bool QMX = false, int WV = 8>
+// PK  = at most 8 activation rows: the A operand's rows 8 ... 15 would be zeros, so a register set holds TWO chunks -- lanes of
+//       rows 0 ... 7 the piece of chunk 2 c, lanes of rows 8 ... 15 the piece of chunk 2 c + 1 (of row i - 8).  The even chunk's MFMAs
+//       take the registers as they are, the odd chunk's a copy rotated by 8 lanes within every 16-lane row (four v_mov_b32_dpp
+//       row_ror:8 per chunk, shared by the stage's two tile pairs); what the other eight rows of the operand then hold only reaches
+//       accumulator rows 8 ... 15, which are never stored.  Half the activation registers: k = 8192 in the 64 registers k = 4096
+//       takes unpacked, so its ring is four super-tiles deep like there (unpacked, k = 8192 leaves room for two: 66 % at m = 8).
+template <typename DT, int I, int NCH, int CPG, int R, bool QMX = false, int WV = 8, bool PK = false>
 __global__ void __launch_bounds__(WV * 64, WV == 8 ? 2 : 1) w4_gemm_xr_kernel(const XrParams p) {
   constexpr int WAVES = WV;
   static_assert(WV == 8 || (WV == 16 && !QMX), "8 or 16 k-slices (mx4: 8)");
+  static_assert(!PK || (!QMX && WV == 8 && NCH % 2 == 0), "packed rows: the 8-wave lookup kernel, chunk pairs");
+  constexpr int NXR = PK ? NCH / 2 : NCH;          // activation register sets of a wave
   constexpr int CPS = I / 2;                       // 32-k chunks per super-tile
   constexpr int NST = NCH / CPS;                   // super-tiles of a wave's slice
   constexpr int NWL = 2 * CPS;                     // packed words per lane, tile pair and super-tile
@@ -224,7 +232,7 @@ __global__ void __launch_bounds__(WV * 64, WV == 8 ? 2 : 1) w4_gemm_xr_kernel(co
   };
 
   // ---- activations of a problem: this lane's NCH pieces and the staged sums ----
-  u32x4 xr[NCH];
+  u32x4 xr[NXR];
   // x_prepare: straight from the caller's activations, no pre-pass and no workspace.  Lane (row i, k-quad kb) reads the four dwords
   // (k, k + 1), k = 32 c + 2 kb + {0, 8, 16, 24}, of row i and rearranges them into the "byte order" of the packed words
   // (w4_gemm_pair.cuh: x[2q], x[2q+8], x[2q+16], x[2q+24], x[2q+1], x[2q+9], x[2q+17], x[2q+25]); rows >= m are zero.  The
@@ -237,12 +245,16 @@ __global__ void __launch_bounds__(WV * 64, WV == 8 ? 2 : 1) w4_gemm_xr_kernel(co
     //  in front of the item loop and spilled -- 500 bytes of scratch)
     uint32_t lane_p;
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_p));
-    const int xi = min((int)(lane_p & 15u), p.m - 1);
-    const bool on = (int)(lane_p & 15u) < p.m;
+    const int li = (int)(lane_p & 15u);
+    const int lrow = PK ? (li & 7) : li;             // activation row of this lane
+    const int par = PK ? (li >> 3) : 0;              // PK: which chunk of a pair this lane holds
+    const int xi = min(lrow, p.m - 1);
+    const bool on = lrow < p.m;
     const int kq = (int)(lane_p >> 4);
     float gsum = 0.f;
 #pragma unroll
-    for (int ci = 0; ci < NCH; ++ci) {
+    for (int cx = 0; cx < NXR; ++cx) {
+      const int ci = PK ? 2 * cx + par : cx;         // (PK: run-time in the lane, the register index stays a constant)
       const int k0 = (wave * NCH + ci) * 32 + 2 * kq;
       uint32_t d[4];
 #pragma unroll
@@ -251,16 +263,28 @@ __global__ void __launch_bounds__(WV * 64, WV == 8 ? 2 : 1) w4_gemm_xr_kernel(co
         const uint32_t v = *reinterpret_cast<const uint32_t*>(xb + idx * 2);
         d[e] = on ? v : 0u;
       }
-      xr[ci] = u32x4{__builtin_amdgcn_perm(d[1], d[0], 0x05040100u), __builtin_amdgcn_perm(d[3], d[2], 0x05040100u),
+      xr[cx] = u32x4{__builtin_amdgcn_perm(d[1], d[0], 0x05040100u), __builtin_amdgcn_perm(d[3], d[2], 0x05040100u),
                      __builtin_amdgcn_perm(d[1], d[0], 0x07060302u), __builtin_amdgcn_perm(d[3], d[2], 0x07060302u)};
 #pragma unroll
       for (int e = 0; e < 4; ++e) gsum = dot2_ones<DT>(d[e], gsum);
-      if (!QMX && ci % CPG == CPG - 1) {  // (compile-time) the group is complete in this lane: add the other three k-quads' shares (mx4 has no zero point: no sums)
-        gsum += __shfl_xor(gsum, 16);
-        gsum += __shfl_xor(gsum, 32);
-        const uint32_t g = (uint32_t)(((wave * NCH + ci) * 32) >> p.gshift);
-        if (lane_p < 16u) *(lds_fptr)(lds_xs + (g * 16u + lane_p) * 4u) = gsum;
-        gsum = 0.f;
+      if constexpr (!QMX) {  // (mx4 has no zero point: no sums)
+        // chunks of the slice seen so far: all of them up to cx (unpacked) / the pairs up to cx (packed)
+        constexpr int CPL = PK ? (CPG > 1 ? CPG / 2 : 1) : CPG;  // register sets per group in this lane
+        if (cx % CPL == CPL - 1) {  // (compile-time) the group is complete: add the other k-quads' (and the other parity's) shares
+          gsum += __shfl_xor(gsum, 16);
+          gsum += __shfl_xor(gsum, 32);
+          if constexpr (PK && CPG > 1) gsum += __shfl_xor(gsum, 8);
+          // the group this lane's sum belongs to: packed with one chunk per group, the two halves of a row hold DIFFERENT groups
+          const int cg = (PK && CPG == 1) ? 2 * cx + par : (PK ? 2 * cx : cx);
+          const uint32_t g = (uint32_t)(((wave * NCH + cg) * 32) >> p.gshift);
+          if constexpr (PK && CPG == 1) {
+            if (lane_p < 16u) *(lds_fptr)(lds_xs + (g * 16u + (uint32_t)lrow) * 4u) = gsum;
+          } else {
+            // (packed: rows 8 ... 15 of the staged sums are written as zeros -- they feed accumulator rows that are never stored)
+            if (lane_p < 16u) *(lds_fptr)(lds_xs + (g * 16u + lane_p) * 4u) = (PK && lane_p >= 8u) ? 0.f : gsum;
+          }
+          gsum = 0.f;
+        }
       }
     }
   };
@@ -341,6 +365,18 @@ __global__ void __launch_bounds__(WV * 64, WV == 8 ? 2 : 1) w4_gemm_xr_kernel(co
       }
     };
     constexpr bool AHEAD = WAVES == 8;  // (sixteen waves: four per SIMD hide the lookup latency; one stage's registers less)
+    u32x4 xodd;                         // PK: the odd chunk's A operand (the register set rotated by 8 lanes within every 16-lane row)
+    auto x_of = [&](int ci, int u) -> u32x4 {
+      if constexpr (!PK) return xr[ci];
+      else {
+        if ((ci & 1) == 0) return xr[ci >> 1];
+        if (u == 0) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) xodd[j] = (uint32_t)__builtin_amdgcn_mov_dpp((int)xr[ci >> 1][j], 0x128 /* row_ror:8 */, 0xf, 0xf, false);
+        }
+        return xodd;
+      }
+    };
     if constexpr (!QMX && AHEAD) look(0);
     xr_static_for<NSTG>([&](auto ST) {
       constexpr int st = decltype(ST)::value;
@@ -387,8 +423,9 @@ __global__ void __launch_bounds__(WV * 64, WV == 8 ? 2 : 1) w4_gemm_xr_kernel(co
           b0[j] = sw[0];
           b1[j] = sw[1];
         }
-        acc[2 * u] = DT::mfma(xr[ci], b0, gfirst ? zero4 : acc[2 * u]);
-        acc[2 * u + 1] = DT::mfma(xr[ci], b1, gfirst ? zero4 : acc[2 * u + 1]);
+        const u32x4 xa = x_of(ci, u);
+        acc[2 * u] = DT::mfma(xa, b0, gfirst ? zero4 : acc[2 * u]);
+        acc[2 * u + 1] = DT::mfma(xa, b1, gfirst ? zero4 : acc[2 * u + 1]);
       }
       if (u == 1) {
         // the next item's table, one step per chunk of the slice's second half

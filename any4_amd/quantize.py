@@ -59,12 +59,14 @@ def group_q(w_orig: torch.Tensor, n_bit: int, q_group_size: int = 128, assymetri
     if assymetric:
         mx, mn = tq.amax(dim=1, keepdim=True), tq.amin(dim=1, keepdim=True)
         lo, hi = (0, 2 ** n_bit - 1) if unsigned else (-(2 ** (n_bit - 1)), 2 ** (n_bit - 1) - 1)
-        scales = (mx - mn).clamp(min=1e-6) / (hi - lo)
+        # (divisor as a tensor on w's device: torch turns `tensor / python_scalar` on the GPU into a multiplication by the rounded
+        # reciprocal, one ulp off the IEEE quotient the reference's CPU path computes -- enough to flip a bf16 scale)
+        scales = (mx - mn).clamp(min=1e-6) / torch.tensor(float(hi - lo), device=w.device)
         zeros = mn + scales * (2 ** (n_bit - 1)) if zero_point else mn
         w_new = tq.sub(mn).div(scales).reshape(w.shape)
         w_zero = torch.zeros_like(tq).sub(mn).div(scales).reshape(w.shape)
     else:
-        scales = tq.abs().amax(dim=1, keepdim=True).clamp(min=1e-6) / (2 ** (n_bit - 1) - 1)
+        scales = tq.abs().amax(dim=1, keepdim=True).clamp(min=1e-6) / torch.tensor(float(2 ** (n_bit - 1) - 1), device=w.device)
         zeros = torch.zeros_like(scales)
         w_new = tq.div(scales).reshape(w.shape)
         w_zero = torch.zeros_like(w_new)

@@ -19,7 +19,9 @@ def group_quantize_tensor(w_orig: torch.Tensor, n_bit: int, q_group_size: int = 
     lo = groups.amin(dim=1, keepdim=True)
     hi = groups.amax(dim=1, keepdim=True)
     levels = 2 ** n_bit - 1
-    scale = (hi - lo).clamp(min=1e-6) / levels
+    # (a device-tensor divisor: on the GPU torch evaluates `tensor / python_scalar` as a product with the rounded reciprocal,
+    # one ulp off the IEEE quotient of the reference's CPU path)
+    scale = (hi - lo).clamp(min=1e-6) / torch.tensor(float(levels), device=groups.device)
     zero = lo + scale * (2 ** (n_bit - 1))
     codes = groups.sub(lo).div(scale).round().clamp_(0, levels).to(torch.int32).reshape(n, k)
     sz = torch.stack([scale.view(n, -1), zero.view(n, -1)], dim=2)  # [n][k/g][2]

@@ -319,7 +319,8 @@ def test_quantizer_on_the_gpu_against_the_reference_fixture(T, oracle):
     codes, lut, sz = Q.anyq_quantize_tensor(W.to(DEV), n_bit=4, q_group_size=128, per_row=True)
     assert codes.is_cuda and lut.is_cuda and sz.is_cuda and codes.dtype == torch.int32 and lut.dtype == torch.bfloat16
     assert int(codes.min()) >= 0 and int(codes.max()) <= 15 and lut.shape == (1024, 16) and sz.shape == (8, 1024, 2)
-    assert np.array_equal(bits16(sz.cpu()), d["sz_bits"])                       # the reference's grouping, bit for bit
+    nbad = int((bits16(sz.cpu()) != d["sz_bits"]).sum())
+    assert nbad == 0, f"{nbad} of {sz.numel()} scale / zero values differ from the reference's bits"   # the reference's grouping
     mine = Q.anyq_dequantize_tensor(codes, lut, sz, n_bit=4, q_group_size=128, per_row=True).cpu()
     mse = lambda a: ((a.float() - W.float()) ** 2).mean().item()
     assert mse(mine) <= 1.02 * mse(ref_deq), (mse(mine), mse(ref_deq))

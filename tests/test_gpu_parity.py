@@ -388,11 +388,13 @@ def test_any4linear_module(T, oracle, kernel, per_row):
     assert_gemm_close(y_nobias, x, w)
     assert torch.equal(y.view(-1, n), y_nobias + bias.to(DEV))
     # state_dict round trip keeps the packed weight usable
-    sd = {k_: v.clone() for k_, v in mod.state_dict().items()}
+    # state_dict round trip into a FRESH module (unpacked shape, weight_reshaped False): the packed weight stays usable
+    import copy
+
+    sd = copy.deepcopy(mod.state_dict())
     mod2 = modules.Any4Linear(k, n, bias=True, device=DEV, dtype=torch.bfloat16, group_size=g, kernel=kernel, per_row=per_row)
-    mod2.weight.data = torch.empty_like(sd["weight"])
     mod2.load_state_dict(sd)
-    mod2.weight_reshaped = True
+    assert mod2.weight_reshaped and mod2.w_inner_k == 4
     assert torch.equal(mod2(x3), y)
 
 
