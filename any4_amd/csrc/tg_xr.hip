@@ -12,6 +12,11 @@ namespace {
 #ifndef TG_XR_R16
 #define TG_XR_R16 2   // ring depth of the sixteen-slice variant (a slice is four super-tiles)
 #endif
+#ifndef TG_XR_WV4
+#define TG_XR_WV4 0   // 1 (developer builds): k = 4096 with at most 8 rows on two 4-slice workgroups per CU, packed rows, one table each (w4_gemm_xr.cuh,
+                      // WV = 4) -- the tail of one workgroup under the main loop of the other.  Measured SLOWER, same box: m = 8 72.3 vs 73.3 %, m = 4 72.7 vs
+                      // 75.4 %, m = 2 75.2 vs 77.1 % (profiles/r05_ab_xr_wv4.txt): it is not the stall of the tail that costs, not shipped
+#endif
 #ifndef TG_XR_PK_K4096
 #define TG_XR_PK_K4096 0  // 1 (developer builds): k = 4096 with at most 8 rows on the packed-rows variant too (32 instead of 64 activation registers)
 #endif
@@ -39,10 +44,11 @@ int launch_pair_xr_n(GemmParams& p, int64_t batch, hipStream_t st) {
   xp.gshift = p.gshift; xp.ngroups = p.ngroups; xp.qtype = p.qtype;
   xp.rblocks = (p.wrows + 63) / 64;
   const int64_t items = (int64_t)xp.rblocks * batch;
-  if (items > INT32_MAX || items < 2 * 256) return TG_PAIR_NA;  // two items per workgroup at least
+  if (items > INT32_MAX || items < 2 * 256 * (WV == 4 ? 2 : 1)) return TG_PAIR_NA;  // two items per workgroup at least
   xp.items = (int32_t)items;
-  xp.lds_xs = 2 * 65536;
-  const unsigned lds = QMX ? 32768u : (unsigned)xp.lds_xs + (unsigned)p.ngroups * 64u;  // two tables, the activation sums (mx4: the partial sums only)
+  xp.lds_xs = WV == 4 ? 65536 : 2 * 65536;
+  // two tables (WV = 4: one, and the 8 KiB hand-over region behind the sums), the activation sums (mx4: the partial sums only)
+  const unsigned lds = QMX ? 32768u : (unsigned)xp.lds_xs + (unsigned)p.ngroups * 64u + (WV == 4 ? 8192u : 0u);
   if (lds > 160u * 1024u) return TG_PAIR_NA;
   xp.x = p.x; xp.stride_x = p.stride_x; xp.x_tc = p.x_tc;  // (no pre-pass, no workspace: the kernel arranges the activations itself)
   p.ws_need = 0;
@@ -50,7 +56,7 @@ int launch_pair_xr_n(GemmParams& p, int64_t batch, hipStream_t st) {
   xp.bias = p.bias; xp.stride_bias = p.stride_bias; xp.bias_row_stride = p.bias_row_stride;
   xp.y_tc = p.y_tc; xp.y_tiles = (p.wrows + 15) / 16; xp.dry = p.dry;
   if (p.dry) return TG_PLAN_PAIR_XR;
-  const unsigned wgs = (unsigned)cu_count();  // one 8-wave workgroup per compute unit, whatever the part has
+  const unsigned wgs = (unsigned)cu_count() * (WV == 4 ? 2u : 1u);  // one 8-wave (two 4-wave) workgroup(s) per compute unit, whatever the part has
   if (items < 2 * (int64_t)wgs) return TG_PAIR_NA;
 #define TG_XR_LAUNCH(CPG_)                                                  \
   do {                                                                      \
@@ -86,6 +92,12 @@ template <typename DT, int I, bool QMX>
 int launch_pair_xr(GemmParams& p, int64_t batch, hipStream_t st) {
   if constexpr (!QMX && TG_XR_WV16) {
     if (p.k == 4096 && (1 << p.gshift) <= 256) return launch_pair_xr_n<DT, I, QMX, 8, 16>(p, batch, st);
+  }
+  if constexpr (!QMX && TG_XR_WV4) {
+    if (p.k == 4096 && p.m <= 8) {
+      const int rc = launch_pair_xr_n<DT, I, QMX, 32, 4, true>(p, batch, st);
+      if (rc != TG_PAIR_NA) return rc;  // (fewer than four items per CU: the 8-wave kernel below)
+    }
   }
   if constexpr (!QMX && TG_XR_PK_K4096) {
     if (p.k == 4096 && p.m <= 8) return launch_pair_xr_n<DT, I, QMX, 16, 8, true>(p, batch, st);
