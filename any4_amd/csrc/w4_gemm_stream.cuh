@@ -173,7 +173,13 @@ __global__ void __launch_bounds__(WAVES * 64, MINW) w4_gemm_stream_kernel(const 
   // stays in LDS, waves do not wait for each other between tiles); every other mode handles one tile per wave ----
   const int tiles_per_wave = XRES ? p.tiles_per_wave : 1;
   for (int tt = 0; tt < tiles_per_wave; ++tt) {
-  const int rt = (blockIdx.x * tiles_per_wave + tt) * (WAVES >> p.sk_shift) + (wave >> p.sk_shift);
+  // One 16-row tile per workgroup: the 128-byte line of scale | zero words of a group covers 32 rows = the tiles 2 j and 2 j + 1, and
+  // workgroup b runs on XCD b % 8 (observed; used for speed only) -- neighbouring tiles on neighbouring workgroups fetched every
+  // such line from HBM TWICE, once per XCD's L2 (round 4 counters: HBM read 1.064 x the algorithmic bytes = the scale-zero bytes
+  // again).  Tile pairs therefore go to the workgroups b and b + 8: the same XCD, dispatched together.
+  int bx = (int)blockIdx.x;
+  if ((WAVES >> p.sk_shift) == 1 && tiles_per_wave == 1 && (gridDim.x & 15u) == 0u) bx = (((bx >> 4) * 8 + (bx & 7)) << 1) + ((bx >> 3) & 1);
+  const int rt = (bx * tiles_per_wave + tt) * (WAVES >> p.sk_shift) + (wave >> p.sk_shift);
   const bool rt_ok = rt < p.rowtiles;
   const int row0 = rt * 16;
   const int row = row0 + i;

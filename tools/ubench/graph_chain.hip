@@ -98,7 +98,8 @@ int main(int argc, char** argv) {
   CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(node_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(node_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 
-  struct Mode { const char* name; int kind; size_t bytes; int warm; size_t pf; int nt; unsigned lds; };
+  CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(node_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  struct Mode { const char* name; int kind; size_t bytes; int warm; size_t pf; int nt; unsigned lds; int ring = 8; };
   std::vector<Mode> modes = {
       {"empty node", 0, 0, 0, 0, 1, 0},
       {"hand-off only (x in, x out)", 1, 0, 0, 0, 1, 64},
@@ -117,6 +118,10 @@ int main(int argc, char** argv) {
       {"64 MiB cold nt", 1, 64u << 20, 0, 0, 1, 64},
       {"64 MiB cold default", 1, 64u << 20, 0, 0, 0, 64},
       {"64 MiB cold nt + prefetch next 8 MiB", 1, 64u << 20, 0, 8u << 20, 1, 64},
+      // (round 5) 16 loads of 16 bytes per lane in flight instead of 8: is a long node latency-bound at 64 KiB per CU in flight?
+      {"16 MiB cold nt, 16 loads in flight", 1, 16u << 20, 0, 0, 1, 64, 16},
+      {"32 MiB cold nt, 16 loads in flight", 1, 32u << 20, 0, 0, 1, 64, 16},
+      {"64 MiB cold nt, 16 loads in flight", 1, 64u << 20, 0, 0, 1, 64, 16},
   };
   for (const Mode& m : modes) {
     hipGraph_t g; hipGraphExec_t ge;
@@ -134,6 +139,7 @@ int main(int argc, char** argv) {
       if (m.kind == 0) hipLaunchKernelGGL(empty_kernel, dim3(256), dim3(512), 0, st, p);
       else if (p.pieces == 0) { p.pieces = 4; p.wg_stride = 0; p.w = w[0]; hipLaunchKernelGGL(node_kernel<4>, dim3(256), dim3(512), m.lds, st, p); }  // hand-off only: every workgroup reads the same 32 KiB
       else if (p.pieces < 8) hipLaunchKernelGGL(node_kernel<4>, dim3(256), dim3(512), m.lds, st, p);
+      else if (m.ring == 16 && p.pieces % 16 == 0) hipLaunchKernelGGL(node_kernel<16>, dim3(256), dim3(512), m.lds, st, p);
       else hipLaunchKernelGGL(node_kernel<8>, dim3(256), dim3(512), m.lds, st, p);
     }
     CHECK(hipStreamEndCapture(st, &g));
