@@ -106,6 +106,8 @@ __global__ void __launch_bounds__(1024) w4_gemm_pair16_kernel(const Pair16Params
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n = lane & 15, q = lane >> 4;
   const int b = blockIdx.y;
+  // (pairing the tiles 2 j, 2 j + 1 -- which share every line of scale | zero words -- on one XCD, as w4_gemm_stream.cuh / w4_gemv.cuh
+  //  do, measured SLOWER here: m = 16 8.2 -> 8.6 us per graph node, m = 8 equal, profiles/r05_ab_xcd_ranges.txt)
   const int row0 = blockIdx.x * (16 * TPW);
 
   // this wave's slice of phase ph: super-tiles [ph ksuper_p + wave spw, + nl)

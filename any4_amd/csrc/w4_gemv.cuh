@@ -109,7 +109,11 @@ __global__ void __launch_bounds__(512, 2) w4_gemv_kernel(const GemvParams p) {
 #endif
 
   // ---- this workgroup's tiles, this lane's place in a pass ----
-  const int bx = blockIdx.x;
+  // Four CONSECUTIVE ranges go to the workgroups b, b + 8, b + 16, b + 24 -- one XCD (workgroup b runs on XCD b % 8: observed, used
+  // for speed only): a 128-byte line of scale | zero words covers 32 weight rows, ranges of 16 / 24 / 112 rows (Llama-3-8B's
+  // projections over 256 CUs) share such lines with their neighbours, and neighbours on different XCDs fetch them from HBM twice.
+  int bx = blockIdx.x;
+  if (p.urem == 0 && (gridDim.x & 31u) == 0u) bx = (((bx >> 5) * 8 + (bx & 7)) << 2) + ((bx >> 3) & 3);
   const int t0 = (bx * p.ubase + min(bx, p.urem)) * p.unit;
   const int t1 = t0 + (p.ubase + (bx < p.urem ? 1 : 0)) * p.unit;
   if (t0 >= t1) return;
