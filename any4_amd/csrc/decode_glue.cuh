@@ -483,7 +483,16 @@ __global__ void __launch_bounds__(512) rope_attn_online_kernel(const uint16_t* _
   extern __shared__ float sm[];  // [8 waves][D + 2]: unnormalised accumulator, max, sum
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int g = lane / LPR, i = lane % LPR, grp = wave * RPW + g;
-  const int b = blockIdx.x / hl, h = blockIdx.x % hl, rep = hl / kvl, kv = h / rep;
+  // Eight KV groups (Llama-3-8B on one GPU), eight XCDs: the `rep` query heads of a group read the same K / V rows, and workgroup w
+  // runs on XCD w % 8 (observed; used for speed only) -- head = rep (w % 8) + w / 8 puts a group's heads behind ONE L2, which then
+  // fetches the rows once instead of once per XCD the group is spread over.
+  const int b = blockIdx.x / hl, rep = hl / kvl;
+  const int hb = blockIdx.x % hl;
+#ifndef DG_ATTN_XCD_HEADS
+#define DG_ATTN_XCD_HEADS 1
+#endif
+  const int h = (DG_ATTN_XCD_HEADS && kvl == 8 && hl == 8 * rep) ? rep * (hb & 7) + (hb >> 3) : hb;
+  const int kv = h / rep;
   const uint16_t* row = qkv + (int64_t)b * (hl + 2 * kvl) * D;
   // (row r, piece i) of this head's K / V at byte ((r * LPR + i) << 4): a 32-bit offset on a scalar base (host: max_seq * d * 2 < 4 GiB)
   const char* K = reinterpret_cast<const char*>(k_cache + ((int64_t)b * kvl + kv) * max_seq * D);

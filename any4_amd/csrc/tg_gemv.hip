@@ -105,7 +105,29 @@ int tgx::gemv(int dt, int I, bool qmx, GemmParams& p, int64_t batch, hipStream_t
   const int cus = p.dry ? 256 : cu_count();
   // one workgroup per CU (two per CU were measured on gate_up of Llama-3-8B: the second workgroup of a CU trails the first by 3 us
   // through its prologue and the launch ends no earlier -- the CU's instruction issue, not latency, bounds the main loop)
-  const int wgs = units < cus ? units : cus;
+  // ... except for the longest layers: a dependent graph node that streams 64 MiB takes 14.3 us from one workgroup per CU and 13.1 us
+  // from two (tools/ubench/graph_chain.hip, round 5: 32 MiB equal, 8 MiB slower) -- more requests in flight per CU, and with the
+  // contraction on the matrix core (MF) the vector ALU no longer bounds the main loop
+#ifndef TG_GEMV_WG2_MIN_BYTES
+#define TG_GEMV_WG2_MIN_BYTES (48ll << 20)
+#endif
+  // (both workgroups of a CU must fit its 160 KiB of LDS together: the formula of `lds` below for the halved ranges)
+  auto lds_two_per_cu = [&]() -> int64_t {
+    const int tpw2 = ((units + 2 * cus - 1) / (2 * cus)) * gp.unit;
+    const int64_t xs = (int64_t)p.m * (p.k / 4), xsmf = mf ? (int64_t)(p.k / 128) * 64 : 0;
+    return 65536 + (p.qtype == TG_Q_ANY4_ROWWISE ? tpw2 * 8 * 32 : 0) + (int64_t)p.m * (p.k * 2 + (p.m > 1 ? 16 : 0)) + (xsmf > xs ? xsmf : xs) +
+           2 * 8 * p.m * 32 * 4 + 8 * p.m * 4;
+  };
+  // (... and the halved ranges must not pad more 16-row passes than the whole ones: 28672 rows as 7-tile ranges run 4 passes where
+  //  14-tile ranges run 7 -- 15.3 -> 16.4 us; the same layer with SwiGLU tile pairs, 8- and 6-tile ranges: the decode step -2.2 %)
+  auto padded_tiles = [&](int n_wgs) -> int64_t {
+    const int ub = units / n_wgs, ur = units % n_wgs;
+    auto pad2 = [&](int u) -> int64_t { return (int64_t)((u * gp.unit + 1) / 2) * 2; };
+    return ur * pad2(ub + 1) + (int64_t)(n_wgs - ur) * pad2(ub);
+  };
+  const bool two_per_cu = (int64_t)p.wrows * p.k / 2 >= TG_GEMV_WG2_MIN_BYTES && units >= 4 * cus && lds_two_per_cu() <= 80 * 1024 &&
+                          padded_tiles(2 * cus) <= padded_tiles(cus);
+  const int wgs = units < cus ? units : (two_per_cu ? 2 * cus : cus);
   const int tpw = ((units + wgs - 1) / wgs) * gp.unit;  // tiles of the largest range
   // rows per pass of ranges longer than two tiles: 16 (two super-tiles of k per ring step), not 32 -- a range is rarely a multiple of
   // four tiles (Llama-3-8B: gate_up 14, q/k/v 3) and the padding tiles of its last pass cost what real ones do.  Same box, per graph

@@ -77,7 +77,7 @@ __global__ void __launch_bounds__(512) node_kernel(const P p) {
   if (t < 8) {
     float s = 0.f;
     for (int i = 0; i < 8; ++i) s += red[i];
-    p.x_out[b * 8 + t] = __builtin_bit_cast(uint32_t, s) | 0x00010001u | (junk == 0x12345u ? 2u : 0u);
+    p.x_out[(b & 255) * 8 + t] = __builtin_bit_cast(uint32_t, s) | 0x00010001u | (junk == 0x12345u ? 2u : 0u);
   }
 }
 
@@ -99,7 +99,7 @@ int main(int argc, char** argv) {
   CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(node_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 
   CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(node_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  struct Mode { const char* name; int kind; size_t bytes; int warm; size_t pf; int nt; unsigned lds; int ring = 8; };
+  struct Mode { const char* name; int kind; size_t bytes; int warm; size_t pf; int nt; unsigned lds; int ring = 8; int wgs = 256; };
   std::vector<Mode> modes = {
       {"empty node", 0, 0, 0, 0, 1, 0},
       {"hand-off only (x in, x out)", 1, 0, 0, 0, 1, 64},
@@ -122,6 +122,11 @@ int main(int argc, char** argv) {
       {"16 MiB cold nt, 16 loads in flight", 1, 16u << 20, 0, 0, 1, 64, 16},
       {"32 MiB cold nt, 16 loads in flight", 1, 32u << 20, 0, 0, 1, 64, 16},
       {"64 MiB cold nt, 16 loads in flight", 1, 64u << 20, 0, 0, 1, 64, 16},
+      // (round 5) two workgroups per CU, 8 loads in flight each
+      {"8 MiB cold nt, 512 workgroups", 1, 8u << 20, 0, 0, 1, 64, 8, 512},
+      {"32 MiB cold nt, 512 workgroups", 1, 32u << 20, 0, 0, 1, 64, 8, 512},
+      {"64 MiB cold nt, 512 workgroups", 1, 64u << 20, 0, 0, 1, 64, 8, 512},
+      {"64 MiB cold nt, 1024 workgroups", 1, 64u << 20, 0, 0, 1, 64, 8, 1024},
   };
   for (const Mode& m : modes) {
     hipGraph_t g; hipGraphExec_t ge;
@@ -131,16 +136,16 @@ int main(int argc, char** argv) {
       p.w = m.warm ? w[0] : w[i];
       p.w_next = m.pf ? w[i + 1] : nullptr;
       p.x_in = x[i & 1]; p.x_out = x[(i + 1) & 1];
-      p.pieces = (int)(m.bytes / 16 / 512 / 256);
+      p.pieces = (int)(m.bytes / 16 / 512 / m.wgs);
       p.pf_pieces = (int)(m.pf / 16 / 512 / 256);
       p.pf_stride = p.pieces;
       p.wg_stride = p.pieces;
       p.nt = m.nt;
       if (m.kind == 0) hipLaunchKernelGGL(empty_kernel, dim3(256), dim3(512), 0, st, p);
-      else if (p.pieces == 0) { p.pieces = 4; p.wg_stride = 0; p.w = w[0]; hipLaunchKernelGGL(node_kernel<4>, dim3(256), dim3(512), m.lds, st, p); }  // hand-off only: every workgroup reads the same 32 KiB
-      else if (p.pieces < 8) hipLaunchKernelGGL(node_kernel<4>, dim3(256), dim3(512), m.lds, st, p);
-      else if (m.ring == 16 && p.pieces % 16 == 0) hipLaunchKernelGGL(node_kernel<16>, dim3(256), dim3(512), m.lds, st, p);
-      else hipLaunchKernelGGL(node_kernel<8>, dim3(256), dim3(512), m.lds, st, p);
+      else if (p.pieces == 0) { p.pieces = 4; p.wg_stride = 0; p.w = w[0]; hipLaunchKernelGGL(node_kernel<4>, dim3(m.wgs), dim3(512), m.lds, st, p); }  // hand-off only: every workgroup reads the same 32 KiB
+      else if (p.pieces < 8) hipLaunchKernelGGL(node_kernel<4>, dim3(m.wgs), dim3(512), m.lds, st, p);
+      else if (m.ring == 16 && p.pieces % 16 == 0) hipLaunchKernelGGL(node_kernel<16>, dim3(m.wgs), dim3(512), m.lds, st, p);
+      else hipLaunchKernelGGL(node_kernel<8>, dim3(m.wgs), dim3(512), m.lds, st, p);
     }
     CHECK(hipStreamEndCapture(st, &g));
     CHECK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
