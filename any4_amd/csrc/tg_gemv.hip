@@ -87,8 +87,8 @@ extern "C" TG_API void tg_dev_gemv_trace(unsigned long long* buf, int slots) {
 int tgx::gemv(int dt, int I, bool qmx, GemmParams& p, int64_t batch, hipStream_t st) {
   const int g0 = 1 << p.gshift;
   // matrix-core contraction: 16-row passes of two super-tiles per step inside ONE group, a piece per thread in the staging
-  const bool mf = p.m >= TG_GEMV_MF_MIN_M && p.m <= 8 && (g0 == 128 || g0 == 256) && (p.k <= 4096 || p.m <= 4) && p.ksuper % 2 == 0;
-  if (I != 4 || qmx || (p.m > 4 && !mf) || p.x_tc || p.y_tc || batch != 1) return TG_PAIR_NA;
+  const bool mf0 = p.m >= TG_GEMV_MF_MIN_M && p.m <= 8 && (g0 == 128 || g0 == 256) && (p.k <= 4096 || p.m <= 4) && p.ksuper % 2 == 0;
+  if (I != 4 || qmx || (p.m > 4 && !mf0) || p.x_tc || p.y_tc || batch != 1) return TG_PAIR_NA;
   if (p.ksuper * 64 != p.k || p.ntiles * 8 != p.wrows || p.ntiles > TG_GEMV_MAX_TILES) return TG_PAIR_NA;
   const int g = 1 << p.gshift;
   const int gps = g == 32 ? 2 : 1;
@@ -114,7 +114,7 @@ int tgx::gemv(int dt, int I, bool qmx, GemmParams& p, int64_t batch, hipStream_t
   // (both workgroups of a CU must fit its 160 KiB of LDS together: the formula of `lds` below for the halved ranges)
   auto lds_two_per_cu = [&]() -> int64_t {
     const int tpw2 = ((units + 2 * cus - 1) / (2 * cus)) * gp.unit;
-    const int64_t xs = (int64_t)p.m * (p.k / 4), xsmf = mf ? (int64_t)(p.k / 128) * 64 : 0;
+    const int64_t xs = (int64_t)p.m * (p.k / 4), xsmf = mf0 ? (int64_t)(p.k / 128) * 64 : 0;
     return 65536 + (p.qtype == TG_Q_ANY4_ROWWISE ? tpw2 * 8 * 32 : 0) + (int64_t)p.m * (p.k * 2 + (p.m > 1 ? 16 : 0)) + (xsmf > xs ? xsmf : xs) +
            2 * 8 * p.m * 32 * 4 + 8 * p.m * 4;
   };
@@ -129,6 +129,14 @@ int tgx::gemv(int dt, int I, bool qmx, GemmParams& p, int64_t batch, hipStream_t
                           padded_tiles(2 * cus) <= padded_tiles(cus);
   const int wgs = units < cus ? units : (two_per_cu ? 2 * cus : cus);
   const int tpw = ((units + wgs - 1) / wgs) * gp.unit;  // tiles of the largest range
+  // Ranges of THREE tiles at one activation row (q/k/v of Llama-3-8B: 6144 rows over 256 CUs): two 16-row passes carry a padding
+  // tile (4 tile slots for 3 tiles); three 8-row passes of the v_dot2 contraction would stream exactly the range -- measured SLOWER
+  // (6144 x 4096 per graph node 6.8 -> 7.2 us, the decode step unchanged; profiles/r05_ab_gemv_odd_p8.txt): developer knob only
+#ifndef TG_GEMV_ODD_P8
+#define TG_GEMV_ODD_P8 0
+#endif
+  const bool odd3 = TG_GEMV_ODD_P8 && p.m == 1 && tpw == 3 && gp.unit == 1 && p.ksuper % 4 == 0;
+  const bool mf = mf0 && !odd3;
   // rows per pass of ranges longer than two tiles: 16 (two super-tiles of k per ring step), not 32 -- a range is rarely a multiple of
   // four tiles (Llama-3-8B: gate_up 14, q/k/v 3) and the padding tiles of its last pass cost what real ones do.  Same box, per graph
   // node, 32 -> 16: 28672 x 4096 17.6 -> 16.2-16.6 us, 8192 rows 7.6 -> 6.4, 10240 11.2 -> 8.9, 12288 10.8 -> 8.4, 32768 (a multiple
@@ -136,7 +144,7 @@ int tgx::gemv(int dt, int I, bool qmx, GemmParams& p, int64_t batch, hipStream_t
 #ifndef TG_GEMV_P_BIG
 #define TG_GEMV_P_BIG 16
 #endif
-  gp.P = mf ? 16 : tpw <= 1 ? 8 : tpw <= 2 ? 16 : TG_GEMV_P_BIG;
+  gp.P = mf ? 16 : (tpw <= 1 || odd3) ? 8 : tpw <= 2 ? 16 : TG_GEMV_P_BIG;
   // a step covers SS = 32 / P consecutive super-tiles: they must all lie inside the matrix (the kernel's addressing has no per-lane
   // clamp), so k = 64 x odd runs 32-row passes whatever the range, k = 128 x odd at least 16-row passes
   if (p.ksuper % 2 != 0) gp.P = 32;
