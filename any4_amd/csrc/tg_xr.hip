@@ -60,7 +60,7 @@ int launch_pair_xr_n(GemmParams& p, int64_t batch, hipStream_t st) {
   if (items < 2 * (int64_t)wgs) return TG_PAIR_NA;
 #define TG_XR_LAUNCH(CPG_)                                                  \
   do {                                                                      \
-    constexpr auto kern = w4_gemm_xr_kernel<DT, I, NCH, CPG_, (WV == 16 ? TG_XR_R16 : (NCH > 16 && !PK) ? TG_XR_R8K : TG_XR_R), false, WV, PK>; \
+    constexpr auto kern = w4_gemm_xr_kernel<DT, I, NCH, CPG_, (WV == 16 ? TG_XR_R16 : ((NCH > 16 && !PK) || NCH > 32) ? TG_XR_R8K : TG_XR_R), false, WV, PK>; \
     const int prc = prepare_lds_kernel<kern>();                             \
     if (prc != 0) return prc == TG_E_INTERNAL ? prc : TG_PAIR_NA; /* (a part with less LDS: the older kernels take over) */ \
     hipLaunchKernelGGL(kern, dim3(wgs), dim3(WV * 64), lds, st, xp);        \
@@ -110,6 +110,12 @@ int launch_pair_xr(GemmParams& p, int64_t batch, hipStream_t st) {
     if (p.k == 8192 && p.m <= 8) return launch_pair_xr_n<DT, I, QMX, 32, 8, true>(p, batch, st);
   }
   if (p.k == 8192 && p.m >= 9) return launch_pair_xr_n<DT, I, QMX, 32>(p, batch, st);
+  // k = 14336 (Llama-3-8B's down-projection) with at most 8 rows: 56 chunks per slice, packed: 112 activation registers, ring of two
+  if constexpr (!QMX) {
+    // (same box, 4096 x 14336 against the workspace variant of w4_gemm_pair_kernel: m = 8 67.9 -> 70.0 %, but m = 4 72.9 -> 69.1 and
+    //  m = 2 76.5 -> 72.3, m = 6 71.1 -> 68.8 -- profiles/r05_ab_xr_k14336.txt: eight rows only)
+    if (p.k == 14336 && p.m == 8) return launch_pair_xr_n<DT, I, QMX, 56, 8, true>(p, batch, st);
+  }
   return TG_PAIR_NA;
 }
 template <typename DT>

@@ -100,7 +100,7 @@ __global__ void __launch_bounds__(WV * 64, WV == 16 ? 1 : 2) w4_gemm_xr_kernel(c
   constexpr int GPS = CPG < CPS ? CPS / CPG : 1;   // groups per super-tile
   constexpr int SPG = CPG > CPS ? CPG / CPS : 1;   // super-tiles per group
   static_assert(NCH % CPS == 0 && NST % R == 0 && NCH % CPG == 0, "slice = whole super-tiles, whole rounds of the ring, whole groups");
-  static_assert(NCH >= 8 && NCH % 8 == 0, "the table build is spread over the second half of the slice");
+  static_assert(NCH >= 16 && NCH % 2 == 0, "the table build (16 steps) is spread over the chunks of the slice's second half");
   constexpr uint32_t TABLE = 65536u;
   static_assert(!QMX || (CPG == 1 && NCH == 16), "mx4: one group per chunk, one 16-byte exponent block per row and slice");
 
@@ -463,9 +463,10 @@ __global__ void __launch_bounds__(WV * 64, WV == 16 ? 1 : 2) w4_gemm_xr_kernel(c
         // the next item's table, one step per chunk of the slice's second half
         if (!ONE_TABLE && ci >= NCH / 2 && XR_ABL != 5) {
           if (ci == NCH / 2) hw = lhw;
-          constexpr int SPC = 32 / NCH;  // build steps per chunk
+          // the 16 build steps spread evenly over the NCH / 2 chunks of the half (k = 4096: two per chunk, 8192: one, 14336: 16 over 28)
+          constexpr int J = ci - NCH / 2, S0 = (J * 16) / (NCH / 2), S1 = ((J + 1) * 16) / (NCH / 2);
 #pragma unroll
-          for (int e = 0; e < SPC; ++e) build_step(buf ^ 1u, (ci - NCH / 2) * SPC + e, hw);
+          for (int e = S0; e < S1; ++e) build_step(buf ^ 1u, e, hw);
         }
         // refill: position l + R of this item, or of the next one (the stage's lookups of this slot were issued a stage ago)
         if (c == CPS - 1) {

@@ -654,8 +654,8 @@ def main():
 
         # (c) single-layer launches: what one module forward issues (the reference's microbenchmark shape) -- Any4Linear's
         # default kernel (per-row LUT any4, weights on the B side) and Int4Linear's (modules.py:21: uniform int4, A side)
-        def single_layer(qtype, on_right, tensors=None):
-            ww, xx, qq, ll, yy = tensors or make_batch(L, m, n, k, g, inner, device, 91, qtype, on_right)
+        def single_layer(qtype, on_right, tensors=None, m=m):
+            ww, xx, qq, ll, yy = tensors or make_batch(L, m, n, k, g, inner, device, 91 + m, qtype, on_right)
             nl = ww.shape[0]
             sl = lambda t, i: None if t is None else t[i:i + 1]  # noqa: E731
             singles = [make_args(_lib, ww[i:i + 1], xx[i:i + 1], qq[i:i + 1], sl(ll, i), yy[i:i + 1], m, n, k, g, qtype, on_right, inner, 1,
@@ -704,6 +704,9 @@ def main():
 
         single_b = single_layer("any4_rowwise", True, (w, x, sz, lut, y)) if world == 1 else {}
         single_a = single_layer("int4", False) if world == 1 else {}
+        # ... and at a few rows (a prefill of a few tokens through the module; what the reference's microbenchmark.py:20-59 times)
+        single_m8 = single_layer("any4_rowwise", True, m=8) if world == 1 else {}
+        single_m16 = single_layer("any4_rowwise", True, m=16) if world == 1 else {}
         # the host floor of the entry point: back-to-back launches of a 16 x 512 problem (5.9 KB) through the same C-ABI call
         tw_, tx_, tq_, tl_, ty_ = make_batch(1, 1, 16, 512, g, inner, device, 5)
         tiny = make_args(_lib, tw_, tx_, tq_, tl_, ty_, 1, 16, 512, g, "any4_rowwise", True, inner, 1)
@@ -778,8 +781,10 @@ def main():
                 **single_b,
                 "us_launch_floor_back_to_back": round(floor_us, 3),
                 "int4_a_side": single_a,
+                "m8": single_m8,
+                "m16": single_m16,
                 "note": "one 4096x4096 GEMV per launch: top level = any4 per-row LUT, weights on the B side (what Any4Linear.forward issues); "
-                        "int4_a_side = uniform int4, weights on the A side (Int4Linear's default kernel, modules.py:21).  back_to_back = launches of "
+                        "int4_a_side = uniform int4, weights on the A side (Int4Linear's default kernel, modules.py:21); m8 / m16 = the top-level layer at 8 / 16 activation rows.  back_to_back = launches of "
                         "distinct cold layers on one stream (event time / launches); cold = median HIP-event time of an isolated launch (event pair "
                         "floor on this stack: ~4.3 us); in_hipgraph = the same launches replayed from one captured graph; launch_floor = a 16 x 512 "
                         "problem through the same entry point, back to back: the host/runtime cost per launch that back_to_back cannot go below",
@@ -803,7 +808,9 @@ def main():
                 "mfma_util_percent": None if a.no_pmc else pmc_mfma_util(),
                 "single_layer_us": {"any4_b_side_back_to_back": single_b.get("us_per_launch_back_to_back"),
                                     "any4_b_side_per_graph_node": single_b.get("us_per_launch_in_hipgraph"),
-                                    "int4_a_side_per_graph_node": single_a.get("us_per_launch_in_hipgraph")},
+                                    "int4_a_side_per_graph_node": single_a.get("us_per_launch_in_hipgraph"),
+                                    "any4_m8_per_graph_node": single_m8.get("us_per_launch_in_hipgraph"),
+                                    "any4_m16_per_graph_node": single_m16.get("us_per_launch_in_hipgraph")},
                 "decode_llama3_8b": None if not decode or "error" in decode else
                 {"ms_per_token": decode["ms_per_token"], "frac_of_hbm_roofline": decode["frac_of_hbm_roofline"],
                  "kernels_per_layer": decode["kernels_per_layer"]},
