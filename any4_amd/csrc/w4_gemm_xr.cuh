@@ -63,6 +63,7 @@ struct XrParams {
   int64_t stride_bias, bias_row_stride;
   int32_t y_tc, y_tiles;
   int32_t dry;
+  int32_t y_f32;     // 1: y is f32 [problem][m][wrows] holding the UNROUNDED sums of a k-window (no bias): the caller adds the windows
 };
 
 // I   = innerKTiles of the Bint4 layout (2, 4, 8)
@@ -637,7 +638,9 @@ __global__ void __launch_bounds__(WV * 64, WV == 16 ? 1 : 2) w4_gemm_xr_kernel(c
           const float sa = ((((((q0v[0] + q0v[2]) + q1v[0]) + q1v[2]) + q2v[0]) + q2v[2]) + q3v[0]) + q3v[2];
           const float sb = ((((((q0v[1] + q0v[3]) + q1v[1]) + q1v[3]) + q2v[1]) + q2v[3]) + q3v[1]) + q3v[3];
           const int row = row0 + 2 * rp;  // (even; the host guarantees wrows % 64 == 0)
-          if (a2 < p.m && (XR_ABL != 7 || sa == 123.456f)) {  // (ablation 7: no output stores)
+          if (a2 < p.m && p.y_f32) {  // a k-window of a longer contraction: the unrounded sums
+            *reinterpret_cast<f32x2*>(yb + ((int64_t)a2 * p.wrows + row) * 4) = f32x2{sa, sb};
+          } else if (a2 < p.m && (XR_ABL != 7 || sa == 123.456f)) {  // (ablation 7: no output stores)
             uint16_t oa = DT::from_f32(sa), ob = DT::from_f32(sb);
             if (p.bias) {  // rounded sum + bias, rounded again: bit-identical to the reference module's separate `y + bias`
               const uint32_t bv = *reinterpret_cast<const uint32_t*>(p.bias + (int64_t)cur.b * p.stride_bias + ((int64_t)a2 * p.bias_row_stride + row) * 2);
@@ -663,7 +666,9 @@ __global__ void __launch_bounds__(WV * 64, WV == 16 ? 1 : 2) w4_gemm_xr_kernel(c
               : "memory");
           const float sa = ((((((v0[0] + v0[1]) + v1[0]) + v1[1]) + v2[0]) + v2[1]) + v3[0]) + v3[1];
           const int row = row0 + (int)lane_t;
-          if (a2 < p.m && (XR_ABL != 7 || sa == 123.456f)) {
+          if (a2 < p.m && p.y_f32) {
+            *reinterpret_cast<float*>(yb + ((int64_t)a2 * p.wrows + row) * 4) = sa;
+          } else if (a2 < p.m && (XR_ABL != 7 || sa == 123.456f)) {
             uint16_t oa = DT::from_f32(sa);
             if (p.bias)
               oa = DT::from_f32(DT::lo_f32(oa) + DT::lo_f32(*reinterpret_cast<const uint16_t*>(p.bias + (int64_t)cur.b * p.stride_bias + ((int64_t)a2 * p.bias_row_stride + row) * 2)));

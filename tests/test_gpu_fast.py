@@ -761,6 +761,10 @@ def test_stacked_weights_on_the_right_beyond_k4096(T, oracle, m, n, k, layers):
     w, x, q, lut, y = _stacked_launch(layers, m, n, k, g, qtype, _lib.TG_NUM_FAST, seed=m + k, calibrate=True)
     assert not torch.isnan(y.float()).any()
     assert ops.gemm_w4_plan(m, n, k, g, QT[qtype], True, 4, batch=layers) == "pair"
+    if k in (8192, 14336) and n % 64 == 0:
+        # activations resident in registers at every one of these shapes: packed rows up to 8 rows (k = 14336: at 8), k-windows with
+        # f32 partial sums in the workspace from 9 rows on (w4_gemm_xr.cuh; TinyGemmImpl.cuh:132-217 takes any k % 32 == 0)
+        assert ops.gemm_w4_plan(m, n, k, g, QT[qtype], True, 4, batch=layers, detail=True) == "pair_xr"
     for b in (0, layers - 1):
         for r0 in (0, n - 192):
             codes = torch.from_numpy(oracle.unpack_Bint4(w[b].cpu().numpy(), n, k))[r0:r0 + 192]
