@@ -48,7 +48,7 @@ int launch_pair_xr_n(GemmParams& p, int64_t batch, hipStream_t st, const XrWindo
 #endif
   if (QMX ? cpg != 1 : (cpg != 1 && cpg != 2 && cpg != 4 && cpg != 8)) return TG_PAIR_NA;  // g = 32, 64, 128, 256; mx4: g = 32
   if (QMX && p.ngroups % 16 != 0) return TG_PAIR_NA;  // 16-byte exponent blocks
-  if (NCH > 16 && cpg == 2 && !PK) return TG_PAIR_NA;   // (k = 8192, g = 64, unpacked: that instantiation spills four registers)
+  if (NCH > 24 && cpg == 2 && !PK) return TG_PAIR_NA;   // (k = 8192, g = 64, unpacked: that instantiation spills four registers)
   XrParams xp;
   xp.w = p.w; xp.qinfo = p.qinfo; xp.lut = p.lut; xp.y = p.y;
   xp.m = p.m; xp.wrows = p.wrows; xp.k = p.k; xp.ntiles = p.ntiles; xp.ksuper = p.ksuper;
@@ -170,9 +170,24 @@ int launch_pair_xr_windows(GemmParams& p, int64_t batch, hipStream_t st) {
     k0 += kw;
     ++part;
   };
+  // every window must have a kernel BEFORE the first one is launched (a dry pass: validation only)
+  const auto dry0 = p.dry;
+  p.dry = 1;
+  int planned = 0;
+  auto check = [&](auto NCH_) {
+    XrWindow w0 = win;
+    w0.ngroups = 256 * decltype(NCH_)::value / g;
+    w0.w_off = w0.x_off = w0.q_off = 0;
+    w0.y32 = p.ws;
+    planned += launch_pair_xr_n<DT, I, false, decltype(NCH_)::value>(p, batch, st, &w0) == TG_PLAN_PAIR_XR;
+  };
+  (check(std::integral_constant<int, NCHS>{}), ...);
+  p.dry = dry0;
+  if (planned != NP) { p.ws_need = 0; return TG_PAIR_NA; }
+  if (p.dry) { p.ws_need = need; return TG_PLAN_PAIR_XR; }
   (one(std::integral_constant<int, NCHS>{}), ...);
   if (rc_all != 0) {
-    p.ws_need = rc_all == TG_PLAN_PAIR_XR ? need : 0;
+    p.ws_need = 0;
     return rc_all;
   }
   p.ws_need = need;

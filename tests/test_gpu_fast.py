@@ -561,7 +561,7 @@ def test_tc_ops_native_fragment_order(T, oracle, qtype, case, monkeypatch):
 # the launches bench.py times, at their own shape: stacked tg_gemm_w4 over >= 16 layers of 4096 x 4096
 # ------------------------------------------------------------------------------------------------
 
-def _stacked_launch(layers, m, n, k, g, qtype, numerics, seed=0, on_right=True, native=False, calibrate=False):
+def _stacked_launch(layers, m, n, k, g, qtype, numerics, seed=0, on_right=True, native=False, calibrate=False, dtype=torch.bfloat16):
     """One tg_gemm_w4 call over `layers` independent problems, built as bench.py builds its legs (make_batch / make_args).
     native (weights on the left): `w` is the Bint4 tensor of the rows, tg_w4_gemm.w_format = TG_WFMT_ROWS -- what bench.py's
     config3 leg launches; otherwise the reference's Aint4 words.  calibrate: bench.calibrate_x on the activations (max|y| in
@@ -574,20 +574,20 @@ def _stacked_launch(layers, m, n, k, g, qtype, numerics, seed=0, on_right=True, 
     assert not (native and on_right)
     wshape = (layers, n // 8, k // (16 * inner), 32, inner // 2) if (on_right or native) else (layers, n // 16, k // (16 * inner), 32, inner)
     w = torch.randint(-2 ** 31, 2 ** 31 - 1, wshape, dtype=torch.int64, device=DEV, generator=gen).to(torch.int32)
-    x = torch.randn(layers, m, k, device=DEV, generator=gen).to(torch.bfloat16)
+    x = torch.randn(layers, m, k, device=DEV, generator=gen).to(dtype)
     if qtype == "mx4":
         q = torch.randint(120, 131, (layers, n, k // g), dtype=torch.uint8, device=DEV, generator=gen)
         qstride = q.stride(0)
     else:
         scales = torch.rand(layers, k // g, n, device=DEV, generator=gen) * 0.02 + 0.005
         zeros = torch.randn(layers, k // g, n, device=DEV, generator=gen) * 0.01
-        q = torch.stack([scales, zeros], dim=3).to(torch.bfloat16).contiguous()
+        q = torch.stack([scales, zeros], dim=3).to(dtype).contiguous()
         qstride = q.stride(0) * 2
-    lut = {"any4_rowwise": torch.randn(layers, n, 16, device=DEV, generator=gen).to(torch.bfloat16),
-           "any4_global": torch.randn(layers, 16, device=DEV, generator=gen).to(torch.bfloat16)}.get(qtype)
-    y = torch.full((layers, m, n), float("nan"), device=DEV, dtype=torch.bfloat16)
+    lut = {"any4_rowwise": torch.randn(layers, n, 16, device=DEV, generator=gen).to(dtype),
+           "any4_global": torch.randn(layers, 16, device=DEV, generator=gen).to(dtype)}.get(qtype)
+    y = torch.full((layers, m, n), float("nan"), device=DEV, dtype=dtype)
     args = _lib.W4Gemm(x=x.data_ptr(), w=w.data_ptr(), qinfo=q.data_ptr(), lut=(lut.data_ptr() if lut is not None else None),
-                       y=y.data_ptr(), m=m, wrows=n, k=k, group=g, qtype=QT[qtype], dtype=_lib.TG_BF16, w_on_right=1 if on_right else 0,
+                       y=y.data_ptr(), m=m, wrows=n, k=k, group=g, qtype=QT[qtype], dtype=_lib.TG_BF16 if dtype == torch.bfloat16 else _lib.TG_F16, w_on_right=1 if on_right else 0,
                        inner_k_tiles=inner, batch=layers, stride_x=x.stride(0) * 2, stride_w=w.stride(0) * 4,
                        stride_qinfo=qstride, stride_lut=(lut.stride(0) * 2 if lut is not None else 0), stride_y=y.stride(0) * 2,
                        numerics=numerics, w_format=_lib.TG_WFMT_ROWS if native else _lib.TG_WFMT_M16N8K16)
@@ -771,6 +771,70 @@ def test_stacked_weights_on_the_right_beyond_k4096(T, oracle, m, n, k, layers):
             xb, qb, lb = x[b].cpu(), q[b].cpu()[:, r0:r0 + 192].contiguous(), lut[b].cpu()[r0:r0 + 192]
             assert_fast_close(oracle, y[b][:, r0:r0 + 192], codes, xb, qb, lb, g, qtype, batch=layers, expect_pair=None)
             assert_north_star(oracle, y[b][:, r0:r0 + 192], codes, xb, qb, lb, g, qtype)
+
+
+@pytest.mark.parametrize("case", [
+    # (m, n, k, g, qtype, dtype, layers): every launch >= 512 64-row work items, so that w4_gemm_xr_kernel takes it
+    (3, 1024, 8192, 128, "any4_rowwise", torch.bfloat16, 32),   # packed rows (two chunks per register set), odd row count
+    (8, 1024, 8192, 32, "int4", torch.bfloat16, 32),            # ... one group per chunk: the two halves of a row hold different groups
+    (5, 1024, 8192, 64, "any4_global", torch.bfloat16, 32),
+    (8, 1024, 8192, 256, "any4_rowwise", torch.float16, 32),    # ... fp16
+    (8, 1024, 14336, 128, "any4_rowwise", torch.bfloat16, 32),  # ... 56 chunks per slice
+    (8, 1024, 14336, 64, "int4", torch.float16, 32),
+    (11, 1024, 14336, 128, "any4_rowwise", torch.bfloat16, 32),  # k-windows 16 + 16 + 24 chunks, f32 partial sums in the workspace
+    (16, 1024, 14336, 64, "any4_global", torch.bfloat16, 32),
+    (9, 1024, 14336, 32, "int4", torch.float16, 32),
+    (13, 1024, 8192, 128, "any4_rowwise", torch.float16, 32),    # k-windows 16 + 16
+    (16, 2048, 8192, 256, "int4", torch.bfloat16, 16),           # (groups of 256: windows of 4096 hold whole groups)
+])
+def test_register_resident_kernel_beyond_k4096_variants(T, oracle, case):
+    """The register-resident-activation kernel's round-5 paths at k = 8192 / 14336 over group sizes, quantisation variants, both
+    dtypes and odd row counts: packed rows (m <= 8) and k-windows (m >= 9), first / last layer, first / last rows, both oracles."""
+    from any4_amd import _lib, ops
+
+    m, n, k, g, qtype, dtype, layers = case
+    assert ops.gemm_w4_plan(m, n, k, g, QT[qtype], True, 4, dtype, layers, detail=True) == "pair_xr"
+    w, x, q, lut, y = _stacked_launch(layers, m, n, k, g, qtype, _lib.TG_NUM_FAST, seed=m * 7 + g, dtype=dtype)
+    assert not torch.isnan(y.float()).any()
+    for b in (0, layers - 1):
+        for r0 in (0, n - 128):
+            codes = torch.from_numpy(oracle.unpack_Bint4(w[b].cpu().numpy(), n, k))[r0:r0 + 128]
+            qb = q[b].cpu()[:, r0:r0 + 128].contiguous()
+            lb = None if lut is None else (lut[b].cpu()[r0:r0 + 128] if qtype == "any4_rowwise" else lut[b].cpu())
+            assert_fast_close(oracle, y[b][:, r0:r0 + 128], codes, x[b].cpu(), qb, lb, g, qtype, dtype=dtype, batch=layers, expect_pair=None)
+
+
+def test_k_windows_bias_and_workspace_protocol(T, oracle):
+    """k-windows (m >= 9 at k = 14336): the fused bias is added by the kernel that sums the windows (rounded sum + bias, rounded
+    again: the bits of the separate add); without the workspace the call still works (on an older kernel) and plan says so."""
+    import ctypes
+
+    from any4_amd import _lib, ops
+
+    layers, m, n, k, g = 32, 12, 1024, 14336, 128
+    L = _lib.load()
+    w, x, q, lut, y = _stacked_launch(layers, m, n, k, g, "any4_rowwise", _lib.TG_NUM_FAST, seed=21)
+    bias = torch.randn(layers, n, device=DEV).to(torch.bfloat16)
+    yb = torch.full_like(y, float("nan"))
+    args = _lib.W4Gemm(x=x.data_ptr(), w=w.data_ptr(), qinfo=q.data_ptr(), lut=lut.data_ptr(), y=yb.data_ptr(), m=m, wrows=n, k=k, group=g,
+                       qtype=QT["any4_rowwise"], dtype=_lib.TG_BF16, w_on_right=1, inner_k_tiles=4, batch=layers, stride_x=x.stride(0) * 2,
+                       stride_w=w.stride(0) * 4, stride_qinfo=q.stride(0) * 2, stride_lut=lut.stride(0) * 2, stride_y=yb.stride(0) * 2,
+                       numerics=_lib.TG_NUM_FAST, bias=bias.data_ptr(), stride_bias=bias.stride(0) * 2)
+    need = L.tg_gemm_w4_workspace_bytes(ctypes.byref(args))
+    assert need == 3 * layers * m * n * 4            # three windows of f32 partial sums
+    assert L.tg_gemm_w4_plan(ctypes.byref(args), 0) != _lib.TG_PLAN_PAIR_XR   # no workspace attached: another kernel would run
+    ws = torch.full((need,), 0xff, dtype=torch.uint8, device=DEV)
+    args.workspace, args.workspace_bytes = ws.data_ptr(), need
+    assert L.tg_gemm_w4_plan(ctypes.byref(args), 0) == _lib.TG_PLAN_PAIR_XR
+    _lib.check(L.tg_gemm_w4(ctypes.byref(args), 0, torch.cuda.current_stream().cuda_stream), "k-windows + bias")
+    torch.cuda.synchronize()
+    assert torch.equal(yb, y + bias[:, None, :])
+    args.workspace, args.workspace_bytes = None, 0    # ... and without the workspace: the same numbers within the tolerance, older kernel
+    y2 = torch.full_like(y, float("nan"))
+    args.y, args.bias = y2.data_ptr(), None
+    _lib.check(L.tg_gemm_w4(ctypes.byref(args), 0, torch.cuda.current_stream().cuda_stream), "no workspace")
+    torch.cuda.synchronize()
+    assert not torch.isnan(y2.float()).any() and (y2.float() - y.float()).abs().max() <= 0.02 * y.float().abs().max()
 
 
 # ------------------------------------------------------------------------------------------------
