@@ -659,7 +659,9 @@ __global__ void __launch_bounds__(512) rope_attn_online_kernel(const uint16_t* _
     // 8-XCD part (measured: NS = 2 / 4 / 8 made the decode step 20 / 30 / 45 % slower at ANY context length).  Instead every value that
     // crosses blocks is written and read with agent-scope atomics (write-through stores, cache-bypassing loads), a thread's stores
     // are complete (vmcnt(0), the workgroup barrier's release) before thread 0 increments the head's counter, and the counter itself
-    // is an agent-scope atomic: the last block to arrive sees every partial.
+    // is an agent-scope atomic: the last block to arrive sees every partial.  (The hardware guide's valid form "sc1 stores AND
+    // sc1 loads on both sides, every writing wave drained before the flag": no acquire is needed because no plain load ever reads
+    // these words.  tests/test_gpu_decode.py::test_rope_attn_split_many_back_to_back_launches pins it under uneven load.)
     if (t < D) __hip_atomic_store(mine + 2 + t, num, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (t == 0) {
       __hip_atomic_store(mine, Mb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -208,25 +208,36 @@ def test_linear16_gemv_vs_torch(dtype):
     assert G.linear16(torch.randn(2, 1024, device=DEV).to(dtype), torch.randn(8, 1024, device=DEV).to(dtype)) is None   # no instantiation: the caller's GEMM
 
 
-def test_rope_attn_split_many_back_to_back_launches():
-    """The split launch's cross-block hand-over uses no device-scope fence (agent-scope atomics for everything that crosses blocks, a
-    self-resetting counter): 300 launches back to back on one stream with fresh inputs each -- a stale partial or an early combine
-    would show as a result of another launch."""
+@pytest.mark.parametrize("ns", [4, 8])
+def test_rope_attn_split_many_back_to_back_launches(ns):
+    """The split launch's cross-block (cross-XCD) hand-over uses no device-scope fence: everything that crosses blocks is written
+    AND read with agent-scope (sc1: write-through / L1-bypassing) accesses, every writing wave drains its stores (vmcnt(0)) before
+    the workgroup barrier in front of the counter's atomic increment, and the counter resets itself -- the `sc1 stores and loads on
+    both sides` form of the hardware guide's inter-workgroup rules.  Pinned the way that guide asks: many launches back to back
+    with fresh inputs (a stale partial or an early combine would show as a result of another launch), nsplit 4 and 8 (blocks of
+    one head on different XCDs), under UNEVEN load (a second stream streams 1 GiB copies meanwhile), every output checked."""
     from any4_amd import decode_ops as G
     from any4_amd.decode import DecodeConfig, _rope_tables
 
-    gen = torch.Generator(device=DEV).manual_seed(3)
-    bs, hl, kvl, d, S, p, ns = 1, 32, 8, 128, 2048, 1500, 4
+    gen = torch.Generator(device=DEV).manual_seed(3 + ns)
+    bs, hl, kvl, d, S, p = 1, 32, 8, 128, 2048, 1500
     cos, sin = _rope_tables(DecodeConfig(max_seq=S), DEV)
     scale = 1.0 / math.sqrt(d)
     kc = torch.randn(bs, kvl, S, d, device=DEV, generator=gen).bfloat16()
     vc = torch.randn(bs, kvl, S, d, device=DEV, generator=gen).bfloat16()
     pos = torch.tensor([p], device=DEV)
     scr = G.rope_attn_split_scratch(bs, hl, d, ns, DEV)
-    qs = [torch.randn(bs, (hl + 2 * kvl) * d, device=DEV, generator=gen).bfloat16() for _ in range(300)]
+    n_launch = 600
+    qs = [torch.randn(bs, (hl + 2 * kvl) * d, device=DEV, generator=gen).bfloat16() for _ in range(n_launch)]
+    load_a, load_b = torch.empty(1 << 28, dtype=torch.float32, device=DEV), torch.empty(1 << 28, dtype=torch.float32, device=DEV)
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        for _ in range(12):
+            load_b.copy_(load_a)
     outs = [G.rope_attn_split(q, cos, sin, pos, kc, vc, hl, kvl, d, scale, scr, ns) for q in qs]   # no sync in between
     torch.cuda.synchronize()
-    for q, o in zip(qs[::7], outs[::7]):
+    for q, o in zip(qs, outs):
         want = G.rope_attn_online(q, cos, sin, pos, kc, vc, hl, kvl, d, scale)
         assert (o.float() - want.float()).abs().max() <= 2.0 ** -6 * want.float().abs().max()
 
