@@ -1,7 +1,7 @@
 # One GPU-box visit: smoke, gpu tests, bench line, rocprofv3 kernel stats of the bench run and of every leg, PMC counters
 # (MfmaUtil, VALU / LDS / L2, HBM bytes) of the bench kernel and of the m = 8 / config 3 / m = 16 legs.  Writes gpurun_out/.
 set -u
-RN=${ROUND:-r04}
+RN=${ROUND:-r05}
 mkdir -p gpurun_out
 R=$GRAFT_REPO_ROOT
 cd $R
@@ -19,11 +19,11 @@ head -4 gpurun_out/${RN}_bench_kernel_stats.csv | cut -c1-250
 # counters
 python tools/collect_counters.py --out gpurun_out/${RN}_counters_bench_m1.json --match w4_gemm_pair_kernel --label "bench kernel: m=1 Bint4 4096^2, 512 layers per launch" -- python bench.py --steps 5 --warmup 2 --settle-s 0.05 --roofline-only | cut -c1-400
 python tools/collect_counters.py --out gpurun_out/${RN}_counters_m8.json --match w4_gemm_xr_kernel --label "m=8 Bint4 4096^2 (w4_gemm_xr_kernel), 512 layers per launch" -- python tools/ab.py 8,4096,4096,1,any4_rowwise,128 | cut -c1-400
-python tools/collect_counters.py --out gpurun_out/${RN}_counters_config3.json --match w4_gemm_pair_kernel --label "config 3: m=8, 8192^2, weights on the left in the native row-per-lane format (TG_WFMT_ROWS), 128 layers per launch" -- python bench.py --steps 5 --warmup 2 --settle-s 0.05 --roofline-only --left --m 8 --n 8192 --k 8192 --layers 128 | cut -c1-400
+python tools/collect_counters.py --out gpurun_out/${RN}_counters_config3.json --match w4_gemm_xr_kernel --label "config 3: m=8, 8192^2, weights on the left in the native format (TG_WFMT_ROWS; w4_gemm_xr_kernel, packed rows), 128 layers per launch" -- python bench.py --steps 5 --warmup 2 --settle-s 0.05 --roofline-only --left --m 8 --n 8192 --k 8192 --layers 128 | cut -c1-400
 python tools/collect_counters.py --out gpurun_out/${RN}_counters_config3_reference_words.json --match w4_gemm_pair_kernel --label "config 3 on the reference's Aint4 words: m=8 8192^2, 128 layers per launch" -- python tools/ab.py 8,8192,8192,0,any4_rowwise,128 | cut -c1-400
 python tools/collect_counters.py --out gpurun_out/${RN}_counters_m16.json --match w4_gemm_xr_kernel --label "m=16 Bint4 4096^2 (w4_gemm_xr_kernel), 512 layers per launch" -- python tools/ab.py 16,4096,4096,1,any4_rowwise,128 | cut -c1-400
 python tools/collect_counters.py --out gpurun_out/${RN}_counters_reference_m1.json --match w4_gemm_stream --label "TG_NUM_REFERENCE m=1 Bint4 4096^2, 512 layers per launch" -- env ANY4_AB_NUMERICS=reference python tools/ab.py 1,4096,4096,1,any4_rowwise,128 | cut -c1-400
-echo "== quick_bench default dispatch"; timeout 600 python tools/quick_bench.py --configs "1,4096,4096,1;2,4096,4096,1;4,4096,4096,1;8,4096,4096,1;16,4096,4096,1;1,8192,8192,1;8,8192,8192,1;1,14336,4096,1;1,4096,14336,1;8,4096,14336,1;1,4096,4096,0;8,4096,4096,0;1,8192,8192,0;8,8192,8192,0;16,8192,8192,0" --L 256 --iters 3 2>&1 | grep -E "^m=|eager|graph|stacked|steady" | tee gpurun_out/${RN}_quick_bench_default.txt
+echo "== quick_bench default dispatch"; timeout 600 python tools/quick_bench.py --configs "1,4096,4096,1;2,4096,4096,1;4,4096,4096,1;8,4096,4096,1;16,4096,4096,1;1,8192,8192,1;8,8192,8192,1;16,8192,8192,1;1,14336,4096,1;1,4096,14336,1;8,4096,14336,1;16,4096,14336,1;1,4096,4096,0;8,4096,4096,0;1,8192,8192,0;8,8192,8192,0;16,8192,8192,0" --L 256 --iters 3 2>&1 | grep -E "^m=|eager|graph|stacked|steady" | tee gpurun_out/${RN}_quick_bench_default.txt
 for q in "int4" "any4_global" "mx4" "int4 --g 32" "any4_rowwise --g 64" "any4_rowwise --g 256"; do timeout 300 python tools/quick_bench.py --configs "1,4096,4096,1;8,4096,4096,1;8,8192,8192,0" --qtype $q --L 256 --iters 3 2>&1 | grep -E "^m=|stacked|steady"; done | tee gpurun_out/${RN}_quick_bench_variants.txt
 
 # the decode step (BASELINE config 5, TP = 1): kernel stats and the per-node timeline of the graph replay
@@ -33,8 +33,10 @@ cd $R
 cp $(find /tmp/dec_prof -name 'dec_kernel_stats.csv' | head -1) gpurun_out/${RN}_decode_kernel_stats.csv
 python tools/decode_timeline.py "$(find /tmp/dec_prof -name 'dec_kernel_trace.csv' | head -1)" --last 10 > gpurun_out/${RN}_decode_timeline.txt 2>&1
 tail -2 gpurun_out/${RN}_decode_bench.log | cut -c1-300; cat gpurun_out/${RN}_decode_timeline.txt
-variants/graph_chain > gpurun_out/${RN}_ubench_graph_chain.txt 2>&1; timeout 60 variants/overlap_chain > gpurun_out/${RN}_ubench_overlap_chain.txt 2>&1
+[ -x variants/graph_chain ] && variants/graph_chain > gpurun_out/${RN}_ubench_graph_chain.txt 2>&1; [ -x variants/overlap_chain ] && timeout 60 variants/overlap_chain > gpurun_out/${RN}_ubench_overlap_chain.txt 2>&1
 # (hipcc --offload-arch=gfx950 -O3 -o variants/<name> tools/ubench/<name>.hip beforehand: the binaries are git-ignored but travel)
 [ -x variants/grid_barrier ] && timeout 120 variants/grid_barrier > gpurun_out/${RN}_ubench_grid_barrier.txt 2>&1
+[ -x variants/fused_qkv_attn ] && timeout 120 variants/fused_qkv_attn > gpurun_out/${RN}_ubench_fused_qkv_attn.txt 2>&1
+[ -x variants/lds_store ] && timeout 120 variants/lds_store > gpurun_out/${RN}_ubench_lds_store.txt 2>&1
 # the reference's module-level protocol (microbenchmark.py)
 (for k in 4096 8192; do for q in "anyq" "intq" "anyq --quantize-args per_row=False"; do echo "##### K=$k --quantize $q"; timeout 600 python tools/microbenchmark.py --input-dim $k --output-dim $k --quantize $q 2>&1 | grep -v "amdgpu.ids\|ROCTracer" | tail -5; done; done) > gpurun_out/${RN}_microbenchmark.txt 2>&1
