@@ -95,6 +95,18 @@ __global__ void __launch_bounds__(WV * 64, WV == 16 ? 1 : 2) w4_gemm_xr_kernel(c
   static_assert(WV == 8 || (WV == 16 && !QMX) || (WV == 4 && PK), "8 or 16 k-slices (mx4: 8); 4 with packed rows");
   static_assert(!PK || (!QMX && WV <= 8 && NCH % 2 == 0), "packed rows: the lookup kernel, chunk pairs");
   constexpr int NXR = PK ? NCH / 2 : NCH;          // activation register sets of a wave
+  // ZM: the zero-point term sum_g zero[g, row] X[g][a] (X = the group's sum of activations) on the MATRIX CORE, once per item and tile,
+  // instead of one FMA per accumulator register and group (64 of the ~680 vector instructions of a wave and item, plus the LDS reads
+  // of the staged sums).  zero is a 16-bit value already; X (f32) is split into three 16-bit parts hi + mid + lo (exact to 2^-27),
+  // so the K = 32 slots of one 16x16x32 MFMA hold up to 8 groups x 3 parts: A operand lane (row i, k-quad kb) = part p = kb R + rep
+  // (R = 8 / NG repeats of the NG groups per k-quad) of X[gidx][i], B operand = zero[gidx][row n] in every k-quad (lane-uniform
+  // in kb: no selects), C = the item's sums: y += A B directly.
+  constexpr int NG = NCH / CPG;                    // quantisation groups of a wave's slice
+#ifndef TG_XR_ZM
+#define TG_XR_ZM 1
+#endif
+  constexpr bool ZM = TG_XR_ZM && !QMX && !PK && WV == 8 && NCH <= 24 && NG <= 8;   // (32 unpacked chunks: its extra registers spill)
+  constexpr int ZR = NG <= 8 ? 8 / NG : 1;         // repeats of the group pattern inside a k-quad's 8 slots
   constexpr int CPS = I / 2;                       // 32-k chunks per super-tile
   constexpr int NST = NCH / CPS;                   // super-tiles of a wave's slice
   constexpr int NWL = 2 * CPS;                     // packed words per lane, tile pair and super-tile
@@ -261,6 +273,7 @@ __global__ void __launch_bounds__(WV * 64, WV == 16 ? 1 : 2) w4_gemm_xr_kernel(c
 
   // ---- activations of a problem: this lane's NCH pieces and the staged sums ----
   u32x4 xr[NXR];
+  u32x4 xza = {0u, 0u, 0u, 0u};  // ZM: the A operand of the zero-point MFMA (this lane's slots of the split group sums)
   // x_prepare: straight from the caller's activations, no pre-pass and no workspace.  Lane (row i, k-quad kb) reads the four dwords
   // (k, k + 1), k = 32 c + 2 kb + {0, 8, 16, 24}, of row i and rearranges them into the "byte order" of the packed words
   // (w4_gemm_pair.cuh: x[2q], x[2q+8], x[2q+16], x[2q+24], x[2q+1], x[2q+9], x[2q+17], x[2q+25]); rows >= m are zero.  The
@@ -280,6 +293,7 @@ __global__ void __launch_bounds__(WV * 64, WV == 16 ? 1 : 2) w4_gemm_xr_kernel(c
     const bool on = lrow < p.m;
     const int kq = (int)(lane_p >> 4);
     float gsum = 0.f;
+    if constexpr (ZM) xza = u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
     for (int cx = 0; cx < NXR; ++cx) {
       const int ci = PK ? 2 * cx + par : cx;         // (PK: run-time in the lane, the register index stays a constant)
@@ -302,6 +316,24 @@ __global__ void __launch_bounds__(WV * 64, WV == 16 ? 1 : 2) w4_gemm_xr_kernel(c
           gsum += __shfl_xor(gsum, 16);
           gsum += __shfl_xor(gsum, 32);
           if constexpr (PK && CPG > 1) gsum += __shfl_xor(gsum, 8);
+          if constexpr (ZM) {
+            // every lane of row i holds the group's sum now: its three 16-bit parts into this lane's slots (k-quad kq)
+            const int gidx = cx / CPG;   // (a constant after unrolling)
+            const uint16_t ph = DT::from_f32(gsum);
+            const float r1 = gsum - DT::lo_f32(ph);
+            const uint16_t pm = DT::from_f32(r1);
+            const uint16_t pl = DT::from_f32(r1 - DT::lo_f32(pm));
+            const uint16_t part[3] = {ph, pm, pl};
+#pragma unroll
+            for (int pp = 0; pp < 3; ++pp) {
+              const int kbs = pp / ZR, rep = pp % ZR;       // (compile-time after unrolling)
+              const int j = rep * NG + gidx, dw = j >> 1;
+              const uint32_t ins = (j & 1) ? ((xza[dw] & 0x0000ffffu) | ((uint32_t)part[pp] << 16)) : ((xza[dw] & 0xffff0000u) | (uint32_t)part[pp]);
+              xza[dw] = kq == kbs ? ins : xza[dw];
+            }
+            gsum = 0.f;
+            continue;
+          }
           // the group this lane's sum belongs to: packed with one chunk per group, the two halves of a row hold DIFFERENT groups
           const int cg = (PK && CPG == 1) ? 2 * cx + par : (PK ? 2 * cx : cx);
           const uint32_t g = (uint32_t)(((wave * NCH + cg) * 32) >> p.gshift);
@@ -362,7 +394,23 @@ __global__ void __launch_bounds__(WV * 64, WV == 16 ? 1 : 2) w4_gemm_xr_kernel(c
     }
     uint32_t gq[4] = {0u, 0u, 0u, 0u};  // scale | zero of the current group, packed as loaded
     // a finished group gi of tile pair u: y += scale * acc + zero * sum(x); the sums come from LDS here (two reads per group)
+    uint32_t zb[4][(NG + 1) / 2 > 0 ? (NG + 1) / 2 : 1];  // ZM: zero[gidx] of this lane's row in tile t, two groups per register
     auto finalize_pair = [&](int u, int gi) {
+      if constexpr (ZM) {
+#pragma unroll
+        for (int t = 2 * u; t < 2 * u + 2; ++t) {
+          const float gs = DT::lo_f32(gq[t]);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            yacc[t][r] = __builtin_fmaf(gs, acc[t][r], yacc[t][r]);
+            asm volatile("" : "+v"(yacc[t][r]));  // (kept HERE: without a memory operation in the update hipcc sinks it behind the loop and
+                                                   //  keeps every group's accumulators alive: 300-600 bytes of scratch)
+          }
+          // the group's zero for the MFMA behind the loop: low half of the pair register for an even group, high half for an odd one
+          zb[t][gi >> 1] = (gi & 1) ? __builtin_amdgcn_perm(gq[t], zb[t][gi >> 1], 0x07060100u) : (gq[t] >> 16);
+        }
+        return;
+      }
       const uint32_t g = (uint32_t)(((wave * NCH + gi * CPG) * 32) >> p.gshift);
       const f32x4 xsv = *(lds_cf32x4ptr)(lds_xs + uni(g * 64u) + (uint32_t)((lane >> 4) * 16));
 #pragma unroll
@@ -487,6 +535,32 @@ __global__ void __launch_bounds__(WV * 64, WV == 16 ? 1 : 2) w4_gemm_xr_kernel(c
     } else {
       finalize_pair(0, NCH / CPG - 1);
       finalize_pair(1, NCH / CPG - 1);
+      if constexpr (ZM) {
+        // y[a][row] += sum over (part, group) of X_part[gidx][a] zero[gidx][row]: one MFMA per tile.  Slot j of a k-quad holds group
+        // j % NG for j < ZR NG: with an even NG a B dword is one of the zb registers as it stands
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          u32x4 bz;
+#pragma unroll
+          for (int dw = 0; dw < 4; ++dw) {
+            const int j0 = 2 * dw, j1 = 2 * dw + 1;
+            const bool v0 = j0 < ZR * NG, v1 = j1 < ZR * NG;
+            const int g0 = j0 % NG, g1 = j1 % NG;
+            if (!v0 && !v1) bz[dw] = 0u;
+            else if (v0 && v1 && (g0 & 1) == 0 && g1 == g0 + 1) bz[dw] = zb[t][g0 >> 1];
+            else {
+              // low half = zero[g0] (half g0 & 1 of zb[g0 / 2]), high half = zero[g1]; an invalid slot = 0 (selector byte 0x0c)
+              const uint32_t lo_sel = v0 ? ((g0 & 1) ? 0x0302u : 0x0100u) : 0x0c0cu;
+              const uint32_t hi_sel = v1 ? ((g1 & 1) ? 0x0706u : 0x0504u) : 0x0c0cu;
+              bz[dw] = __builtin_amdgcn_perm(zb[t][v1 ? g1 >> 1 : 0], zb[t][v0 ? g0 >> 1 : 0], (hi_sel << 16) | lo_sel);
+            }
+          }
+          f32x4 yv = {yacc[t][0], yacc[t][1], yacc[t][2], yacc[t][3]};
+          yv = DT::mfma(xza, bz, yv);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) yacc[t][r] = yv[r];
+        }
+      }
     }
 
     const bool new_problem = has_next && inext.b != cur.b;

@@ -233,7 +233,13 @@ def _run_xr(T, codes, x, qinfo, lut, g, qtype, copies, bias=None, residual=False
                        numerics=_lib.TG_NUM_FAST, bias=(bs.data_ptr() if bs is not None else None),
                        stride_bias=(bs.stride(0) * 2 if bs is not None else 0), bias_row_stride=(n if residual else 0),
                        x_layout=1 if tc else 0, y_layout=1 if tc else 0)
-    assert L.tg_gemm_w4_workspace_bytes(ctypes.byref(args)) == 0  # the xr kernel arranges the activations itself: no scratch
+    need = L.tg_gemm_w4_workspace_bytes(ctypes.byref(args))
+    if k == 4096 or m <= 8:
+        assert need == 0  # the xr kernel arranges the activations itself: no scratch
+    else:                 # 9 ... 16 rows beyond k = 4096: k-windows, f32 partial sums of every window in the caller's workspace
+        assert need == (2 if k == 8192 else 3) * copies * m * n * 4
+        ws = torch.full((need,), 0xff, dtype=torch.uint8, device=DEV)
+        args.workspace, args.workspace_bytes = ws.data_ptr(), need
     assert L.tg_gemm_w4_plan(ctypes.byref(args), 0) == _lib.TG_PLAN_PAIR_XR
     _lib.check(L.tg_gemm_w4(ctypes.byref(args), 0, torch.cuda.current_stream().cuda_stream), "stacked launch (xr)")
     torch.cuda.synchronize()
