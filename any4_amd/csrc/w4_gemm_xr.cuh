@@ -105,7 +105,7 @@ __global__ void __launch_bounds__(WV * 64, WV == 16 ? 1 : 2) w4_gemm_xr_kernel(c
 #ifndef TG_XR_ZM
 #define TG_XR_ZM 1
 #endif
-  constexpr bool ZM = TG_XR_ZM && !QMX && !PK && WV == 8 && NCH <= 24 && NG <= 8;   // (32 unpacked chunks: its extra registers spill)
+  constexpr bool ZM = TG_XR_ZM && !QMX && WV == 8 && NG <= 8 && (PK ? (CPG > 1 && NCH <= 32) : NCH <= 24);  // (32 unpacked chunks: its extra registers spill)
   constexpr int ZR = NG <= 8 ? 8 / NG : 1;         // repeats of the group pattern inside a k-quad's 8 slots
   constexpr int CPS = I / 2;                       // 32-k chunks per super-tile
   constexpr int NST = NCH / CPS;                   // super-tiles of a wave's slice
@@ -318,7 +318,7 @@ __global__ void __launch_bounds__(WV * 64, WV == 16 ? 1 : 2) w4_gemm_xr_kernel(c
           if constexpr (PK && CPG > 1) gsum += __shfl_xor(gsum, 8);
           if constexpr (ZM) {
             // every lane of row i holds the group's sum now: its three 16-bit parts into this lane's slots (k-quad kq)
-            const int gidx = cx / CPG;   // (a constant after unrolling)
+            const int gidx = cx / CPL;   // (a constant after unrolling; packed rows: cx counts chunk PAIRS)
             const uint16_t ph = DT::from_f32(gsum);
             const float r1 = gsum - DT::lo_f32(ph);
             const uint16_t pm = DT::from_f32(r1);
