@@ -278,8 +278,8 @@ def test_bench_cpu_baseline_leg_and_byte_formula():
 
 
 def test_xr_kernel_routing():
-    """Which stacked launches the xr kernel takes (tg_gemm_w4_plan, no GPU work): Bint4, k = 4096 (k = 8192 from 9 rows), innerKTiles 4, rows a multiple
-    of 64, 2 <= m <= 16, every group size, at least two work items per CU; everything else stays where it was."""
+    """Which stacked launches the xr kernel takes (tg_gemm_w4_plan, no GPU work): Bint4, k = 4096 / 8192 / 14336, innerKTiles 4, rows a
+    multiple of 64, 2 <= m <= 16, every group size (k = 4096), at least two work items per CU; everything else stays where it was."""
     from any4_amd import ops
 
     plan = lambda m, n, k, g, q, inner=4, batch=64, right=True: ops.gemm_w4_plan(m, n, k, g, {'int4': 0, 'any4_global': 1, 'any4_rowwise': 2, 'mx4': 3}[q], right, inner, batch=batch, detail=True)
@@ -290,9 +290,14 @@ def test_xr_kernel_routing():
     assert plan(1, 4096, 4096, 128, "any4_rowwise") == "pair"             # m = 1: the 32x32x16 kernel
     assert plan(8, 4096, 4096, 32, "mx4") == "pair_xr" and plan(16, 4096, 4096, 32, "mx4") == "pair_xr"  # mx4: bf16, g = 32, k = 4096
     assert plan(8, 4096, 8192, 32, "mx4") != "pair_xr"
-    assert plan(8, 4096, 8192, 128, "any4_rowwise") != "pair_xr"          # k = 8192: only above 8 rows (two super-tiles in flight)
+    # k = 8192 / 14336 (round 5): packed activation rows up to 8 rows (k = 14336: at 8 rows), k-windows with f32 partial sums in the
+    # caller's workspace from 9 rows on (without the workspace those calls stay on the older kernels)
+    assert plan(8, 4096, 8192, 128, "any4_rowwise") == "pair_xr" and plan(2, 4096, 8192, 64, "int4") == "pair_xr"
     assert plan(9, 4096, 8192, 128, "any4_rowwise", batch=16) == "pair_xr" and plan(16, 8192, 8192, 256, "int4", batch=8) == "pair_xr"
-    assert plan(16, 4096, 2048, 128, "any4_rowwise") != "pair_xr" and plan(16, 4096, 14336, 128, "any4_rowwise") != "pair_xr"
+    assert plan(16, 4096, 14336, 128, "any4_rowwise") == "pair_xr" and plan(8, 4096, 14336, 128, "any4_rowwise") == "pair_xr"
+    assert plan(6, 4096, 14336, 128, "any4_rowwise") == "pair"            # (measured slower there: the workspace variant keeps it)
+    assert ops.gemm_w4_plan(16, 4096, 14336, 128, 2, True, 4, batch=64, detail=True, workspace=False) != "pair_xr"
+    assert plan(16, 4096, 2048, 128, "any4_rowwise") != "pair_xr" and plan(16, 4096, 14336, 256, "any4_rowwise") == "pair_xr"
     assert plan(8, 4096, 4096, 128, "any4_rowwise", inner=8) != "pair_xr"
     assert plan(8, 4104, 4096, 128, "any4_rowwise") != "pair_xr"          # rows not a multiple of 64
     assert plan(8, 4096, 4096, 128, "any4_rowwise", batch=4) != "pair_xr"  # 256 items: fewer than two per CU
