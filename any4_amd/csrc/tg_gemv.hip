@@ -99,6 +99,12 @@ int tgx::gemv(int dt, int I, bool qmx, GemmParams& p, int64_t batch, hipStream_t
   gp.m = p.m; gp.wrows = p.wrows; gp.k = p.k; gp.ntiles = p.ntiles; gp.ksuper = p.ksuper; gp.qtype = p.qtype;
   gp.sg_shift = g <= 64 ? 0 : g == 128 ? 1 : 2;
   gp.norm_eps = p.norm_eps; gp.epilogue = p.epilogue; gp.trace = nullptr;
+#ifndef TG_GEMV_CM
+#define TG_GEMV_CM 1
+#endif
+  // (per graph node, same box: 4096^2 m = 8 6.74 -> 6.50 us, 6144 rows 9.2 -> 8.7, m = 6 + 1.6 %, m = 5 - 2 %: from six rows on;
+  //  profiles/r05_ab_gemv_chunk_staging.txt)
+  gp.cm = (TG_GEMV_CM && mf0 && p.m >= 6 && (p.k == 4096 || p.k == 2048)) ? 1 : 0;
   gp.unit = p.epilogue == TG_EPI_SWIGLU ? 2 : 1;
   if (p.ntiles % gp.unit != 0) return TG_PAIR_NA;
   const int units = p.ntiles / gp.unit;

@@ -70,6 +70,7 @@ struct GemvParams {
   int32_t lds_lut, lds_x, lds_xs, lds_red, lds_nrm;  // LDS byte offsets (lds_nrm: 8 x m f32 partial sums of squares)
   float norm_eps;
   int32_t epilogue;
+  int32_t cm;        // 1: chunk-mode staging (5 ... 8 activation rows on the matrix-core path, k = 2048 / 4096: w4_gemv_kernel, `cm`)
   unsigned long long* trace;
 };
 
@@ -199,9 +200,44 @@ __global__ void __launch_bounds__(512, 2) w4_gemv_kernel(const GemvParams p) {
       }
     }
   };
+  // Chunk mode (5 ... 8 rows, k = 2048 / 4096): thread t of round j owns the WHOLE 32-k chunk t % nch of row j (NT / nch) + t / nch --
+  // four 16-byte loads per round instead of four 4-byte loads per ROW (M = 8: 8 wide loads per thread instead of 32 narrow ones;
+  // the narrow form touches every 64-byte line of the block four times and was ~2 us of the launch's critical path), a wave's 64
+  // chunks belong to ONE row.  xd[j] = the chunk of round j.
+  bool cm = false;
+  int cm_row = 0, cm_chunk = 0, cm_rpr = 1;  // first row of this thread, its chunk, rows per round
+  if constexpr (M >= 5) {
+    cm = p.cm != 0;
+    cm_rpr = NT / nch;
+    cm_row = tid / nch;
+    cm_chunk = tid - cm_row * nch;
+  }
+  if (M >= 5 && cm) {
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
+      if (j * cm_rpr < M) {  // (wave-uniform)
+        const int row = min(j * cm_rpr + cm_row, M - 1);
+        const u32x4* src = reinterpret_cast<const u32x4*>(xb + (int64_t)row * p.k * 2 + cm_chunk * 64);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const u32x4 v = src[q];
+          xd[j][4 * q] = v[0]; xd[j][4 * q + 1] = v[1]; xd[j][4 * q + 2] = v[2]; xd[j][4 * q + 3] = v[3];
+        }
+      }
+    }
+    if constexpr (NORM) {
+      const u32x4* src = reinterpret_cast<const u32x4*>(p.norm_w + cm_chunk * 64);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const u32x4 v = src[q];
+        gwd[4 * q] = v[0]; gwd[4 * q + 1] = v[1]; gwd[4 * q + 2] = v[2]; gwd[4 * q + 3] = v[3];
+      }
+    }
+  } else {
 #pragma unroll
   for (int a = 0; a < M; ++a) stage_load(xb + (int64_t)a * p.k * 2, xd[a]);
   if constexpr (NORM) stage_load(p.norm_w, gwd);
+  }
   // LUT: the 16 values of table column c of pass 0 as 8 packed pairs
   const int c = tid & 31;   // table column this thread builds
   const int hi = tid >> 5;  // ... for the bytes with this high nibble (16 x 32 = 512 threads)
@@ -268,6 +304,54 @@ __global__ void __launch_bounds__(512, 2) w4_gemv_kernel(const GemvParams p) {
   auto xs_store = [&](int a, int ch, int hh, float sum) {
     *(lds_fptr)(lds_xs + (uint32_t)(a * p.xs_pitch + (((ch >> 1) * 2 + hh) * 2 + (ch & 1)) * 4)) = sum;
   };
+  if (M >= 5 && cm) {
+    // chunk mode: round j stages chunk cm_chunk of row j cm_rpr + cm_row: its four pieces, the step's sum (four consecutive chunks =
+    // four consecutive threads), the row's sum of squares (a wave's chunks are one row's: every wave writes ALL M partials, zeros
+    // for the rows it does not hold)
+    float nrm[M];
+#pragma unroll
+    for (int a = 0; a < M; ++a) nrm[a] = 0.f;
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
+      if (j * cm_rpr < M) {  // (wave-uniform)
+        const int a = j * cm_rpr + cm_row;
+        const bool on = a < M;
+        if constexpr (NORM) {
+          float v = 0.f;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            if constexpr (std::is_same<DT, BF16>::value)
+              v = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, xd[j][e]), __builtin_bit_cast(bf16x2, xd[j][e]), v, false);
+            else
+              v = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, xd[j][e]), __builtin_bit_cast(f16x2, xd[j][e]), v, false);
+          }
+          v = on ? v : 0.f;
+#pragma unroll
+          for (int o = 1; o < 64; o <<= 1) v += __shfl_xor(v, o);
+#pragma unroll
+          for (int a2 = 0; a2 < M; ++a2) nrm[a2] = a2 == a ? v : nrm[a2];
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const uint32_t xv = xd[j][e], g = gwd[e];
+            xd[j][e] = DT::pack2(DT::lo_f32(xv) * DT::lo_f32(g), DT::hi_f32(xv) * DT::hi_f32(g));
+          }
+        }
+        float sum = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sum += piece_store(on ? a : 0, 4 * cm_chunk + q, xd[j][q], xd[j][q + 4], xd[j][q + 8], xd[j][q + 12], on);
+        sum = on ? sum : 0.f;
+        sum += __shfl_xor(sum, 1);
+        sum += __shfl_xor(sum, 2);
+        if (on && (cm_chunk & 3) == 0) *(lds_fptr)(lds_xs + (uint32_t)((cm_chunk >> 2) * 64 + a * 4)) = sum;
+      }
+    }
+    if constexpr (NORM) {
+      if (lane == 0) {
+#pragma unroll
+        for (int a = 0; a < M; ++a) *(lds_fptr)((uint32_t)p.lds_nrm + (uint32_t)((wave * M + a) * 4)) = nrm[a];
+      }
+    }
+  } else {
 #pragma unroll
   for (int a = 0; a < M; ++a) {
     const bool on = wide ? tid < nch : tid < npc;
@@ -323,6 +407,7 @@ __global__ void __launch_bounds__(512, 2) w4_gemv_kernel(const GemvParams p) {
       }
     }
   }
+  }  // !cm
   if (stage_lut && tid < wg_rows * 2) *(lds_u32x4ptr)((uint32_t)p.lds_lut + (uint32_t)tid * 16u) = lstage;
   if (stage_lut)
     for (int i = tid + NT; i < wg_rows * 2; i += NT)
