@@ -165,6 +165,7 @@ int tgx::gemv(int dt, int I, bool qmx, GemmParams& p, int64_t batch, hipStream_t
   gp.rounds = (gp.spp + d - 1) / d;
   gp.ubase = units / wgs;
   gp.urem = units % wgs;
+  gp.xcd4 = (gp.urem == 0 && wgs % 32 == 0) ? 1 : 0;
   if (p.k > 16384) return TG_PAIR_NA;  // a thread keeps its pieces of the activation block in registers: four rounds of 512 per row
   gp.lds_lut = 65536;
   const bool stage_lut = p.qtype == TG_Q_ANY4_ROWWISE && passes > 1;
