@@ -39,7 +39,9 @@ int launch_pair_xr_n(GemmParams& p, int64_t batch, hipStream_t st, const XrWindo
   if constexpr (!std::is_same<DT, BF16>::value) return TG_PAIR_NA;
   else {
 #endif
-  if (p.m > (PK ? 8 : 16) || p.m < TG_XR_MIN_M || p.norm_w || p.epilogue) return TG_PAIR_NA;
+  // (one row: only when the caller asks for the MATRIX-CORE contraction, TG_NUM_FAST_MFMA -- this kernel's 16x16x32 MFMAs do it at
+  //  79.4 % where the 32x32x16 ones of w4_gemm_pair_kernel reach 76.3 %; the default m = 1 contraction is v_dot2 there: 81.9 %, same box)
+  if (p.m > (PK ? 8 : 16) || p.m < (p.numerics == TG_NUM_FAST_MFMA ? 1 : TG_XR_MIN_M) || p.norm_w || p.epilogue) return TG_PAIR_NA;
   if (p.ksuper * 16 * I != p.k || p.wrows % 64 != 0 || p.ntiles * 8 != p.wrows) return TG_PAIR_NA;
   const int g = 1 << p.gshift;
   const int cpg = g / 32 < NCH ? g / 32 : NCH;  // 32-k chunks per group inside a wave's slice

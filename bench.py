@@ -639,7 +639,7 @@ def main():
             "m16": leg("any4_rowwise", 16, n, k, g, True, L // 2, f"m=16 (the reference's full 16-row tile, TinyGemmImpl.cuh:53-54), n=k={n}, g={g}, Bint4"),
             "config3": leg("any4_rowwise", 8, 8192, 8192, 128, False, 128, "BASELINE config 3: m=8, n=k=8192, g=128, weights on the A side (weightOnRight=False ops), in the packed format convert_matrix_to_m16n8k16_Aint4_layout returns (row-per-lane order, TG_WFMT_ROWS)"),
             "config3_reference_words": leg("any4_rowwise", 8, 8192, 8192, 128, False, 128, "config 3 on a tensor that holds the reference's own Aint4 words (a checkpoint packed by the CUDA implementation, any4_amd.weight_format('reference'))", native=False),
-            "m1_mfma": leg("any4_rowwise", 1, n, k, g, True, L, "the headline workload with the m = 1 contraction on the 32x32x16 MFMA (TG_NUM_FAST_MFMA: north_star's 'fed to bf16 MFMA') instead of the per-lane v_dot2 the default takes", "fast_mfma"),
+            "m1_mfma": leg("any4_rowwise", 1, n, k, g, True, L, "the headline workload with the m = 1 contraction on the matrix core (TG_NUM_FAST_MFMA: north_star's 'fed to bf16 MFMA'; w4_gemm_xr_kernel's 16x16x32 MFMAs) instead of the per-lane v_dot2 the default takes", "fast_mfma"),
             "int4": leg("int4", 1, n, k, g, True, L, "BASELINE config 4: uniform int4, m=1"),
             "nf4": leg("any4_global", 1, n, k, g, True, L, "BASELINE config 4: one global 16-entry LUT (the reference's NF4 path), m=1"),
             "mx4": leg("mx4", 1, n, k, 32, True, L, "BASELINE config 4: mx4 (fp4-e2m1 codes, e8m0 exponent per 32), m=1; weights converted by v_cvt_scalef32_pk_bf16_fp4"),

@@ -75,9 +75,11 @@ enum {
 enum { TG_NUM_FAST = 0, TG_NUM_REFERENCE = 1, TG_NUM_FAST_MFMA = 2 };
 /*   TG_NUM_FAST_MFMA  TG_NUM_FAST with the m = 1 contraction on the matrix cores: since round 3 the default contracts ONE activation
  *                     row with per-lane v_dot2_f32_bf16 (a 32x32x16 MFMA spends 16384 multiplier slots on 512 useful products and,
- *                     under the power cap, clock: 76 -> 81 % of the HBM roofline).  This value keeps the MFMA kernel reachable for the
- *                     headline shape (Bint4, innerKTiles 4, g = 128, stacked launches) so that both can be timed and compared
- *                     (bench.py `m1_mfma`, tests/test_gpu_fast.py); everything else runs as TG_NUM_FAST. */
+ *                     under the power cap, clock: 76 -> 81 % of the HBM roofline).  This value keeps the matrix-core contraction
+ *                     reachable for stacked m = 1 launches so that both can be timed and compared (bench.py `m1_mfma`,
+ *                     tests/test_gpu_fast.py): on w4_gemm_xr_kernel's 16x16x32 MFMAs where that kernel applies (k = 4096, rows a
+ *                     multiple of 64, >= 512 work items: 79 %), else on the 32x32x16 ones of w4_gemm_pair_kernel (76 %);
+ *                     everything else runs as TG_NUM_FAST. */
 
 /* precondition failures (wording of the matching TORCH_CHECK is in tg_error_string) */
 enum {
