@@ -57,7 +57,26 @@ int launch_pair_xr_n(GemmParams& p, int64_t batch, hipStream_t st, const XrWindo
   xp.gshift = p.gshift; xp.ngroups = p.ngroups; xp.qtype = p.qtype;
   xp.rblocks = (p.wrows + 63) / 64;
   const int64_t items = (int64_t)xp.rblocks * batch;
-  if (items > INT32_MAX || items < 2 * 256 * (WV == 4 ? 2 : 1)) return TG_PAIR_NA;  // two items per workgroup at least
+#ifndef TG_XR_MIN_ITEMS_PER_WG
+#define TG_XR_MIN_ITEMS_PER_WG 2  // work items per workgroup from which this kernel takes a launch (developer builds: 1 for one large layer per launch)
+#endif
+  // Two items per workgroup at least -- except ONE layer per launch at k = 4096 (what a module's forward issues at that batch; up to 8
+  // rows only what w4_gemv_kernel declined: groups of 32 / 64): one workgroup per 64-row item.  Per hipGraph node, same box
+  // (profiles/r05_ab_xr_single_crossover.txt; the first problem's activations staged through LDS, r05_ab_xr_xlds.txt):
+  //     rows x 4096, m = 16    4096   5120   8192  11008  14336  16384  28672      m = 8, g = 64:  8192  16384   m = 6: 28672
+  //     pair16 / stream         8.4   14.9   15.5   38.6   39.2   39.2   41.1                      13.6   17.6          29.7
+  //     here                   12.8   13.0   13.7   14.0   14.7   14.8   22.0                      14.0   15.4          22.2
+  // (an item is ~6.5 us of one CU's time whatever the launch: below 80 items the 16-row workgroups of w4_gemm_pair16_kernel win)
+#ifndef TG_XR_SINGLE_MIN_ITEMS
+#define TG_XR_SINGLE_MIN_ITEMS 80
+#endif
+#ifndef TG_XR_SINGLE_MIN_ITEMS_M8
+#define TG_XR_SINGLE_MIN_ITEMS_M8 256
+#endif
+  const bool single = batch == 1 && NCH == 16 && !PK && WV == 8 && !win &&
+                      ((p.m >= 9 && items >= TG_XR_SINGLE_MIN_ITEMS) || (p.m >= 5 && items >= TG_XR_SINGLE_MIN_ITEMS_M8));
+  if (items > INT32_MAX) return TG_PAIR_NA;
+  if (!single && items < TG_XR_MIN_ITEMS_PER_WG * 256 * (WV == 4 ? 2 : 1)) return TG_PAIR_NA;
   xp.items = (int32_t)items;
   xp.lds_xs = WV == 4 ? 65536 : 2 * 65536;
   // two tables (WV = 4: one, and the 8 KiB hand-over region behind the sums), the activation sums (mx4: the partial sums only)
@@ -75,8 +94,9 @@ int launch_pair_xr_n(GemmParams& p, int64_t batch, hipStream_t st, const XrWindo
     xp.y = win->y32; xp.stride_y = win->stride_y32; xp.y_f32 = 1; xp.bias = nullptr;
   }
   if (p.dry) return TG_PLAN_PAIR_XR;
-  const unsigned wgs = (unsigned)cu_count() * (WV == 4 ? 2u : 1u);  // one 8-wave (two 4-wave) workgroup(s) per compute unit, whatever the part has
-  if (items < 2 * (int64_t)wgs) return TG_PAIR_NA;
+  unsigned wgs = (unsigned)cu_count() * (WV == 4 ? 2u : 1u);  // one 8-wave (two 4-wave) workgroup(s) per compute unit, whatever the part has
+  if (single) wgs = items < (int64_t)wgs ? (unsigned)items : wgs;
+  else if (items < TG_XR_MIN_ITEMS_PER_WG * (int64_t)wgs) return TG_PAIR_NA;
 #define TG_XR_LAUNCH(CPG_)                                                  \
   do {                                                                      \
     constexpr auto kern = w4_gemm_xr_kernel<DT, I, NCH, CPG_, (WV == 16 ? TG_XR_R16 : ((NCH > 24 && !PK) || NCH > 32) ? TG_XR_R8K : TG_XR_R), false, WV, PK>; \

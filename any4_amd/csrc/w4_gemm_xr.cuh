@@ -280,7 +280,21 @@ __global__ void __launch_bounds__(WV * 64, WV == 16 ? 1 : 2) w4_gemm_xr_kernel(c
   // per-group sums of the wave's slice (its NCH / CPG groups) are formed from the same registers -- two-element dot products, the
   // group's chunks, then the four k-quads across lanes -- and written to LDS by the lanes of k-quad 0.  Runs once per PROBLEM and
   // workgroup, behind the barrier that ends the previous problem's last main loop.
-  auto x_prepare = [&](int b) {
+  // The launch's FIRST problem (XLDS instantiations, row-major x) goes through LDS instead: the gather above is 64 four-byte loads per
+  // lane whose wave-instruction touches 16 different 64-byte lines -- ~8 us of vector-memory issue per CU, nothing next to the 128
+  // items of a stacked launch, a third of a launch with ONE item per workgroup (16384 x 4096 at 16 rows: 25 us per graph node).  There
+  // the wave reads its slice of 8 rows as eight whole 1 KiB runs (16 bytes per lane, requested in front of the weight ring: `xg`),
+  // writes them into its 8 KiB of table buffer 1 (free until the first item's second half) with the 16-byte piece index XORed by the
+  // row -- lanes (row i, k-quad kq) of a 4-byte read then hit 8 x 4 distinct banks, rows 8 ... 15 of the OTHER round read their
+  // partner's address (a broadcast) --, and picks its dwords up from there: rows 0 ... 7, then rows 8 ... 15.  No barrier: the
+  // region is the wave's own and LDS operations of a wave execute in order.
+#ifndef TG_XR_XLDS
+#define TG_XR_XLDS 1
+#endif
+  constexpr bool XLDS = TG_XR_XLDS && !PK && !QMX && WV == 8 && NCH == 16;  // (mx4: its eight-deep ring plus the 64 staging registers spill)
+  u32x4 xg[XLDS ? 16 : 1];
+  auto x_prepare = [&](int b, auto STAGED) {
+    constexpr bool staged = decltype(STAGED)::value;
     const char* xb = p.x + (int64_t)b * p.stride_x;
     // (the lane id read HERE, opaque: derived from the kernel's `tid` the 64 per-lane offsets below are loop-invariant, get hoisted
     //  in front of the item loop and spilled -- 500 bytes of scratch)
@@ -294,6 +308,24 @@ __global__ void __launch_bounds__(WV * 64, WV == 16 ? 1 : 2) w4_gemm_xr_kernel(c
     const int kq = (int)(lane_p >> 4);
     float gsum = 0.f;
     if constexpr (ZM) xza = u32x4{0u, 0u, 0u, 0u};
+    if constexpr (staged) {
+      const uint32_t stg = TABLE + (uint32_t)wave * 8192u;
+      const uint32_t il = (uint32_t)li & 7u;
+      const uint32_t rb = stg + il * 1024u + (uint32_t)kq * 4u, sw = il << 4;
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) *(lds_u32x4ptr)(stg + (uint32_t)(j * 1024) + ((lane_p ^ (uint32_t)j) << 4)) = xg[8 * r + j];
+        const bool act = (li >> 3) == r;
+#pragma unroll
+        for (int cx = 0; cx < NXR; ++cx)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const uint32_t v = *(lds_cu32ptr)((rb + (uint32_t)((4 * cx + e) << 4)) ^ sw);
+            xr[cx][e] = (r == 0 || act) ? v : xr[cx][e];
+          }
+      }
+    }
 #pragma unroll
     for (int cx = 0; cx < NXR; ++cx) {
       const int ci = PK ? 2 * cx + par : cx;         // (PK: run-time in the lane, the register index stays a constant)
@@ -301,9 +333,13 @@ __global__ void __launch_bounds__(WV * 64, WV == 16 ? 1 : 2) w4_gemm_xr_kernel(c
       uint32_t d[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const int64_t idx = p.x_tc ? tc_a_index(xi, k0 + 8 * e, p.k >> 4) : (int64_t)xi * p.k + k0 + 8 * e;
-        const uint32_t v = *reinterpret_cast<const uint32_t*>(xb + idx * 2);
-        d[e] = on ? v : 0u;
+        if constexpr (staged) {
+          d[e] = on ? xr[cx][e] : 0u;
+        } else {
+          const int64_t idx = p.x_tc ? tc_a_index(xi, k0 + 8 * e, p.k >> 4) : (int64_t)xi * p.k + k0 + 8 * e;
+          const uint32_t v = *reinterpret_cast<const uint32_t*>(xb + idx * 2);
+          d[e] = on ? v : 0u;
+        }
       }
       xr[cx] = u32x4{__builtin_amdgcn_perm(d[1], d[0], 0x05040100u), __builtin_amdgcn_perm(d[3], d[2], 0x05040100u),
                      __builtin_amdgcn_perm(d[1], d[0], 0x07060302u), __builtin_amdgcn_perm(d[3], d[2], 0x07060302u)};
@@ -351,6 +387,15 @@ __global__ void __launch_bounds__(WV * 64, WV == 16 ? 1 : 2) w4_gemm_xr_kernel(c
 
   // ---- prologue: first item's table (buffer 0) and activations, the first R super-tiles ----
   Rows rcur = rows_of(cur);
+  bool x_staged = false;
+  if constexpr (XLDS) {
+    x_staged = !p.x_tc;  // (wave-uniform)
+    if (x_staged) {      // the first problem's activations, in front of the ring: vector memory returns in request order
+      const char* xs = p.x + (int64_t)cur.b * p.stride_x + (int64_t)(wave * NCH * 32) * 2 + lane * 16;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) xg[j] = *reinterpret_cast<const u32x4*>(xs + (int64_t)min(j, p.m - 1) * p.k * 2);
+    }
+  }
 #pragma unroll
   for (int j = 0; j < R; ++j) {
     __builtin_amdgcn_sched_barrier(0);
@@ -362,7 +407,12 @@ __global__ void __launch_bounds__(WV * 64, WV == 16 ? 1 : 2) w4_gemm_xr_kernel(c
 #pragma unroll
     for (int a = 0; a < 16; ++a) build_step(0u, a, hw);
   }
-  x_prepare(cur.b);
+  if constexpr (XLDS) {
+    if (x_staged) x_prepare(cur.b, std::true_type{});
+    else x_prepare(cur.b, std::false_type{});
+  } else {
+    x_prepare(cur.b, std::false_type{});
+  }
   __syncthreads();
 
   // lookup address = byte << 8 | column << 2 | buffer << 16: one v_perm_b32 of the word with (column << 2 | buffer << 8)
@@ -569,7 +619,7 @@ __global__ void __launch_bounds__(WV * 64, WV == 16 ? 1 : 2) w4_gemm_xr_kernel(c
     if constexpr (XR_ABL == 6) {  // ablation: no split-K tail (one barrier per item, nothing stored)
       __syncthreads();
       if (yacc[0][0] == 123.f) *reinterpret_cast<float*>(p.y) = yacc[1][1] + yacc[2][2] + yacc[3][3];
-      if (new_problem) x_prepare(inext.b);
+      if (new_problem) x_prepare(inext.b, std::false_type{});
       rcur = rnext; cur = inext; buf ^= 1u; colreg[0] ^= 0x100u; colreg[1] ^= 0x100u;
       continue;
     }
@@ -628,7 +678,7 @@ __global__ void __launch_bounds__(WV * 64, WV == 16 ? 1 : 2) w4_gemm_xr_kernel(c
 #pragma unroll
         for (int a = 0; a < 16; ++a) build_step(0u, a, hwn);
       }
-      if (new_problem) x_prepare(inext.b);
+      if (new_problem) x_prepare(inext.b, std::false_type{});
       __syncthreads();  // table, sums and hand-over region are free / ready for the next item
       rcur = rnext;
       cur = inext;
@@ -651,7 +701,7 @@ __global__ void __launch_bounds__(WV * 64, WV == 16 ? 1 : 2) w4_gemm_xr_kernel(c
 #pragma unroll
       for (int r = 0; r < 4; ++r) *(lds_fptr)(lds_red + (uint32_t)((((wave * 4 + t) * 4 + r) * 64 + (int)lane_t) * 4)) = yacc[t][r];
     }
-    if (new_problem) x_prepare(inext.b);  // (every wave is behind its last use of the old registers and sums)
+    if (new_problem) x_prepare(inext.b, std::false_type{});  // (every wave is behind its last use of the old registers and sums)
     __syncthreads();
     {
       // this thread's two outputs o = tid, tid + 512: (tile t, register r, lane l) -> activation row a, weight row; their eight

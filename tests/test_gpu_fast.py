@@ -278,6 +278,21 @@ def test_xr_kernel_vs_oracle(T, oracle, case):
     assert torch.equal(ys[1].view(torch.int16), ys[copies - 1 - (copies - 2) % m].view(torch.int16))
 
 
+@pytest.mark.parametrize("case", [(16384, 16, 128, "any4_rowwise", torch.bfloat16), (16384, 9, 64, "int4", torch.float16),
+                                  (28672, 13, 128, "any4_rowwise", torch.bfloat16), (5120, 16, 128, "any4_rowwise", torch.bfloat16),
+                                  (11008, 10, 256, "any4_global", torch.bfloat16), (16384, 5, 64, "any4_rowwise", torch.bfloat16),
+                                  (16384, 8, 32, "int4", torch.bfloat16)])
+def test_xr_kernel_single_large_layer(T, oracle, case):
+    """ONE layer per launch at k = 4096 (tg_xr.hip, `single`): the xr kernel with one workgroup per 64-row item -- fewer workgroups
+    than CUs (5120 / 11008 rows), one each, one or two (28672) -- with the activations of the launch's first problem staged through
+    LDS (w4_gemm_xr.cuh, XLDS), for 9 ... 16 rows and for the 5 ... 8-row launches w4_gemv_kernel declines (groups of 32 / 64)."""
+    n, m, g, qtype, dtype = case
+    codes, x, qinfo, lut = rand_problem(n, 4096, g, m, qtype, dtype=dtype, seed=n + m)
+    xs, ys = _run_xr(T, codes, x, qinfo, lut, g, qtype, 1)
+    assert not torch.isnan(ys.float()).any()
+    assert_fast_close(oracle, ys[0], codes, xs[0], qinfo, lut, g, qtype, dtype=dtype, batch=1)
+
+
 def test_xr_kernel_mx4_nan_exponent(T, oracle):
     """e = 255 is NaN (Dequantization.cuh:331-339): one such group makes its weight row's outputs NaN -- for every activation row and
     every problem -- and nothing else; the other outputs are bit-equal to the run without it."""
