@@ -84,9 +84,21 @@ struct GemvParams {
 //       row lane & 15 (rows >= M read row M - 1: their accumulator rows are never stored), so ONE LDS read per word serves all rows.
 //       D[a][n]: lane (n, sub) holds rows 4 sub + r.  A step (two super-tiles) lies inside one quantisation group (g >= 128, the host
 //       checks): one scale / zero update per step, the step's activation sums [step][16 rows] come from the staging.
+#ifndef TG_GEMV_MF_ONES
+#define TG_GEMV_MF_ONES 1  // MF: a step's activation sums (the zero-point term) from the matrix core -- four more MFMAs per step against an all-ones B operand leave sum_k x[4 sub + r][k] in
+                           // the lane that needs it -- instead of from the staging (8 two-element dot products per piece, a 16-lane butterfly per row = four LDS-latency
+                           // shuffles on the launch's critical path in front of the first barrier, an LDS write, and a 16-byte LDS read per step); 0: developer A/B
+#endif
+#ifndef TG_GEMV_DPP_SUMS
+#define TG_GEMV_DPP_SUMS 1
+#endif
 template <typename DT, int M, int GPS, int D, bool NORM, bool MF = false>
 __global__ void __launch_bounds__(512, 2) w4_gemv_kernel(const GemvParams p) {
   static_assert(!MF || GPS == 1, "matrix-core contraction: groups of at least two super-tiles");
+#ifndef TG_GEMV_MF_ONES_MIN_M
+#define TG_GEMV_MF_ONES_MIN_M 5  // (one row in a long layer: the four extra MFMAs per step cost more than the staging saves -- 28672 x 4096 15.6 vs 15.0 us)
+#endif
+  constexpr bool MFS = MF && TG_GEMV_MF_ONES && M >= TG_GEMV_MF_ONES_MIN_M;
   constexpr int NW = 8, NT = NW * 64;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -342,10 +354,12 @@ __global__ void __launch_bounds__(512, 2) w4_gemv_kernel(const GemvParams p) {
         float sum = 0.f;
 #pragma unroll
         for (int q = 0; q < 4; ++q) sum += piece_store(on ? a : 0, 4 * cm_chunk + q, xd[j][q], xd[j][q + 4], xd[j][q + 8], xd[j][q + 12], on);
-        sum = on ? sum : 0.f;
-        sum += __shfl_xor(sum, 1);
-        sum += __shfl_xor(sum, 2);
-        if (on && (cm_chunk & 3) == 0) *(lds_fptr)(lds_xs + (uint32_t)((cm_chunk >> 2) * 64 + a * 4)) = sum;
+        if constexpr (!MFS) {
+          sum = on ? sum : 0.f;
+          sum += __shfl_xor(sum, 1);
+          sum += __shfl_xor(sum, 2);
+          if (on && (cm_chunk & 3) == 0) *(lds_fptr)(lds_xs + (uint32_t)((cm_chunk >> 2) * 64 + a * 4)) = sum;
+        }
       }
     }
     if constexpr (NORM) {
@@ -385,17 +399,30 @@ __global__ void __launch_bounds__(512, 2) w4_gemv_kernel(const GemvParams p) {
       float sum = 0.f;
 #pragma unroll
       for (int q = 0; q < 4; ++q) sum += piece_store(a, 4 * tid + q, xd[a][q], xd[a][q + 4], xd[a][q + 8], xd[a][q + 12], on);
-      sum = on ? sum : 0.f;
-      sum += __shfl_xor(sum, 1);
-      sum += __shfl_xor(sum, 2);
-      if (on && (tid & 3) == 0) *(lds_fptr)(lds_xs + (uint32_t)((tid >> 2) * 64 + a * 4)) = sum;
+      if constexpr (!MFS) {
+        sum = on ? sum : 0.f;
+        sum += __shfl_xor(sum, 1);
+        sum += __shfl_xor(sum, 2);
+        if (on && (tid & 3) == 0) *(lds_fptr)(lds_xs + (uint32_t)((tid >> 2) * 64 + a * 4)) = sum;
+      }
     } else if (MF) {
       // the sums of a STEP's 128 k (the zero-point term is added per step): its 16 pieces are 16 consecutive threads
       float sum = piece_store(a, tid, xd[a][0], xd[a][1], xd[a][2], xd[a][3], on);
-      sum = on ? sum : 0.f;
+      if constexpr (!MFS) {
+        sum = on ? sum : 0.f;
+#if TG_GEMV_DPP_SUMS
+        // 16-lane sum by row rotations (v_add_f32 with a DPP operand: full-rate vector ops; `__shfl_xor` by 4 and 8 is a trip through the LDS
+        // crossbar each, four of them back to back per row on the launch's critical path in front of the first barrier)
+        sum += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sum), 0x128 /* row_ror:8 */, 0xf, 0xf, false));
+        sum += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sum), 0x124 /* row_ror:4 */, 0xf, 0xf, false));
+        sum += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sum), 0x122 /* row_ror:2 */, 0xf, 0xf, false));
+        sum += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sum), 0x121 /* row_ror:1 */, 0xf, 0xf, false));
+#else
 #pragma unroll
-      for (int o = 1; o < 16; o <<= 1) sum += __shfl_xor(sum, o);
-      if (on && (tid & 15) == 0) *(lds_fptr)(lds_xs + (uint32_t)((tid >> 4) * 64 + a * 4)) = sum;
+        for (int o = 1; o < 16; o <<= 1) sum += __shfl_xor(sum, o);
+#endif
+        if (on && (tid & 15) == 0) *(lds_fptr)(lds_xs + (uint32_t)((tid >> 4) * 64 + a * 4)) = sum;
+      }
     } else if (!wide) {
       float sum = piece_store(a, tid, xd[a][0], xd[a][1], xd[a][2], xd[a][3], on);
       sum += __shfl_xor(sum, 1);  // the two quads of a half sit in adjacent lanes
@@ -538,10 +565,20 @@ __global__ void __launch_bounds__(512, 2) w4_gemv_kernel(const GemvParams p) {
         for (int j = 0; j < 4; ++j) e4[u][j] = *(lds_cu32ptr)(__builtin_amdgcn_perm(w, colreg, 0x0c0c0400u + ((uint32_t)j << 8)));
         xf4[u] = *(lds_cu32x4ptr)(xr + (uint32_t)(jc * 64 + qq * 16));
       }
-      const f32x4 gs4 = *(lds_cf32x4ptr)(lds_xs + (uint32_t)((su >> 1) * 64 + (lane >> 4) * 16));
+      f32x4_t gs4 = {0.f, 0.f, 0.f, 0.f};
+      if constexpr (!MFS) {
+        const f32x4 v = *(lds_cf32x4ptr)(lds_xs + (uint32_t)((su >> 1) * 64 + (lane >> 4) * 16));
+        gs4 = f32x4_t{v[0], v[1], v[2], v[3]};
+      }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int u = 0; u < 4; ++u) acc = mfma16<DT>(xf4[u], e4[u], acc);
+      if constexpr (MFS) {
+        const uint32_t one2 = DT::pack2(1.f, 1.f);
+        const u32x4 ones = {one2, one2, one2, one2};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) gs4 = mfma16<DT>(xf4[u], ones, gs4);
+      }
       const float sc = on ? DT::lo_f32(sl.q[0]) : 0.f;
       const float zz = on ? DT::hi_f32(sl.q[0]) : 0.f;
 #pragma unroll

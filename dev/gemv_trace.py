@@ -96,7 +96,7 @@ def repeat_p16(n, m):
     show_p16(t, n)
 
 
-def repeat(n):
+def repeat(n, m=1):
     from any4_amd import _lib, ops
     import tinygemm  # noqa: F401
 
@@ -106,7 +106,7 @@ def repeat(n):
     ws = [torch.randint(-2 ** 31, 2 ** 31 - 1, (N // 8, K // 64, 32, 2), dtype=torch.int64, device=dev).to(torch.int32) for _ in range(n)]
     sz = torch.rand(K // 128, N, 2, device=dev).bfloat16()
     lut = torch.randn(N, 16, device=dev).bfloat16()
-    x = torch.randn(1, K, device=dev).bfloat16()
+    x = torch.randn(m, K, device=dev).bfloat16()
     buf = torch.zeros(n * 512 * 8, dtype=torch.int64, device=dev)
     for w in ws[:2]:
         ops.w4_linear_fused(x, w, 128, sz, lut)
@@ -132,12 +132,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--layers", type=int, default=3)
     ap.add_argument("--repeat", type=int, default=0, help="instead of a decode step: this many launches of ONE 4096 x 4096 layer shape back to back (distinct weights), from a graph")
-    ap.add_argument("--m", type=int, default=1, help="with --repeat: activation rows (5 ... 16: the stamps of w4_gemm_pair16_kernel)")
+    ap.add_argument("--m", type=int, default=1, help="with --repeat: activation rows (9 ... 16: the stamps of w4_gemm_pair16_kernel)")
     a = ap.parse_args()
-    if a.repeat and a.m > 4:
+    if a.repeat and a.m > 8:
         return repeat_p16(a.repeat, a.m)
     if a.repeat:
-        return repeat(a.repeat)
+        return repeat(a.repeat, a.m)
     from any4_amd import _lib
     from any4_amd.decode import Any4Factory, DecodeConfig, DecodeStack
 
