@@ -8,16 +8,9 @@
 
 namespace {
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
-}
+// (tg_common.cuh, tgl: DPP rotations and row swaps instead of six trips through the LDS crossbar)
+__device__ __forceinline__ float wave_sum(float v) { return tgl::wave_sum(v); }
+__device__ __forceinline__ float wave_max(float v) { return tgl::wave_max(v); }
 // all threads of a 256-thread block get the reduction; `scratch` holds >= 4 floats and is reusable afterwards
 template <bool MAX>
 __device__ __forceinline__ float block_reduce(float v, float* scratch) {
@@ -546,7 +539,9 @@ __global__ void __launch_bounds__(512) rope_attn_online_kernel(const uint16_t* _
     unpack8<DT>(raw, x);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const float partner = __shfl_xor(x[e], LPR / 2, 64);
+      float partner;
+      if constexpr (LPR == 16) partner = tgl::lane_xor<8>(x[e], lane);  // (one DPP move)
+      else partner = __shfl_xor(x[e], LPR / 2, 64);
       // rope_kv_kernel: o1 = x1 c1 + (-x2) s1 (lower half), o2 = x2 c2 + x1 s2 (upper half); every product and the sum rounded once
       // (two rounded products and a rounded sum, never an fma: hipcc contracts __fmul_rn / __fadd_rn across a lambda, so the
       //  products are made opaque)
@@ -619,17 +614,24 @@ __global__ void __launch_bounds__(512) rope_attn_online_kernel(const uint16_t* _
   DG_STAMP(5);
   // ---- the groups meet: out[e] = sum_g exp(m_g - M) acc_g[e] / sum_g exp(m_g - M) l_g.  First the RPW groups of a wave through
   // lane exchanges (no barrier), then the 8 waves once through LDS ----
-#pragma unroll
-  for (int o = LPR; o < 64; o <<= 1) {
-    const float mo = __shfl_xor(m, o, 64), lo = __shfl_xor(l, o, 64);
+  auto meet = [&](auto OO) {
+    constexpr int o = decltype(OO)::value;
+    auto other = [&](float v) -> float {
+      if constexpr (o >= 16) return tgl::lane_xor<o>(v, lane);  // (one row swap and a select instead of a trip through the LDS crossbar)
+      else return __shfl_xor(v, o, 64);
+    };
+    const float mo = other(m), lo = other(l);
     const float mn = fmaxf(m, mo);
     // (both sides empty: keep the zeros, never exp(-inf - -inf))
     const float wa = mn > -INFINITY ? __expf(m - mn) : 0.f, wb = mn > -INFINITY ? __expf(mo - mn) : 0.f;
     l = l * wa + lo * wb;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) acc[e] = acc[e] * wa + __shfl_xor(acc[e], o, 64) * wb;
+    for (int e = 0; e < 8; ++e) acc[e] = acc[e] * wa + other(acc[e]) * wb;
     m = mn;
-  }
+  };
+  if constexpr (LPR <= 8) meet(std::integral_constant<int, 8>{});
+  meet(std::integral_constant<int, 16>{});
+  meet(std::integral_constant<int, 32>{});
   float* mine = sm + wave * (D + 2);
   if (g == 0) {
 #pragma unroll
@@ -738,8 +740,7 @@ __global__ void __launch_bounds__(512) linear16_gemv_kernel(const uint16_t* __re
           acc[a] = dot2_16<DT>(wr[i][j][2], xr[a][j][2], acc[a]);
           acc[a] = dot2_16<DT>(wr[i][j][3], xr[a][j][3], acc[a]);
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) acc[a] += __shfl_xor(acc[a], o, 64);
+        acc[a] = wave_sum(acc[a]);
       }
       if (lane == 0 && r + i < r1) {
 #pragma unroll

@@ -57,6 +57,101 @@ struct GemmParams {
   int32_t x_tc, y_tc;  // fragment-order activations / output (pair-table kernels only)
 };
 
+// Lane exchanges WITHOUT the LDS crossbar.  hipcc turns every `__shfl_xor` into ds_bpermute_b32 -- an LDS-pipeline round trip (address
+// register, lgkmcnt wait, ~100 cycles) -- and a butterfly is four to six of them back to back, usually on a launch's critical path in
+// front of its first barrier (dev/gemv_trace.py: the 16-lane step sums were 0.6 us of a 5.8 us launch).  gfx950 has the data paths in
+// the vector ALU: DPP operands (quad permutes, rotations within a 16-lane row) and v_permlane16_swap / v_permlane32_swap across rows.
+// TG_LANE_SHFL=1 (developer A/B) restores the shuffles.
+#ifndef TG_LANE_SHFL
+#define TG_LANE_SHFL 0
+#endif
+namespace tgl {
+template <int CTRL>
+__device__ __forceinline__ float dpp(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+// the two halves of a pair of 16-lane rows / of the wave, side by side: [0] = (r0, r0, r2, r2) / (lo, lo), [1] = (r1, r1, r3, r3) / (hi, hi)
+__device__ __forceinline__ void rows16(float v, float& even, float& odd) {
+  const auto sw = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
+  even = __builtin_bit_cast(float, (unsigned)sw[0]);
+  odd = __builtin_bit_cast(float, (unsigned)sw[1]);
+}
+__device__ __forceinline__ void halves32(float v, float& lo, float& hi) {
+  const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
+  lo = __builtin_bit_cast(float, (unsigned)sw[0]);
+  hi = __builtin_bit_cast(float, (unsigned)sw[1]);
+}
+// the value lane ^ O holds (O = 1, 2, 8: one DPP move; 16, 32: one row swap and a select on this lane's side; `lane` = lane id)
+template <int O>
+__device__ __forceinline__ float lane_xor(float v, int lane) {
+  static_assert(O == 1 || O == 2 || O == 8 || O == 16 || O == 32, "xor by 4 has no DPP form on gfx9: rotate (row_sum) or shuffle");
+#if TG_LANE_SHFL
+  return __shfl_xor(v, O, 64);
+#else
+  if constexpr (O == 1) return dpp<0xB1>(v);        // quad_perm [1,0,3,2]
+  else if constexpr (O == 2) return dpp<0x4E>(v);   // quad_perm [2,3,0,1]
+  else if constexpr (O == 8) return dpp<0x128>(v);  // row_ror:8
+  else if constexpr (O == 16) { float a, b; rows16(v, a, b); return (lane & 16) ? a : b; }
+  else { float a, b; halves32(v, a, b); return (lane & 32) ? a : b; }
+#endif
+}
+// every lane of a 16-lane row gets the row's sum (rotations by 8, 4, 2, 1: the same bits in all 16 lanes)
+__device__ __forceinline__ float row_sum(float v) {
+#if TG_LANE_SHFL
+#pragma unroll
+  for (int o = 1; o < 16; o <<= 1) v += __shfl_xor(v, o, 64);
+  return v;
+#else
+  v += dpp<0x128>(v);
+  v += dpp<0x124>(v);
+  v += dpp<0x122>(v);
+  v += dpp<0x121>(v);
+  return v;
+#endif
+}
+__device__ __forceinline__ float row_max(float v) {
+#if TG_LANE_SHFL
+#pragma unroll
+  for (int o = 1; o < 16; o <<= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+#else
+  v = fmaxf(v, dpp<0x128>(v));
+  v = fmaxf(v, dpp<0x124>(v));
+  v = fmaxf(v, dpp<0x122>(v));
+  v = fmaxf(v, dpp<0x121>(v));
+  return v;
+#endif
+}
+// ... of the rows 2 j, 2 j + 1 / of the whole wave (every lane the same bits)
+__device__ __forceinline__ float rows16_sum(float v) {
+#if TG_LANE_SHFL
+  return v + __shfl_xor(v, 16, 64);
+#else
+  float a, b; rows16(v, a, b); return a + b;
+#endif
+}
+__device__ __forceinline__ float halves32_sum(float v) {
+#if TG_LANE_SHFL
+  return v + __shfl_xor(v, 32, 64);
+#else
+  float a, b; halves32(v, a, b); return a + b;
+#endif
+}
+__device__ __forceinline__ float wave_sum(float v) { return halves32_sum(rows16_sum(row_sum(v))); }
+__device__ __forceinline__ float wave_max(float v) {
+#if TG_LANE_SHFL
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+#else
+  v = row_max(v);
+  float a, b;
+  rows16(v, a, b); v = fmaxf(a, b);
+  halves32(v, a, b); return fmaxf(a, b);
+#endif
+}
+}  // namespace tgl
+
 enum { CANON_NONE = 0, CANON_PAIR = 1, CANON_QUAD = 2 };
 
 // Returned by a family's launch path when the shape does not fit its plan (the caller then takes another kernel).

@@ -557,8 +557,7 @@ __global__ void __launch_bounds__(512, 4) w4_gemm_pair_kernel(const PairParams p
 #pragma unroll
       for (int j = 0; j < 4; ++j) gw[j] = reinterpret_cast<const u32x4*>(p.norm_w + (on ? tid - a * nch : 0) * 64)[j];
       float ss = chunk_sumsq<DT>(xd);
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) ss += __shfl_xor(ss, o);
+      ss = tgl::wave_sum(ss);
       if (lane == 0) *(lds_fptr)(lds_xs + (uint32_t)(wave * 4)) = ss;
       __syncthreads();
       ss = 0.f;

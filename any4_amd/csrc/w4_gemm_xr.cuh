@@ -349,9 +349,9 @@ __global__ void __launch_bounds__(WV * 64, WV == 16 ? 1 : 2) w4_gemm_xr_kernel(c
         // chunks of the slice seen so far: all of them up to cx (unpacked) / the pairs up to cx (packed)
         constexpr int CPL = PK ? (CPG > 1 ? CPG / 2 : 1) : CPG;  // register sets per group in this lane
         if (cx % CPL == CPL - 1) {  // (compile-time) the group is complete: add the other k-quads' (and the other parity's) shares
-          gsum += __shfl_xor(gsum, 16);
-          gsum += __shfl_xor(gsum, 32);
-          if constexpr (PK && CPG > 1) gsum += __shfl_xor(gsum, 8);
+          gsum = tgl::rows16_sum(gsum);  // (row swaps / a DPP rotation: tg_common.cuh)
+          gsum = tgl::halves32_sum(gsum);
+          if constexpr (PK && CPG > 1) gsum += tgl::lane_xor<8>(gsum, (int)lane_p);
           if constexpr (ZM) {
             // every lane of row i holds the group's sum now: its three 16-bit parts into this lane's slots (k-quad kq)
             const int gidx = cx / CPL;   // (a constant after unrolling; packed rows: cx counts chunk PAIRS)

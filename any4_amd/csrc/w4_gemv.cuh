@@ -89,9 +89,6 @@ struct GemvParams {
                            // the lane that needs it -- instead of from the staging (8 two-element dot products per piece, a 16-lane butterfly per row = four LDS-latency
                            // shuffles on the launch's critical path in front of the first barrier, an LDS write, and a 16-byte LDS read per step); 0: developer A/B
 #endif
-#ifndef TG_GEMV_DPP_SUMS
-#define TG_GEMV_DPP_SUMS 1
-#endif
 template <typename DT, int M, int GPS, int D, bool NORM, bool MF = false>
 __global__ void __launch_bounds__(512, 2) w4_gemv_kernel(const GemvParams p) {
   static_assert(!MF || GPS == 1, "matrix-core contraction: groups of at least two super-tiles");
@@ -341,8 +338,7 @@ __global__ void __launch_bounds__(512, 2) w4_gemv_kernel(const GemvParams p) {
               v = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, xd[j][e]), __builtin_bit_cast(f16x2, xd[j][e]), v, false);
           }
           v = on ? v : 0.f;
-#pragma unroll
-          for (int o = 1; o < 64; o <<= 1) v += __shfl_xor(v, o);
+          v = tgl::wave_sum(v);
 #pragma unroll
           for (int a2 = 0; a2 < M; ++a2) nrm[a2] = a2 == a ? v : nrm[a2];
 #pragma unroll
@@ -356,8 +352,8 @@ __global__ void __launch_bounds__(512, 2) w4_gemv_kernel(const GemvParams p) {
         for (int q = 0; q < 4; ++q) sum += piece_store(on ? a : 0, 4 * cm_chunk + q, xd[j][q], xd[j][q + 4], xd[j][q + 8], xd[j][q + 12], on);
         if constexpr (!MFS) {
           sum = on ? sum : 0.f;
-          sum += __shfl_xor(sum, 1);
-          sum += __shfl_xor(sum, 2);
+          sum += tgl::lane_xor<1>(sum, lane);
+          sum += tgl::lane_xor<2>(sum, lane);
           if (on && (cm_chunk & 3) == 0) *(lds_fptr)(lds_xs + (uint32_t)((cm_chunk >> 2) * 64 + a * 4)) = sum;
         }
       }
@@ -385,8 +381,7 @@ __global__ void __launch_bounds__(512, 2) w4_gemv_kernel(const GemvParams p) {
           v = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, xd[a][j]), __builtin_bit_cast(f16x2, xd[a][j]), v, false);
       }
       v = on ? v : 0.f;
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) v += __shfl_xor(v, o);
+      v = tgl::wave_sum(v);
       if (lane == 0) *(lds_fptr)((uint32_t)p.lds_nrm + (uint32_t)((wave * M + a) * 4)) = v;
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
@@ -401,8 +396,8 @@ __global__ void __launch_bounds__(512, 2) w4_gemv_kernel(const GemvParams p) {
       for (int q = 0; q < 4; ++q) sum += piece_store(a, 4 * tid + q, xd[a][q], xd[a][q + 4], xd[a][q + 8], xd[a][q + 12], on);
       if constexpr (!MFS) {
         sum = on ? sum : 0.f;
-        sum += __shfl_xor(sum, 1);
-        sum += __shfl_xor(sum, 2);
+        sum += tgl::lane_xor<1>(sum, lane);
+        sum += tgl::lane_xor<2>(sum, lane);
         if (on && (tid & 3) == 0) *(lds_fptr)(lds_xs + (uint32_t)((tid >> 2) * 64 + a * 4)) = sum;
       }
     } else if (MF) {
@@ -410,22 +405,12 @@ __global__ void __launch_bounds__(512, 2) w4_gemv_kernel(const GemvParams p) {
       float sum = piece_store(a, tid, xd[a][0], xd[a][1], xd[a][2], xd[a][3], on);
       if constexpr (!MFS) {
         sum = on ? sum : 0.f;
-#if TG_GEMV_DPP_SUMS
-        // 16-lane sum by row rotations (v_add_f32 with a DPP operand: full-rate vector ops; `__shfl_xor` by 4 and 8 is a trip through the LDS
-        // crossbar each, four of them back to back per row on the launch's critical path in front of the first barrier)
-        sum += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sum), 0x128 /* row_ror:8 */, 0xf, 0xf, false));
-        sum += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sum), 0x124 /* row_ror:4 */, 0xf, 0xf, false));
-        sum += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sum), 0x122 /* row_ror:2 */, 0xf, 0xf, false));
-        sum += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sum), 0x121 /* row_ror:1 */, 0xf, 0xf, false));
-#else
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) sum += __shfl_xor(sum, o);
-#endif
+        sum = tgl::row_sum(sum);  // (tg_common.cuh: DPP rotations; four shuffles here were 0.6 us of the launch's critical path)
         if (on && (tid & 15) == 0) *(lds_fptr)(lds_xs + (uint32_t)((tid >> 4) * 64 + a * 4)) = sum;
       }
     } else if (!wide) {
       float sum = piece_store(a, tid, xd[a][0], xd[a][1], xd[a][2], xd[a][3], on);
-      sum += __shfl_xor(sum, 1);  // the two quads of a half sit in adjacent lanes
+      sum += tgl::lane_xor<1>(sum, lane);  // the two quads of a half sit in adjacent lanes
       if (on && (tid & 1) == 0) xs_store(a, tid >> 2, (tid >> 1) & 1, sum);
     } else {
       float sq[4];
@@ -488,9 +473,9 @@ __global__ void __launch_bounds__(512, 2) w4_gemv_kernel(const GemvParams p) {
     for (int a = 0; a < M; ++a) {
       v[a] = yacc[a];
       yacc[a] = 0.f;
-      v[a] += __shfl_xor(v[a], 32);
-      if (P <= 16) v[a] += __shfl_xor(v[a], 16);
-      if (P <= 8) v[a] += __shfl_xor(v[a], 8);
+      v[a] = tgl::halves32_sum(v[a]);
+      if (P <= 16) v[a] = tgl::rows16_sum(v[a]);
+      if (P <= 8) v[a] += tgl::lane_xor<8>(v[a], lane);
     }
     if (lane < P) {
 #pragma unroll
