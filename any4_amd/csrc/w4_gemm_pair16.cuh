@@ -256,7 +256,17 @@ __global__ void __launch_bounds__(1024) w4_gemm_pair16_kernel(const Pair16Params
       }
     }
   };
-  if (P16_ABL != 1) { w_request(wregA, qregA, 0); x_request(xfA, 0); }
+  // XREG: the activations FIRST.  Vector memory returns in request order per wave and a CU's vector-memory path moves 64 bytes per clock:
+  // the 128 KiB of activations a workgroup needs at 16 rows (four times its 32 KiB of weights) are ~1 us of that path.  Requested behind
+  // the weights they could only be delivered after the weights' HBM latency; in front of them they arrive while the weights are in flight:
+  // 4096^2 per graph node at m = 16 / 12 / 9: 8.09 -> 7.71 / 7.36 -> 6.98 / 6.79 -> 6.49 us (profiles/r05_ab_p16_prologue.txt).
+#ifndef P16_XFIRST
+#define P16_XFIRST 1
+#endif
+  if (P16_ABL != 1) {
+    if constexpr (XREG && P16_XFIRST) { x_request(xfA, 0); w_request(wregA, qregA, 0); }
+    else { w_request(wregA, qregA, 0); x_request(xfA, 0); }
+  }
   else {
 #pragma unroll
     for (int t = 0; t < TPW; ++t)
@@ -356,7 +366,16 @@ __global__ void __launch_bounds__(1024) w4_gemm_pair16_kernel(const Pair16Params
     }
   }
   P16_STAMP(2);
-  __syncthreads();
+#ifndef P16_ASM_BARRIER
+#define P16_ASM_BARRIER 0
+#endif
+  if constexpr (XREG && P16_ASM_BARRIER) {
+    // (developer A/B: `__syncthreads()` waits vmcnt(0) -- for every weight and activation request of the wave -- where only the table's LDS
+    //  stores have to be done; spelled out without that wait the launch measured 0.35 us SLOWER in either request order: not used)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  } else {
+    __syncthreads();
+  }
   P16_STAMP(3);
 
   // ---- main loop ----
