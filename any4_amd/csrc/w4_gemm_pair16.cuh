@@ -365,6 +365,15 @@ __global__ void __launch_bounds__(1024) w4_gemm_pair16_kernel(const Pair16Params
       ((lds_u32ptr)base)[a * 64] = e;  // (one LDS pointer + constant offsets: immediate offset fields, no address arithmetic per store)
     }
   }
+#ifndef P16_ARRANGE_EARLY
+#define P16_ARRANGE_EARLY 0
+#endif
+  // (developer A/B) XREG, the whole slice in one block: the fragment transposes in front of the barrier instead of behind it -- no
+  // difference (7.71 vs 7.67 us): the stamps say the LAST wave's activations land ~3.8 us after the requests whatever the order. Every
+  // CU of an XCD pulls the same 128 KiB of x out of that XCD's L2 -- 4 MiB per XCD and launch at ~2 TB/s: the launch is bound by that
+  // broadcast, not by the weights (profiles/r05_p16_trace_xfirst.txt)
+  constexpr bool ARRANGE_EARLY = XREG && CH == 4 && P16_XFIRST && P16_ARRANGE_EARLY && P16_ABL != 6;
+  if constexpr (ARRANGE_EARLY) x_arrange(xfA);
   P16_STAMP(2);
 #ifndef P16_ASM_BARRIER
 #define P16_ASM_BARRIER 0
@@ -509,7 +518,7 @@ __global__ void __launch_bounds__(1024) w4_gemm_pair16_kernel(const Pair16Params
     chunk_ph = ph * p.ksuper_p * CPS;
     if (P16_ABL == 2) continue;
     if (nl <= CH || (XREG && CH == 4)) {  // (wave-uniform) the whole slice was requested up front (XREG, CH = 4: always -- the host's choice)
-      if (P16_ABL != 6) x_arrange(xfA);  // (ablation 6: fragments used as loaded)
+      if (P16_ABL != 6 && !ARRANGE_EARLY) x_arrange(xfA);  // (ablation 6: fragments used as loaded)
 #if GEMV_TRACE
       asm volatile("" ::"v"(xfA[0]), "v"(xfA[NXF - 1]));
 #endif
