@@ -186,7 +186,17 @@ __global__ void __launch_bounds__(1024) w4_gemm_pair16_kernel(const Pair16Params
   u32x4 xfA[NXF], xfB[PIPE ? NXF : 1];
   // address = (wave-uniform chunk base, SGPRs) + (per-lane 32-bit offset: the host checks m k 2 < 4 GiB): the saddr form, no 64-bit
   // vector address per load
-  uint32_t xoff = (uint32_t)((min(n, p.m - 1) * p.k + 8 * q) * 2);
+  // XQ: the four lanes of a QUAD read one aligned 64-byte chunk of one row (lane 4 a + b: quarter b of row a) instead of lane (row, quarter)
+  // = 16 q + i.  The vector-memory path coalesces per quad of adjacent lanes: with 16 different rows in adjacent lanes every lane's 16
+  // bytes were a request of their own, and a workgroup's 128 KiB of activations took 3 us instead of 0.8 (tools/ubench/x_broadcast.hip:
+  // 4.74 vs 2.47 us per node -- rows per wave-load, order within the quad, XCD-private copies, rotations: all irrelevant).  Two more bit
+  // exchanges in x_arrange then put quarter b into register b of lane (b' = dword, row), and the A operand's row index becomes a ROTATED
+  // row number: lane i holds activation row 4 (i & 3) + (i >> 2), so accumulator register r of lane (n, q) is row 4 r + q (not 4 q + r).
+#ifndef P16_XQUAD
+#define P16_XQUAD 1
+#endif
+  constexpr bool XQ = XREG && !XTC && P16_XQUAD;
+  uint32_t xoff = XQ ? (uint32_t)((min(lane >> 2, p.m - 1) * p.k + 8 * (lane & 3)) * 2) : (uint32_t)((min(n, p.m - 1) * p.k + 8 * q) * 2);
   auto x_request = [&](u32x4 (&xf)[NXF], int l0) {
     if constexpr (XREG) {
 #pragma unroll
@@ -216,7 +226,22 @@ __global__ void __launch_bounds__(1024) w4_gemm_pair16_kernel(const Pair16Params
         const auto s13 = __builtin_amdgcn_permlane32_swap(xf[c][1], xf[c][3], false, false);
         const auto t01 = __builtin_amdgcn_permlane16_swap(s02[0], s13[0], false, false);
         const auto t23 = __builtin_amdgcn_permlane16_swap(s02[1], s13[1], false, false);
-        const uint32_t d0 = t01[0], d1 = t01[1], d2 = t23[0], d3 = t23[1];
+        uint32_t d0 = t01[0], d1 = t01[1], d2 = t23[0], d3 = t23[1];
+        if constexpr (XQ) {
+          // register bit 1 <-> lane bit 1, register bit 0 <-> lane bit 0 (within the quad: a DPP quad permute and a select each)
+          auto qx = [&](uint32_t& x, uint32_t& y, auto CTRL, bool hi) {
+            constexpr int ctrl = decltype(CTRL)::value;
+            const uint32_t yx = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)y, ctrl, 0xf, 0xf, false);
+            const uint32_t xx = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, ctrl, 0xf, 0xf, false);
+            const uint32_t nx = hi ? yx : x, ny = hi ? y : xx;
+            x = nx; y = ny;
+          };
+          const bool l1 = (lane & 2) != 0, l0 = (lane & 1) != 0;
+          qx(d0, d2, std::integral_constant<int, 0x4E>{}, l1);  // quad_perm [2,3,0,1]
+          qx(d1, d3, std::integral_constant<int, 0x4E>{}, l1);
+          qx(d0, d1, std::integral_constant<int, 0xB1>{}, l0);  // quad_perm [1,0,3,2]
+          qx(d2, d3, std::integral_constant<int, 0xB1>{}, l0);
+        }
         xf[c] = u32x4{__builtin_amdgcn_perm(d1, d0, 0x05040100u), __builtin_amdgcn_perm(d3, d2, 0x05040100u),
                       __builtin_amdgcn_perm(d1, d0, 0x07060302u), __builtin_amdgcn_perm(d3, d2, 0x07060302u)};
       }
@@ -573,7 +598,7 @@ __global__ void __launch_bounds__(1024) w4_gemm_pair16_kernel(const Pair16Params
 #endif
   if (tid < 256 * TPW) {
     const int t = tid >> 8, r = (tid >> 6) & 3, l = tid & 63;
-    const int a = 4 * (l >> 4) + r, row = row0 + 16 * t + (l & 15);
+    const int a = XQ ? 4 * r + (l >> 4) : 4 * (l >> 4) + r, row = row0 + 16 * t + (l & 15);  // (XQ: the A operand's rows are rotated)
     if (a < p.m && row < p.wrows) {
       float sum = 0.f;
 #pragma unroll
