@@ -654,8 +654,8 @@ def main():
 
         # (c) single-layer launches: what one module forward issues (the reference's microbenchmark shape) -- Any4Linear's
         # default kernel (per-row LUT any4, weights on the B side) and Int4Linear's (modules.py:21: uniform int4, A side)
-        def single_layer(qtype, on_right, tensors=None, m=m):
-            ww, xx, qq, ll, yy = tensors or make_batch(L, m, n, k, g, inner, device, 91 + m, qtype, on_right)
+        def single_layer(qtype, on_right, tensors=None, m=m, n=n, k=k, layers=None):
+            ww, xx, qq, ll, yy = tensors or make_batch(layers or L, m, n, k, g, inner, device, 91 + m, qtype, on_right)
             nl = ww.shape[0]
             sl = lambda t, i: None if t is None else t[i:i + 1]  # noqa: E731
             singles = [make_args(_lib, ww[i:i + 1], xx[i:i + 1], qq[i:i + 1], sl(ll, i), yy[i:i + 1], m, n, k, g, qtype, on_right, inner, 1,
@@ -707,6 +707,8 @@ def main():
         # ... and at a few rows (a prefill of a few tokens through the module; what the reference's microbenchmark.py:20-59 times)
         single_m8 = single_layer("any4_rowwise", True, m=8) if world == 1 else {}
         single_m16 = single_layer("any4_rowwise", True, m=16) if world == 1 else {}
+        # ... and a gate+up-shaped layer (28672 x 4096, Llama-3-8B) at 16 rows: one workgroup per 64-row item on w4_gemm_xr_kernel
+        single_m16_gate_up = single_layer("any4_rowwise", True, m=16, n=28672, k=4096, layers=16) if world == 1 and (n, k) == (4096, 4096) else {}
         # the host floor of the entry point: back-to-back launches of a 16 x 512 problem (5.9 KB) through the same C-ABI call
         tw_, tx_, tq_, tl_, ty_ = make_batch(1, 1, 16, 512, g, inner, device, 5)
         tiny = make_args(_lib, tw_, tx_, tq_, tl_, ty_, 1, 16, 512, g, "any4_rowwise", True, inner, 1)
@@ -783,6 +785,7 @@ def main():
                 "int4_a_side": single_a,
                 "m8": single_m8,
                 "m16": single_m16,
+                "m16_28672x4096": single_m16_gate_up,
                 "note": "one 4096x4096 GEMV per launch: top level = any4 per-row LUT, weights on the B side (what Any4Linear.forward issues); "
                         "int4_a_side = uniform int4, weights on the A side (Int4Linear's default kernel, modules.py:21); m8 / m16 = the top-level layer at 8 / 16 activation rows.  back_to_back = launches of "
                         "distinct cold layers on one stream (event time / launches); cold = median HIP-event time of an isolated launch (event pair "
@@ -810,7 +813,8 @@ def main():
                                     "any4_b_side_per_graph_node": single_b.get("us_per_launch_in_hipgraph"),
                                     "int4_a_side_per_graph_node": single_a.get("us_per_launch_in_hipgraph"),
                                     "any4_m8_per_graph_node": single_m8.get("us_per_launch_in_hipgraph"),
-                                    "any4_m16_per_graph_node": single_m16.get("us_per_launch_in_hipgraph")},
+                                    "any4_m16_per_graph_node": single_m16.get("us_per_launch_in_hipgraph"),
+                                    "any4_m16_28672x4096_per_graph_node": single_m16_gate_up.get("us_per_launch_in_hipgraph")},
                 "decode_llama3_8b": None if not decode or "error" in decode else
                 {"ms_per_token": decode["ms_per_token"], "frac_of_hbm_roofline": decode["frac_of_hbm_roofline"],
                  "kernels_per_layer": decode["kernels_per_layer"]},
