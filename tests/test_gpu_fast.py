@@ -201,7 +201,7 @@ def test_pair_kernel_9_to_16_rows(T, oracle, case):
     assert_fast_close(oracle, y, codes, x, qinfo, lut, g, qtype, inner=inner, batch=copies, expect_pair=True if inner < 8 else None)
 
 
-def _run_xr(T, codes, x, qinfo, lut, g, qtype, copies, bias=None, residual=False, tc=False):
+def _run_xr(T, codes, x, qinfo, lut, g, qtype, copies, bias=None, residual=False, tc=False, plan=None):
     """One stacked tg_gemm_w4 launch over `copies` problems with the SAME weights and DIFFERENT activations (problem j's rows are
     x rolled by j along the batch: the register-resident activations of w4_gemm_xr_kernel must follow the problem); optional
     fused bias / residual (bias_row_stride = wrows) and A-fragment-order activations / outputs.  Returns y [copies][m][n]."""
@@ -240,7 +240,7 @@ def _run_xr(T, codes, x, qinfo, lut, g, qtype, copies, bias=None, residual=False
         assert need == (2 if k == 8192 else 3) * copies * m * n * 4
         ws = torch.full((need,), 0xff, dtype=torch.uint8, device=DEV)
         args.workspace, args.workspace_bytes = ws.data_ptr(), need
-    assert L.tg_gemm_w4_plan(ctypes.byref(args), 0) == _lib.TG_PLAN_PAIR_XR
+    assert L.tg_gemm_w4_plan(ctypes.byref(args), 0) == (_lib.TG_PLAN_PAIR_XR if plan is None else plan)
     _lib.check(L.tg_gemm_w4(ctypes.byref(args), 0, torch.cuda.current_stream().cuda_stream), "stacked launch (xr)")
     torch.cuda.synchronize()
     if tc:
@@ -291,6 +291,21 @@ def test_xr_kernel_single_large_layer(T, oracle, case):
     xs, ys = _run_xr(T, codes, x, qinfo, lut, g, qtype, 1)
     assert not torch.isnan(ys.float()).any()
     assert_fast_close(oracle, ys[0], codes, xs[0], qinfo, lut, g, qtype, dtype=dtype, batch=1)
+
+
+def test_xr_kernel_single_large_layer_bias_and_fragment_order(T, oracle):
+    """The single-layer route (fewer workgroups than CUs: 6144 rows = 96 items) with a fused residual and with fragment-order
+    activations / outputs (x_layout = TG_LAYOUT_TC_A takes x_prepare's gather path instead of the LDS staging): the plain launch's
+    bits plus a separate rounded add / re-laid out."""
+    n, m, g, k = 6144, 16, 128, 4096
+    codes, x, qinfo, lut = rand_problem(n, k, g, m, "any4_rowwise", seed=321)
+    xs, y0 = _run_xr(T, codes, x, qinfo, lut, g, "any4_rowwise", 1)
+    assert_fast_close(oracle, y0[0], codes, xs[0], qinfo, lut, g, "any4_rowwise", batch=1)
+    res = torch.randn(m, n, generator=torch.Generator().manual_seed(6)).bfloat16()
+    _, y1 = _run_xr(T, codes, x, qinfo, lut, g, "any4_rowwise", 1, bias=res, residual=True)
+    assert torch.equal((y0.float() + res.to(DEV).float()).bfloat16().view(torch.int16), y1.view(torch.int16))
+    _, y2 = _run_xr(T, codes, x, qinfo, lut, g, "any4_rowwise", 1, tc=True)
+    assert torch.equal(y2.view(torch.int16), y0.view(torch.int16))
 
 
 def test_xr_kernel_mx4_nan_exponent(T, oracle):
@@ -444,6 +459,26 @@ def _check_rows(oracle, y_hip, codes, x, qinfo, lut, g, qtype, dtype):
     assert not bad.any(), f"vs group-scaled oracle: {bad.sum()} / {bad.size} outside tolerance; worst {np.abs(got - y_gs).max()} at {np.argwhere(bad)[:4]}"
     eps16 = 2.0 ** -9 if dtype == torch.bfloat16 else 2.0 ** -12
     assert not (np.abs(got - y_ref) > 0.5 * ulp16(y_ref, dtype) * (1 + 2.0 ** -7) + (4e-6 + eps16) * S + 1e-37).any()
+
+
+@pytest.mark.parametrize("m", [5, 11, 16])
+def test_pair16_register_resident_residual_and_fragment_order(T, oracle, m):
+    """w4_gemm_pair16_kernel's register-resident activations hold the A operand's rows in a ROTATED order (quad-contiguous loads:
+    accumulator register r of lane (n, q) = activation row 4 r + q): a fused residual (one bias row per activation row) and the
+    fragment-order output must follow it -- the plain launch's bits plus a separate rounded add / re-laid out."""
+    from any4_amd import _lib
+
+    n, g, k = 4096 if m > 8 else 208, 64, 4096   # (groups of 64: the gemv kernel declines them at 5 ... 8 rows)
+    codes, x, qinfo, lut = rand_problem(n, k, g, m, "any4_rowwise", seed=500 + m)
+    xs, y0 = _run_xr(T, codes, x, qinfo, lut, g, "any4_rowwise", 1, plan=_lib.TG_PLAN_PAIR)
+    rows = torch.cat([torch.arange(0, 64), torch.arange(n - 64, n)])
+    _check_rows(oracle, y0[0][:, rows], codes[rows], xs[0], qinfo[:, rows].contiguous(), lut[rows].contiguous(), g, "any4_rowwise", torch.bfloat16)
+    res = torch.randn(m, n, generator=torch.Generator().manual_seed(8)).bfloat16()
+    _, y1 = _run_xr(T, codes, x, qinfo, lut, g, "any4_rowwise", 1, bias=res, residual=True, plan=_lib.TG_PLAN_PAIR)
+    assert torch.equal((y0.float() + res.to(DEV).float()).bfloat16().view(torch.int16), y1.view(torch.int16))
+    if m == 16:  # (fragment order: whole 16-row tiles; x in fragment order takes the XTC loads, y in fragment order the rotated rows)
+        _, y2 = _run_xr(T, codes, x, qinfo, lut, g, "any4_rowwise", 1, tc=True, plan=_lib.TG_PLAN_PAIR)
+        assert torch.equal(y2.view(torch.int16), y0.view(torch.int16))
 
 
 def test_pair16_fp16_bias_and_batch(T, oracle):
