@@ -714,6 +714,46 @@ static int gemm_w4_impl(const tg_w4_gemm* caller, int device, tg_stream_t stream
   // packed words per lane-quad in the layout decide the in-register transpose
   const int canon = on_right ? (I == 2 ? CANON_NONE : I == 4 ? CANON_PAIR : CANON_QUAD)
                              : (I == 1 ? CANON_NONE : I == 2 ? CANON_PAIR : CANON_QUAD);
+  // More than 16 activation rows in the default numerics (row-major operands, weights on the B side): the group-scaled kernels hold at
+  // most one 16-row MFMA tile of activations, so the call is issued as ceil(m / 16) launches of up to 16 rows each on the caller's stream
+  // (the reference's own grid walks the 16-row tiles of m the same way and re-reads the weights per tile, TinyGemmImpl.cuh:379-392).
+  // Stacked 4096^2 layers at m = 17 ... 32: 5.2-5.3 us per layer on the reference-numerics stream kernel (22 % of the roofline for
+  // ONE pass over the weights) against 3.0-3.3 here; one layer per graph node at m = 32 / 64: 15.3 / 35.5 us against 14 / 28.
+#ifndef TG_ROW_BLOCKS
+#define TG_ROW_BLOCKS 1
+#endif
+  if (TG_ROW_BLOCKS && on_right && a->m > 16 && a->m <= 16 * 64 && (a->numerics == TG_NUM_FAST || a->numerics == TG_NUM_FAST_MFMA) && !p.x_tc && !p.y_tc &&
+      !p.norm_w && !p.epilogue) {
+    // decided on a dry pass over the two block shapes of the call (16 rows, the ragged last block): both on a group-scaled kernel, or the
+    // whole call stays on the path below
+    auto block_plan = [&](int mb) {
+      GemmParams q = p;
+      q.m = mb;
+      q.dry = true;
+      q.ws_need = 0;
+      return launch_w4(a->dtype, false, canon, a->qtype == TG_Q_MX4, q, 1, batch, st);
+    };
+    auto group_scaled = [](int rc) { return rc == TG_PLAN_PAIR || rc == TG_PLAN_PAIR_XR || rc == TG_PLAN_GEMV; };
+    const int last = (int)(a->m % 16 ? a->m % 16 : 16);
+    const int r16 = block_plan(16), rl = last == 16 ? r16 : block_plan(last);
+    if (group_scaled(r16) && group_scaled(rl)) {
+      int64_t need = 0;
+      for (int64_t m0 = 0; m0 < a->m; m0 += 16) {
+        GemmParams q = p;
+        q.m = (int32_t)(a->m - m0 < 16 ? a->m - m0 : 16);
+        q.x = p.x + m0 * a->k * 2;
+        q.y = p.y + m0 * a->wrows * 2;
+        if (q.bias && q.bias_row_stride) q.bias = p.bias + m0 * q.bias_row_stride * 2;
+        q.ws_need = 0;
+        const int rc = launch_w4(a->dtype, false, canon, a->qtype == TG_Q_MX4, q, 1, batch, st);
+        if (rc < 0) return rc;
+        if (rc == TG_PLAN_PAIR || rc == TG_PLAN_PAIR_XR) need = q.ws_need > need ? q.ws_need : need;
+      }
+      if (ws_need) *ws_need = need;
+      return dry ? r16 : 0;
+    }
+    p.ws_need = 0;
+  }
   const int rc = launch_w4(a->dtype, !on_right, canon, a->qtype == TG_Q_MX4, p, coltiles, batch, st);
   if (ws_need) *ws_need = (rc == TG_PLAN_PAIR || rc == TG_PLAN_PAIR_XR) ? p.ws_need : 0;
   return rc;

@@ -352,6 +352,57 @@ def test_xr_kernel_fragment_order(T, oracle):
 
 
 @pytest.mark.parametrize("case", [
+    # (n, k, m, g, qtype, copies): more than 16 activation rows = ceil(m / 16) launches of up to 16 rows each (tinygemm_hip.hip, row blocks)
+    (4096, 4096, 17, 128, "any4_rowwise", 12),   # stacked: xr for the 16-row block, the m = 1 kernel for the ragged block
+    (4096, 4096, 40, 64, "int4", 10),            # three blocks (16 + 16 + 8)
+    (256, 4096, 33, 128, "any4_rowwise", 1),     # one layer per launch: pair16 twice, the gemv kernel for the last row
+    (4096, 8192, 25, 128, "any4_global", 10),    # k-windows (f32 partial sums in the workspace, reused by the blocks) + packed rows
+    (64, 4096, 64, 32, "mx4", 40),               # mx4, four full blocks
+])
+def test_more_than_16_rows_in_row_blocks(T, oracle, case):
+    """Default numerics with more than 16 activation rows: every row within the group-scaled tolerance, every problem of a stacked
+    launch, a fused per-row residual bit-identical to the separate add."""
+    from any4_amd import _lib
+
+    L = _lib.load()
+    n, k, m, g, qtype, copies = case
+    codes, x, qinfo, lut = rand_problem(n, k, g, m, qtype, seed=n + k + m)
+    packed1 = T.convert_matrix_to_m16n8k16_Bint4_layout(codes.to(DEV), 4)
+    rep = lambda t: None if t is None else t.to(DEV).unsqueeze(0).repeat(copies, *([1] * t.dim())).contiguous()
+    packed, qs, luts = rep(packed1.cpu()), rep(qinfo), rep(lut)
+    xs = torch.stack([torch.roll(x, j % m, 0) for j in range(copies)]).to(DEV).contiguous()
+    res = torch.randn(copies, m, n, generator=torch.Generator().manual_seed(3)).bfloat16().to(DEV)
+
+    def run(bias):
+        ys = torch.full((copies, m, n), float("nan"), dtype=torch.bfloat16, device=DEV)
+        args = _lib.W4Gemm(x=xs.data_ptr(), w=packed.data_ptr(), qinfo=qs.data_ptr(), lut=(luts.data_ptr() if luts is not None else None),
+                           y=ys.data_ptr(), m=m, wrows=n, k=k, group=g, qtype=QT[qtype], dtype=_lib.TG_BF16, w_on_right=1, inner_k_tiles=4,
+                           batch=copies, stride_x=xs.stride(0) * 2, stride_w=packed.stride(0) * 4, stride_qinfo=qs.stride(0) * qs.element_size(),
+                           stride_lut=(luts.stride(0) * 2 if luts is not None else 0), stride_y=ys.stride(0) * 2, numerics=_lib.TG_NUM_FAST,
+                           bias=(bias.data_ptr() if bias is not None else None), stride_bias=(bias.stride(0) * 2 if bias is not None else 0),
+                           bias_row_stride=(n if bias is not None else 0))
+        need = L.tg_gemm_w4_workspace_bytes(ctypes.byref(args))
+        assert need >= 0
+        if need:
+            ws = torch.full((need,), 0xff, dtype=torch.uint8, device=DEV)
+            args.workspace, args.workspace_bytes = ws.data_ptr(), need
+        assert L.tg_gemm_w4_plan(ctypes.byref(args), 0) in (_lib.TG_PLAN_PAIR, _lib.TG_PLAN_PAIR_XR, _lib.TG_PLAN_GEMV)
+        _lib.check(L.tg_gemm_w4(ctypes.byref(args), 0, torch.cuda.current_stream().cuda_stream), "row-blocked launch")
+        torch.cuda.synchronize()
+        return ys
+
+    y0 = run(None)
+    assert not torch.isnan(y0.float()).any()
+    rows = slice(None) if n <= 256 else torch.cat([torch.arange(0, 64), torch.arange(n - 64, n)])
+    q = qinfo[rows] if qtype == "mx4" else qinfo[:, rows].contiguous()
+    lt = lut if lut is None or lut.dim() == 1 else lut[rows].contiguous()
+    for j in sorted({0, copies // 2, copies - 1}):
+        _check_rows(oracle, y0[j][:, rows], codes[rows], xs[j].cpu(), q, lt, g, qtype, torch.bfloat16)
+    y1 = run(res)
+    assert torch.equal((y0.float() + res.float()).bfloat16().view(torch.int16), y1.view(torch.int16))
+
+
+@pytest.mark.parametrize("case", [
     # (n, k, m, g, inner, qtype): activation blocks that do not fit next to the table -> workspace variant
     (64, 4096, 8, 64, 4, "any4_rowwise"), (72, 4096, 5, 128, 4, "any4_rowwise"), (64, 4096, 7, 256, 4, "int4"),
     (64, 8192, 1, 128, 4, "any4_rowwise"), (40, 8192, 3, 64, 4, "any4_global"), (64, 14336, 1, 128, 4, "any4_rowwise"),
@@ -501,17 +552,17 @@ def test_pair_kernel_fp16(T, oracle):
 
 
 def test_fast_equals_reference_where_no_fast_kernel(T, oracle):
-    """Shapes without a group-scaled kernel (small launches of A-side weights, more than 16 activation rows at k = 4096): the
-    fast setting then runs the reference kernels, bit for bit."""
+    """Shapes without a group-scaled kernel (small launches of A-side weights, innerKTiles 8 at one layer per launch with more than 16
+    activation rows): the fast setting then runs the reference kernels, bit for bit."""
     import any4_amd
     from any4_amd import ops
 
-    for on_right, m, k in ((False, 2, 1024), (True, 17, 4096), (False, 1, 4096)):
+    for on_right, m, k, inner in ((False, 2, 1024, 4), (True, 17, 4096, 8), (False, 1, 4096, 4)):
         codes, x, qinfo, lut = rand_problem(64, k, 128, m, "any4_rowwise", seed=3)
-        assert ops.gemm_w4_plan(m, 64, k, 128, QT["any4_rowwise"], on_right, 4) != "pair"
-        y_fast = run_rm(T, codes, x, qinfo, lut, 128, "any4_rowwise", on_right, 4)
+        assert ops.gemm_w4_plan(m, 64, k, 128, QT["any4_rowwise"], on_right, inner) != "pair"
+        y_fast = run_rm(T, codes, x, qinfo, lut, 128, "any4_rowwise", on_right, inner)
         with any4_amd.numerics("reference"):
-            y_ref = run_rm(T, codes, x, qinfo, lut, 128, "any4_rowwise", on_right, 4)
+            y_ref = run_rm(T, codes, x, qinfo, lut, 128, "any4_rowwise", on_right, inner)
         assert torch.equal(y_fast, y_ref)
 
 

@@ -324,7 +324,12 @@ def test_xr_kernel_routing():
     assert ops.gemm_w4_plan(8, 8192, 4096, 64, q2["any4_rowwise"], True, 4, detail=True) != "pair_xr"
     assert ops.gemm_w4_plan(16, 8192, 8192, 128, q2["any4_rowwise"], True, 4, detail=True) != "pair_xr"    # (k = 4096 only)
     assert ops.gemm_w4_plan(4, 4096, 4096, 32, q2["any4_rowwise"], True, 4) == "gemv"   # (the v_dot2 contraction: any group size)
-    assert plan(17, 4096, 4096, 128, "any4_rowwise") != "pair_xr"
+    # more than 16 rows (default numerics, row-major operands): ceil(m / 16) launches of up to 16 rows on the same kernels -- the plan is
+    # the 16-row block's; shapes whose blocks have no group-scaled kernel (innerKTiles 8 at one layer per launch) stay where they were
+    assert plan(17, 4096, 4096, 128, "any4_rowwise") == "pair_xr" and plan(64, 4096, 4096, 128, "any4_rowwise") == "pair_xr"
+    assert ops.gemm_w4_plan(33, 4096, 4096, 128, q2["any4_rowwise"], True, 4) == "pair"
+    assert ops.gemm_w4_plan(33, 4096, 4096, 128, q2["any4_rowwise"], True, 8, detail=True) in ("stream", "splitk")
+    assert ops.gemm_w4_plan(33, 4096, 4096, 128, q2["any4_rowwise"], True, 4, numerics="reference", detail=True) in ("stream", "splitk")
 
 
 def test_integration_md_binding_and_struct_bytes():
