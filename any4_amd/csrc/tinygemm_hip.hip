@@ -719,10 +719,16 @@ static int gemm_w4_impl(const tg_w4_gemm* caller, int device, tg_stream_t stream
   // (the reference's own grid walks the 16-row tiles of m the same way and re-reads the weights per tile, TinyGemmImpl.cuh:379-392).
   // Stacked 4096^2 layers at m = 17 ... 32: 5.2-5.3 us per layer on the reference-numerics stream kernel (22 % of the roofline for
   // ONE pass over the weights) against 3.0-3.3 here; one layer per graph node at m = 32 / 64: 15.3 / 35.5 us against 14 / 28.
+  // Up to 64 rows: from 128 rows on the stream kernel's ONE launch (its 16-row tiles of m run concurrently and share the weights in
+  // L2) wins -- one 4096^2 layer per graph node at m = 128 / 256 / 1024: 37.8 / 44.5 / 166 us against 55 / 102 / 427 in blocks
+  // (profiles/r05_row_blocks_large_m.txt).
 #ifndef TG_ROW_BLOCKS
 #define TG_ROW_BLOCKS 1
 #endif
-  if (TG_ROW_BLOCKS && on_right && a->m > 16 && a->m <= 16 * 64 && (a->numerics == TG_NUM_FAST || a->numerics == TG_NUM_FAST_MFMA) && !p.x_tc && !p.y_tc &&
+#ifndef TG_ROW_BLOCKS_MAX_M
+#define TG_ROW_BLOCKS_MAX_M 64
+#endif
+  if (TG_ROW_BLOCKS && on_right && a->m > 16 && a->m <= TG_ROW_BLOCKS_MAX_M && (a->numerics == TG_NUM_FAST || a->numerics == TG_NUM_FAST_MFMA) && !p.x_tc && !p.y_tc &&
       !p.norm_w && !p.epilogue) {
     // decided on a dry pass over the two block shapes of the call (16 rows, the ragged last block): both on a group-scaled kernel, or the
     // whole call stays on the path below

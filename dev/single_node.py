@@ -18,9 +18,13 @@ def main():
     ap.add_argument("--g", type=int, default=128)
     ap.add_argument("--layers", type=int, default=64)
     ap.add_argument("--reps", type=int, default=50)
+    ap.add_argument("--numerics", default="fast", choices=["fast", "reference"])
     a = ap.parse_args()
+    import any4_amd
     from any4_amd import ops
     import tinygemm  # noqa: F401
+
+    any4_amd.set_numerics(a.numerics)
 
     dev = torch.device("cuda:0")
     N, K = a.n, a.k

@@ -68,7 +68,7 @@ enum {
  *                     No per-weight rounding to 16 bits, so y differs from the reference's by at most the reference's own
  *                     rounding of its dequantised weights (<= 2^-9 * sum_k |x_k w_k|, about one output ulp at k = 4096);
  *                     mx4 weights are exact either way (and its kernels the same in both settings).  More than 16 activation
- *                     rows (row-major operands, no fused norm / SwiGLU) are issued as ceil(m / 16) launches of up to 16 rows
+ *                     rows, up to 64 (row-major operands, no fused norm / SwiGLU), are issued as ceil(m / 16) launches of up to 16 rows
  *                     on the caller's stream (the reference's grid walks m's 16-row tiles the same way, TinyGemmImpl.cuh:379-392).
  *                     Other shapes run the TG_NUM_REFERENCE kernels.
  *   TG_NUM_REFERENCE  w = RNE16(fma(lut[code], scale, zero)) per element exactly as the reference kernels compute it

@@ -328,6 +328,7 @@ def test_xr_kernel_routing():
     # the 16-row block's; shapes whose blocks have no group-scaled kernel (innerKTiles 8 at one layer per launch) stay where they were
     assert plan(17, 4096, 4096, 128, "any4_rowwise") == "pair_xr" and plan(64, 4096, 4096, 128, "any4_rowwise") == "pair_xr"
     assert ops.gemm_w4_plan(33, 4096, 4096, 128, q2["any4_rowwise"], True, 4) == "pair"
+    assert ops.gemm_w4_plan(65, 4096, 4096, 128, q2["any4_rowwise"], True, 4, detail=True) in ("stream", "splitk")   # (one launch wins from here on)
     assert ops.gemm_w4_plan(33, 4096, 4096, 128, q2["any4_rowwise"], True, 8, detail=True) in ("stream", "splitk")
     assert ops.gemm_w4_plan(33, 4096, 4096, 128, q2["any4_rowwise"], True, 4, numerics="reference", detail=True) in ("stream", "splitk")
 
