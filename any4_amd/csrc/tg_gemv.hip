@@ -134,7 +134,23 @@ int tgx::gemv(int dt, int I, bool qmx, GemmParams& p, int64_t batch, hipStream_t
   const bool two_per_cu = (int64_t)p.wrows * p.k / 2 >= TG_GEMV_WG2_MIN_BYTES && units >= 4 * cus && lds_two_per_cu() <= 80 * 1024 &&
                           padded_tiles(2 * cus) <= padded_tiles(cus);
   const int wgs = units < cus ? units : (two_per_cu ? 2 * cus : cus);
-  const int tpw = ((units + wgs - 1) / wgs) * gp.unit;  // tiles of the largest range
+  gp.ubase = units / wgs;
+  gp.urem = units % wgs;
+  gp.uextra = 1;
+  // Two workgroups per CU: the workgroups 0 ... cus - 1 are the first on their CU and through their prologue ~2 us before the second
+  // ones (dev/gemv_trace.py).  TG_GEMV_WG2_EXTRA = E (odd) deals them E units more than the second ones instead of one (units a
+  // multiple of the CU count: Llama-3-8B's gate_up, 7 SwiGLU units per CU as 4 + 3)
+  // Same box, the decode step: 4 + 3 (E = 1) 1.523-1.545 ms, 5 + 2 (E = 3) **1.490-1.498**, 6 + 1 (E = 5) 1.542-1.550
+  // (profiles/r05_ab_gemv_wg2_extra.txt)
+#ifndef TG_GEMV_WG2_EXTRA
+#define TG_GEMV_WG2_EXTRA 3
+#endif
+  if (TG_GEMV_WG2_EXTRA > 1 && two_per_cu && wgs == 2 * cus && units % cus == 0 && (units / cus) % 2 == 1 && units / cus > TG_GEMV_WG2_EXTRA) {
+    gp.ubase = (units / cus - TG_GEMV_WG2_EXTRA) / 2;
+    gp.urem = cus;
+    gp.uextra = TG_GEMV_WG2_EXTRA;
+  }
+  const int tpw = (gp.ubase + (gp.urem ? gp.uextra : 0)) * gp.unit;  // tiles of the largest range
   // Ranges of THREE tiles at one activation row (q/k/v of Llama-3-8B: 6144 rows over 256 CUs): two 16-row passes carry a padding
   // tile (4 tile slots for 3 tiles); three 8-row passes of the v_dot2 contraction would stream exactly the range -- measured SLOWER
   // (6144 x 4096 per graph node 6.8 -> 7.2 us, the decode step unchanged; profiles/r05_ab_gemv_odd_p8.txt): developer knob only
@@ -163,8 +179,6 @@ int tgx::gemv(int dt, int I, bool qmx, GemmParams& p, int64_t batch, hipStream_t
   gp.spp = gp.spw / SS;
   const int d = gp.spp <= 4 ? 4 : 8;  // ring depth: a pass occupies whole rounds of D slots
   gp.rounds = (gp.spp + d - 1) / d;
-  gp.ubase = units / wgs;
-  gp.urem = units % wgs;
   gp.xcd4 = (gp.urem == 0 && wgs % 32 == 0) ? 1 : 0;
   if (p.k > 16384) return TG_PAIR_NA;  // a thread keeps its pieces of the activation block in registers: four rounds of 512 per row
   gp.lds_lut = 65536;

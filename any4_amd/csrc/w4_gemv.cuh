@@ -62,7 +62,8 @@ struct GemvParams {
   int32_t sg_shift;  // log2(super-tiles per quantisation group), g >= 64 (GPS = 1)
   int32_t P, p_shift;  // weight rows per pass (8, 16, 32) and its log2
   int32_t unit;      // tiles are dealt to workgroups in units of this many (2 with the SwiGLU epilogue: a gate / up block):
-  int32_t ubase, urem;  // workgroup b owns ubase + (b < urem) units, starting at unit b * ubase + min(b, urem)
+  int32_t ubase, urem;  // workgroup b owns ubase + (b < urem ? uextra : 0) units, starting at unit b * ubase + min(b, urem) * uextra
+  int32_t uextra;       // 1; more when the first `urem` workgroups are the FIRST on their CU and should stream longer (two workgroups per CU)
   int32_t spw;       // k super-tiles per wave
   int32_t spp;       // steps per pass and wave
   int32_t rounds;    // ceil(spp / D): rounds of D ring slots a pass occupies
@@ -114,7 +115,7 @@ __global__ void __launch_bounds__(512, 2) w4_gemv_kernel(const GemvParams p) {
                "s"(p.stride_qinfo), "s"(p.stride_lut), "s"(p.stride_y), "s"(p.stride_bias), "s"(p.bias_row_stride));
   asm volatile("" ::"s"(p.m), "s"(p.wrows), "s"(p.k), "s"(p.ksuper), "s"(p.qtype), "s"(p.sg_shift), "s"(p.P), "s"(p.p_shift), "s"(p.unit),
                "s"(p.ubase), "s"(p.urem), "s"(p.spw), "s"(p.spp), "s"(p.rounds), "s"(p.x_pitch), "s"(p.xs_pitch), "s"(p.lds_lut),
-               "s"(p.lds_x), "s"(p.lds_xs), "s"(p.lds_red), "s"(p.lds_nrm), "s"(p.norm_eps), "s"(p.epilogue), "s"(p.xcd4), "s"(p.cm));
+               "s"(p.lds_x), "s"(p.lds_xs), "s"(p.lds_red), "s"(p.lds_nrm), "s"(p.norm_eps), "s"(p.epilogue), "s"(p.xcd4), "s"(p.cm), "s"(p.uextra));
 #if GEMV_TRACE
   tr[6] = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -127,8 +128,8 @@ __global__ void __launch_bounds__(512, 2) w4_gemv_kernel(const GemvParams p) {
   //  top of the launch)
   int bx = blockIdx.x;
   if (p.xcd4) bx = (((bx >> 5) * 8 + (bx & 7)) << 2) + ((bx >> 3) & 3);
-  const int t0 = (bx * p.ubase + min(bx, p.urem)) * p.unit;
-  const int t1 = t0 + (p.ubase + (bx < p.urem ? 1 : 0)) * p.unit;
+  const int t0 = (bx * p.ubase + min(bx, p.urem) * p.uextra) * p.unit;
+  const int t1 = t0 + (p.ubase + (bx < p.urem ? p.uextra : 0)) * p.unit;
   if (t0 >= t1) return;
   const int P = p.P, Pm = P - 1, tpp = P >> 3;        // tiles per pass
   const int passes = (t1 - t0 + tpp - 1) >> (p.p_shift - 3);
