@@ -150,7 +150,12 @@ int tgx::gemv(int dt, int I, bool qmx, GemmParams& p, int64_t batch, hipStream_t
     gp.urem = cus;
     gp.uextra = TG_GEMV_WG2_EXTRA;
   }
-  const int tpw = (gp.ubase + (gp.urem ? gp.uextra : 0)) * gp.unit;  // tiles of the largest range
+  gp.uh = 0;
+#ifndef TG_GEMV_WG2_HALF
+#define TG_GEMV_WG2_HALF 0  // (developer A/B) with E = 1: this many of the CUs run 5 + 2 instead of 4 + 3
+#endif
+  if (TG_GEMV_WG2_HALF > 0 && gp.uextra == 1 && two_per_cu && wgs == 2 * cus && gp.urem == cus && gp.ubase >= 2) gp.uh = TG_GEMV_WG2_HALF < cus ? TG_GEMV_WG2_HALF : cus;
+  const int tpw = (gp.ubase + (gp.urem ? gp.uextra : 0) + (gp.uh ? 1 : 0)) * gp.unit;  // tiles of the largest range
   // Ranges of THREE tiles at one activation row (q/k/v of Llama-3-8B: 6144 rows over 256 CUs): two 16-row passes carry a padding
   // tile (4 tile slots for 3 tiles); three 8-row passes of the v_dot2 contraction would stream exactly the range -- measured SLOWER
   // (6144 x 4096 per graph node 6.8 -> 7.2 us, the decode step unchanged; profiles/r05_ab_gemv_odd_p8.txt): developer knob only

@@ -64,6 +64,7 @@ struct GemvParams {
   int32_t unit;      // tiles are dealt to workgroups in units of this many (2 with the SwiGLU epilogue: a gate / up block):
   int32_t ubase, urem;  // workgroup b owns ubase + (b < urem ? uextra : 0) units, starting at unit b * ubase + min(b, urem) * uextra
   int32_t uextra;       // 1; more when the first `urem` workgroups are the FIRST on their CU and should stream longer (two workgroups per CU)
+  int32_t uh;           // 0; else (two workgroups per CU, urem = CUs): the pairs (b, b + urem) with b < uh move ONE more unit from the second workgroup to the first
   int32_t spw;       // k super-tiles per wave
   int32_t spp;       // steps per pass and wave
   int32_t rounds;    // ceil(spp / D): rounds of D ring slots a pass occupies
@@ -115,7 +116,7 @@ __global__ void __launch_bounds__(512, 2) w4_gemv_kernel(const GemvParams p) {
                "s"(p.stride_qinfo), "s"(p.stride_lut), "s"(p.stride_y), "s"(p.stride_bias), "s"(p.bias_row_stride));
   asm volatile("" ::"s"(p.m), "s"(p.wrows), "s"(p.k), "s"(p.ksuper), "s"(p.qtype), "s"(p.sg_shift), "s"(p.P), "s"(p.p_shift), "s"(p.unit),
                "s"(p.ubase), "s"(p.urem), "s"(p.spw), "s"(p.spp), "s"(p.rounds), "s"(p.x_pitch), "s"(p.xs_pitch), "s"(p.lds_lut),
-               "s"(p.lds_x), "s"(p.lds_xs), "s"(p.lds_red), "s"(p.lds_nrm), "s"(p.norm_eps), "s"(p.epilogue), "s"(p.xcd4), "s"(p.cm), "s"(p.uextra));
+               "s"(p.lds_x), "s"(p.lds_xs), "s"(p.lds_red), "s"(p.lds_nrm), "s"(p.norm_eps), "s"(p.epilogue), "s"(p.xcd4), "s"(p.cm), "s"(p.uextra), "s"(p.uh));
 #if GEMV_TRACE
   tr[6] = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -128,8 +129,14 @@ __global__ void __launch_bounds__(512, 2) w4_gemv_kernel(const GemvParams p) {
   //  top of the launch)
   int bx = blockIdx.x;
   if (p.xcd4) bx = (((bx >> 5) * 8 + (bx & 7)) << 2) + ((bx >> 3) & 3);
-  const int t0 = (bx * p.ubase + min(bx, p.urem) * p.uextra) * p.unit;
-  const int t1 = t0 + (p.ubase + (bx < p.urem ? p.uextra : 0)) * p.unit;
+  int t0 = bx * p.ubase + min(bx, p.urem) * p.uextra, nu = p.ubase + (bx < p.urem ? p.uextra : 0);
+  if (p.uh) {  // (wave-uniform) first workgroups b < uh: one unit more; their partners b + urem: one less
+    const int c = bx < p.urem ? bx : bx - p.urem;
+    t0 += bx < p.urem ? min(c, p.uh) : p.uh - min(c, p.uh);
+    nu += c < p.uh ? (bx < p.urem ? 1 : -1) : 0;
+  }
+  t0 *= p.unit;
+  const int t1 = t0 + nu * p.unit;
   if (t0 >= t1) return;
   const int P = p.P, Pm = P - 1, tpp = P >> 3;        // tiles per pass
   const int passes = (t1 - t0 + tpp - 1) >> (p.p_shift - 3);
