@@ -81,6 +81,19 @@ __global__ void __launch_bounds__(512) node_kernel(const P p) {
   }
 }
 
+// touches its slice like dg_prefetch / the prefetch blocks of rope_attn_online_kernel: 4-byte reads of every 16-byte piece, default policy or nt
+template <int NT>
+__global__ void __launch_bounds__(512) touch_kernel(const P p) {
+  const int t = threadIdx.x, b = blockIdx.x;
+  const u32x4* base = p.w + (size_t)b * p.wg_stride * 512 + t;
+  uint32_t acc = 0;
+  for (int i = 0; i < p.pieces; ++i) {
+    const uint32_t* q = reinterpret_cast<const uint32_t*>(base + (size_t)i * 512);
+    acc ^= NT ? __builtin_nontemporal_load(q) : *q;
+  }
+  if (acc == 0x12345u) p.x_out[0] = acc;
+}
+
 __global__ void __launch_bounds__(512) empty_kernel(const P p) {
   if (p.pieces == -1) p.x_out[0] = 0;
 }
@@ -99,7 +112,7 @@ int main(int argc, char** argv) {
   CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(node_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 
   CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(node_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  struct Mode { const char* name; int kind; size_t bytes; int warm; size_t pf; int nt; unsigned lds; int ring = 8; int wgs = 256; };
+  struct Mode { const char* name; int kind; size_t bytes; int warm; size_t pf; int nt; unsigned lds; int ring = 8; int wgs = 256; int touch = 0; };
   std::vector<Mode> modes = {
       {"empty node", 0, 0, 0, 0, 1, 0},
       {"hand-off only (x in, x out)", 1, 0, 0, 0, 1, 64},
@@ -127,6 +140,11 @@ int main(int argc, char** argv) {
       {"32 MiB cold nt, 512 workgroups", 1, 32u << 20, 0, 0, 1, 64, 8, 512},
       {"64 MiB cold nt, 512 workgroups", 1, 64u << 20, 0, 0, 1, 64, 8, 512},
       {"64 MiB cold nt, 1024 workgroups", 1, 64u << 20, 0, 0, 1, 64, 8, 1024},
+      // (round 5) a touch-only node (4-byte reads of every 16-byte piece, same slices) in FRONT of every streaming node: the PAIR's time
+      {"touch (default) + 8 MiB nt stream: the pair", 1, 8u << 20, 0, 0, 1, 64, 8, 256, 1},
+      {"touch (nt) + 8 MiB nt stream: the pair", 1, 8u << 20, 0, 0, 1, 64, 8, 256, 2},
+      {"touch (default) + 8 MiB default stream: the pair", 1, 8u << 20, 0, 0, 0, 64, 8, 256, 1},
+      {"touch only (default), 8 MiB", 2, 8u << 20, 0, 0, 0, 64, 8, 256, 1},
   };
   for (const Mode& m : modes) {
     hipGraph_t g; hipGraphExec_t ge;
@@ -141,6 +159,9 @@ int main(int argc, char** argv) {
       p.pf_stride = p.pieces;
       p.wg_stride = p.pieces;
       p.nt = m.nt;
+      if (m.touch == 1) hipLaunchKernelGGL(touch_kernel<0>, dim3(m.wgs), dim3(512), 0, st, p);
+      if (m.touch == 2) hipLaunchKernelGGL(touch_kernel<1>, dim3(m.wgs), dim3(512), 0, st, p);
+      if (m.kind == 2) continue;
       if (m.kind == 0) hipLaunchKernelGGL(empty_kernel, dim3(256), dim3(512), 0, st, p);
       else if (p.pieces == 0) { p.pieces = 4; p.wg_stride = 0; p.w = w[0]; hipLaunchKernelGGL(node_kernel<4>, dim3(m.wgs), dim3(512), m.lds, st, p); }  // hand-off only: every workgroup reads the same 32 KiB
       else if (p.pieces < 8) hipLaunchKernelGGL(node_kernel<4>, dim3(m.wgs), dim3(512), m.lds, st, p);
