@@ -987,6 +987,42 @@ def test_module_bias_is_fused_and_bit_identical(T, kernel, cls, numerics):
     assert torch.equal(y, y_plain + bias)
 
 
+@pytest.mark.parametrize("kernel,cls", [("linear_y_f16RM_x_f16RM_W_any4TC", "Any4Linear"), ("linear_y_f16RM_W_any4TC_x_f16RM", "Any4Linear"),
+                                        ("linear_y_f16RM_W_int4TC_x_f16RM", "Int4Linear")])
+def test_module_more_than_16_rows(T, oracle, kernel, cls):
+    """A module forward with 2 x 21 = 42 activation rows (default numerics): three launches of up to 16 rows inside ONE op call, on both
+    operand sides (weights on the left = the native row-per-lane words, a B-side call), bias fused into every block's store -- every row
+    within the group-scaled tolerance of the oracle, the same bits as the separate add."""
+    import any4_amd
+    import modules
+    from any4_amd import ops
+
+    n, k, g, m = 256, 4096, 128, 21
+    gen = torch.Generator().manual_seed(18)
+    mod = getattr(modules, cls)(k, n, bias=True, device=DEV, dtype=torch.bfloat16, group_size=g, kernel=kernel)
+    qtype = "any4_rowwise" if cls == "Any4Linear" else "int4"
+    codes, x2, qinfo, lut = rand_problem(n, k, g, 2 * m, qtype, seed=77)
+    mod.weight.data = codes.to(DEV)
+    mod.scales_and_zeros.data = qinfo.to(DEV)
+    if cls == "Any4Linear":
+        mod.lut.data = lut.to(DEV)
+    mod.bias.data = torch.randn(n, generator=gen).bfloat16().to(DEV)
+    with any4_amd.weight_format("native"):   # (this file's fixture packs the reference's Aint4 words, which keep their own kernels)
+        mod.reshape_weight()
+    on_right = "x_f16RM_W" in kernel
+    assert mod.weight_format == (None if on_right else "native")
+    assert ops.gemm_w4_plan(2 * m, n, k, g, QT[qtype], on_right, 4, weight_format="native") in ("pair", "pair_xr", "gemv")
+    x = x2.view(2, m, k).to(DEV)
+    y = mod(x)
+    bias = mod.bias
+    mod.bias = None
+    y_plain = mod(x)
+    mod.bias = bias
+    assert y.shape == (2, m, n)
+    assert torch.equal(y, y_plain + bias)
+    _check_rows(oracle, y_plain.view(2 * m, n), codes, x2, qinfo, lut, g, qtype, torch.bfloat16)
+
+
 def test_pair_kernel_fused_bias(T, oracle):
     """The same store-side bias in the pair-table kernel (reached through the stacked C-ABI launch)."""
     codes, x, qinfo, lut = rand_problem(128, 1024, 128, 2, "any4_rowwise", seed=12)
