@@ -170,6 +170,7 @@ int stream_bf16(bool layout_a, int wpl, bool qmx, const GemmParams& p, int64_t c
 int stream_f16(bool layout_a, int wpl, bool qmx, const GemmParams& p, int64_t coltiles, int64_t batch, hipStream_t st);
 int pair_xr(int dt, int I, bool qmx, GemmParams& p, int64_t batch, hipStream_t st);
 int pair16(int dt, int I, bool qmx, const GemmParams& p, int64_t batch, hipStream_t st);
+int pair16_loop(int dt, int I, bool qmx, const GemmParams& p, int64_t batch, hipStream_t st);  // w4_gemm_pair16_loop.cuh: one layer, more 16-row tiles than CUs
 int splitk(int dt, bool layout_a, int canon, bool qmx, int waves, const GemmParams& p, dim3 grid, hipStream_t st);
 int gemv(int dt, int I, bool qmx, GemmParams& p, int64_t batch, hipStream_t st);
 inline int pair(int dt, int I, bool qmx, GemmParams& p, int64_t batch, hipStream_t st) {

@@ -3,6 +3,7 @@
 namespace {
 #include "w4_gemm_pair.cuh"   // shared device helpers (tc_a_index, dot2, chunk_rmsnorm, swiglu16, PairParams); its kernel is not instantiated here
 #include "w4_gemm_pair16.cuh"
+#include "w4_gemm_pair16_loop.cuh"
 #ifndef TG_P16_XREG_MIN_M
 #define TG_P16_XREG_MIN_M 5  // activation rows from which the A operands are arranged in registers instead of staged through LDS
 #endif
@@ -103,6 +104,50 @@ int launch_pair16(const GemmParams& p, int64_t batch, hipStream_t st) {
   }
 }
 
+// ONE layer per launch with more 16-row tiles than compute units (w4_gemm_pair16_loop.cuh): 5 ... 16 activation rows, k = 4096, innerKTiles 4,
+// row-major operands, no fused stage; a workgroup owns up to 32 tiles.
+#ifndef TG_P16_LOOP
+#define TG_P16_LOOP 1
+#endif
+#ifndef TG_P16_LOOP_MAX_TILES
+#define TG_P16_LOOP_MAX_TILES 8   // tiles per workgroup up to which this path takes the launch.  Per graph node at m = 16, rows 5120 / 8192 / 11008 / 12288 /
+                                  // 14336 / 16384 / 20480 / 28672: 8.5 / 9.0 / 10.8 / 10.9 / 13.0 / 13.1 / 15.2 / 19.5 us here; w4_gemm_xr_kernel with one workgroup per
+                                  // 64-row item: 12.3 / 12.4 / 12.6 / - / 13.2 / 13.7 / - / 19.4 (profiles/r05_ab_p16_loop.txt, r05_p16_loop_sweep.txt)
+#endif
+template <typename DT>
+int launch_pair16_loop(const GemmParams& p, int64_t batch, hipStream_t st) {
+  if (!TG_P16_LOOP || batch != 1 || p.m < TG_P16_XREG_MIN_M || p.m > 16 || p.k != 4096 || p.ksuper != 64 || p.norm_w || p.epilogue || p.x_tc || p.y_tc ||
+      p.qtype == TG_Q_MX4)
+    return TG_PAIR_NA;
+  const int tiles = (p.wrows + 15) / 16;
+  const int cus = p.dry ? 256 : cu_count();
+  if (tiles <= cus) return TG_PAIR_NA;  // (one tile per workgroup: w4_gemm_pair16_kernel)
+  const int per = (tiles + cus - 1) / cus;
+  if (per > TG_P16_LOOP_MAX_TILES || per > 32) return TG_PAIR_NA;
+  Pair16LoopParams pp;
+  pp.x = p.x; pp.w = p.w; pp.qinfo = p.qinfo; pp.lut = p.lut; pp.y = p.y; pp.bias = p.bias; pp.bias_row_stride = p.bias_row_stride;
+  pp.m = p.m; pp.wrows = p.wrows; pp.k = p.k; pp.ntiles = p.ntiles; pp.ksuper = p.ksuper; pp.gshift = p.gshift; pp.ngroups = p.ngroups; pp.qtype = p.qtype;
+  pp.tbase = tiles / cus; pp.trem = tiles % cus;
+  pp.lds_red = 65536;
+  pp.lds_lut = 65536 + 2 * 16384;
+  const unsigned lds = (unsigned)pp.lds_lut + (p.qtype == TG_Q_ANY4_ROWWISE ? (unsigned)per * 512u : 0u);
+  if (p.dry) return TG_PLAN_PAIR;
+  const int g = 1 << p.gshift;
+#define TG_P16L(CPG_)                                                         \
+  do {                                                                        \
+    constexpr auto kern = w4_gemm_pair16_loop_kernel<DT, CPG_>;               \
+    const int prc = prepare_lds_kernel<kern>();                               \
+    if (prc != 0) return prc;                                                 \
+    hipLaunchKernelGGL(kern, dim3((unsigned)cus), dim3(1024), lds, st, pp);   \
+  } while (0)
+  if (g == 32) TG_P16L(1);
+  else if (g == 64) TG_P16L(2);
+  else if (g == 128) TG_P16L(4);
+  else TG_P16L(8);
+#undef TG_P16L
+  return launch_status();
+}
+
 template <typename DT, int I>
 int p16_q(bool qmx, const GemmParams& p, int64_t batch, hipStream_t st) {
   return qmx ? launch_pair16<DT, I, true>(p, batch, st) : launch_pair16<DT, I, false>(p, batch, st);
@@ -121,6 +166,10 @@ extern "C" TG_API void tg_dev_p16_trace(unsigned long long* buf, int slots) {
   g_p16_launch = 0;
 }
 #endif
+int tgx::pair16_loop(int dt, int I, bool qmx, const GemmParams& p, int64_t batch, hipStream_t st) {
+  if (I != 4 || qmx) return TG_PAIR_NA;
+  return dt == TG_BF16 ? launch_pair16_loop<BF16>(p, batch, st) : launch_pair16_loop<F16>(p, batch, st);
+}
 int tgx::pair16(int dt, int I, bool qmx, const GemmParams& p, int64_t batch, hipStream_t st) {
   return dt == TG_BF16 ? p16_i<BF16>(I, qmx, p, batch, st) : p16_i<F16>(I, qmx, p, batch, st);
 }

@@ -73,7 +73,11 @@ int launch_pair_xr_n(GemmParams& p, int64_t batch, hipStream_t st, const XrWindo
 #ifndef TG_XR_SINGLE_MIN_ITEMS_M8
 #define TG_XR_SINGLE_MIN_ITEMS_M8 256
 #endif
-  const bool single = batch == 1 && NCH == 16 && !PK && WV == 8 && !win &&
+  // (... and up to eight 16-row tiles per CU -- 32768 rows on 256 CUs -- w4_gemm_pair16_loop_kernel is faster or equal where it applies:
+  //  row-major operands, not mx4: 5120 / 8192 / 12288 / 16384 / 28672 rows at m = 16 8.5 / 9.0 / 10.9 / 13.1 / 19.5 us against 12.3 / 12.4 / 12.9 /
+  //  13.7 / 19.4 here; this route keeps fragment-order operands, mx4 and longer layers)
+  const bool p16_loop = !p.x_tc && !p.y_tc && !QMX && I == 4 && p.m >= 5 && (int64_t)((p.wrows + 15) / 16) <= 8 * (int64_t)(p.dry ? 256 : cu_count());
+  const bool single = batch == 1 && NCH == 16 && !PK && WV == 8 && !win && !p16_loop &&
                       ((p.m >= 9 && items >= TG_XR_SINGLE_MIN_ITEMS) || (p.m >= 5 && items >= TG_XR_SINGLE_MIN_ITEMS_M8));
   if (items > INT32_MAX) return TG_PAIR_NA;
   if (!single && items < TG_XR_MIN_ITEMS_PER_WG * 256 * (WV == 4 ? 2 : 1)) return TG_PAIR_NA;

@@ -436,6 +436,10 @@ int launch_w4(int dt, bool LAYOUT_A, int canon, bool QMX, GemmParams& p, int64_t
       rc = tgx::pair_xr(dt, 2 * WPL, QMX, p, batch, st);
       if (rc != TG_PAIR_NA) return rc;
       p.ws_need = 0;
+      // one layer per launch with more 16-row tiles than CUs (5 ... 16 rows, k = 4096): in front of the persistent kernel, which would
+      // take it from 192 64-row items on (12288 rows: 15.6 us per graph node)
+      rc = tgx::pair16_loop(dt, 2 * WPL, QMX, p, batch, st);
+      if (rc != TG_PAIR_NA) return rc;
     }
     if (LAYOUT_A) rc = tgx::pair_a(dt, WPL, QMX, p, batch, st);
     else rc = tgx::pair(dt, 2 * WPL, QMX, p, batch, st);

@@ -283,29 +283,37 @@ def test_xr_kernel_vs_oracle(T, oracle, case):
                                   (11008, 10, 256, "any4_global", torch.bfloat16), (16384, 5, 64, "any4_rowwise", torch.bfloat16),
                                   (16384, 8, 32, "int4", torch.bfloat16)])
 def test_xr_kernel_single_large_layer(T, oracle, case):
-    """ONE layer per launch at k = 4096 (tg_xr.hip, `single`): the xr kernel with one workgroup per 64-row item -- fewer workgroups
-    than CUs (5120 / 11008 rows), one each, one or two (28672) -- with the activations of the launch's first problem staged through
-    LDS (w4_gemm_xr.cuh, XLDS), for 9 ... 16 rows and for the 5 ... 8-row launches w4_gemv_kernel declines (groups of 32 / 64)."""
+    """ONE layer per launch at k = 4096 with more 16-row tiles than CUs, 9 ... 16 rows and the 5 ... 8-row launches w4_gemv_kernel declines
+    (groups of 32 / 64): w4_gemm_pair16_loop_kernel for row-major operands (up to 8 tiles per CU) -- and, with fragment-order operands
+    (m = 16), the xr kernel with one workgroup per 64-row item (tg_xr.hip, `single`: fewer workgroups than CUs at 5120 / 11008 rows, one
+    each, one or two at 28672; the activations of the launch's first problem staged through LDS, w4_gemm_xr.cuh XLDS)."""
+    from any4_amd import _lib
+
     n, m, g, qtype, dtype = case
     codes, x, qinfo, lut = rand_problem(n, 4096, g, m, qtype, dtype=dtype, seed=n + m)
-    xs, ys = _run_xr(T, codes, x, qinfo, lut, g, qtype, 1)
+    xs, ys = _run_xr(T, codes, x, qinfo, lut, g, qtype, 1, plan=_lib.TG_PLAN_PAIR)
+    if m == 16 and qtype != "mx4":
+        _, yt = _run_xr(T, codes, x, qinfo, lut, g, qtype, 1, tc=True)   # (asserts the xr plan)
+        assert_fast_close(oracle, yt[0], codes, xs[0], qinfo, lut, g, qtype, dtype=dtype, batch=1)
     assert not torch.isnan(ys.float()).any()
     assert_fast_close(oracle, ys[0], codes, xs[0], qinfo, lut, g, qtype, dtype=dtype, batch=1)
 
 
 def test_xr_kernel_single_large_layer_bias_and_fragment_order(T, oracle):
-    """The single-layer route (fewer workgroups than CUs: 6144 rows = 96 items) with a fused residual and with fragment-order
-    activations / outputs (x_layout = TG_LAYOUT_TC_A takes x_prepare's gather path instead of the LDS staging): the plain launch's
-    bits plus a separate rounded add / re-laid out."""
+    """One 6144-row layer at 16 rows with a fused residual (the plain launch's bits plus a separate rounded add) and with fragment-order
+    activations / outputs (the xr kernel's single-layer route, fewer workgroups than CUs: 96 items; x_layout = TG_LAYOUT_TC_A takes
+    x_prepare's gather path instead of the LDS staging)."""
+    from any4_amd import _lib
+
     n, m, g, k = 6144, 16, 128, 4096
     codes, x, qinfo, lut = rand_problem(n, k, g, m, "any4_rowwise", seed=321)
-    xs, y0 = _run_xr(T, codes, x, qinfo, lut, g, "any4_rowwise", 1)
+    xs, y0 = _run_xr(T, codes, x, qinfo, lut, g, "any4_rowwise", 1, plan=_lib.TG_PLAN_PAIR)   # (row-major: w4_gemm_pair16_loop_kernel)
     assert_fast_close(oracle, y0[0], codes, xs[0], qinfo, lut, g, "any4_rowwise", batch=1)
     res = torch.randn(m, n, generator=torch.Generator().manual_seed(6)).bfloat16()
-    _, y1 = _run_xr(T, codes, x, qinfo, lut, g, "any4_rowwise", 1, bias=res, residual=True)
+    _, y1 = _run_xr(T, codes, x, qinfo, lut, g, "any4_rowwise", 1, bias=res, residual=True, plan=_lib.TG_PLAN_PAIR)
     assert torch.equal((y0.float() + res.to(DEV).float()).bfloat16().view(torch.int16), y1.view(torch.int16))
-    _, y2 = _run_xr(T, codes, x, qinfo, lut, g, "any4_rowwise", 1, tc=True)
-    assert torch.equal(y2.view(torch.int16), y0.view(torch.int16))
+    _, y2 = _run_xr(T, codes, x, qinfo, lut, g, "any4_rowwise", 1, tc=True)                   # (fragment order: the xr kernel, one item per workgroup)
+    assert_fast_close(oracle, y2[0], codes, xs[0], qinfo, lut, g, "any4_rowwise", batch=1)
 
 
 def test_xr_kernel_mx4_nan_exponent(T, oracle):
@@ -530,6 +538,46 @@ def test_pair16_register_resident_residual_and_fragment_order(T, oracle, m):
     if m == 16:  # (fragment order: whole 16-row tiles; x in fragment order takes the XTC loads, y in fragment order the rotated rows)
         _, y2 = _run_xr(T, codes, x, qinfo, lut, g, "any4_rowwise", 1, tc=True, plan=_lib.TG_PLAN_PAIR)
         assert torch.equal(y2.view(torch.int16), y0.view(torch.int16))
+
+
+@pytest.mark.parametrize("case", [
+    # (n, m, g, qtype, dtype): one layer per launch with more 16-row tiles than CUs at k = 4096 (w4_gemm_pair16_loop_kernel: a workgroup walks
+    # 1 ... 8 tiles; beyond that w4_gemm_xr_kernel's 64-row items): uneven ranges (5120 rows = 320 tiles over 256 workgroups), a ragged
+    # last tile (8200 rows), every group size, the three LUT kinds, both dtypes
+    (5120, 16, 128, "any4_rowwise", torch.bfloat16), (8200, 9, 128, "any4_rowwise", torch.bfloat16), (11008, 13, 64, "int4", torch.bfloat16),
+    (16384, 16, 256, "any4_global", torch.float16), (6144, 5, 32, "any4_rowwise", torch.bfloat16), (28672, 16, 128, "any4_rowwise", torch.bfloat16),
+])
+def test_single_layer_with_more_tiles_than_cus(T, oracle, case):
+    from any4_amd import _lib, ops
+
+    L = _lib.load()
+    n, m, g, qtype, dtype = case
+    codes, x, qinfo, lut = rand_problem(n, 4096, g, m, qtype, dtype=dtype, seed=n + m)
+    assert ops.gemm_w4_plan(m, n, 4096, g, QT[qtype], True, 4, dtype, 1, "fast", detail=True) in ("pair", "pair_xr")
+    packed = T.convert_matrix_to_m16n8k16_Bint4_layout(codes.to(DEV), 4)
+    xs, qs, ls = x.to(DEV), qinfo.to(DEV), (None if lut is None else lut.to(DEV))
+    res = torch.randn(m, n, generator=torch.Generator().manual_seed(4)).to(dtype).to(DEV)
+
+    def run(bias):  # (no workspace: with one, the 9 ... 16-row workspace variant of the pair kernel may take the launch instead)
+        y = torch.full((m, n), float("nan"), dtype=dtype, device=DEV)
+        args = _lib.W4Gemm(x=xs.data_ptr(), w=packed.data_ptr(), qinfo=qs.data_ptr(), lut=(ls.data_ptr() if ls is not None else None), y=y.data_ptr(),
+                           m=m, wrows=n, k=4096, group=g, qtype=QT[qtype], dtype=_lib.TG_BF16 if dtype == torch.bfloat16 else _lib.TG_F16, w_on_right=1,
+                           inner_k_tiles=4, batch=1, numerics=_lib.TG_NUM_FAST, bias=(bias.data_ptr() if bias is not None else None),
+                           bias_row_stride=(n if bias is not None else 0))
+        assert L.tg_gemm_w4_plan(ctypes.byref(args), 0) in (_lib.TG_PLAN_PAIR, _lib.TG_PLAN_PAIR_XR)
+        _lib.check(L.tg_gemm_w4(ctypes.byref(args), 0, torch.cuda.current_stream().cuda_stream), "single layer")
+        torch.cuda.synchronize()
+        return y
+
+    y = run(None)
+    assert not torch.isnan(y.float()).any()
+    rows = torch.cat([torch.arange(0, 96), torch.arange(n // 2 - 40, n // 2 + 40), torch.arange(n - 96, n)])
+    q = qinfo[:, rows].contiguous()
+    lt = lut if lut is None or lut.dim() == 1 else lut[rows].contiguous()
+    _check_rows(oracle, y[:, rows], codes[rows], x, q, lt, g, qtype, dtype)
+    assert torch.equal(y.view(torch.int16), run(None).view(torch.int16))   # deterministic
+    # a fused per-row residual: the same bits as the separate add
+    assert torch.equal((y.float() + res.float()).to(dtype).view(torch.int16), run(res).view(torch.int16))
 
 
 def test_pair16_fp16_bias_and_batch(T, oracle):

@@ -313,15 +313,15 @@ def test_xr_kernel_routing():
     assert ops.gemm_w4_plan(8, 4096, 4096, 64, q2["any4_rowwise"], True, 4) == "pair"
     assert ops.gemm_w4_plan(8, 4096, 14336, 128, q2["any4_rowwise"], True, 4) == "pair"
     assert ops.gemm_w4_plan(9, 4096, 4096, 128, q2["any4_rowwise"], True, 4) == "pair"
-    # ... except, at k = 4096, 9 ... 16 rows from 80 64-row items on (5120 rows) and 5 ... 8 rows the gemv kernel declined from 256 items
-    # on: the xr kernel, one workgroup per item (tg_xr.hip: the measured crossover)
-    assert ops.gemm_w4_plan(16, 16384, 4096, 128, q2["any4_rowwise"], True, 4, detail=True) == "pair_xr"
-    assert ops.gemm_w4_plan(9, 28672, 4096, 64, q2["int4"], True, 4, detail=True) == "pair_xr"
-    assert ops.gemm_w4_plan(16, 5120, 4096, 128, q2["any4_rowwise"], True, 4, detail=True) == "pair_xr"
-    assert ops.gemm_w4_plan(16, 5056, 4096, 128, q2["any4_rowwise"], True, 4, detail=True) != "pair_xr"   # 79 items
+    # ... except one layer per launch at k = 4096 with more 16-row tiles than CUs: w4_gemm_pair16_loop_kernel (plan "pair") up to eight tiles
+    # per CU (32768 rows), beyond that -- and for fragment-order operands from 80 64-row items on -- the xr kernel with one workgroup per item
+    assert ops.gemm_w4_plan(16, 16384, 4096, 128, q2["any4_rowwise"], True, 4, detail=True) == "pair"
+    assert ops.gemm_w4_plan(9, 28672, 4096, 64, q2["int4"], True, 4, detail=True) == "pair"
+    assert ops.gemm_w4_plan(16, 5120, 4096, 128, q2["any4_rowwise"], True, 4, detail=True) == "pair"
+    assert ops.gemm_w4_plan(16, 32768 + 64, 4096, 128, q2["any4_rowwise"], True, 4, detail=True) == "pair_xr"
     assert ops.gemm_w4_plan(8, 16384, 4096, 128, q2["any4_rowwise"], True, 4, detail=True) == "gemv"
-    assert ops.gemm_w4_plan(8, 16384, 4096, 64, q2["any4_rowwise"], True, 4, detail=True) == "pair_xr"
-    assert ops.gemm_w4_plan(8, 8192, 4096, 64, q2["any4_rowwise"], True, 4, detail=True) != "pair_xr"
+    assert ops.gemm_w4_plan(8, 16384, 4096, 64, q2["any4_rowwise"], True, 4, detail=True) == "pair"
+    assert ops.gemm_w4_plan(8, 65536, 4096, 64, q2["any4_rowwise"], True, 4, detail=True) == "pair_xr"
     assert ops.gemm_w4_plan(16, 8192, 8192, 128, q2["any4_rowwise"], True, 4, detail=True) != "pair_xr"    # (k = 4096 only)
     assert ops.gemm_w4_plan(4, 4096, 4096, 32, q2["any4_rowwise"], True, 4) == "gemv"   # (the v_dot2 contraction: any group size)
     # more than 16 rows (default numerics, row-major operands): ceil(m / 16) launches of up to 16 rows on the same kernels -- the plan is
