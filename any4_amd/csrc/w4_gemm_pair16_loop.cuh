@@ -176,7 +176,30 @@ __global__ void __launch_bounds__(1024) w4_gemm_pair16_loop_kernel(const Pair16L
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) *(lds_fptr)((uint32_t)p.lds_red + (uint32_t)(par * 16384 + ((wave * 4 + rr) * 64 + lane) * 4)) = yacc[rr];
   };
+#ifndef TG_P16L_SPREAD
+#define TG_P16L_SPREAD 1
+#endif
   auto store = [&](int tile, int par) {
+    if constexpr (TG_P16L_SPREAD) {
+      // every wave takes 16 of the tile's 256 outputs: lane = 16 part + o -- four partial sums per lane (waves 4 part ... 4 part + 3, in wave
+      // order), the four parts across the lane rows by two row swaps (tg_common.cuh) -- instead of the waves 0 ... 3 reading 16 partial sums
+      // per output while the other twelve run ahead to the next barrier and wait there
+      const int o = wave * 16 + (lane & 15), part = lane >> 4;
+      const int rr = o >> 6, l = o & 63;
+      const int a = 4 * rr + (l >> 4), row = tile * 16 + (l & 15);
+      const uint32_t src = (uint32_t)p.lds_red + (uint32_t)(par * 16384 + ((part * 16 + rr) * 64 + l) * 4);
+      float sum = *(lds_fptr)(src);
+#pragma unroll
+      for (int i = 1; i < 4; ++i) sum += *(lds_fptr)(src + (uint32_t)(i * 4 * 64 * 4));
+      sum = tgl::halves32_sum(tgl::rows16_sum(sum));
+      if (lane < 16 && a < p.m && row < p.wrows) {
+        uint16_t o16 = DT::from_f32(sum);
+        if (p.bias)  // rounded sum + bias, rounded again: the reference module's separate `y + bias` (modules.py:221-222)
+          o16 = DT::from_f32(DT::lo_f32(o16) + DT::lo_f32(*reinterpret_cast<const uint16_t*>(p.bias + ((int64_t)a * p.bias_row_stride + row) * 2)));
+        *reinterpret_cast<uint16_t*>(p.y + ((int64_t)a * p.wrows + row) * 2) = o16;
+      }
+      return;
+    }
     if (tid < 256) {
       const int rr = (tid >> 6) & 3, l = tid & 63;
       const int a = 4 * rr + (l >> 4), row = tile * 16 + (l & 15);  // (the A operand's rows are rotated: register rr of lane (n, q) = row 4 rr + q)
