@@ -177,7 +177,7 @@ __global__ void __launch_bounds__(1024) w4_gemm_pair16_loop_kernel(const Pair16L
     for (int rr = 0; rr < 4; ++rr) *(lds_fptr)((uint32_t)p.lds_red + (uint32_t)(par * 16384 + ((wave * 4 + rr) * 64 + lane) * 4)) = yacc[rr];
   };
 #ifndef TG_P16L_SPREAD
-#define TG_P16L_SPREAD 1
+#define TG_P16L_SPREAD 0  // (developer A/B: no difference -- 8192 / 16384 rows 9.6-9.8 / 14.4-14.8 us either way, profiles/r05_ab_p16_loop_spread.txt; the waves 0 ... 3 keep the wave-order sum of w4_gemm_pair16_kernel)
 #endif
   auto store = [&](int tile, int par) {
     if constexpr (TG_P16L_SPREAD) {
