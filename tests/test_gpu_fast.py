@@ -580,6 +580,45 @@ def test_single_layer_with_more_tiles_than_cus(T, oracle, case):
     assert torch.equal((y.float() + res.float()).to(dtype).view(torch.int16), run(res).view(torch.int16))
 
 
+def test_single_layer_with_more_tiles_than_cus_random_shapes(T, oracle):
+    """Seeded random shapes through the same launches: rows any multiple of 8 in (4096, 33000) -- ragged last tiles, ranges of 1 ... 8 tiles,
+    workgroups with one tile less than their neighbours --, 5 ... 16 activation rows, every group size / LUT kind / dtype: sampled rows
+    against the oracle, the whole output deterministic."""
+    import random
+
+    from any4_amd import _lib
+
+    L = _lib.load()
+    rng = random.Random(20260930)
+    for _ in range(10):
+        n = rng.randrange(4104, 33000, 8)
+        m = rng.randint(5, 16)
+        g = rng.choice([32, 64, 128, 256])
+        qtype = rng.choice(["any4_rowwise", "any4_rowwise", "int4", "any4_global"])
+        dtype = rng.choice([torch.bfloat16, torch.float16])
+        codes, x, qinfo, lut = rand_problem(n, 4096, g, m, qtype, dtype=dtype, seed=n + m)
+        packed = T.convert_matrix_to_m16n8k16_Bint4_layout(codes.to(DEV), 4)
+        xs, qs, ls = x.to(DEV), qinfo.to(DEV), (None if lut is None else lut.to(DEV))
+
+        def run():
+            y = torch.full((m, n), float("nan"), dtype=dtype, device=DEV)
+            args = _lib.W4Gemm(x=xs.data_ptr(), w=packed.data_ptr(), qinfo=qs.data_ptr(), lut=(ls.data_ptr() if ls is not None else None), y=y.data_ptr(),
+                               m=m, wrows=n, k=4096, group=g, qtype=QT[qtype], dtype=_lib.TG_BF16 if dtype == torch.bfloat16 else _lib.TG_F16,
+                               w_on_right=1, inner_k_tiles=4, batch=1, numerics=_lib.TG_NUM_FAST)
+            assert L.tg_gemm_w4_plan(ctypes.byref(args), 0) in (_lib.TG_PLAN_PAIR, _lib.TG_PLAN_PAIR_XR, _lib.TG_PLAN_GEMV), (n, m, g, qtype)
+            _lib.check(L.tg_gemm_w4(ctypes.byref(args), 0, torch.cuda.current_stream().cuda_stream), "single layer")
+            torch.cuda.synchronize()
+            return y
+
+        y = run()
+        assert not torch.isnan(y.float()).any(), (n, m, g, qtype)
+        rows = torch.cat([torch.arange(0, 48), torch.arange(n // 3, n // 3 + 48), torch.arange(n - 48, n)])
+        q = qinfo[:, rows].contiguous()
+        lt = lut if lut is None or lut.dim() == 1 else lut[rows].contiguous()
+        _check_rows(oracle, y[:, rows], codes[rows], x, q, lt, g, qtype, dtype)
+        assert torch.equal(y.view(torch.int16), run().view(torch.int16)), (n, m, g, qtype)
+
+
 def test_pair16_fp16_bias_and_batch(T, oracle):
     codes, x, qinfo, lut = rand_problem(96, 1024, 128, 5, "any4_rowwise", dtype=torch.float16, seed=21)
     bias = torch.randn(96).half()
