@@ -131,7 +131,10 @@ int tgx::gemv(int dt, int I, bool qmx, GemmParams& p, int64_t batch, hipStream_t
     auto pad2 = [&](int u) -> int64_t { return (int64_t)((u * gp.unit + 1) / 2) * 2; };
     return ur * pad2(ub + 1) + (int64_t)(n_wgs - ur) * pad2(ub);
   };
-  const bool two_per_cu = (int64_t)p.wrows * p.k / 2 >= TG_GEMV_WG2_MIN_BYTES && units >= 4 * cus && lds_two_per_cu() <= 80 * 1024 &&
+#ifndef TG_GEMV_WG2_MIN_UNITS_PER_CU
+#define TG_GEMV_WG2_MIN_UNITS_PER_CU 4
+#endif
+  const bool two_per_cu = (int64_t)p.wrows * p.k / 2 >= TG_GEMV_WG2_MIN_BYTES && units >= TG_GEMV_WG2_MIN_UNITS_PER_CU * cus && lds_two_per_cu() <= 80 * 1024 &&
                           padded_tiles(2 * cus) <= padded_tiles(cus);
   const int wgs = units < cus ? units : (two_per_cu ? 2 * cus : cus);
   gp.ubase = units / wgs;
