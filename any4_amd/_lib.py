@@ -76,6 +76,7 @@ SYMBOLS = {
     "tg_convert_from_B16": [_vp, _i64, _i64, ctypes.c_int, _vp, ctypes.c_int, _vp],
     "tg_dequant_int4": [_vp, _i64, _vp, ctypes.c_int, _vp],
     "tg_unpack_int4": [_vp, ctypes.c_int, _i64, _i64, ctypes.c_int, _vp, ctypes.c_int, _vp],
+    "tg_dequant_w4": [_vp, _vp, _vp, _i64, _i64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, ctypes.c_int, _vp],
     "tg_gemm_w4": [ctypes.POINTER(W4Gemm), ctypes.c_int, _vp],
     "tg_gemm_w4_plan": [ctypes.POINTER(W4Gemm), ctypes.c_int],
     "tg_gemm_w4_workspace_bytes": [ctypes.POINTER(W4Gemm)],

@@ -234,6 +234,56 @@ __global__ void __launch_bounds__(256) unpack_int4_kernel(const uint32_t* __rest
   codes[idx] = (int32_t)((packed[word] >> shift) & 15u);
 }
 
+// ---- dequantise a Bint4-packed weight matrix into row-major 16-bit values (what a GEMM library multiplies for MANY activation rows) ----
+// w[r][k] = RNE16(fma(f32(lut[r][code]), f32(scale[g][r]), f32(zero[g][r]))) -- the reference's dequantisation, element for element
+// (MatrixLayoutB.cuh:1042-1046; int4: lut = code - 8, Dequantization.cuh:136-178).  Thread = (row, 64-k super-tile of innerKTiles 4 /
+// 32-k of 2 / 128-k of 8): its words are 4 lanes x I / 2 words = 8 I contiguous bytes of the packed layout (ConvertB.cu:252-308), its
+// output 32 I contiguous bytes of the row.
+template <typename DT, int I>
+__global__ void __launch_bounds__(256) dequant_w4_kernel(const uint32_t* __restrict__ packed, const uint16_t* __restrict__ qinfo, const uint16_t* __restrict__ lut,
+                                                        uint16_t* __restrict__ out, int64_t rows, int64_t wrows_q, int64_t k, int64_t ksuper, int gshift, int qtype) {
+  constexpr int W = I / 2;   // words per lane of the packed layout = 32-k runs per super-tile
+  // thread = (row, super-tile, word column j, run h of 8 consecutive k): a quad of threads writes 64 contiguous bytes, the 4 W threads of a
+  // (row, super-tile) 32 I contiguous bytes, consecutive super-tiles follow: whole lines per wave-store; the 4 words a thread needs (lanes
+  // 0 ... 3 of its row, column j) are the same for the four h -- one request per quad
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= rows * ksuper * (4 * W)) return;
+  const int h = (int)(idx & 3), j = (int)((idx >> 2) % W);
+  const int64_t rs = idx / (4 * W), r = rs / ksuper, s = rs - r * ksuper;
+  const uint32_t* src = packed + (((r >> 3) * ksuper + s) * 32 + 4 * (r & 7)) * W + j;
+  uint32_t wd[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) wd[i] = src[i * W];
+  uint32_t lp[8];
+  if (qtype == TG_Q_INT4) {
+#pragma unroll
+    for (int e = 0; e < 16; e += 2) lp[e >> 1] = DT::pack2((float)(e - 8), (float)(e - 7));
+  } else {
+    const u32x4* lsrc = reinterpret_cast<const u32x4*>(lut + (qtype == TG_Q_ANY4_ROWWISE ? r * 16 : 0));
+    const u32x4 l0 = lsrc[0], l1 = lsrc[1];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { lp[e] = l0[e]; lp[4 + e] = l1[e]; }
+  }
+  auto lutv = [&](uint32_t code) -> float {
+    uint32_t pr = lp[0];
+#pragma unroll
+    for (int e = 1; e < 8; ++e) pr = (code >> 1) == (uint32_t)e ? lp[e] : pr;
+    return (code & 1u) ? DT::hi_f32(pr) : DT::lo_f32(pr);
+  };
+  const int64_t k0 = s * (16 * I) + j * 32;
+  const uint32_t sz = reinterpret_cast<const uint32_t*>(qinfo)[(k0 >> gshift) * wrows_q + r];  // (a group is a multiple of 32 k: one per word column)
+  const float sc = DT::lo_f32(sz), zr = DT::hi_f32(sz);
+  // word i holds k = 2 i + {0, 1, 8, 9, 16, 17, 24, 25} of the run of 32 in the nibbles (v & 1) * 16 + (v >> 1) * 4, v = 0 ... 7: the pair
+  // (k, k + 1) = (2 i + 8 h, 2 i + 8 h + 1) sits at bits 4 h and 16 + 4 h
+  u32x4 o;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const uint32_t c0 = (wd[i] >> (h * 4)) & 15u, c1 = (wd[i] >> (16 + h * 4)) & 15u;
+    o[i] = DT::pack2(__builtin_fmaf(lutv(c0), sc, zr), __builtin_fmaf(lutv(c1), sc, zr));
+  }
+  *reinterpret_cast<u32x4*>(out + r * k + k0 + 8 * h) = o;
+}
+
 // ---- 16-bit fragment-order conversions (pure data movement) ------------------------------------
 // ref TinyGemmConvertA.cu:19-141 / 442-546 and TinyGemmConvertB.cu:20-66 / 136-176
 __global__ void __launch_bounds__(256) to_A16_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out,
@@ -540,6 +590,31 @@ int tg_unpack_int4(const int32_t* packed, int layout_a, int64_t rows, int64_t k,
   const int64_t ksuper = cdiv(k, 16 * I);
   hipLaunchKernelGGL(unpack_int4_kernel, dim3((unsigned)cdiv(rows * k, 256)), dim3(256), 0, (hipStream_t)stream,
                      reinterpret_cast<const uint32_t*>(packed), codes, layout_a, rows, k, I, ksuper);
+  return launch_status();
+}
+
+int tg_dequant_w4(const void* packed, const void* qinfo, const void* lut, int64_t wrows, int64_t k, int group, int qtype, int dtype, int I, void* out,
+                  int device, tg_stream_t stream) {
+  if (!packed || !qinfo || !out) return TG_E_NULL;
+  if (!(qtype == TG_Q_INT4 || qtype == TG_Q_ANY4_GLOBAL || qtype == TG_Q_ANY4_ROWWISE)) return TG_E_QTYPE;
+  if (qtype != TG_Q_INT4 && !lut) return TG_E_NULL;
+  if (!(dtype == TG_BF16 || dtype == TG_F16)) return TG_E_DTYPE;
+  if (!(I == 2 || I == 4 || I == 8)) return TG_E_INNER_K;
+  if (wrows <= 0 || k <= 0 || wrows % 8 != 0 || wrows > INT32_MAX || k > INT32_MAX) return TG_E_SHAPE;
+  if (k % (16 * I) != 0 || k % 32 != 0) return TG_E_K_DIV;
+  if (!(group == 32 || group == 64 || group == 128 || group == 256) || k % group != 0) return TG_E_GROUP;
+  if (!aligned16(packed) || !aligned16(out) || (reinterpret_cast<uintptr_t>(qinfo) & 3u) || (lut && !aligned16(lut))) return TG_E_ALIGN;
+  DeviceScope ds(device);
+  if (!ds.ok) return TG_E_DEVICE;
+  const int64_t ksuper = k / (16 * I);
+  const int gshift = group == 32 ? 5 : group == 64 ? 6 : group == 128 ? 7 : 8;
+  const dim3 grid((unsigned)cdiv(wrows * ksuper * 2 * I, 256));
+#define TG_DQ(DTT, I_)                                                                                                                      \
+  hipLaunchKernelGGL((dequant_w4_kernel<DTT, I_>), grid, dim3(256), 0, (hipStream_t)stream, (const uint32_t*)packed, (const uint16_t*)qinfo, \
+                     (const uint16_t*)lut, (uint16_t*)out, wrows, wrows, k, ksuper, gshift, qtype)
+  if (dtype == TG_BF16) { if (I == 2) TG_DQ(BF16, 2); else if (I == 4) TG_DQ(BF16, 4); else TG_DQ(BF16, 8); }
+  else { if (I == 2) TG_DQ(F16, 2); else if (I == 4) TG_DQ(F16, 4); else TG_DQ(F16, 8); }
+#undef TG_DQ
   return launch_status();
 }
 

@@ -384,6 +384,32 @@ class _FragX:
 _WS_BYTES: dict = {}  # tg_gemm_w4_workspace_bytes per problem shape (pure function of the key below)
 
 
+_LARGE_M = None
+
+
+def large_m_rows(weights: int = 0) -> int:
+    """Activation rows from which a 4-bit GEMM call dequantises the weights once and multiplies with the GEMM library
+    (ANY4_LARGE_M overrides; 0 = never).  Measured on MI355X (profiles/r05_large_m.txt): one 4096 x 4096 layer
+    per graph node 47.6 vs 41.8 us at 256 rows, 50 vs 73 at 384, 52 vs 83 at 512, 65 vs 165 at 1024; 14336 x 4096 equal at 128 (86 vs 85),
+    95 vs 123 at 192, 103 vs 153 at 256: from 320 rows on, 128 for layers of 32 M weights or more."""
+    global _LARGE_M
+    if _LARGE_M is None:
+        v = os.environ.get("ANY4_LARGE_M")
+        _LARGE_M = -1 if v is None else (int(v) if int(v) > 0 else 1 << 62)
+    if _LARGE_M >= 0:
+        return _LARGE_M
+    return 128 if weights >= (1 << 25) else 320
+
+
+def dequant_w4(w: torch.Tensor, qinfo: torch.Tensor, lut, q_group: int, qtype: int, k: int, inner: int, wrows: int) -> torch.Tensor:
+    """[wrows][k] 16-bit = the dequantised weights of a Bint4-packed tensor (or the native weights-on-the-left tensor: the same words):
+    RNE16(fma(lut[row][code], scale, zero)) per element (tg_dequant_w4)."""
+    out = torch.empty((wrows, k), dtype=qinfo.dtype, device=w.device)
+    _lib.check(_L.tg_dequant_w4(w.data_ptr(), qinfo.data_ptr(), None if lut is None else lut.data_ptr(), wrows, k, q_group, qtype,
+                                TG_BF16 if qinfo.dtype == torch.bfloat16 else TG_F16, inner, out.data_ptr(), _dev(w), _stream(w)), "tg_dequant_w4")
+    return out
+
+
 def _w4_rm(A, B, q_group, qinfo, lut, qtype, weight_on_right, opname, frag=False):
     """Row-major activations / output.  Mirrors tinygemm_y_FT16RM_x_FT16RM_w_int4TC
     (TinyGemm_int4.cu:294-548).  frag=True (weights on the right only): A is a _FragX, the output comes back in A-fragment
@@ -443,6 +469,16 @@ def _w4_rm(A, B, q_group, qinfo, lut, qtype, weight_on_right, opname, frag=False
     _check(k % 32 == 0 and k_tiles % inner == 0, "k must be a multiple of 32 and of innerKTiles * 16")
     if lut is not None and lut.data_ptr() % 16:
         lut = lut.clone()
+    if not frag and m >= large_m_rows(wrows * k) and qtype != TG_Q_MX4 and (weight_on_right or w_format == _lib.TG_WFMT_ROWS):
+        # MANY activation rows: the 4-bit kernels walk the weights once per 16-row tile of m (as the reference's grid does) -- from
+        # about a hundred rows on it is cheaper to dequantise the matrix once (tg_dequant_w4: the reference's per-element formula,
+        # bit for bit) and hand the product to the GEMM library (hipBLASLt behind torch.matmul: 16-bit operands, f32 accumulation)
+        wdq = dequant_w4(w, qinfo, lut, q_group, qtype, k, inner, wrows)
+        if x.data_ptr() % 16:
+            x = x.clone()
+        y = torch.matmul(x, wdq.t())
+        bias = _take_bias(wrows, x)
+        return y if bias is None else y + bias
     if frag:
         if m == 0 or get_numerics() == "reference":
             return None

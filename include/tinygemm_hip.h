@@ -251,6 +251,15 @@ TG_API int tg_gemm_w4_plan(const tg_w4_gemm* args, int device);
  * once per call (w4_xprep_kernel) so that the waves can stream them like the weights.  Needs no GPU. */
 TG_API int64_t tg_gemm_w4_workspace_bytes(const tg_w4_gemm* args);
 
+/* out[wrows][k] (16-bit, row-major) = the dequantised weights of a Bint4-packed tensor (also the native weights-on-the-left format,
+ * which holds the same words): w = RNE16(fma(lut[row][code], scale[g][row], zero[g][row])), the reference's per-element formula
+ * (MatrixLayoutB.cuh:1042-1046; int4: code - 8) -- what tinygemm_lib/utils.py's dequantize helpers compute on the host.  For MANY
+ * activation rows (from ~100 on) the Python layer multiplies by this matrix with the GEMM library instead of walking the 4-bit
+ * weights once per 16-row tile: qinfo [k/group][wrows][2], lut [wrows][16] / [16] / NULL (int4), I = innerKTiles of the packed tensor.
+ * mx4 is not covered (TG_E_QTYPE). */
+TG_API int tg_dequant_w4(const void* packed, const void* qinfo, const void* lut, int64_t wrows, int64_t k, int group, int qtype, int dtype,
+                         int inner_k_tiles, void* out, int device, tg_stream_t stream);
+
 /*
  * int8 weights.
  * tg_convert_to_Bint8 replaces convert_matrix_to_m16n8k16_Bint8_layout (TinyGemmConvertB.cu:415-465, kernel 366-411):

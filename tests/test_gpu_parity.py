@@ -723,6 +723,35 @@ def test_int8linear_module(T, oracle):
         assert_gemm_close(y.view(7, n), x, oracle.dequant(codes.numpy(), g, oracle.Q_INT8, bits16(sz), None))
 
 
+@pytest.mark.parametrize("qtype,g,inner,dtype", [("any4_rowwise", 128, 4, torch.bfloat16), ("int4", 32, 2, torch.float16), ("any4_global", 256, 8, torch.bfloat16),
+                                                 ("any4_rowwise", 64, 4, torch.float16)])
+def test_dequant_w4_is_the_reference_weights_bit_for_bit(T, oracle, qtype, g, inner, dtype):
+    """tg_dequant_w4 (what a call with ~100 activation rows or more multiplies with the GEMM library): every element equal to the
+    oracle's reference-faithful weight RNE16(fma(lut[code], scale, zero)) (MatrixLayoutB.cuh:1042-1046); the op on 130 rows within
+    the GEMM tolerance of the oracle, on both operand sides."""
+    import any4_amd
+    from any4_amd import ops
+
+    n, k, m = 144, 1024, 130
+    codes, x, qinfo, lut = rand_problem(n, k, g, m, qtype, dtype=dtype, seed=n + g + inner)
+    packed = T.convert_matrix_to_m16n8k16_Bint4_layout(codes.to(DEV), inner)
+    wrows = packed.shape[0] * 8
+    w = ops.dequant_w4(packed, qinfo.to(DEV), None if lut is None else lut.to(DEV), g, {"int4": 0, "any4_global": 1, "any4_rowwise": 2}[qtype], k, inner, wrows)
+    want = oracle_weights(oracle, codes, g, qtype, qinfo, lut, dtype)
+    assert np.array_equal(bits16(w[:n].cpu()), np.asarray(want).reshape(n, k))
+    assert ops.large_m_rows(n * k) == 320 and ops.large_m_rows(14336 * 4096) == 128
+    ops._LARGE_M = 100   # (the automatic threshold is 320 rows for a layer of this size)
+    try:
+        y = run_rm(T, codes, x, qinfo, lut, g, qtype, True, inner)
+        assert_gemm_close(y[:, :n], x, want, dtype)
+        if inner <= 4:
+            with any4_amd.weight_format("native"):
+                y2 = run_rm(T, codes, x, qinfo, lut, g, qtype, False, inner)
+            assert_gemm_close(y2[:, :n], x, want, dtype)
+    finally:
+        ops._LARGE_M = None
+
+
 @pytest.mark.parametrize("on_right,inner", [(True, 4), (False, 2)])
 @pytest.mark.parametrize("m,copies", [(33, 50), (20, 700)])
 def test_stream_kernel_several_column_tiles(T, oracle, on_right, inner, m, copies):
