@@ -261,10 +261,22 @@ __global__ void __launch_bounds__(256) dequant_w4_kernel(const uint32_t* __restr
 #pragma unroll
     for (int e = 0; e < 16; e += 2) lp[e >> 1] = DT::pack2((float)(e - 8), (float)(e - 7));
   } else {
-    const u32x4* lsrc = reinterpret_cast<const u32x4*>(lut + (qtype == TG_Q_ANY4_ROWWISE ? r * 16 : 0));
-    const u32x4 l0 = lsrc[0], l1 = lsrc[1];
+    // (a wave's 64 threads are one row's when 4 W ksuper is a multiple of 64 -- k = 4096 at innerKTiles 4: 512 --: the LUT row then comes
+    //  through the scalar cache instead of two 16-byte vector loads per lane)
+    const int64_t ru = __builtin_amdgcn_readfirstlane((int)r);
+#ifndef TG_DQ_SCALAR_LUT
+#define TG_DQ_SCALAR_LUT 1
+#endif
+    if (TG_DQ_SCALAR_LUT && __builtin_amdgcn_ballot_w64(r != ru) == 0ull) {
+      const uint32_t* lsrc = reinterpret_cast<const uint32_t*>(lut + (qtype == TG_Q_ANY4_ROWWISE ? ru * 16 : 0));
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { lp[e] = l0[e]; lp[4 + e] = l1[e]; }
+      for (int e = 0; e < 8; ++e) lp[e] = lsrc[e];
+    } else {
+      const u32x4* lsrc = reinterpret_cast<const u32x4*>(lut + (qtype == TG_Q_ANY4_ROWWISE ? r * 16 : 0));
+      const u32x4 l0 = lsrc[0], l1 = lsrc[1];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { lp[e] = l0[e]; lp[4 + e] = l1[e]; }
+    }
   }
   auto lutv = [&](uint32_t code) -> float {
     uint32_t pr = lp[0];
