@@ -245,55 +245,47 @@ __global__ void __launch_bounds__(256) dequant_w4_kernel(const uint32_t* __restr
   constexpr int W = I / 2;   // words per lane of the packed layout = 32-k runs per super-tile
   // thread = (row, super-tile, word column j, run h of 8 consecutive k): a quad of threads writes 64 contiguous bytes, the 4 W threads of a
   // (row, super-tile) 32 I contiguous bytes, consecutive super-tiles follow: whole lines per wave-store; the 4 words a thread needs (lanes
-  // 0 ... 3 of its row, column j) are the same for the four h -- one request per quad
-  // (a flat index: one block per row -- blockIdx.y = row, no run-time division -- measured SLOWER, 41 vs 31 us for a 4096 x 4096 matrix;
-  //  the kernel is bound by its 8-way LUT select per value, ~150 vector ops per 16 bytes of output, not by memory: 1.3 TB/s)
+  // 0 ... 3 of its row, column j) are the same for the four h -- one request per quad.
+  // A WAVE is 512 consecutive k of ONE row (host: 16 I ksuper is a multiple of 512): at most 16 quantisation groups.  Their dequantised
+  // tables -- 16 values RNE16(fma(lut[e], scale, zero)) per group, one fma per lane and round of 64 -- go to the wave's own 512 bytes of
+  // LDS, and every weight is then ONE 2-byte LDS read at table + 2 code (a 32-byte table is 8 banks: different entries never collide,
+  // equal ones broadcast) instead of an 8-way select and an fma per element (~150 vector ops per 16 bytes of output: 31 us for a
+  // 4096 x 4096 matrix, 1.3 TB/s).
+  __shared__ uint16_t tables[4][16][16];  // [wave][group of the wave][entry]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= rows * ksuper * (4 * W)) return;
-  const int h = (int)(idx & 3), j = (int)((idx >> 2) % W);
-  const int64_t rs = idx / (4 * W), r = rs / ksuper, s = rs - r * ksuper;
+  const int64_t wave0 = idx - lane;                  // first thread of the wave: (row, k0w)
+  const int64_t per_row = ksuper * (4 * W);          // threads per row (a multiple of 64)
+  const int64_t r = wave0 / per_row;                 // (wave-uniform)
+  if (r >= rows) return;
+  const int64_t k0w = (wave0 - r * per_row) * 8;     // first k of the wave
+  const int ngw = (512 >> gshift) > 0 ? (512 >> gshift) : 1;   // groups of the wave (g = 256 / 128 / 64 / 32: 2 / 4 / 8 / 16)
+  const int64_t g0 = k0w >> gshift;
+  for (int t = lane; t < ngw * 16; t += 64) {
+    const int gw = t >> 4, e = t & 15;
+    float lv;
+    if (qtype == TG_Q_INT4) lv = (float)(e - 8);
+    else lv = DT::lo_f32((uint32_t)lut[(qtype == TG_Q_ANY4_ROWWISE ? r * 16 : 0) + e]);
+    const uint32_t sz = reinterpret_cast<const uint32_t*>(qinfo)[(g0 + gw) * wrows_q + r];
+    tables[wave][gw][e] = DT::from_f32(__builtin_fmaf(lv, DT::lo_f32(sz), DT::hi_f32(sz)));
+  }
+  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave's own LDS stores (a wave's LDS operations execute in order; no barrier: the region is its own)
+  const int t = (int)(idx - r * per_row);
+  const int h = t & 3, j = (t >> 2) % W;
+  const int64_t s = t / (4 * W);
   const uint32_t* src = packed + (((r >> 3) * ksuper + s) * 32 + 4 * (r & 7)) * W + j;
   uint32_t wd[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) wd[i] = src[i * W];
-  uint32_t lp[8];
-  if (qtype == TG_Q_INT4) {
-#pragma unroll
-    for (int e = 0; e < 16; e += 2) lp[e >> 1] = DT::pack2((float)(e - 8), (float)(e - 7));
-  } else {
-    // (a wave's 64 threads are one row's when 4 W ksuper is a multiple of 64 -- k = 4096 at innerKTiles 4: 512 --: the LUT row then comes
-    //  through the scalar cache instead of two 16-byte vector loads per lane)
-    const int64_t ru = __builtin_amdgcn_readfirstlane((int)r);
-#ifndef TG_DQ_SCALAR_LUT
-#define TG_DQ_SCALAR_LUT 1
-#endif
-    if (TG_DQ_SCALAR_LUT && __builtin_amdgcn_ballot_w64(r != ru) == 0ull) {
-      const uint32_t* lsrc = reinterpret_cast<const uint32_t*>(lut + (qtype == TG_Q_ANY4_ROWWISE ? ru * 16 : 0));
-#pragma unroll
-      for (int e = 0; e < 8; ++e) lp[e] = lsrc[e];
-    } else {
-      const u32x4* lsrc = reinterpret_cast<const u32x4*>(lut + (qtype == TG_Q_ANY4_ROWWISE ? r * 16 : 0));
-      const u32x4 l0 = lsrc[0], l1 = lsrc[1];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { lp[e] = l0[e]; lp[4 + e] = l1[e]; }
-    }
-  }
-  auto lutv = [&](uint32_t code) -> float {
-    uint32_t pr = lp[0];
-#pragma unroll
-    for (int e = 1; e < 8; ++e) pr = (code >> 1) == (uint32_t)e ? lp[e] : pr;
-    return (code & 1u) ? DT::hi_f32(pr) : DT::lo_f32(pr);
-  };
   const int64_t k0 = s * (16 * I) + j * 32;
-  const uint32_t sz = reinterpret_cast<const uint32_t*>(qinfo)[(k0 >> gshift) * wrows_q + r];  // (a group is a multiple of 32 k: one per word column)
-  const float sc = DT::lo_f32(sz), zr = DT::hi_f32(sz);
+  const uint16_t* tb = &tables[wave][(int)((k0 >> gshift) - g0)][0];
   // word i holds k = 2 i + {0, 1, 8, 9, 16, 17, 24, 25} of the run of 32 in the nibbles (v & 1) * 16 + (v >> 1) * 4, v = 0 ... 7: the pair
   // (k, k + 1) = (2 i + 8 h, 2 i + 8 h + 1) sits at bits 4 h and 16 + 4 h
   u32x4 o;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const uint32_t c0 = (wd[i] >> (h * 4)) & 15u, c1 = (wd[i] >> (16 + h * 4)) & 15u;
-    o[i] = DT::pack2(__builtin_fmaf(lutv(c0), sc, zr), __builtin_fmaf(lutv(c1), sc, zr));
+    o[i] = (uint32_t)tb[c0] | ((uint32_t)tb[c1] << 16);
   }
   *reinterpret_cast<u32x4*>(out + r * k + k0 + 8 * h) = o;
 }
@@ -616,6 +608,7 @@ int tg_dequant_w4(const void* packed, const void* qinfo, const void* lut, int64_
   if (!(I == 2 || I == 4 || I == 8)) return TG_E_INNER_K;
   if (wrows <= 0 || k <= 0 || wrows % 8 != 0 || wrows > INT32_MAX || k > INT32_MAX) return TG_E_SHAPE;
   if (k % (16 * I) != 0 || k % 32 != 0) return TG_E_K_DIV;
+  if (k % 512 != 0) return TG_E_K_DIV;   // (a wave of the kernel is 512 consecutive k of one row)
   if (!(group == 32 || group == 64 || group == 128 || group == 256) || k % group != 0) return TG_E_GROUP;
   if (!aligned16(packed) || !aligned16(out) || (reinterpret_cast<uintptr_t>(qinfo) & 3u) || (lut && !aligned16(lut))) return TG_E_ALIGN;
   DeviceScope ds(device);

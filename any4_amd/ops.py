@@ -389,16 +389,17 @@ _LARGE_M = None
 
 def large_m_rows(weights: int = 0) -> int:
     """Activation rows from which a 4-bit GEMM call dequantises the weights once and multiplies with the GEMM library
-    (ANY4_LARGE_M overrides; 0 = never).  Measured on MI355X (profiles/r05_large_m.txt): one 4096 x 4096 layer
-    per graph node 47.6 vs 41.8 us at 256 rows, 50 vs 73 at 384, 52 vs 83 at 512, 65 vs 165 at 1024; 14336 x 4096 equal at 128 (86 vs 85),
-    95 vs 123 at 192, 103 vs 153 at 256: from 320 rows on, 128 for layers of 32 M weights or more."""
+    (ANY4_LARGE_M overrides; 0 = never).  Measured on MI355X (profiles/r05_large_m.txt), 4-bit kernels vs
+    dequantise (14 us for 4096 x 4096) + GEMM, one layer per graph node: 4096 x 4096 at 64 / 96 / 128 / 256 / 1024 rows 28.6 / 35.9 / 36.9 /
+    41.7 / 166 vs 26.8 / 31.4 / 33.9 / 32.2 / 50 us; 14336 x 4096 at 64 / 96 / 128 / 256: 53.5 / 76 / 85 / 152 vs 68.7 / 68.2 / 70 / 85: beyond the
+    64 rows the row blocks of the 4-bit kernels cover; from 96 rows for layers of 32 M weights or more."""
     global _LARGE_M
     if _LARGE_M is None:
         v = os.environ.get("ANY4_LARGE_M")
         _LARGE_M = -1 if v is None else (int(v) if int(v) > 0 else 1 << 62)
     if _LARGE_M >= 0:
         return _LARGE_M
-    return 128 if weights >= (1 << 25) else 320
+    return 96 if weights >= (1 << 25) else 65
 
 
 def dequant_w4(w: torch.Tensor, qinfo: torch.Tensor, lut, q_group: int, qtype: int, k: int, inner: int, wrows: int) -> torch.Tensor:
@@ -469,7 +470,7 @@ def _w4_rm(A, B, q_group, qinfo, lut, qtype, weight_on_right, opname, frag=False
     _check(k % 32 == 0 and k_tiles % inner == 0, "k must be a multiple of 32 and of innerKTiles * 16")
     if lut is not None and lut.data_ptr() % 16:
         lut = lut.clone()
-    if not frag and m >= large_m_rows(wrows * k) and qtype != TG_Q_MX4 and (weight_on_right or w_format == _lib.TG_WFMT_ROWS):
+    if not frag and m >= large_m_rows(wrows * k) and qtype != TG_Q_MX4 and k % 512 == 0 and (weight_on_right or w_format == _lib.TG_WFMT_ROWS):
         # MANY activation rows: the 4-bit kernels walk the weights once per 16-row tile of m (as the reference's grid does) -- from
         # about a hundred rows on it is cheaper to dequantise the matrix once (tg_dequant_w4: the reference's per-element formula,
         # bit for bit) and hand the product to the GEMM library (hipBLASLt behind torch.matmul: 16-bit operands, f32 accumulation)

@@ -739,8 +739,7 @@ def test_dequant_w4_is_the_reference_weights_bit_for_bit(T, oracle, qtype, g, in
     w = ops.dequant_w4(packed, qinfo.to(DEV), None if lut is None else lut.to(DEV), g, {"int4": 0, "any4_global": 1, "any4_rowwise": 2}[qtype], k, inner, wrows)
     want = oracle_weights(oracle, codes, g, qtype, qinfo, lut, dtype)
     assert np.array_equal(bits16(w[:n].cpu()), np.asarray(want).reshape(n, k))
-    assert ops.large_m_rows(n * k) == 320 and ops.large_m_rows(14336 * 4096) == 128
-    ops._LARGE_M = 100   # (the automatic threshold is 320 rows for a layer of this size)
+    assert ops.large_m_rows(n * k) == 65 and ops.large_m_rows(14336 * 4096) == 96
     try:
         y = run_rm(T, codes, x, qinfo, lut, g, qtype, True, inner)
         assert_gemm_close(y[:, :n], x, want, dtype)
@@ -749,7 +748,7 @@ def test_dequant_w4_is_the_reference_weights_bit_for_bit(T, oracle, qtype, g, in
                 y2 = run_rm(T, codes, x, qinfo, lut, g, qtype, False, inner)
             assert_gemm_close(y2[:, :n], x, want, dtype)
     finally:
-        ops._LARGE_M = None
+        pass
 
 
 @pytest.mark.parametrize("on_right,inner", [(True, 4), (False, 2)])
