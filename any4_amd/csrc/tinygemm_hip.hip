@@ -253,12 +253,25 @@ __global__ void __launch_bounds__(256) dequant_w4_kernel(const uint32_t* __restr
   // 4096 x 4096 matrix, 1.3 TB/s).
   __shared__ uint16_t tables[4][16][16];  // [wave][group of the wave][entry]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#ifndef TG_DQ_GRID2D
+#define TG_DQ_GRID2D 1
+#endif
+#if TG_DQ_GRID2D
+  // blockIdx.y (+ 65535 blockIdx.z) = the row, blockIdx.x = a 256-thread piece of it: no 64-bit division by the run-time row length
+  const int64_t per_row = ksuper * (4 * W);          // threads per row (a multiple of 64)
+  const int64_t r = (int64_t)blockIdx.y + (int64_t)blockIdx.z * 65535;
+  const int tr = (int)blockIdx.x * 256 + (int)threadIdx.x;   // thread of the row
+  if (r >= rows || tr - lane >= (int)per_row) return;          // (wave-uniform)
+  const int64_t idx = r * per_row + tr;
+  const int64_t k0w = (int64_t)(tr - lane) * 8;      // first k of the wave
+#else
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t wave0 = idx - lane;                  // first thread of the wave: (row, k0w)
   const int64_t per_row = ksuper * (4 * W);          // threads per row (a multiple of 64)
   const int64_t r = wave0 / per_row;                 // (wave-uniform)
   if (r >= rows) return;
   const int64_t k0w = (wave0 - r * per_row) * 8;     // first k of the wave
+#endif
   const int ngw = (512 >> gshift) > 0 ? (512 >> gshift) : 1;   // groups of the wave (g = 256 / 128 / 64 / 32: 2 / 4 / 8 / 16)
   const int64_t g0 = k0w >> gshift;
   for (int t = lane; t < ngw * 16; t += 64) {
@@ -615,7 +628,11 @@ int tg_dequant_w4(const void* packed, const void* qinfo, const void* lut, int64_
   if (!ds.ok) return TG_E_DEVICE;
   const int64_t ksuper = k / (16 * I);
   const int gshift = group == 32 ? 5 : group == 64 ? 6 : group == 128 ? 7 : 8;
+#if TG_DQ_GRID2D
+  const dim3 grid((unsigned)cdiv(ksuper * 2 * I, 256), (unsigned)(wrows < 65535 ? wrows : 65535), (unsigned)cdiv(wrows, 65535));
+#else
   const dim3 grid((unsigned)cdiv(wrows * ksuper * 2 * I, 256));
+#endif
 #define TG_DQ(DTT, I_)                                                                                                                      \
   hipLaunchKernelGGL((dequant_w4_kernel<DTT, I_>), grid, dim3(256), 0, (hipStream_t)stream, (const uint32_t*)packed, (const uint16_t*)qinfo, \
                      (const uint16_t*)lut, (uint16_t*)out, wrows, wrows, k, ksuper, gshift, qtype)
