@@ -239,68 +239,64 @@ __global__ void __launch_bounds__(256) unpack_int4_kernel(const uint32_t* __rest
 // (MatrixLayoutB.cuh:1042-1046; int4: lut = code - 8, Dequantization.cuh:136-178).  Thread = (row, 64-k super-tile of innerKTiles 4 /
 // 32-k of 2 / 128-k of 8): its words are 4 lanes x I / 2 words = 8 I contiguous bytes of the packed layout (ConvertB.cu:252-308), its
 // output 32 I contiguous bytes of the row.
-template <typename DT, int I>
+template <typename DT, int I, int CHK>
 __global__ void __launch_bounds__(256) dequant_w4_kernel(const uint32_t* __restrict__ packed, const uint16_t* __restrict__ qinfo, const uint16_t* __restrict__ lut,
                                                         uint16_t* __restrict__ out, int64_t rows, int64_t wrows_q, int64_t k, int64_t ksuper, int gshift, int qtype) {
   constexpr int W = I / 2;   // words per lane of the packed layout = 32-k runs per super-tile
-  // thread = (row, super-tile, word column j, run h of 8 consecutive k): a quad of threads writes 64 contiguous bytes, the 4 W threads of a
-  // (row, super-tile) 32 I contiguous bytes, consecutive super-tiles follow: whole lines per wave-store; the 4 words a thread needs (lanes
+  // lane = (super-tile, word column j, run h of 8 consecutive k) of a 512-k chunk: a quad of lanes writes 64 contiguous bytes, the 4 W lanes
+  // of a super-tile 32 I contiguous bytes, consecutive super-tiles follow: whole lines per wave-store; the 4 words a lane needs (lanes
   // 0 ... 3 of its row, column j) are the same for the four h -- one request per quad.
-  // A WAVE is 512 consecutive k of ONE row (host: 16 I ksuper is a multiple of 512): at most 16 quantisation groups.  Their dequantised
-  // tables -- 16 values RNE16(fma(lut[e], scale, zero)) per group, one fma per lane and round of 64 -- go to the wave's own 512 bytes of
-  // LDS, and every weight is then ONE 2-byte LDS read at table + 2 code (a 32-byte table is 8 banks: different entries never collide,
-  // equal ones broadcast) instead of an 8-way select and an fma per element (~150 vector ops per 16 bytes of output: 31 us for a
-  // 4096 x 4096 matrix, 1.3 TB/s).
-  __shared__ uint16_t tables[4][16][16];  // [wave][group of the wave][entry]
+  // A WAVE is CHK consecutive 512-k chunks of ONE row (host: k a multiple of 512 CHK): at most 16 quantisation groups per chunk.  Their
+  // dequantised tables -- 16 values RNE16(fma(lut[e], scale, zero)) per group, one fma per lane and round of 64 -- go to the wave's own LDS,
+  // and every weight is then ONE 2-byte LDS read at table + 2 code (a 32-byte table is 8 banks: different entries never collide, equal
+  // ones broadcast) instead of an 8-way select and an fma per element (~150 vector ops per 16 bytes of output: 31 us for a 4096 x 4096
+  // matrix against 14 with one chunk per wave; CHK = 4: every load of the wave's 2048 k in flight before the first table is built).
+  __shared__ uint16_t tables[4][CHK][16][16];  // [wave][chunk][group of the chunk][entry]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#ifndef TG_DQ_GRID2D
-#define TG_DQ_GRID2D 1
-#endif
-#if TG_DQ_GRID2D
   // blockIdx.y (+ 65535 blockIdx.z) = the row, blockIdx.x = a 256-thread piece of it: no 64-bit division by the run-time row length
-  const int64_t per_row = ksuper * (4 * W);          // threads per row (a multiple of 64)
+  const int per_row = (int)(k >> 3) / CHK;             // threads per row (a multiple of 64)
   const int64_t r = (int64_t)blockIdx.y + (int64_t)blockIdx.z * 65535;
-  const int tr = (int)blockIdx.x * 256 + (int)threadIdx.x;   // thread of the row
-  if (r >= rows || tr - lane >= (int)per_row) return;          // (wave-uniform)
-  const int64_t idx = r * per_row + tr;
-  const int64_t k0w = (int64_t)(tr - lane) * 8;      // first k of the wave
-#else
-  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int64_t wave0 = idx - lane;                  // first thread of the wave: (row, k0w)
-  const int64_t per_row = ksuper * (4 * W);          // threads per row (a multiple of 64)
-  const int64_t r = wave0 / per_row;                 // (wave-uniform)
-  if (r >= rows) return;
-  const int64_t k0w = (wave0 - r * per_row) * 8;     // first k of the wave
-#endif
-  const int ngw = (512 >> gshift) > 0 ? (512 >> gshift) : 1;   // groups of the wave (g = 256 / 128 / 64 / 32: 2 / 4 / 8 / 16)
-  const int64_t g0 = k0w >> gshift;
-  for (int t = lane; t < ngw * 16; t += 64) {
-    const int gw = t >> 4, e = t & 15;
+  const int tr = (int)blockIdx.x * 256 + (int)threadIdx.x;
+  if (r >= rows || tr - lane >= per_row) return;       // (wave-uniform)
+  const int64_t k0w = (int64_t)(tr - lane) * 8 * CHK;  // first k of the wave
+  const int ngw = (512 >> gshift) > 0 ? (512 >> gshift) : 1;   // groups of a chunk (g = 256 / 128 / 64 / 32: 2 / 4 / 8 / 16)
+  // ---- requests: the packed words of every chunk, then the table inputs ----
+  uint32_t wd[CHK][4];
+  int hh[CHK];
+  const uint16_t* tb[CHK];
+#pragma unroll
+  for (int c = 0; c < CHK; ++c) {
+    const int t = (int)((k0w >> 3) + c * 64 + lane);   // this lane's 8-k run of the row
+    const int h = t & 3, j = (t >> 2) % W;
+    const int64_t s = t / (4 * W);
+    const uint32_t* src = packed + (((r >> 3) * ksuper + s) * 32 + 4 * (r & 7)) * W + j;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wd[c][i] = src[i * W];
+    hh[c] = h;
+    const int64_t k0 = s * (16 * I) + j * 32;
+    tb[c] = &tables[wave][c][(int)((k0 >> gshift) - ((k0w + c * 512) >> gshift))][0];
+  }
+  for (int t = lane; t < CHK * ngw * 16; t += 64) {
+    const int e = t & 15, cg = t >> 4, c = cg / ngw, gw = cg - c * ngw;
     float lv;
     if (qtype == TG_Q_INT4) lv = (float)(e - 8);
     else lv = DT::lo_f32((uint32_t)lut[(qtype == TG_Q_ANY4_ROWWISE ? r * 16 : 0) + e]);
-    const uint32_t sz = reinterpret_cast<const uint32_t*>(qinfo)[(g0 + gw) * wrows_q + r];
-    tables[wave][gw][e] = DT::from_f32(__builtin_fmaf(lv, DT::lo_f32(sz), DT::hi_f32(sz)));
+    const uint32_t sz = reinterpret_cast<const uint32_t*>(qinfo)[(((k0w + c * 512) >> gshift) + gw) * wrows_q + r];
+    tables[wave][c][gw][e] = DT::from_f32(__builtin_fmaf(lv, DT::lo_f32(sz), DT::hi_f32(sz)));
   }
-  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave's own LDS stores (a wave's LDS operations execute in order; no barrier: the region is its own)
-  const int t = (int)(idx - r * per_row);
-  const int h = t & 3, j = (t >> 2) % W;
-  const int64_t s = t / (4 * W);
-  const uint32_t* src = packed + (((r >> 3) * ksuper + s) * 32 + 4 * (r & 7)) * W + j;
-  uint32_t wd[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) wd[i] = src[i * W];
-  const int64_t k0 = s * (16 * I) + j * 32;
-  const uint16_t* tb = &tables[wave][(int)((k0 >> gshift) - g0)][0];
+  // (the region is the wave's own and a wave's LDS operations execute in order: no barrier)
   // word i holds k = 2 i + {0, 1, 8, 9, 16, 17, 24, 25} of the run of 32 in the nibbles (v & 1) * 16 + (v >> 1) * 4, v = 0 ... 7: the pair
   // (k, k + 1) = (2 i + 8 h, 2 i + 8 h + 1) sits at bits 4 h and 16 + 4 h
-  u32x4 o;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const uint32_t c0 = (wd[i] >> (h * 4)) & 15u, c1 = (wd[i] >> (16 + h * 4)) & 15u;
-    o[i] = (uint32_t)tb[c0] | ((uint32_t)tb[c1] << 16);
+  for (int c = 0; c < CHK; ++c) {
+    u32x4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const uint32_t c0 = (wd[c][i] >> (hh[c] * 4)) & 15u, c1 = (wd[c][i] >> (16 + hh[c] * 4)) & 15u;
+      o[i] = (uint32_t)tb[c][c0] | ((uint32_t)tb[c][c1] << 16);
+    }
+    *reinterpret_cast<u32x4*>(out + r * k + k0w + (int64_t)(c * 64 + lane) * 8) = o;
   }
-  *reinterpret_cast<u32x4*>(out + r * k + k0 + 8 * h) = o;
 }
 
 // ---- 16-bit fragment-order conversions (pure data movement) ------------------------------------
@@ -628,16 +624,16 @@ int tg_dequant_w4(const void* packed, const void* qinfo, const void* lut, int64_
   if (!ds.ok) return TG_E_DEVICE;
   const int64_t ksuper = k / (16 * I);
   const int gshift = group == 32 ? 5 : group == 64 ? 6 : group == 128 ? 7 : 8;
-#if TG_DQ_GRID2D
-  const dim3 grid((unsigned)cdiv(ksuper * 2 * I, 256), (unsigned)(wrows < 65535 ? wrows : 65535), (unsigned)cdiv(wrows, 65535));
-#else
-  const dim3 grid((unsigned)cdiv(wrows * ksuper * 2 * I, 256));
-#endif
-#define TG_DQ(DTT, I_)                                                                                                                      \
-  hipLaunchKernelGGL((dequant_w4_kernel<DTT, I_>), grid, dim3(256), 0, (hipStream_t)stream, (const uint32_t*)packed, (const uint16_t*)qinfo, \
+  const int chk = k % 2048 == 0 ? 4 : 1;   // chunks of 512 k per wave
+  const unsigned bs = k / 8 / chk < 256 ? (unsigned)(k / 8 / chk) : 256u;   // (a row's threads: a multiple of 64)
+  const dim3 grid((unsigned)cdiv(k / 8 / chk, 256), (unsigned)(wrows < 65535 ? wrows : 65535), (unsigned)cdiv(wrows, 65535));
+#define TG_DQ2(DTT, I_, C_)                                                                                                                       \
+  hipLaunchKernelGGL((dequant_w4_kernel<DTT, I_, C_>), grid, dim3(bs), 0, (hipStream_t)stream, (const uint32_t*)packed, (const uint16_t*)qinfo, \
                      (const uint16_t*)lut, (uint16_t*)out, wrows, wrows, k, ksuper, gshift, qtype)
+#define TG_DQ(DTT, I_) do { if (chk == 4) TG_DQ2(DTT, I_, 4); else TG_DQ2(DTT, I_, 1); } while (0)
   if (dtype == TG_BF16) { if (I == 2) TG_DQ(BF16, 2); else if (I == 4) TG_DQ(BF16, 4); else TG_DQ(BF16, 8); }
   else { if (I == 2) TG_DQ(F16, 2); else if (I == 4) TG_DQ(F16, 4); else TG_DQ(F16, 8); }
+#undef TG_DQ2
 #undef TG_DQ
   return launch_status();
 }
