@@ -87,7 +87,10 @@ extern "C" TG_API void tg_dev_gemv_trace(unsigned long long* buf, int slots) {
 int tgx::gemv(int dt, int I, bool qmx, GemmParams& p, int64_t batch, hipStream_t st) {
   const int g0 = 1 << p.gshift;
   // matrix-core contraction: 16-row passes of two super-tiles per step inside ONE group, a piece per thread in the staging
-  const bool mf0 = p.m >= TG_GEMV_MF_MIN_M && p.m <= 8 && (g0 == 128 || g0 == 256) && (p.k <= 4096 || p.m <= 4) && p.ksuper % 2 == 0;
+#ifndef TG_GEMV_MF_MAX_M
+#define TG_GEMV_MF_MAX_M 8  // (developer A/B against w4_gemm_pair16_kernel / the loop kernel at 5 ... 8 rows)
+#endif
+  const bool mf0 = p.m >= TG_GEMV_MF_MIN_M && p.m <= TG_GEMV_MF_MAX_M && (g0 == 128 || g0 == 256) && (p.k <= 4096 || p.m <= 4) && p.ksuper % 2 == 0;
   if (I != 4 || qmx || (p.m > 4 && !mf0) || p.x_tc || p.y_tc || batch != 1) return TG_PAIR_NA;
   if (p.ksuper * 64 != p.k || p.ntiles * 8 != p.wrows || p.ntiles > TG_GEMV_MAX_TILES) return TG_PAIR_NA;
   const int g = 1 << p.gshift;
