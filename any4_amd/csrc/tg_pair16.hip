@@ -130,7 +130,7 @@ int launch_pair16_loop(const GemmParams& p, int64_t batch, hipStream_t st) {
   pp.tbase = tiles / cus; pp.trem = tiles % cus;
   pp.lds_red = 65536;
   pp.lds_lut = 65536 + 2 * 16384;
-  const unsigned lds = (unsigned)pp.lds_lut + (p.qtype == TG_Q_ANY4_ROWWISE ? (unsigned)per * 512u : 0u);
+  const unsigned lds = (unsigned)pp.lds_lut + (p.qtype == TG_Q_ANY4_ROWWISE ? (unsigned)per * 544u : 0u);
   if (p.dry) return TG_PLAN_PAIR;
   const int g = 1 << p.gshift;
 #define TG_P16L(CPG_)                                                         \

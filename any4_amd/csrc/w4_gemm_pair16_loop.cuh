@@ -27,7 +27,7 @@ struct Pair16LoopParams {
   int32_t ksuper;        // 64
   int32_t gshift, ngroups, qtype;
   int32_t tbase, trem;   // workgroup b owns tbase + (b < trem) 16-row tiles, starting at tile b * tbase + min(b, trem)
-  int32_t lds_lut;       // LDS byte offset of the staged LUT rows (row-wise LUT, more than one tile per workgroup): 32 bytes per row
+  int32_t lds_lut;       // LDS byte offset of the staged LUT rows (row-wise LUT, more than one tile per workgroup): 32 bytes per row, 544 per tile
   int32_t lds_red;       // ... of the two partial-sum regions, 16 KiB each
 };
 
@@ -116,7 +116,12 @@ __global__ void __launch_bounds__(1024) w4_gemm_pair16_loop_kernel(const Pair16L
     for (int a = 0; a < 8; ++a) ((lds_u32ptr)base)[a * 64] = __builtin_amdgcn_perm(hw, lq[a >> 1], hsel | ((a & 1) ? 0x0302u : 0x0100u));
   };
   build_table(0);
-  if (stage_lut && tid < nt * 32) *(lds_u32x4ptr)((uint32_t)p.lds_lut + (uint32_t)tid * 16u) = lstage;
+  // (a tile's 16 rows at a pitch of 544 bytes, rows 8 ... 15 shifted by 16 bytes: the 16-byte reads of next_table -- 16 rows per wave,
+  //  32 bytes apart -- then touch 64 distinct banks instead of colliding two by two: 32768 bank-conflict cycles per launch before)
+  if (stage_lut && tid < nt * 32) {
+    const uint32_t row = (uint32_t)tid >> 1, ti = row >> 4, i = row & 15u;
+    *(lds_u32x4ptr)((uint32_t)p.lds_lut + ti * 544u + i * 32u + (i >> 3) * 16u + ((uint32_t)tid & 1u) * 16u) = lstage;
+  }
   __syncthreads();
 
   // ---- the A operands: a 4 x 4 dword transpose over the lane bits 4, 5 and two bit exchanges inside the quad (w4_gemm_pair16.cuh, XQ) ----
@@ -217,7 +222,7 @@ __global__ void __launch_bounds__(1024) w4_gemm_pair16_loop_kernel(const Pair16L
   // tile ti + 1's table into the other 32 columns, from the LUT rows staged in LDS (int4 / one global LUT: the columns never change)
   auto next_table = [&](int ti) {
     if (rowwise) {
-      const uint32_t lrow = (uint32_t)p.lds_lut + (uint32_t)(((ti + 1) * 16 + (tcol & 15)) * 32);
+      const uint32_t lrow = (uint32_t)p.lds_lut + (uint32_t)((ti + 1) * 544 + (tcol & 15) * 32 + ((tcol & 15) >> 3) * 16);
       const u32x4 l0 = *(lds_cu32x4ptr)(lrow), l1 = *(lds_cu32x4ptr)(lrow + 16u);
 #pragma unroll
       for (int j = 0; j < 4; ++j) { lp[j] = l0[j]; lp[4 + j] = l1[j]; }
