@@ -116,9 +116,10 @@ int launch_pair16(const GemmParams& p, int64_t batch, hipStream_t st) {
 #endif
 template <typename DT>
 int launch_pair16_loop(const GemmParams& p, int64_t batch, hipStream_t st) {
-  if (!TG_P16_LOOP || batch != 1 || p.m < TG_P16_XREG_MIN_M || p.m > 16 || p.k != 4096 || p.ksuper != 64 || p.norm_w || p.epilogue || p.x_tc || p.y_tc ||
+  if (!TG_P16_LOOP || batch != 1 || p.m < TG_P16_XREG_MIN_M || p.m > 16 || p.k != 4096 || p.ksuper != 64 || (p.epilogue && (p.epilogue != TG_EPI_SWIGLU || p.bias || p.wrows % 16 != 0)) || p.x_tc || p.y_tc ||
       p.qtype == TG_Q_MX4)
     return TG_PAIR_NA;
+  if (p.norm_w && p.gshift == 5) return TG_PAIR_NA;  // (groups of 32 with the fused norm: not instantiated, see the kernel)
   const int tiles = (p.wrows + 15) / 16;
   const int cus = p.dry ? 256 : cu_count();
   if (tiles <= cus) return TG_PAIR_NA;  // (one tile per workgroup: w4_gemm_pair16_kernel)
@@ -128,22 +129,31 @@ int launch_pair16_loop(const GemmParams& p, int64_t batch, hipStream_t st) {
   pp.x = p.x; pp.w = p.w; pp.qinfo = p.qinfo; pp.lut = p.lut; pp.y = p.y; pp.bias = p.bias; pp.bias_row_stride = p.bias_row_stride;
   pp.m = p.m; pp.wrows = p.wrows; pp.k = p.k; pp.ntiles = p.ntiles; pp.ksuper = p.ksuper; pp.gshift = p.gshift; pp.ngroups = p.ngroups; pp.qtype = p.qtype;
   pp.tbase = tiles / cus; pp.trem = tiles % cus;
+  pp.epilogue = p.epilogue;
+  pp.norm_w = p.norm_w; pp.norm_eps = p.norm_eps;
   pp.lds_red = 65536;
   pp.lds_lut = 65536 + 2 * 16384;
-  const unsigned lds = (unsigned)pp.lds_lut + (p.qtype == TG_Q_ANY4_ROWWISE ? (unsigned)per * 544u : 0u);
+  pp.lds_nrm = pp.lds_lut + (p.qtype == TG_Q_ANY4_ROWWISE ? per * 544 : 0);
+  const unsigned lds = (unsigned)pp.lds_nrm + 16u * 16u * 4u;
   if (p.dry) return TG_PLAN_PAIR;
   const int g = 1 << p.gshift;
-#define TG_P16L(CPG_)                                                         \
+#define TG_P16L(CPG_, NORM_)                                                  \
   do {                                                                        \
-    constexpr auto kern = w4_gemm_pair16_loop_kernel<DT, CPG_>;               \
+    constexpr auto kern = w4_gemm_pair16_loop_kernel<DT, CPG_, NORM_>;        \
     const int prc = prepare_lds_kernel<kern>();                               \
     if (prc != 0) return prc;                                                 \
     hipLaunchKernelGGL(kern, dim3((unsigned)cus), dim3(1024), lds, st, pp);   \
   } while (0)
-  if (g == 32) TG_P16L(1);
-  else if (g == 64) TG_P16L(2);
-  else if (g == 128) TG_P16L(4);
-  else TG_P16L(8);
+  if (p.norm_w) {
+    if (g == 64) TG_P16L(2, true);
+    else if (g == 128) TG_P16L(4, true);
+    else TG_P16L(8, true);
+  } else {
+    if (g == 32) TG_P16L(1, false);
+    else if (g == 64) TG_P16L(2, false);
+    else if (g == 128) TG_P16L(4, false);
+    else TG_P16L(8, false);
+  }
 #undef TG_P16L
   return launch_status();
 }

@@ -29,14 +29,18 @@ struct Pair16LoopParams {
   int32_t tbase, trem;   // workgroup b owns tbase + (b < trem) 16-row tiles, starting at tile b * tbase + min(b, trem)
   int32_t lds_lut;       // LDS byte offset of the staged LUT rows (row-wise LUT, more than one tile per workgroup): 32 bytes per row, 544 per tile
   int32_t lds_red;       // ... of the two partial-sum regions, 16 KiB each
+  int32_t epilogue;      // TG_EPI_SWIGLU: a tile is 8 gate + 8 up rows, y is [m][wrows / 2]
+  const char* norm_w;    // fused LlamaRMSNorm of the activations (tg_w4_gemm.norm_weight), nullptr = off
+  float norm_eps;
+  int32_t lds_nrm;       // LDS byte offset of the sums of squares, f32 [16 waves][16 rows]
 };
 
-template <typename DT, int CPG>
+template <typename DT, int CPG, bool NORM>
 __global__ void __launch_bounds__(1024) w4_gemm_pair16_loop_kernel(const Pair16LoopParams p) {
   constexpr int I = 4, CPS = I / 2, CH = 4, NCHK = CH * CPS;  // a wave's k-slice: four super-tiles = eight 32-k chunks (k = 4096 over 16 waves)
   static_assert(NCHK % CPG == 0, "a slice is whole groups");
   asm volatile("" ::"s"(p.x), "s"(p.w), "s"(p.qinfo), "s"(p.lut), "s"(p.y), "s"(p.bias), "s"(p.bias_row_stride), "s"(p.m), "s"(p.wrows), "s"(p.k),
-               "s"(p.ntiles), "s"(p.ksuper), "s"(p.gshift), "s"(p.ngroups), "s"(p.qtype), "s"(p.tbase), "s"(p.trem), "s"(p.lds_lut), "s"(p.lds_red));
+               "s"(p.ntiles), "s"(p.ksuper), "s"(p.gshift), "s"(p.ngroups), "s"(p.qtype), "s"(p.tbase), "s"(p.trem), "s"(p.lds_lut), "s"(p.lds_red), "s"(p.epilogue), "s"(p.norm_w), "s"(p.norm_eps), "s"(p.lds_nrm));
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -76,6 +80,17 @@ __global__ void __launch_bounds__(1024) w4_gemm_pair16_loop_kernel(const Pair16L
   for (int c = 0; c < NCHK; ++c) {
     asm volatile("" : "+v"(xoff));
     xf[c] = *reinterpret_cast<const u32x4*>(p.x + (uint32_t)__builtin_amdgcn_readfirstlane((wave * NCHK + c) * 64) + xoff);
+  }
+  // fused LlamaRMSNorm (dg_add_rmsnorm's formula, as in w4_gemv.cuh): y = rs * sum_k w_k x'_k with x'_k = RNE16(x_k g_k) and rs = rsqrt(mean(x^2)
+  // + eps) applied to the f32 sum in the output store.  The squares of this lane's 64 values -> the row's four lanes (one quad) -> one
+  // partial per wave and row in LDS, added over the 16 waves by the threads that store the outputs.
+  constexpr bool norm = NORM;
+  // the norm weights of the whole k (8 KiB) through LDS: one 16-byte load per thread of the first 8 waves now, read back piece by piece behind
+  // the prologue's barrier (32 registers of them in flight next to the activations spilled).  They borrow the SECOND partial-sum region:
+  // it is first written behind the first tile's barrier, when every wave is through its norm block.
+  u32x4 gstage = {0u, 0u, 0u, 0u};
+  if constexpr (NORM) {
+    if (tid < 512) gstage = reinterpret_cast<const u32x4*>(p.norm_w)[tid];
   }
   // weights of a tile: row n of the tile, quad q; the scale | zero word of every group of the slice
   struct W {
@@ -118,11 +133,35 @@ __global__ void __launch_bounds__(1024) w4_gemm_pair16_loop_kernel(const Pair16L
   build_table(0);
   // (a tile's 16 rows at a pitch of 544 bytes, rows 8 ... 15 shifted by 16 bytes: the 16-byte reads of next_table -- 16 rows per wave,
   //  32 bytes apart -- then touch 64 distinct banks instead of colliding two by two: 32768 bank-conflict cycles per launch before)
+  if constexpr (NORM) {
+    if (tid < 512) *(lds_u32x4ptr)((uint32_t)p.lds_red + 16384u + (uint32_t)tid * 16u) = gstage;
+  }
   if (stage_lut && tid < nt * 32) {
     const uint32_t row = (uint32_t)tid >> 1, ti = row >> 4, i = row & 15u;
     *(lds_u32x4ptr)((uint32_t)p.lds_lut + ti * 544u + i * 32u + (i >> 3) * 16u + ((uint32_t)tid & 1u) * 16u) = lstage;
   }
   __syncthreads();
+
+  // fused LlamaRMSNorm (dg_add_rmsnorm's formula, as in w4_gemv.cuh): y = rs * sum_k w_k x'_k with x'_k = RNE16(x_k g_k) and rs = rsqrt(mean(x^2)
+  // + eps) applied to the f32 sum in the output store.  The squares of this lane's 64 values -> the row's four lanes (one quad) -> one
+  // partial per wave and row in LDS, added over the 16 waves by the threads that store the outputs.
+  if constexpr (NORM) {
+    float v = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCHK; ++c) {
+      const u32x4 gw = *(lds_cu32x4ptr)((uint32_t)p.lds_red + 16384u + (uint32_t)(((wave * NCHK + c) * 32 + 8 * (lane & 3)) * 2));
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const uint32_t xv = xf[c][e], g = gw[e];
+        if constexpr (std::is_same<DT, BF16>::value) v = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, xv), __builtin_bit_cast(bf16x2, xv), v, false);
+        else v = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, xv), __builtin_bit_cast(f16x2, xv), v, false);
+        xf[c][e] = DT::pack2(DT::lo_f32(xv) * DT::lo_f32(g), DT::hi_f32(xv) * DT::hi_f32(g));
+      }
+    }
+    v += tgl::lane_xor<1>(v, lane);
+    v += tgl::lane_xor<2>(v, lane);
+    if ((lane & 3) == 0) *(lds_fptr)((uint32_t)p.lds_nrm + (uint32_t)((wave * 16 + (lane >> 2)) * 4)) = v;  // (rows >= m: row m - 1 again, never read)
+  }
 
   // ---- the A operands: a 4 x 4 dword transpose over the lane bits 4, 5 and two bit exchanges inside the quad (w4_gemm_pair16.cuh, XQ) ----
   {
@@ -184,8 +223,9 @@ __global__ void __launch_bounds__(1024) w4_gemm_pair16_loop_kernel(const Pair16L
 #ifndef TG_P16L_SPREAD
 #define TG_P16L_SPREAD 0  // (developer A/B: no difference -- 8192 / 16384 rows 9.6-9.8 / 14.4-14.8 us either way, profiles/r05_ab_p16_loop_spread.txt; the waves 0 ... 3 keep the wave-order sum of w4_gemm_pair16_kernel)
 #endif
+  float rsn = NORM ? 0.f : 1.f;  // 1 / rms of this thread's activation row (set with the first tile's store)
   auto store = [&](int tile, int par) {
-    if constexpr (TG_P16L_SPREAD) {
+    if (TG_P16L_SPREAD && p.epilogue == 0 && !norm) {
       // every wave takes 16 of the tile's 256 outputs: lane = 16 part + o -- four partial sums per lane (waves 4 part ... 4 part + 3, in wave
       // order), the four parts across the lane rows by two row swaps (tg_common.cuh) -- instead of the waves 0 ... 3 reading 16 partial sums
       // per output while the other twelve run ahead to the next barrier and wait there
@@ -206,16 +246,39 @@ __global__ void __launch_bounds__(1024) w4_gemm_pair16_loop_kernel(const Pair16L
       return;
     }
     if (tid < 256) {
-      const int rr = (tid >> 6) & 3, l = tid & 63;
+      int lt = tid & 63;
+      asm volatile("" : "+v"(lt));  // (opaque per tile: the 64-bit row offsets derived from it are loop-invariant, get hoisted and -- in the norm
+                                     //  instantiations -- spilled: a scratch reload in every tile's store)
+      const int rr = (tid >> 6) & 3, l = lt;
       const int a = 4 * rr + (l >> 4), row = tile * 16 + (l & 15);  // (the A operand's rows are rotated: register rr of lane (n, q) = row 4 rr + q)
       if (a < p.m && row < p.wrows) {
         float sum = 0.f;
 #pragma unroll
         for (int w16 = 0; w16 < 16; ++w16) sum += *(lds_fptr)((uint32_t)p.lds_red + (uint32_t)(par * 16384 + ((w16 * 4 + rr) * 64 + l) * 4));
-        uint16_t o16 = DT::from_f32(sum);
-        if (p.bias)  // rounded sum + bias, rounded again: the reference module's separate `y + bias` (modules.py:221-222)
-          o16 = DT::from_f32(DT::lo_f32(o16) + DT::lo_f32(*reinterpret_cast<const uint16_t*>(p.bias + ((int64_t)a * p.bias_row_stride + row) * 2)));
-        *reinterpret_cast<uint16_t*>(p.y + ((int64_t)a * p.wrows + row) * 2) = o16;
+        if constexpr (NORM) {
+          if (rsn == 0.f) {  // the first tile: this thread's activation row is the same for every tile
+            float tot = 0.f;
+#pragma unroll 4
+            for (int w16 = 0; w16 < 16; ++w16) tot += *(lds_fptr)((uint32_t)p.lds_nrm + (uint32_t)((w16 * 16 + a) * 4));
+            rsn = rsqrtf(tot * (1.0f / (float)p.k) + p.norm_eps);
+          }
+          sum *= rsn;
+        }
+        if (p.epilogue == TG_EPI_SWIGLU) {
+          // the tile is one block of 8 gate + 8 up rows: lane l + 8 holds the up row of gate row l (w4_gemm_pair16.cuh, dg_swiglu's formula)
+          if ((l & 15) < 8) {
+            float up = 0.f;
+#pragma unroll
+            for (int w16 = 0; w16 < 16; ++w16) up += *(lds_fptr)((uint32_t)p.lds_red + (uint32_t)(par * 16384 + ((w16 * 4 + rr) * 64 + l + 8) * 4));
+            up *= rsn;
+            *reinterpret_cast<uint16_t*>(p.y + ((int64_t)a * (p.wrows >> 1) + tile * 8 + (l & 7)) * 2) = swiglu16<DT>(sum, up);
+          }
+        } else {
+          uint16_t o16 = DT::from_f32(sum);
+          if (p.bias)  // rounded sum + bias, rounded again: the reference module's separate `y + bias` (modules.py:221-222)
+            o16 = DT::from_f32(DT::lo_f32(o16) + DT::lo_f32(*reinterpret_cast<const uint16_t*>(p.bias + ((int64_t)a * p.bias_row_stride + row) * 2)));
+          *reinterpret_cast<uint16_t*>(p.y + ((int64_t)a * p.wrows + row) * 2) = o16;
+        }
       }
     }
   };

@@ -75,7 +75,8 @@ def _interleave8(t):
     return torch.stack([t[:half].reshape(-1, 8, *t.shape[1:]), t[half:].reshape(-1, 8, *t.shape[1:])], dim=1).reshape(t.shape)
 
 
-@pytest.mark.parametrize("m,il,k,copies", [(1, 2048, 4096, 1), (4, 1792, 2048, 1), (8, 512, 4096, 1), (1, 14336, 4096, 1)])
+@pytest.mark.parametrize("m,il,k,copies", [(1, 2048, 4096, 1), (4, 1792, 2048, 1), (8, 512, 4096, 1), (1, 14336, 4096, 1),
+                                          (16, 14336, 4096, 1), (9, 4096, 4096, 1), (13, 2560, 4096, 1)])   # (9 ... 16 rows, more tiles than CUs: w4_gemm_pair16_loop_kernel)
 def test_swiglu_in_the_output_store(m, il, k, copies):
     """gate_up GEMM with the SwiGLU epilogue (weight rows in blocks of 8 gate + 8 up) == dg_swiglu of the plain GEMM's output:
     same sums, same rounding points."""
@@ -93,7 +94,8 @@ def test_swiglu_in_the_output_store(m, il, k, copies):
     assert torch.equal(act.view(torch.int16), want.view(torch.int16))
 
 
-@pytest.mark.parametrize("m,n,k", [(1, 6144, 4096), (1, 28672, 4096), (2, 512, 2048), (8, 1024, 4096), (1, 4096, 14336)])
+@pytest.mark.parametrize("m,n,k", [(1, 6144, 4096), (1, 28672, 4096), (2, 512, 2048), (8, 1024, 4096), (1, 4096, 14336),
+                                   (16, 6144, 4096), (9, 28672, 4096), (13, 8192, 4096)])   # (9 ... 16 rows, more tiles than CUs: w4_gemm_pair16_loop_kernel)
 def test_rmsnorm_in_the_activation_staging(oracle, m, n, k):
     """GEMM with norm_weight against the CPU oracle's group-scaled contraction of dg_add_rmsnorm's output (the separate launch it
     replaces).  The fused kernels add the squares in another order, so 1 / rms can differ in its last bit and a few normalised
@@ -126,6 +128,25 @@ def test_rmsnorm_in_the_activation_staging(oracle, m, n, k):
     nw2[k // 2:] *= 2
     fused2 = ops.w4_linear_fused(x, w, g, sz, lut, norm_weight=nw2, norm_eps=1e-5)
     assert (fused2.float() - fused.float()).abs().max() > 0.05
+
+
+@pytest.mark.parametrize("m,il", [(16, 14336), (11, 4096)])
+def test_rmsnorm_and_swiglu_together_at_9_to_16_rows(m, il):
+    """Both stages in one launch of the loop kernel (a gate_up projection of a 9 ... 16-sequence decode step): the bits of dg_swiglu applied
+    to the norm-fused launch's own output."""
+    from any4_amd import decode_ops as G
+    from any4_amd import ops
+
+    n, k, g = 2 * il, 4096, 128
+    w, sz, lut = _layer(n, k, g, seed=il + m)
+    gen = torch.Generator().manual_seed(17)
+    x = (torch.randn(m, k, generator=gen) * 2).bfloat16().to(DEV)
+    nw = (1 + 0.1 * torch.randn(k, generator=gen)).bfloat16().to(DEV)
+    gu = ops.w4_linear_fused(x, w, g, sz, lut, norm_weight=nw, norm_eps=1e-5)
+    act = ops.w4_linear_fused(x, w, g, sz, lut, norm_weight=nw, norm_eps=1e-5, swiglu=True)
+    assert gu is not None and act is not None and act.shape == (m, il)
+    want = G.swiglu(gu.view(m, -1, 2, 8).transpose(1, 2).reshape(m, -1).contiguous())
+    assert torch.equal(act.view(torch.int16), want.view(torch.int16))
 
 
 def test_fusion_not_available_is_reported_not_faked():
