@@ -554,12 +554,15 @@ __global__ void __launch_bounds__(1024) w4_gemm_pair16_kernel(const Pair16Params
     if constexpr (PIPE) {
       // long slices: two blocks per turn, the next block always requested before the current one is consumed
       for (int l0 = 0; l0 < nl; l0 += 2 * CH) {
-        w_request(wregB, qregB, l0 + CH);
-        x_request(xfB, l0 + CH);
+#ifndef P16_XFIRST_PIPE
+#define P16_XFIRST_PIPE 0
+#endif
+        if constexpr (XREG && P16_XFIRST_PIPE) { x_request(xfB, l0 + CH); w_request(wregB, qregB, l0 + CH); }
+        else { w_request(wregB, qregB, l0 + CH); x_request(xfB, l0 + CH); }
         x_arrange(xfA);
         consume_block(wregA, qregA, xfA, l0);
-        w_request(wregA, qregA, l0 + 2 * CH);
-        x_request(xfA, l0 + 2 * CH);
+        if constexpr (XREG && P16_XFIRST_PIPE) { x_request(xfA, l0 + 2 * CH); w_request(wregA, qregA, l0 + 2 * CH); }
+        else { w_request(wregA, qregA, l0 + 2 * CH); x_request(xfA, l0 + 2 * CH); }
         x_arrange(xfB);
         if (l0 + CH < nl) consume_block(wregB, qregB, xfB, l0 + CH);
       }
