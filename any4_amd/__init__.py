@@ -16,7 +16,8 @@ if not _BUILD_CLI:
     from . import ops as _ops  # noqa: F401
     from . import functional, modules, utils  # noqa: F401
     from .modules import Any4Linear, Int4Linear, Int8Linear  # noqa: F401
-    from .ops import get_numerics, get_weight_format, numerics, set_numerics, set_weight_format, weight_format  # noqa: F401
+    from .ops import (get_auto_relayout, get_numerics, get_weight_format, numerics, set_auto_relayout, set_numerics,  # noqa: F401
+                      set_weight_format, weight_format)
 
 __all__ = ["functional", "modules", "utils", "Any4Linear", "Int4Linear", "Int8Linear", "get_numerics", "set_numerics", "numerics",
-           "get_weight_format", "set_weight_format", "weight_format"]
+           "get_weight_format", "set_weight_format", "weight_format", "get_auto_relayout", "set_auto_relayout"]

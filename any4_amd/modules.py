@@ -68,45 +68,70 @@ class _PackedLinear(torch.nn.Module):
             raise ValueError("relayout() applies to a packed weights-on-the-left (Aint4) tensor")
         self.weight.data = _ops.relayout_Aint4(self.weight.data, self.in_features, to, self.w_inner_k)
 
-    # ---- checkpoints: what the reference keeps in plain attributes (modules.py:38-41: kernel, w_inner_k, weight_reshaped) decides
-    # how the `weight` tensor of a state_dict has to be read, so for a PACKED module it travels with it (eval.py:180-210 saves /
-    # loads state_dicts).  An unpacked module's state_dict has exactly the reference's keys.
+    # ---- checkpoints (eval.py:180-210 saves / loads state_dicts).  The reference keeps kernel / w_inner_k / weight_reshaped in plain
+    # attributes (modules.py:38-41); here a state_dict holds TENSORS ONLY -- exactly the reference's keys, packed or not, so tensor-only
+    # consumers (safetensors, `{k: v.cpu()}`) and the reference's strict load_state_dict take it -- and everything that decides how
+    # `weight` has to be read is recovered from the tensor's own shape (_read_packed_shape).
     _TAG = torch.nn.modules.module._EXTRA_STATE_KEY_SUFFIX
 
-    def _save_to_state_dict(self, destination, prefix, keep_vars):
-        super()._save_to_state_dict(destination, prefix, keep_vars)
-        if self.weight_reshaped:
-            destination[prefix + self._TAG] = {"kernel": self.kernel, "w_inner_k": int(self.w_inner_k), "weight_reshaped": True}
+    def _read_packed_shape(self, w: torch.Tensor):
+        """(w_inner_k or None) of a packed 4-D checkpoint tensor for THIS module's kernel; raises when the tensor was packed for
+        the other operand side / another problem size (it would be mis-multiplied or read out of bounds, never 'just slower')."""
+        packer = self._PACKERS.get(self.kernel, "")
+        n, k = self.out_features, self.in_features
+        s0, s1, s2, s3 = w.shape
+        ok, inner = False, None
+        if s2 == 32:
+            if "Bint4" in packer:     # [ceil(n/8)][k/(16 I)][32][I/2], TinyGemm_int4.cu:322-364
+                ok, inner = s0 == -(-n // 8) and s3 in (1, 2, 4) and s1 * s3 * 32 == k, s3 * 2
+            elif "Aint4" in packer:   # the reference's [ceil(n/16)][k/(16 I)][32][I] or the native Bint4 tensor of the 16-row-padded rows
+                if s0 == -(-n // 16) and s3 in (1, 2, 4) and s1 * s3 * 16 == k:
+                    ok, inner = True, s3
+                elif s0 == 2 * -(-n // 16) and s1 * s3 * 32 == k and s3 * 2 == _ops._rows_inner(k):
+                    ok, inner = True, None   # (the Aint4 innerKTiles of a native tensor is a request for relayout('reference') only)
+            elif "Bint8" in packer:   # [ceil(n/8)][k/(16 I)][32][I]
+                ok, inner = s0 == -(-n // 8) and s3 in (1, 2, 4) and s1 * s3 * 16 == k, s3
+            elif "Aint8" in packer:   # [ceil(n/16)][ceil(ceil(k/16)/I)][32][2 I]
+                ok, inner = s0 == -(-n // 16) and s3 in (2, 4) and s1 == -(-(-(-k // 16)) // (s3 // 2)), s3 // 2
+        if not ok:
+            raise RuntimeError(f"checkpoint weight {tuple(w.shape)} was not packed for kernel {self.kernel!r} of a "
+                               f"[{n}][{k}] layer (packed for kernel of the other operand side, or another layer size)")
+        return inner
 
     def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
         w = state_dict.get(prefix + "weight")
-        tag = state_dict.get(prefix + self._TAG)
-        if tag is not None and tag.get("weight_reshaped") and tag.get("kernel", self.kernel) != self.kernel \
-                and self._PACKERS.get(tag["kernel"]) != self._PACKERS.get(self.kernel):
-            # a tensor packed for the other operand side cannot be multiplied by this kernel: refuse instead of mis-computing
-            raise RuntimeError(f"checkpoint weight was packed for kernel {tag['kernel']!r}, this module runs {self.kernel!r}")
-        if w is not None and w.dim() != self.weight.dim():
-            # a packed checkpoint into an unpacked module (or the reverse): take the checkpoint's shape
-            self.weight.data = torch.empty(w.shape, dtype=self.weight.dtype, device=self.weight.device)
-        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs)
-        if prefix + self._TAG in unexpected_keys:
-            unexpected_keys.remove(prefix + self._TAG)
+        tag = state_dict.pop(prefix + self._TAG, None)   # (round-5 checkpoints carried a dict here; the shape says the same)
+        inner = None
         if w is not None:
-            packed = w.dim() == 4
-            self.weight_reshaped = packed
-            if tag is not None:
-                self.w_inner_k = int(tag.get("w_inner_k", self.w_inner_k))
-            elif packed:
-                # a state_dict of the reference implementation (no tag): the tensor's innermost size says the innerKTiles
-                # (TinyGemm_int4.cu:322-364), and a weights-on-the-left tensor says its format by its shape (ops.aside_format)
-                packer = self._PACKERS.get(self.kernel, "")
-                if "Bint4" in packer:
-                    self.w_inner_k = w.size(3) * 2
-                elif "Aint8" in packer:
-                    self.w_inner_k = w.size(3) // 2
-                elif "Bint8" in packer or _ops.aside_format(w, self.in_features) == "reference":
-                    self.w_inner_k = w.size(3)
+            if w.dim() == 4:
+                inner = self._read_packed_shape(w)
+            if w.shape != self.weight.shape:
+                # a packed checkpoint into an unpacked module, the reverse, or another packed format / innerKTiles of the same
+                # matrix (the reference's Aint4 words into a natively packed module, I = 2 into I = 4): take the checkpoint's shape
+                self.weight.data = torch.empty(w.shape, dtype=self.weight.dtype, device=self.weight.device)
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs)
+        if w is not None:
+            self.weight_reshaped = w.dim() == 4
+            if inner is not None:
+                self.w_inner_k = inner
+            elif isinstance(tag, dict) and self.weight_reshaped and "w_inner_k" in tag:
+                self.w_inner_k = int(tag["w_inner_k"])
+            # A checkpoint packed by the CUDA implementation for the weights-on-the-left kernels holds the reference's Aint4 words,
+            # which only the reference-numerics kernels read (config 3: 0.59 vs 0.79 of the HBM roofline): repacked ONCE, losslessly,
+            # to the row-per-lane order -- here when the parameter already lives on the GPU, else at the first forward on it.
+            # Opt out: any4_amd.set_auto_relayout(False) / ANY4_AUTO_RELAYOUT=0, or a process default of weight_format 'reference'.
+            self.__dict__["_relayout_pending"] = bool(
+                self.weight_reshaped and _ops.get_auto_relayout() and _ops.get_weight_format() == "native"
+                and self.weight_format == "reference" and self.in_features % 32 == 0)
+            if self.__dict__["_relayout_pending"] and self.weight.is_cuda:
+                self._auto_relayout()
         self.__dict__.pop("_plan", None)
+
+    def _auto_relayout(self):
+        self.__dict__["_relayout_pending"] = False
+        if self.weight_format == "reference":
+            self.relayout("native")
+            self.__dict__.pop("_plan", None)
 
     def _gemm(self, x2d: torch.Tensor) -> torch.Tensor:
         raise NotImplementedError
@@ -125,11 +150,14 @@ class _PackedLinear(torch.nn.Module):
     def _plan_key(self, x2d):
         p = self._parameters
         # (pointer AND version of every parameter: an in-place update -- load_state_dict, copy_ -- drops the plan as well)
-        tag = tuple((t.data_ptr(), t._version, t.shape) for t in (p.get(n) for n in self._PLAN_PARAMS) if t is not None)
+        # (inference tensors -- a model built under torch.inference_mode() -- keep no version counter: the pointer alone)
+        tag = tuple((t.data_ptr(), 0 if t.is_inference() else t._version, t.shape) for t in (p.get(n) for n in self._PLAN_PARAMS) if t is not None)
         return (x2d.shape, x2d.dtype, x2d.device, self.kernel, self.group_size, self.w_inner_k, tag, _ops.get_numerics())
 
     def _forward(self, input: torch.Tensor) -> torch.Tensor:
         lead = input.shape[:-1]
+        if self.__dict__.get("_relayout_pending") and self.weight.is_cuda:
+            self._auto_relayout()    # (a checkpoint in the reference's Aint4 words that was loaded on the CPU: repacked once, see above)
         if input.is_cuda and self.bias is None and self.weight_reshaped:
             # the validated launch of this (module, activation shape) re-issued with new pointers (ops.LaunchPlan); a packed weight
             # only: the plan points at the parameters themselves

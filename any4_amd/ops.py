@@ -135,6 +135,21 @@ def weight_format(name: str):
             _tls.wformat = prev
 
 
+_auto_relayout = os.environ.get("ANY4_AUTO_RELAYOUT", "1") not in ("0", "false", "False", "")
+
+
+def get_auto_relayout() -> bool:
+    """Whether a module that RECEIVES a weights-on-the-left tensor in the reference's Aint4 words through load_state_dict (a checkpoint
+    packed by the CUDA implementation, modules.py:197-205) repacks it once to the row-per-lane order (lossless; relayout_Aint4).  On by
+    default while the process default weight format is 'native'; ANY4_AUTO_RELAYOUT=0 or set_auto_relayout(False) keeps the words."""
+    return _auto_relayout
+
+
+def set_auto_relayout(on: bool) -> None:
+    global _auto_relayout
+    _auto_relayout = bool(on)
+
+
 def _rows_inner(k: int) -> int:
     """innerKTiles of the Bint4 word order of a native weights-on-the-left tensor (tg_w4_gemm.w_format = TG_WFMT_ROWS)."""
     return 4 if k % 64 == 0 else 2

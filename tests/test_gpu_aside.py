@@ -199,23 +199,56 @@ def test_state_dict_round_trip_into_a_fresh_module(T, fmt, cls):
     torch.save(src.state_dict(), buf)
     buf.seek(0)
     sd = torch.load(buf)
+    assert set(sd) == {"weight", "scales_and_zeros"} | ({"lut"} if cls == "Any4Linear" else set())    # tensors only: the reference's keys
     other = "reference" if fmt == "native" else "native"
     with any4_amd.weight_format(other):
         dst = fresh()
         assert not dst.weight_reshaped
         dst.load_state_dict(sd)                      # strict
-        assert dst.weight_reshaped and dst.weight_format == fmt and dst.w_inner_k == src.w_inner_k
-        assert torch.equal(dst(x.to(DEV)), want)
-    # a state_dict WITHOUT the tag (what the reference implementation writes: eval.py:195): rank and shape of `weight` decide
-    bare = {k_: v for k_, v in sd.items() if not k_.endswith("_extra_state")}
-    dst2 = fresh()
-    dst2.load_state_dict(bare)                       # strict, no "missing key"
-    assert dst2.weight_reshaped and dst2.weight_format == fmt and torch.equal(dst2(x.to(DEV)), want)
-    # a tensor packed for the other operand side is refused, not mis-multiplied
+        # native words stay; the reference's words under the 'native' default are repacked once at load (modules.py:197-205 checkpoints)
+        assert dst.weight_reshaped and dst.weight_format == "native"
+        assert fmt == "native" or dst.w_inner_k == src.w_inner_k
+        if fmt == "native":
+            assert torch.equal(dst(x.to(DEV)), want)
+        else:
+            assert torch.equal(dst.weight, ops_relayout(src))
+            y = dst(x.to(DEV))
+            assert (y.float() - want.float()).abs().max() <= 0.02 * want.float().abs().max()   # (two kernel families, one result within the reference's own weight rounding)
+    # the same checkpoint INTO AN ALREADY PACKED module of the other format (quantize_model ends in reshape_weight())
+    dst3 = fresh()
+    dst3.weight.data, dst3.scales_and_zeros.data = codes.to(DEV), qinfo.to(DEV)
+    with any4_amd.weight_format(other):
+        dst3.reshape_weight(4 if other == "native" else 2)
+    assert dst3.weight_format == other
+    any4_amd.set_auto_relayout(False)                # opt-out: the words are kept as they came
+    try:
+        dst3.load_state_dict(sd)
+        assert dst3.weight_format == fmt and torch.equal(dst3.weight, src.weight) and torch.equal(dst3(x.to(DEV)), want)
+        # loaded on the CPU, moved to the GPU: (with the repack enabled) done at the first forward
+        cpu = getattr(modules, cls)(k, n, bias=False, dtype=torch.bfloat16, group_size=g, kernel=kernel)
+        any4_amd.set_auto_relayout(True)
+        cpu.load_state_dict({k_: v.cpu() for k_, v in sd.items()})
+        assert cpu.weight_format == fmt
+        cpu = cpu.to(DEV)
+        y = cpu(x.to(DEV))
+        assert cpu.weight_format == "native" and (y.float() - want.float()).abs().max() <= 0.02 * want.float().abs().max()
+        assert torch.equal(cpu(x.to(DEV)), y)
+    finally:
+        any4_amd.set_auto_relayout(True)
+    # a tensor packed for the other operand side is refused, not mis-multiplied (a native tensor IS a Bint4 tensor: either side takes it)
     wrong = getattr(modules, cls)(k, n, bias=False, device=DEV, dtype=torch.bfloat16, group_size=g,
                                   kernel="linear_y_f16RM_x_f16RM_W_any4TC" if cls == "Any4Linear" else "linear_y_f16RM_x_f16RM_W_int4TC")
-    with pytest.raises(RuntimeError, match="packed for kernel"):
+    if fmt == "reference":
+        with pytest.raises(RuntimeError, match="packed for kernel"):
+            wrong.load_state_dict(sd)
+    else:
         wrong.load_state_dict(sd)
+        assert (wrong(x.to(DEV)).float() - want.float()).abs().max() <= 0.02 * want.float().abs().max()
+
+
+def ops_relayout(mod):
+    from any4_amd import ops
+    return ops.relayout_Aint4(mod.weight.data, mod.in_features, "native")
 
 
 def test_same_module_from_two_threads_on_two_streams(T):

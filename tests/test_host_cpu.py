@@ -423,35 +423,71 @@ def test_weights_on_the_left_format_is_read_off_the_tensor():
 
 def test_state_dict_carries_what_decides_how_weight_is_read():
     """eval.py:180-210 (save / load of state_dicts).  The reference keeps kernel / w_inner_k / weight_reshaped in plain attributes
-    (modules.py:38-41); here they travel in the module's extra state, a fresh module takes a packed tensor's shape, a state_dict
-    without the tag (the reference implementation's) is read by rank and shape, and a tensor packed for the other operand side is
-    refused."""
+    (modules.py:38-41); here a state_dict holds tensors only (the reference's own keys) and the packed tensor's SHAPE says how it
+    has to be read: a fresh module or an already packed one (other format, other innerKTiles) takes the checkpoint's shape, and a
+    tensor packed for the other operand side is refused."""
     import modules
 
+    import any4_amd
+
     k, n, g = 256, 64, 64
-    src = modules.Int4Linear(k, n, bias=False, dtype=torch.bfloat16, group_size=g)          # default kernel: weights on the left
+    mk = lambda **kw: modules.Int4Linear(k, n, bias=False, dtype=torch.bfloat16, group_size=g, **kw)
+    src = mk()          # default kernel: weights on the left
     assert src.weight_format is None
-    for fmt, shape, inner in (("native", (2 * n // 16, k // 64, 32, 2), 4), ("reference", (n // 16, k // 32, 32, 2), 2)):
-        src.weight.data = torch.randint(0, 2 ** 31 - 1, shape, dtype=torch.int32)
-        src.weight_reshaped, src.w_inner_k = True, inner
-        assert src.weight_format == fmt
-        sd = src.state_dict()
-        assert sd["_extra_state"] == {"kernel": src.kernel, "w_inner_k": inner, "weight_reshaped": True}
-        dst = modules.Int4Linear(k, n, bias=False, dtype=torch.bfloat16, group_size=g)
-        dst.__dict__["_plan"] = ("stale",)
-        dst.load_state_dict(sd)
-        assert dst.weight_reshaped and dst.w_inner_k == inner and dst.weight_format == fmt and torch.equal(dst.weight, src.weight)
-        assert "_plan" not in dst.__dict__
-        bare = {key: v for key, v in sd.items() if key != "_extra_state"}
-        dst2 = modules.Int4Linear(k, n, bias=False, dtype=torch.bfloat16, group_size=g)
-        dst2.load_state_dict(bare)
-        assert dst2.weight_reshaped and dst2.weight_format == fmt and (fmt == "native" or dst2.w_inner_k == inner)
-        wrong = modules.Int4Linear(k, n, bias=False, dtype=torch.bfloat16, group_size=g, kernel="linear_y_f16RM_x_f16RM_W_int4TC")
-        with pytest.raises(RuntimeError, match="packed for kernel"):
-            wrong.load_state_dict(sd)
-        assert set(modules.Int4Linear(k, n, bias=False, dtype=torch.bfloat16, group_size=g).state_dict()) == {"weight", "scales_and_zeros"}
+    any4_amd.set_auto_relayout(False)       # (this test reads the words back; the repack itself needs the GPU: test_gpu_aside.py)
+    try:
+        for fmt, shape, inner in (("native", (2 * n // 16, k // 64, 32, 2), 4), ("reference", (n // 16, k // 32, 32, 2), 2)):
+            src.weight.data = torch.randint(0, 2 ** 31 - 1, shape, dtype=torch.int32)
+            src.weight_reshaped, src.w_inner_k = True, inner
+            assert src.weight_format == fmt
+            sd = src.state_dict()
+            assert set(sd) == {"weight", "scales_and_zeros"} and all(isinstance(v, torch.Tensor) for v in sd.values())
+            {key: v.cpu() for key, v in sd.items()}              # tensor-only consumers (safetensors, save_pretrained) work
+            dst = mk()
+            dst.__dict__["_plan"] = ("stale",)
+            dst.load_state_dict(sd)
+            assert dst.weight_reshaped and dst.weight_format == fmt and torch.equal(dst.weight, src.weight)
+            assert fmt == "native" or dst.w_inner_k == inner
+            assert "_plan" not in dst.__dict__
+            # a round-5 checkpoint (a dict under _extra_state) still loads, strict
+            old = dict(sd, _extra_state={"kernel": src.kernel, "w_inner_k": inner, "weight_reshaped": True})
+            dst2 = mk()
+            dst2.load_state_dict(old)
+            assert dst2.weight_reshaped and dst2.weight_format == fmt and dst2.w_inner_k == inner
+            wrong = mk(kernel="linear_y_f16RM_x_f16RM_W_int4TC")
+            if fmt == "reference":       # the other operand side's words: refused, not mis-multiplied
+                with pytest.raises(RuntimeError, match="packed for kernel"):
+                    wrong.load_state_dict(sd)
+                with pytest.raises(RuntimeError, match="packed for kernel"):
+                    wrong.load_state_dict(old)
+            else:                        # a native weights-on-the-left tensor IS the Bint4 tensor of the same rows: either side multiplies it
+                wrong.load_state_dict(sd)
+                assert wrong.weight_reshaped and wrong.w_inner_k == 4
+            # ... INTO AN ALREADY PACKED module of the other format (quantize_model always ends in reshape_weight())
+            for fmt2, shape2, inner2 in (("native", (2 * n // 16, k // 64, 32, 2), 4), ("reference", (n // 16, k // 64, 32, 4), 4)):
+                packed = mk()
+                packed.weight.data = torch.zeros(shape2, dtype=torch.int32)
+                packed.weight_reshaped, packed.w_inner_k = True, inner2
+                assert packed.weight_format == fmt2
+                packed.load_state_dict(sd)
+                assert packed.weight_format == fmt and torch.equal(packed.weight, src.weight)
+                assert fmt == "native" or packed.w_inner_k == inner
+    finally:
+        any4_amd.set_auto_relayout(True)
+    # a Bint4 checkpoint with innerKTiles 2 into a module packed with innerKTiles 4 (and into a fresh one)
+    b2 = mk(kernel="linear_y_f16RM_x_f16RM_W_int4TC")
+    b2.weight.data = torch.randint(0, 2 ** 31 - 1, (n // 8, k // 32, 32, 1), dtype=torch.int32)
+    b2.weight_reshaped, b2.w_inner_k = True, 2
+    b4 = mk(kernel="linear_y_f16RM_x_f16RM_W_int4TC")
+    b4.weight.data = torch.zeros((n // 8, k // 64, 32, 2), dtype=torch.int32)
+    b4.weight_reshaped, b4.w_inner_k = True, 4
+    b4.load_state_dict(b2.state_dict())
+    assert b4.w_inner_k == 2 and torch.equal(b4.weight, b2.weight)
+    with pytest.raises(RuntimeError, match="packed for kernel"):       # another layer size
+        mk(kernel="linear_y_f16RM_x_f16RM_W_int4TC").load_state_dict({"weight": torch.zeros((n // 8 + 1, k // 64, 32, 2), dtype=torch.int32),
+                                                                     "scales_and_zeros": b2.scales_and_zeros.data})
     # an unpacked checkpoint into a packed module: back to unpacked
-    plain = modules.Int4Linear(k, n, bias=False, dtype=torch.bfloat16, group_size=g)
+    plain = mk()
     dst.load_state_dict(plain.state_dict())
     assert not dst.weight_reshaped and dst.weight.shape == (n, k)
     # inside a parent module (prefix handling), B side, any4
@@ -459,8 +495,56 @@ def test_state_dict_carries_what_decides_how_weight_is_read():
     parent[0].weight.data = torch.zeros((n // 8, k // 64, 32, 2), dtype=torch.int32)
     parent[0].weight_reshaped = True
     twin = torch.nn.Sequential(modules.Any4Linear(k, n, bias=True, dtype=torch.bfloat16, group_size=g))
-    twin.load_state_dict({key: v for key, v in parent.state_dict().items() if not key.endswith("_extra_state")})
+    twin.load_state_dict(parent.state_dict())
     assert twin[0].weight_reshaped and twin[0].w_inner_k == 4 and twin[0].weight.shape == (n // 8, k // 64, 32, 2)
+    # int8 packed shapes are read the same way
+    i8 = modules.Int8Linear(k, n, bias=False, dtype=torch.bfloat16, group_size=g, kernel="linear_y_f16RM_x_f16RM_W_int8TC")
+    i8.load_state_dict({"weight": torch.zeros((n // 8, k // 32, 32, 2), dtype=torch.int32), "scales_and_zeros": i8.scales_and_zeros.data})
+    assert i8.weight_reshaped and i8.w_inner_k == 2
+    a8 = modules.Int8Linear(k, n, bias=False, dtype=torch.bfloat16, group_size=g)
+    a8.load_state_dict({"weight": torch.zeros((n // 16, k // 32, 32, 4), dtype=torch.int32), "scales_and_zeros": a8.scales_and_zeros.data})
+    assert a8.weight_reshaped and a8.w_inner_k == 2
+
+
+def test_reference_words_from_a_checkpoint_are_marked_for_one_repack():
+    """modules.py:197-205: a CUDA-packed checkpoint for the weights-on-the-left kernels.  Loaded on the CPU, the module remembers that the
+    tensor is to be repacked at its first forward on the GPU; with the opt-out (or a 'reference' process default) it is left alone."""
+    import modules
+
+    import any4_amd
+
+    k, n, g = 256, 64, 64
+    sd = {"weight": torch.randint(0, 2 ** 31 - 1, (n // 16, k // 64, 32, 4), dtype=torch.int32),
+          "scales_and_zeros": torch.zeros((k // g, n, 2), dtype=torch.bfloat16)}
+    lin = modules.Int4Linear(k, n, bias=False, dtype=torch.bfloat16, group_size=g)
+    lin.load_state_dict(sd)
+    assert lin.weight_format == "reference" and lin.__dict__["_relayout_pending"] is True and lin.w_inner_k == 4
+    for ctx in (any4_amd.weight_format("reference"),):
+        with ctx:
+            lin2 = modules.Int4Linear(k, n, bias=False, dtype=torch.bfloat16, group_size=g)
+            lin2.load_state_dict(sd)
+            assert lin2.__dict__["_relayout_pending"] is False
+    any4_amd.set_auto_relayout(False)
+    try:
+        lin3 = modules.Int4Linear(k, n, bias=False, dtype=torch.bfloat16, group_size=g)
+        lin3.load_state_dict(sd)
+        assert lin3.__dict__["_relayout_pending"] is False and not any4_amd.get_auto_relayout()
+    finally:
+        any4_amd.set_auto_relayout(True)
+    # a B-side module / a native tensor: nothing to repack
+    nat = modules.Int4Linear(k, n, bias=False, dtype=torch.bfloat16, group_size=g)
+    nat.load_state_dict({"weight": torch.zeros((2 * n // 16, k // 64, 32, 2), dtype=torch.int32), "scales_and_zeros": sd["scales_and_zeros"]})
+    assert nat.__dict__["_relayout_pending"] is False
+
+
+def test_plan_key_under_inference_mode():
+    """Parameters created under torch.inference_mode() keep no version counter: the plan key falls back to the pointer."""
+    import modules
+
+    with torch.inference_mode():
+        lin = modules.Any4Linear(256, 64, bias=False, dtype=torch.bfloat16, group_size=64)
+        key = lin._plan_key(torch.zeros((1, 256), dtype=torch.bfloat16))
+    assert key[0] == (1, 256)
 
 
 def test_launch_plan_is_per_thread_and_plan_sink_thread_local():
