@@ -10,8 +10,8 @@ LIB_PATH = os.path.join(_HERE, "lib", "libtinygemm_hip.so")
 
 TG_BF16, TG_F16 = 0, 1
 TG_Q_INT4, TG_Q_ANY4_GLOBAL, TG_Q_ANY4_ROWWISE, TG_Q_MX4, TG_Q_INT8 = 0, 1, 2, 3, 4
-TG_NUM_FAST, TG_NUM_REFERENCE, TG_NUM_FAST_MFMA = 0, 1, 2
-TG_ABI_VERSION = 6
+TG_NUM_FAST, TG_NUM_REFERENCE, TG_NUM_FAST_MFMA, TG_NUM_FAST_DOT2 = 0, 1, 2, 3
+TG_ABI_VERSION = 7
 TG_PLAN_SPLITK, TG_PLAN_STREAM, TG_PLAN_PAIR, TG_PLAN_PAIR_XR, TG_PLAN_GEMV = 1, 2, 3, 4, 5
 TG_LAYOUT_RM, TG_LAYOUT_TC_A = 0, 1
 TG_E_LAYOUT = -12
@@ -67,6 +67,7 @@ class PeerGather(ctypes.Structure):
 # name -> argtypes, exactly the prototypes of include/tinygemm_hip.h
 SYMBOLS = {
     "tg_abi_version": [],
+    "tg_m1_default_contraction": [],
     "tg_error_string": [ctypes.c_int],
     "tg_convert_to_Bint4": [_vp, _i64, _i64, ctypes.c_int, _vp, ctypes.c_int, _vp],
     "tg_convert_to_Aint4": [_vp, _i64, _i64, ctypes.c_int, _vp, ctypes.c_int, _vp],

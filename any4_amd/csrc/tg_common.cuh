@@ -42,6 +42,7 @@ struct GemmParams {
   int32_t rowtiles;  // ceil(wrows / 16)
   int32_t dbg;       // developer ablation flags (0 in production)
   int32_t numerics;  // TG_NUM_* (host-side dispatch only)
+  int32_t dot2;      // host-side only: TG_NUM_FAST_DOT2 was asked for (never promote a stacked m = 1 launch to the matrix-core contraction)
   int32_t dry;       // host-side only: report the kernel family instead of launching (tg_gemm_w4_plan)
   int64_t stride_x, stride_w, stride_qinfo, stride_lut, stride_y;
   const char* bias;   // optional [wrows] 16-bit, added after the first rounding (see store_rows4)
@@ -352,6 +353,9 @@ inline int cu_count() {
 #endif
 #ifndef TG_B16_CHUNK
 #define TG_B16_CHUNK 4         // consecutive 32-row work items per workgroup visit of those kernels (1 / 4 / 8 within 1 %)
+#endif
+#ifndef TG_M1_DEFAULT_MFMA
+#define TG_M1_DEFAULT_MFMA 0  // which contraction a STACKED m = 1 launch takes under TG_NUM_FAST: 0 = per-lane v_dot2, 1 = the matrix core (tg_m1_default_contraction())
 #endif
 #ifndef TG_PAIR_MIN_ITEMS
 #define TG_PAIR_MIN_ITEMS 192  // fewer work items: the launch is latency-bound, w4_gemm_pair16_kernel / the reference kernels take

@@ -498,6 +498,9 @@ int launch_w4(int dt, bool LAYOUT_A, int canon, bool QMX, GemmParams& p, int64_t
       // one layer per launch with up to 4 activation rows (a decode step's GEMMs): its own kernel (w4_gemv.cuh)
       rc = p.numerics == TG_NUM_FAST_MFMA ? (int)TG_PAIR_NA : tgx::gemv(dt, 2 * WPL, QMX, p, batch, st);  // (w4_gemv contracts with v_dot2)
       if (rc != TG_PAIR_NA) return rc;
+      // STACKED launches of one activation row in the default numerics: the contraction tg_m1_default_contraction() names
+      // (TG_M1_DEFAULT_MFMA; TG_NUM_FAST_DOT2 / TG_NUM_FAST_MFMA pin either one for A/B runs -- p.dot2 is set by the entry point)
+      if (TG_M1_DEFAULT_MFMA && p.numerics == TG_NUM_FAST && p.m == 1 && !p.dot2 && !QMX) p.numerics = TG_NUM_FAST_MFMA;
       rc = tgx::pair_xr(dt, 2 * WPL, QMX, p, batch, st);
       if (rc != TG_PAIR_NA) return rc;
       p.ws_need = 0;
@@ -540,6 +543,7 @@ int launch_w4(int dt, bool LAYOUT_A, int canon, bool QMX, GemmParams& p, int64_t
 extern "C" {
 
 int tg_abi_version(void) { return TG_ABI_VERSION; }
+int tg_m1_default_contraction(void) { return TG_M1_DEFAULT_MFMA ? 1 : 0; }
 
 const char* tg_error_string(int code) {
   switch (code) {
@@ -743,7 +747,7 @@ static int gemm_w4_impl(const tg_w4_gemm* caller, int device, tg_stream_t stream
   if (!aligned16(a->x) || !aligned16(a->w) || (reinterpret_cast<uintptr_t>(a->qinfo) & 3u)) return TG_E_ALIGN;
   if (a->lut && !aligned16(a->lut)) return TG_E_ALIGN;          // LUT rows are read as two 16-byte vectors
   if (a->bias && (reinterpret_cast<uintptr_t>(a->bias) & 7u)) return TG_E_ALIGN;
-  if (!(a->numerics == TG_NUM_FAST || a->numerics == TG_NUM_REFERENCE || a->numerics == TG_NUM_FAST_MFMA) || a->reserved != 0) return TG_E_SHAPE;
+  if (!(a->numerics == TG_NUM_FAST || a->numerics == TG_NUM_REFERENCE || a->numerics == TG_NUM_FAST_MFMA || a->numerics == TG_NUM_FAST_DOT2) || a->reserved != 0) return TG_E_SHAPE;
   if (a->workspace && (!aligned16(a->workspace) || a->workspace_bytes < 0)) return TG_E_ALIGN;
   if (!(a->x_layout == TG_LAYOUT_RM || a->x_layout == TG_LAYOUT_TC_A) || !(a->y_layout == TG_LAYOUT_RM || a->y_layout == TG_LAYOUT_TC_A)) return TG_E_LAYOUT;
   if ((a->x_layout || a->y_layout) && (!on_right || a->m % 16 != 0 || a->bias)) return TG_E_LAYOUT;
@@ -778,7 +782,8 @@ static int gemm_w4_impl(const tg_w4_gemm* caller, int device, tg_stream_t stream
   p.qtype = a->qtype;
   p.dbg = 0;
   p.dry = dry != 0;
-  p.numerics = a->numerics;
+  p.numerics = a->numerics == TG_NUM_FAST_DOT2 ? (int)TG_NUM_FAST : a->numerics;
+  p.dot2 = a->numerics == TG_NUM_FAST_DOT2;
   p.ws = (char*)a->workspace;
   p.ws_bytes = a->workspace ? a->workspace_bytes : 0;
   p.ws_query = dry == 2;
@@ -827,7 +832,7 @@ static int gemm_w4_impl(const tg_w4_gemm* caller, int device, tg_stream_t stream
 #ifndef TG_ROW_BLOCKS_MAX_M
 #define TG_ROW_BLOCKS_MAX_M 64
 #endif
-  if (TG_ROW_BLOCKS && on_right && a->m > 16 && a->m <= TG_ROW_BLOCKS_MAX_M && (a->numerics == TG_NUM_FAST || a->numerics == TG_NUM_FAST_MFMA) && !p.x_tc && !p.y_tc &&
+  if (TG_ROW_BLOCKS && on_right && a->m > 16 && a->m <= TG_ROW_BLOCKS_MAX_M && (p.numerics == TG_NUM_FAST || p.numerics == TG_NUM_FAST_MFMA) && !p.x_tc && !p.y_tc &&
       !p.norm_w && !p.epilogue) {
     // decided on a dry pass over the two block shapes of the call (16 rows, the ragged last block): both on a group-scaled kernel, or the
     // whole call stays on the path below

@@ -52,7 +52,7 @@ _F16_TYPES = (torch.bfloat16, torch.float16)
 # ---------------------------------------------------------------------------------------------
 # call-side state the reference's op schemas have no argument for: GEMM numerics and a fused bias
 # ---------------------------------------------------------------------------------------------
-_NUMERICS = {"fast": _lib.TG_NUM_FAST, "reference": _lib.TG_NUM_REFERENCE, "fast_mfma": _lib.TG_NUM_FAST_MFMA}
+_NUMERICS = {"fast": _lib.TG_NUM_FAST, "reference": _lib.TG_NUM_REFERENCE, "fast_mfma": _lib.TG_NUM_FAST_MFMA, "fast_dot2": _lib.TG_NUM_FAST_DOT2}
 _numerics = os.environ.get("ANY4_NUMERICS", "fast")
 if _numerics not in _NUMERICS:
     raise ImportError(f"ANY4_NUMERICS must be one of {sorted(_NUMERICS)}, got {_numerics!r}")

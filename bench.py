@@ -23,9 +23,16 @@ After the timed region rank 0 (a) checks three layers of the timed launch's outp
 config 4 = int4 / nf4-style global LUT / mx4 at m = 1), (c) times single-layer launches (what one
 Any4Linear.forward issues), (d) times the reference's CPU path on the host cores.
 
-N > 1: the projection is row-sharded (rank r owns rows [r*n, (r+1)*n) of an [N*n, k] weight; the
-activation is replicated); every step ends with the RCCL all-gather of the partial outputs, inside
-the timed region.  Per-GPU work is fixed as N grows -> "scaling": "weak".
+N > 1 (north_star / SURVEY.md 8e): ONE stack of L layers of n rows, row-sharded -- rank r owns rows
+[r*n/N, (r+1)*n/N) of every layer (packed codes, LUT rows, scale/zero columns); the activations are
+replicated; every step ends with ONE gather of the partial outputs of the whole layer batch, inside the
+timed region (RCCL all_gather_into_tensor over xGMI; the one-shot peer-write gather of
+include/peer_gather_hip.h timed beside it).  Total work is fixed as N grows -> "scaling": "strong";
+`value` = algorithmic bytes of the WHOLE problem per step / max-over-ranks step time, `roofline` = the
+per-rank kernel on its shard.  The weak-scaling protocol of rounds 1-5 (every rank its own n rows) stays
+as the extra key `weak_scaling`.
+--same-device / --dist-backend gloo: a dry run of the N > 1 path with every rank on GPU 0 (one-GPU boxes;
+RCCL refuses two ranks on one device, so the exchange is then the peer-write gather over IPC).
 """
 import argparse
 import ctypes
@@ -100,7 +107,7 @@ def make_args(_lib, w, x, q, lut, y, m, n, k, g, qtype, on_right, inner, batch, 
         m=m, wrows=n, k=k, group=g, qtype=QT[qtype], dtype=_lib.TG_BF16, w_on_right=1 if on_right else 0,
         inner_k_tiles=inner, batch=batch, stride_x=x.stride(0) * 2, stride_w=w.stride(0) * 4,
         stride_qinfo=q.stride(0) * q.element_size(), stride_lut=(lut.stride(0) * 2 if lut is not None else 0),
-        stride_y=y.stride(0) * 2, numerics={"fast": _lib.TG_NUM_FAST, "reference": _lib.TG_NUM_REFERENCE, "fast_mfma": _lib.TG_NUM_FAST_MFMA}[numerics])
+        stride_y=y.stride(0) * 2, numerics={"fast": _lib.TG_NUM_FAST, "reference": _lib.TG_NUM_REFERENCE, "fast_mfma": _lib.TG_NUM_FAST_MFMA, "fast_dot2": _lib.TG_NUM_FAST_DOT2}[numerics])
 
 
 def calibrate_x(run, x, y):
@@ -337,7 +344,7 @@ def decode_leg(device, steps=48, warmup=8, start_pos=128, layers=None):
     return out
 
 
-def decode_shaped_exchange(lib, _lib, w, x, sz, lut, y, m, n, k, g, inner, device, local_rank, stream, world, iters=256):
+def decode_shaped_exchange(lib, _lib, w, x, sz, lut, y, m, n, k, g, inner, device, local_rank, stream, world, rccl=True, iters=256):
     """N > 1 only: the exchange as a decode step issues it -- ONE layer per launch (this rank's [n, k] shard of an
     [N n, k] projection), then the gather of the [m, n] partial outputs (m n 2 bytes per rank: latency-bound), back to back on
     one stream, for (a) no exchange, (b) RCCL all_gather_into_tensor, (c) the one-shot peer-write gather of
@@ -365,13 +372,14 @@ def decode_shaped_exchange(lib, _lib, w, x, sz, lut, y, m, n, k, g, inner, devic
             after(i)
         e1.record(stream)
         torch.cuda.synchronize()
-        t = torch.tensor([e0.elapsed_time(e1) * 1e3 / iters], device=device, dtype=torch.float64)
+        t = torch.tensor([e0.elapsed_time(e1) * 1e3 / iters], device=device if rccl else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return round(float(t[0]), 3)
 
     out = {"layers_in_rotation": nl, "iters": iters, "bytes_per_rank_per_gather": m * n * 2,
-           "us_per_layer_gemv_only": timed(lambda i: None),
-           "us_per_layer_gemv_plus_rccl_all_gather": timed(lambda i: dist.all_gather_into_tensor(parts, y[i % nl]))}
+           "us_per_layer_gemv_only": timed(lambda i: None)}
+    if rccl:
+        out["us_per_layer_gemv_plus_rccl_all_gather"] = timed(lambda i: dist.all_gather_into_tensor(parts, y[i % nl]))
     pg, err = None, None
     try:  # (the constructor either succeeds on every rank or raises on every rank)
         from any4_amd.shard import PeerWriteGather
@@ -387,7 +395,7 @@ def decode_shaped_exchange(lib, _lib, w, x, sz, lut, y, m, n, k, g, inner, devic
             pg.check()
         except Exception as e:  # noqa: BLE001
             ok, err = 0, f"{type(e).__name__}: {e}"
-        t = torch.tensor([ok], device=device, dtype=torch.int32)
+        t = torch.tensor([ok], device=device if rccl else "cpu", dtype=torch.int32)
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         if int(t[0]) == 1:
             out["us_per_layer_gemv_plus_peer_write_gather"] = timed(lambda i: pg.gather(y[i % nl].view(m, n)))
@@ -402,6 +410,33 @@ def decode_shaped_exchange(lib, _lib, w, x, sz, lut, y, m, n, k, g, inner, devic
         out["peer_write_gather_error"] = err
     out["note"] = ("one single-layer tg_gemm_w4 launch per layer + the gather of its [m, n] outputs, back to back on one stream, max over ranks; "
                    "the stacked 4 MiB-per-rank all-gather inside `value` is the bandwidth-shaped exchange, this is the latency-shaped one a decode step issues")
+    return out
+
+
+def m1_contraction_ab(_lib, lib, ops, timed, args_default, tensors, shape, device, bytes_per_launch, rounds=6, reps=60):
+    """The headline launch with its m = 1 contraction (a) per lane on v_dot2_f32_bf16 (TG_NUM_FAST_DOT2) and (b) on the matrix core
+    (TG_NUM_FAST_MFMA: v_mfma_f32_32x32x16_bf16, north_star's "fed to bf16 MFMA"), ALTERNATING on this box in the sustained state of
+    the timed region: `rounds` alternations of `reps` back-to-back launches each between one HIP-event pair.  Which of the two the
+    library's default (TG_NUM_FAST) takes is reported next to it (`default_contraction`, tg_m1_default_contraction())."""
+    w, x, sz, lut, y = tensors
+    m, n, k, g, inner, L = shape
+    arms = {}
+    for name in ("fast_dot2", "fast_mfma"):
+        aa = make_args(_lib, w, x, sz, lut, y, m, n, k, g, "any4_rowwise", True, inner, L, name, native=True)
+        arms[name] = (aa, attach_workspace(lib, aa, device))
+    us = {name: [] for name in arms}
+    for _ in range(rounds):
+        for name, (aa, _ws) in arms.items():
+            us[name].append(timed(aa, reps))
+    out = {}
+    for name, v in us.items():
+        fr = [bytes_per_launch / (t * 1e-6) / 1e9 / HBM_PEAK_GBPS for t in v]
+        out[name] = {"launch_us": [round(t, 2) for t in v], "frac_mean": round(sum(fr) / len(fr), 4), "frac_min": round(min(fr), 4),
+                     "frac_max": round(max(fr), 4)}
+    d = out["fast_mfma"]["frac_mean"] / out["fast_dot2"]["frac_mean"] - 1.0
+    out["mfma_over_dot2_percent"] = round(100.0 * d, 2)
+    out["default_contraction"] = {0: "v_dot2", 1: "mfma"}.get(int(lib.tg_m1_default_contraction()), "?")
+    out["protocol"] = f"{rounds} alternations x {reps} stacked launches of {L} layers per arm, one HIP-event pair per arm and round, same process, after the timed region"
     return out
 
 
@@ -484,6 +519,9 @@ def main():
     ap.add_argument("--no-decode", action="store_true", help="skip the Llama-3-8B decode leg (config 5)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 PMC passes that fill roofline.traffic")
     ap.add_argument("--left", action="store_true", help="weights on the left (weightOnRight=False ops) in the library's default packed format")
+    ap.add_argument("--dist-backend", default=os.environ.get("BENCH_DIST_BACKEND", "nccl"), choices=("nccl", "gloo"),
+                    help="torch.distributed backend for N > 1 (nccl = RCCL; gloo: control plane only, the data exchange is the peer-write gather)")
+    ap.add_argument("--same-device", action="store_true", help="N > 1 dry run on a one-GPU box: every rank on GPU 0")
     ap.add_argument("--roofline-only", action="store_true",
                     help="skip the informational legs (other configs, single-layer, cpu): every launch of the stacked "
                          "kernel is then a timed-shape launch, which is what the rocprofv3 --stats pass wants")
@@ -496,25 +534,49 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    if a.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
 
     import torch.distributed as dist
 
     if world > 1:
-        dist.init_process_group(backend="nccl")  # RCCL on ROCm
+        dist.init_process_group(backend=a.dist_backend)  # "nccl" is RCCL on ROCm
+    rccl = world > 1 and a.dist_backend == "nccl"
+
+    def barrier():
+        # (gloo: a CPU barrier; the ranks' GPU work is fenced by the synchronize() next to every call)
+        dist.barrier()
+
+    def all_max(vals):
+        """max over ranks of a list of floats (on the device for RCCL, on the host for gloo)."""
+        if world == 1:
+            return [float(v) for v in vals]
+        t = torch.tensor(vals, dtype=torch.float64, device=device if rccl else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return [float(v) for v in t]
 
     from any4_amd import _lib, ops
 
     lib = _lib.load()
-    L, m, n, k, g, inner = a.layers, a.m, a.n, a.k, a.group, 4
+    L, m, n_full, k, g, inner = a.layers, a.m, a.n, a.k, a.group, 4
     on_right = not a.left
+    if n_full % (world * 16):
+        raise SystemExit(f"--n {n_full} must split into whole 16-row tiles per rank (N = {world})")
+    n = n_full // world          # this rank's rows of every layer (strong scaling: the whole problem is L layers of n_full rows)
     w, x, sz, lut, y = make_batch(L, m, n, k, g, inner, device, seed=1234 + rank, on_right=on_right)
-    if world > 1:
-        # replicated activations: every rank sees rank 0's x (as after the previous layer's all-gather)
-        dist.broadcast(x, src=0)
-        y_all = torch.empty(world, L, m, n, device=device, dtype=torch.bfloat16)
 
+    def replicate(t):
+        """Every rank sees rank 0's activations (as after the previous layer's gather)."""
+        if rccl:
+            dist.broadcast(t, src=0)
+        elif world > 1:
+            c = t.cpu()
+            dist.broadcast(c, src=0)
+            t.copy_(c)
+
+    replicate(x)
     args = make_args(_lib, w, x, sz, lut, y, m, n, k, g, "any4_rowwise", on_right, inner, L, native=True)
     args_ws = attach_workspace(lib, args, device)  # noqa: F841  (kept alive)
     plan = ops.gemm_w4_plan(m, n, k, g, QT["any4_rowwise"], on_right, inner, torch.bfloat16, L, "fast", weight_format="native")
@@ -524,18 +586,40 @@ def main():
         _lib.check(lib.tg_gemm_w4(ctypes.byref(aa), local_rank, stream.cuda_stream), "tg_gemm_w4")
 
     x_scale = calibrate_x(lambda: launch(args), x, y)
+    replicate(x)
+
+    # the exchange of a step: ONE gather of the [L m][n / N] partial outputs of the whole layer batch
+    pg, pg_err, y_all = None, None, None
     if world > 1:
-        dist.broadcast(x, src=0)
+        y_all = torch.empty(world, L, m, n, device=device, dtype=torch.bfloat16)   # RCCL's layout: rank-major
+        try:  # (the constructor either succeeds on every rank or raises on every rank)
+            from any4_amd.shard import PeerWriteGather
+
+            pg = PeerWriteGather(L * m, n, device=device, dtype=torch.bfloat16, timeout_us=5_000_000)   # -> [L m][n_full], feature order
+        except Exception as e:  # noqa: BLE001
+            pg_err = f"{type(e).__name__}: {e}"
+        if not rccl and pg is None:
+            raise SystemExit(f"bench.py: --dist-backend gloo needs the peer-write gather for the data exchange ({pg_err})")
+    exchange_kind = "none" if world == 1 else ("rccl_all_gather_into_tensor" if rccl else "peer_write_gather")
+
+    def gather_rccl():
+        dist.all_gather_into_tensor(y_all, y)
+
+    def gather_peer():
+        return pg.gather(y.view(L * m, n))
+
+    gather = (lambda: None) if world == 1 else (gather_rccl if rccl else gather_peer)
 
     def step():
         launch(args)
-        if world > 1:
-            dist.all_gather_into_tensor(y_all, y)
+        gather()
 
     def fence():
-        if world > 1:
-            dist.barrier()
+        # (the device is drained first: a rank arrives at the barrier when ITS work is done; then once more for RCCL's own barrier kernel)
         torch.cuda.synchronize()
+        if world > 1:
+            barrier()
+            torch.cuda.synchronize()
 
     if a.warmup > 0:  # the first warm-up step also pays for one-off initialisation (code load, RCCL communicator): keep it
         step()        # out of the clock that decides about settling steps
@@ -545,10 +629,7 @@ def main():
         step()
     fence()
     # untimed settling under the timed load; every rank derives the SAME number of steps
-    tw = torch.tensor([time.perf_counter() - t_w], device=device, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
-    t_warm = float(tw[0])
+    t_warm = all_max([time.perf_counter() - t_w])[0]
     per_step = t_warm / (a.warmup - 1) if a.warmup > 1 else 1.0e-3
     settle = 0 if t_warm >= a.settle_s else min(5000, int((a.settle_s - t_warm) / max(per_step, 1e-5)) + 1)
     for _ in range(settle):
@@ -569,50 +650,105 @@ def main():
         launch(args)
         if per_launch:
             ev[s][1].record(stream)
-            dist.all_gather_into_tensor(y_all, y)
+            gather()
     if not per_launch:
         ev[0][1].record(stream)
     fence()
     elapsed = time.perf_counter() - t0
     kern_ms = sum(e0.elapsed_time(e1) for e0, e1 in ev) / a.steps
 
-    t = torch.tensor([elapsed, kern_ms], device=device, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed, kern_ms = float(t[0]), float(t[1])
+    elapsed, kern_ms = all_max([elapsed, kern_ms])
 
-    bytes_layer = alg_bytes(m, n, k, g)
+    bytes_layer = alg_bytes(m, n, k, g)              # this rank's shard of one layer (x is read by every rank)
+    bytes_layer_full = alg_bytes(m, n_full, k, g)    # the layer of the whole problem (x counted once)
     bytes_step_rank = L * bytes_layer
     ms_per_step = elapsed / a.steps * 1e3
-    value = world * bytes_step_rank / (elapsed / a.steps) / 1e9
+    value = L * bytes_layer_full / (elapsed / a.steps) / 1e9
     achieved = bytes_step_rank / (kern_ms * 1e-3) / 1e9
 
-    exchange = None
-    if world > 1 and not a.roofline_only:
-        exchange = decode_shaped_exchange(lib, _lib, w, x, sz, lut, y, m, n, k, g, inner, device, local_rank, stream, world)
+    def timed_steps(fn, steps):
+        """`steps` calls of fn between two fences, max over ranks, ms per step."""
+        fn()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        fence()
+        return all_max([(time.perf_counter() - t0) / steps * 1e3])[0]
 
-    if rank == 0 and a.roofline_only:
-        print(json.dumps({"roofline_only": True, "launch_us": round(kern_ms * 1e3, 3), "GBps": round(achieved, 2),
-                          "steps": a.steps, "warmup": a.warmup, "settle_steps": settle, "layers": L, "kernel_plan": plan}), flush=True)
-    elif rank == 0:
-        def timed(aa, reps):
-            for _ in range(3):
-                launch(aa)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(stream)
-            for _ in range(reps):
-                launch(aa)
-            e1.record(stream)
-            torch.cuda.synchronize()
-            return e0.elapsed_time(e1) * 1e3 / reps  # us per launch
+    def timed(aa, reps):
+        for _ in range(3):
+            launch(aa)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(reps):
+            launch(aa)
+        e1.record(stream)
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e3 / reps  # us per launch
 
+    slope_us = main_check = m1_ab = None
+    if rank == 0 and not a.roofline_only:
         # marginal rate (SURVEY 8d): slope of launch time over the number of stacked layers -- measured first, while the
         # clock is still in the steady state of the timed region
         half = make_args(_lib, w, x, sz, lut, y, m, n, k, g, "any4_rowwise", on_right, inner, L // 2, native=True)
         t_half, t_full = timed(half, 40), timed(args, 40)
         slope_us = (t_full - t_half) / (L - L // 2)
+        if m == 1 and on_right and world == 1:
+            m1_ab = m1_contraction_ab(_lib, lib, ops, timed, args, (w, x, sz, lut, y), (m, n, k, g, inner, L), device, bytes_step_rank)
         # (a) the timed launch's own output against the oracle
         main_check = check_layers(w, x, sz, lut, y, g, "any4_rowwise", on_right, inner, plan, native=True)
+
+    exchange = strong_extra = weak = None
+    if world > 1 and not a.roofline_only:
+        # the same strong-scaling step with the other exchange, and with none (what the exchange costs)
+        side = min(a.steps, 50)
+        strong_extra = {"ms_per_step_no_exchange": round(timed_steps(lambda: launch(args), side), 5)}
+        both = pg is not None and rccl
+        if both:
+            ok = 1
+            try:
+                for _ in range(3):
+                    gather_peer()
+                pg.check()
+            except Exception as e:  # noqa: BLE001
+                ok, pg_err = 0, f"{type(e).__name__}: {e}"
+            if min(all_max([-float(ok)])) == -1.0 and ok:   # every rank's peer-write gather worked
+                ms_peer = timed_steps(lambda: (launch(args), gather_peer()), side)
+                strong_extra["peer_write_gather"] = {"ms_per_step": round(ms_peer, 5), "value_GBps": round(L * bytes_layer_full / ms_peer / 1e6, 2)}
+        if pg_err is not None:
+            strong_extra["peer_write_gather_error"] = pg_err
+        strong_extra["note"] = (f"{side} steps each, same protocol as the timed region: the kernel alone, and (RCCL runs) the step with the one-shot "
+                                "peer-write gather (include/peer_gather_hip.h: [L m][n] in feature order) instead of RCCL's all_gather_into_tensor")
+        exchange = decode_shaped_exchange(lib, _lib, w, x, sz, lut, y, m, n, k, g, inner, device, local_rank, stream, world, rccl)
+        if pg is not None:
+            pg.close()
+            pg = None
+        # the weak-scaling protocol of rounds 1-5: every rank ITS OWN n_full rows of every layer, RCCL all-gather of y per step
+        torch.cuda.synchronize()
+        del w, sz, lut
+        torch.cuda.empty_cache()
+        ww, _, wq, wl, wy = make_batch(L, m, n_full, k, g, inner, device, seed=4321 + rank, on_right=on_right)
+        wargs = make_args(_lib, ww, x, wq, wl, wy, m, n_full, k, g, "any4_rowwise", on_right, inner, L, native=True)
+        wargs_ws = attach_workspace(lib, wargs, device)  # noqa: F841
+        wy_all = torch.empty(world, L, m, n_full, device=device, dtype=torch.bfloat16) if rccl else None
+
+        def weak_step():
+            launch(wargs)
+            if rccl:
+                dist.all_gather_into_tensor(wy_all, wy)
+
+        ms_weak = timed_steps(weak_step, side)
+        weak = {"value": round(world * L * bytes_layer_full / ms_weak / 1e6, 2), "unit": "GB/s", "ms_per_step": round(ms_weak, 5), "steps": side,
+                "scaling": "weak", "exchange": "rccl_all_gather_into_tensor" if rccl else "none (gloo dry run)",
+                "note": f"every rank its own {n_full} rows of each of the {L} layers (an [N n, k] projection), all-gather of the [L m][n] outputs per step"}
+        del ww, wq, wl, wy, wy_all
+        w = sz = lut = None
+
+    if rank == 0 and a.roofline_only:
+        print(json.dumps({"roofline_only": True, "launch_us": round(kern_ms * 1e3, 3), "GBps": round(achieved, 2),
+                          "steps": a.steps, "warmup": a.warmup, "settle_steps": settle, "layers": L, "kernel_plan": plan}), flush=True)
+    elif rank == 0:
 
         def leg(qtype, mm, nn, kk, gg, on_right, layers, note, numerics="fast", native=True):
             """One more BASELINE config as a stacked launch of `layers` layers (same protocol: steady clock, HIP events).
@@ -742,17 +878,19 @@ def main():
             "settle_steps": settle,
             "ms_per_step": round(ms_per_step, 5),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong",
             "vs_baseline": None,
             "dtype": "bf16",
             "data": "synthetic",
             "config": {
-                "workload": f"any4 W4A16 GEMV m={m} n={n} k={k} g={g} per-row LUT, Bint4 innerKTiles=4, default (group-scaled) numerics; "
+                "workload": f"any4 W4A16 GEMV m={m} n={n_full} k={k} g={g} per-row LUT, Bint4 innerKTiles=4, default (group-scaled) numerics; "
                             f"one step = {L} independent layers (distinct cold weights) in one stacked launch"
-                            + (f"; rows sharded over {world} ranks + RCCL all-gather of y" if world > 1 else ""),
-                "layers_per_step": L, "m": m, "n": n, "k": k, "group": g,
+                            + (f"; the {n_full} rows of every layer sharded over {world} ranks ({n} rows each, x replicated) + one gather of the layer batch's "
+                               f"outputs per step ({exchange_kind})" if world > 1 else ""),
+                "layers_per_step": L, "m": m, "n": n_full, "k": k, "group": g, "rows_per_rank": n, "exchange": exchange_kind,
                 "x_scale": x_scale,  # activations = randn * this power of two (calibrate_x): max|y| in (0.95, 1.9]
-                "algorithmic_bytes_per_layer": bytes_layer,
+                "algorithmic_bytes_per_layer": bytes_layer_full,
+                "algorithmic_bytes_per_layer_per_rank": bytes_layer,
                 "numerics": "TG_NUM_FAST (group-scaled: scale / zero applied per quantisation group to the f32 accumulator; the reference "
                             "rounds every dequantised weight to bf16 first, MatrixLayoutB.cuh:1042-1046 -- see `numerics_check` for the distance "
                             "and `reference_numerics` for the kernels with the reference's own arithmetic)",
@@ -761,8 +899,12 @@ def main():
             "numerics_check": main_check,
             "roofline": {
                 "bound": "hbm",
-                "kernel": {"pair": "w4_gemm_pair_kernel<BF16, I=4> (persistent, 64-row work items, pair-table lookups, v_dot2 contraction at m = 1, group-scaled accumulators)",
+                "kernel": {"pair": ("w4_gemm_xr_kernel<BF16> / w4_gemm_pair_kernel<BF16, I=4> (persistent work items, pair-table lookups, m = 1 contraction on the matrix core: "
+                                    "v_mfma_f32_16x16x32_bf16 / 32x32x16_bf16, group-scaled accumulators)" if (m == 1 and lib.tg_m1_default_contraction() == 1) else
+                                    "w4_gemm_pair_kernel<BF16, I=4> (persistent, 64-row work items, pair-table lookups, v_dot2 contraction at m = 1, group-scaled accumulators; "
+                                    "the matrix-core contraction timed beside it, alternating: `m1_contraction_ab`)"),
                            "stream": "w4_gemm_stream_kernel<BF16, Bint4 innerK=4>", "splitk": "w4_gemm_kernel<BF16>"}[plan],
+                "m1_default_contraction": {0: "v_dot2", 1: "mfma"}.get(int(lib.tg_m1_default_contraction())),
                 "achieved": round(achieved, 2),
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
@@ -794,6 +936,13 @@ def main():
             },
             "decode_llama3_8b": decode,
         }
+        if m1_ab is not None:
+            out["m1_contraction_ab"] = m1_ab
+        if world > 1:
+            out["strong_scaling"] = {"value": round(value, 2), "unit": "GB/s", "ms_per_step": round(ms_per_step, 5), "exchange": exchange_kind,
+                                     "rows_per_rank": n, "per_rank_roofline_frac": round(achieved / HBM_PEAK_GBPS, 4),
+                                     "per_rank_kernel_us": round(kern_ms * 1e3, 3), **(strong_extra or {})}
+            out["weak_scaling"] = weak
         if exchange is not None:
             out["decode_shaped_exchange"] = exchange
         if world == 1 and not a.no_cpu_baseline:

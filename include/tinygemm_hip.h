@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define TG_ABI_VERSION 6
+#define TG_ABI_VERSION 7
 
 #if defined(__GNUC__)
 #define TG_API __attribute__((visibility("default")))
@@ -74,14 +74,17 @@ enum {
  *   TG_NUM_REFERENCE  w = RNE16(fma(lut[code], scale, zero)) per element exactly as the reference kernels compute it
  *                     (MatrixLayoutB.cuh:1042-1046, MatrixLayoutA.cuh:747-754): bit-identical weights, e.g. the identity
  *                     known-answer tests of the reference come out bit-equal.                                           */
-enum { TG_NUM_FAST = 0, TG_NUM_REFERENCE = 1, TG_NUM_FAST_MFMA = 2 };
+enum { TG_NUM_FAST = 0, TG_NUM_REFERENCE = 1, TG_NUM_FAST_MFMA = 2, TG_NUM_FAST_DOT2 = 3 };
 /*   TG_NUM_FAST_MFMA  TG_NUM_FAST with the m = 1 contraction on the matrix cores: since round 3 the default contracts ONE activation
  *                     row with per-lane v_dot2_f32_bf16 (a 32x32x16 MFMA spends 16384 multiplier slots on 512 useful products and,
  *                     under the power cap, clock: 76 -> 81 % of the HBM roofline).  This value keeps the matrix-core contraction
  *                     reachable for stacked m = 1 launches so that both can be timed and compared (bench.py `m1_mfma`,
  *                     tests/test_gpu_fast.py): on w4_gemm_xr_kernel's 16x16x32 MFMAs where that kernel applies (k = 4096, rows a
  *                     multiple of 64, >= 512 work items: 79 %), else on the 32x32x16 ones of w4_gemm_pair_kernel (76 %);
- *                     everything else runs as TG_NUM_FAST. */
+ *                     everything else runs as TG_NUM_FAST.
+ *   TG_NUM_FAST_DOT2  TG_NUM_FAST with the m = 1 contraction of stacked launches pinned to the per-lane v_dot2_f32_bf16 (the other arm of
+ *                     the same A/B).  Which of the two TG_NUM_FAST itself takes is a build-time default, reported by
+ *                     tg_m1_default_contraction() and timed both ways, alternating, by bench.py (`m1_contraction_ab`). */
 
 /* precondition failures (wording of the matching TORCH_CHECK is in tg_error_string) */
 enum {
@@ -102,6 +105,9 @@ enum {
 };
 
 TG_API int tg_abi_version(void);
+/* ABI 7: which contraction a STACKED one-row launch takes under TG_NUM_FAST: 0 = per-lane v_dot2_f32_bf16, 1 = the matrix core
+ * (v_mfma_f32_16x16x32 / 32x32x16_bf16).  TG_NUM_FAST_DOT2 / TG_NUM_FAST_MFMA pin either one. */
+TG_API int tg_m1_default_contraction(void);
 TG_API const char* tg_error_string(int code);
 
 /* ---- layout conversion ------------------------------------------------------------------ */

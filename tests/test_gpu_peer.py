@@ -298,3 +298,60 @@ def test_peer_that_never_arrives_sets_status_and_poisons_its_slice():
     assert 0.25 < waited < 5.0, waited          # bounded by timeout_us = 0.3 s, never a hang
     assert own_ok and peer_nan                  # own slice intact, the missing slice is NaN (loud)
     assert raised_check and raised_poll         # both the synchronising and the non-blocking check report it
+
+
+def _run_bench_two_ranks(backend, extra=(), timeout=420):
+    """`python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2 ...` exactly as the driver launches it, with both ranks on
+    GPU 0 (--same-device) when the box has one GPU.  Returns (returncode, parsed JSON line or None, tail of the output)."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    multi = torch.cuda.device_count() >= 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+           "--layers", "64", "--settle-s", "0", "--no-pmc", "--no-decode", "--no-cpu-baseline", "--dist-backend", backend,
+           *([] if multi else ["--same-device"]), *extra]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    try:
+        r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=timeout)
+    except subprocess.TimeoutExpired as e:
+        return -9, None, f"timeout: {(e.stdout or b'')[-2000:]!r} {(e.stderr or b'')[-2000:]!r}"
+    line = None
+    for ln in r.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = json.loads(ln)
+    return r.returncode, line, (r.stdout[-1500:] + "\n" + r.stderr[-3000:])
+
+
+def test_bench_strong_scaling_leg_two_ranks():
+    """SURVEY.md 8(e) / north_star: `bench.py --gpus 2` partitions ONE stack of n = 4096 layers into rows [r n/2, (r+1) n/2) per rank,
+    gathers the layer batch's outputs once per step and reports the WHOLE problem's GB/s ("scaling": "strong") with the per-rank
+    roofline fraction, the weak-scaling protocol as an extra key and the decode-shaped (latency) exchange.  Two ranks: on two GPUs over
+    RCCL where the box has them; on a one-GPU box RCCL is tried first (it refuses two ranks on one device) and the same code path then
+    runs with the gloo control plane and the peer-write gather over IPC -- so the first run on a real node is not the first run of this
+    code."""
+    rc, line, tail = _run_bench_two_ranks("nccl", timeout=420 if torch.cuda.device_count() >= 2 else 150)
+    used = "nccl"
+    if rc != 0 or line is None:
+        assert torch.cuda.device_count() < 2, f"RCCL run failed on a multi-GPU box:\n{tail}"
+        rc, line, tail = _run_bench_two_ranks("gloo")
+        used = "gloo"
+    assert rc == 0 and line is not None, tail
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["unit"] == "GB/s" and line["value"] > 0
+    cfg = line["config"]
+    assert cfg["n"] == 4096 and cfg["rows_per_rank"] == 2048 and cfg["layers_per_step"] == 64
+    assert cfg["exchange"] == ("rccl_all_gather_into_tensor" if used == "nccl" else "peer_write_gather")
+    assert cfg["algorithmic_bytes_per_layer"] == 9060352
+    ss, ws = line["strong_scaling"], line["weak_scaling"]
+    assert ss["rows_per_rank"] == 2048 and 0 < ss["per_rank_roofline_frac"] < 1 and ss["ms_per_step_no_exchange"] > 0
+    assert ws["scaling"] == "weak" and ws["value"] > 0
+    # the whole problem's rate from the line's own numbers
+    assert abs(line["value"] - 64 * 9060352 / (line["ms_per_step"] * 1e-3) / 1e9) <= 0.02 * line["value"]
+    assert line["numerics_check"]["max_abs_err_vs_reference"] <= 1e-2          # rank 0's shard of the timed launch against the oracle
+    ex = line["decode_shaped_exchange"]
+    assert ex["us_per_layer_gemv_only"] > 0 and ("us_per_layer_gemv_plus_peer_write_gather" in ex or "peer_write_gather_error" in ex)
+    if used == "nccl":
+        assert ex["us_per_layer_gemv_plus_rccl_all_gather"] > 0
+    print(f"bench.py --gpus 2 ran with backend {used}: value {line['value']} GB/s, per-rank frac {ss['per_rank_roofline_frac']}")
