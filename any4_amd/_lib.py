@@ -12,7 +12,7 @@ TG_BF16, TG_F16 = 0, 1
 TG_Q_INT4, TG_Q_ANY4_GLOBAL, TG_Q_ANY4_ROWWISE, TG_Q_MX4, TG_Q_INT8 = 0, 1, 2, 3, 4
 TG_NUM_FAST, TG_NUM_REFERENCE, TG_NUM_FAST_MFMA, TG_NUM_FAST_DOT2 = 0, 1, 2, 3
 TG_ABI_VERSION = 7
-TG_PLAN_SPLITK, TG_PLAN_STREAM, TG_PLAN_PAIR, TG_PLAN_PAIR_XR, TG_PLAN_GEMV = 1, 2, 3, 4, 5
+TG_PLAN_SPLITK, TG_PLAN_STREAM, TG_PLAN_PAIR, TG_PLAN_PAIR_XR, TG_PLAN_GEMV, TG_PLAN_TILE = 1, 2, 3, 4, 5, 6
 TG_LAYOUT_RM, TG_LAYOUT_TC_A = 0, 1
 TG_E_LAYOUT = -12
 TG_E_FUSION = -13
@@ -78,6 +78,7 @@ SYMBOLS = {
     "tg_dequant_int4": [_vp, _i64, _vp, ctypes.c_int, _vp],
     "tg_unpack_int4": [_vp, ctypes.c_int, _i64, _i64, ctypes.c_int, _vp, ctypes.c_int, _vp],
     "tg_dequant_w4": [_vp, _vp, _vp, _i64, _i64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, ctypes.c_int, _vp],
+    "tg_dequant_w4_panel": [_vp, _vp, _vp, _i64, _i64, _i64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, ctypes.c_int, _vp],
     "tg_gemm_w4": [ctypes.POINTER(W4Gemm), ctypes.c_int, _vp],
     "tg_gemm_w4_plan": [ctypes.POINTER(W4Gemm), ctypes.c_int],
     "tg_gemm_w4_workspace_bytes": [ctypes.POINTER(W4Gemm)],

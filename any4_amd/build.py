@@ -31,6 +31,7 @@ UNITS = [
     ("tg_pair16", "tg_pair16.hip", []),
     ("tg_splitk", "tg_splitk.hip", []),
     ("tg_gemv", "tg_gemv.hip", []),
+    ("tg_tile", "tg_tile.hip", []),
     ("tinygemm_hip", "tinygemm_hip.hip", []),
 ]
 FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wno-comment", "-Wno-int-to-pointer-cast"]

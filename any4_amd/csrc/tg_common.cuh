@@ -9,6 +9,7 @@
 //   tg_pair16.hip      w4_gemm_pair16_kernel     (w4_gemm_pair16.cuh)
 //   tg_xr.hip          w4_gemm_xr_kernel         (w4_gemm_xr.cuh)
 //   tg_gemv.hip        w4_gemv_kernel            (w4_gemv.cuh)
+//   tg_tile.hip        w4_gemm_tile_kernel       (w4_gemm_tile.cuh)
 // Kernels and their helpers stay in each unit's anonymous namespace (one device code object per unit, no symbol shared between
 // them); only GemmParams and the tgx:: functions cross unit boundaries.
 #pragma once
@@ -174,6 +175,7 @@ int pair16(int dt, int I, bool qmx, const GemmParams& p, int64_t batch, hipStrea
 int pair16_loop(int dt, int I, bool qmx, const GemmParams& p, int64_t batch, hipStream_t st);  // w4_gemm_pair16_loop.cuh: one layer, more 16-row tiles than CUs
 int splitk(int dt, bool layout_a, int canon, bool qmx, int waves, const GemmParams& p, dim3 grid, hipStream_t st);
 int gemv(int dt, int I, bool qmx, GemmParams& p, int64_t batch, hipStream_t st);
+int tile(int dt, int I, bool qmx, const GemmParams& p, int64_t batch, hipStream_t st);  // w4_gemm_tile.cuh: many activation rows
 inline int pair(int dt, int I, bool qmx, GemmParams& p, int64_t batch, hipStream_t st) {
   return dt == TG_BF16 ? pair_bf16(I, qmx, p, batch, st) : pair_f16(I, qmx, p, batch, st);
 }
@@ -353,6 +355,9 @@ inline int cu_count() {
 #endif
 #ifndef TG_B16_CHUNK
 #define TG_B16_CHUNK 4         // consecutive 32-row work items per workgroup visit of those kernels (1 / 4 / 8 within 1 %)
+#endif
+#ifndef TG_TILE_MIN_M
+#define TG_TILE_MIN_M 65  // activation rows from which a call takes the LDS-tiled MFMA GEMM (w4_gemm_tile.cuh): beyond the 64 rows the row blocks of the group-scaled kernels cover
 #endif
 #ifndef TG_M1_DEFAULT_MFMA
 #define TG_M1_DEFAULT_MFMA 0  // which contraction a STACKED m = 1 launch takes under TG_NUM_FAST: 0 = per-lane v_dot2, 1 = the matrix core (tg_m1_default_contraction())

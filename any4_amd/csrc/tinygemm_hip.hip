@@ -614,7 +614,13 @@ int tg_unpack_int4(const int32_t* packed, int layout_a, int64_t rows, int64_t k,
 
 int tg_dequant_w4(const void* packed, const void* qinfo, const void* lut, int64_t wrows, int64_t k, int group, int qtype, int dtype, int I, void* out,
                   int device, tg_stream_t stream) {
+  return tg_dequant_w4_panel(packed, qinfo, lut, wrows, wrows, k, group, qtype, dtype, I, out, device, stream);
+}
+
+int tg_dequant_w4_panel(const void* packed, const void* qinfo, const void* lut, int64_t wrows, int64_t wrows_q, int64_t k, int group, int qtype,
+                        int dtype, int I, void* out, int device, tg_stream_t stream) {
   if (!packed || !qinfo || !out) return TG_E_NULL;
+  if (wrows_q < wrows) return TG_E_SHAPE;
   if (!(qtype == TG_Q_INT4 || qtype == TG_Q_ANY4_GLOBAL || qtype == TG_Q_ANY4_ROWWISE)) return TG_E_QTYPE;
   if (qtype != TG_Q_INT4 && !lut) return TG_E_NULL;
   if (!(dtype == TG_BF16 || dtype == TG_F16)) return TG_E_DTYPE;
@@ -633,7 +639,7 @@ int tg_dequant_w4(const void* packed, const void* qinfo, const void* lut, int64_
   const dim3 grid((unsigned)cdiv(k / 8 / chk, 256), (unsigned)(wrows < 65535 ? wrows : 65535), (unsigned)cdiv(wrows, 65535));
 #define TG_DQ2(DTT, I_, C_)                                                                                                                       \
   hipLaunchKernelGGL((dequant_w4_kernel<DTT, I_, C_>), grid, dim3(bs), 0, (hipStream_t)stream, (const uint32_t*)packed, (const uint16_t*)qinfo, \
-                     (const uint16_t*)lut, (uint16_t*)out, wrows, wrows, k, ksuper, gshift, qtype)
+                     (const uint16_t*)lut, (uint16_t*)out, wrows, wrows_q, k, ksuper, gshift, qtype)
 #define TG_DQ(DTT, I_) do { if (chk == 4) TG_DQ2(DTT, I_, 4); else TG_DQ2(DTT, I_, 1); } while (0)
   if (dtype == TG_BF16) { if (I == 2) TG_DQ(BF16, 2); else if (I == 4) TG_DQ(BF16, 4); else TG_DQ(BF16, 8); }
   else { if (I == 2) TG_DQ(F16, 2); else if (I == 4) TG_DQ(F16, 4); else TG_DQ(F16, 8); }
@@ -863,6 +869,16 @@ static int gemm_w4_impl(const tg_w4_gemm* caller, int device, tg_stream_t stream
       return dry ? r16 : 0;
     }
     p.ws_need = 0;
+  }
+  // MANY activation rows (a prefill through the modules): the LDS-tiled MFMA GEMM that dequantises the weights once per 128-row tile of m
+  // instead of once per 16 rows (w4_gemm_tile.cuh; the reference's weights bit for bit, so it serves both numerics settings).  4096^2 at
+  // m = 128 / 256 / 1024: 37 / 40 / 69 us against 37.8 / 44.5 / 166 on the stream kernel and 55 / 102 / 427 in 16-row blocks.
+  if (on_right && a->m >= TG_TILE_MIN_M) {
+    const int trc = tgx::tile(a->dtype, I, a->qtype == TG_Q_MX4, p, batch, st);
+    if (trc != TG_PAIR_NA) {
+      if (ws_need) *ws_need = 0;
+      return trc;
+    }
   }
   const int rc = launch_w4(a->dtype, !on_right, canon, a->qtype == TG_Q_MX4, p, coltiles, batch, st);
   if (ws_need) *ws_need = (rc == TG_PLAN_PAIR || rc == TG_PLAN_PAIR_XR) ? p.ws_need : 0;

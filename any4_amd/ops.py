@@ -167,7 +167,8 @@ def aside_format(w: torch.Tensor, k: int) -> str:
     return "native"
 
 
-_PLANS = {_lib.TG_PLAN_SPLITK: "splitk", _lib.TG_PLAN_STREAM: "stream", _lib.TG_PLAN_PAIR: "pair", _lib.TG_PLAN_PAIR_XR: "pair_xr", _lib.TG_PLAN_GEMV: "gemv"}
+_PLANS = {_lib.TG_PLAN_SPLITK: "splitk", _lib.TG_PLAN_STREAM: "stream", _lib.TG_PLAN_PAIR: "pair", _lib.TG_PLAN_PAIR_XR: "pair_xr", _lib.TG_PLAN_GEMV: "gemv",
+          _lib.TG_PLAN_TILE: "tile"}
 
 
 def gemm_w4_plan(m: int, wrows: int, k: int, group: int, qtype: int, weight_on_right: bool = True, inner_k_tiles: int = 4,
@@ -403,27 +404,53 @@ _LARGE_M = None
 
 
 def large_m_rows(weights: int = 0) -> int:
-    """Activation rows from which a 4-bit GEMM call dequantises the weights once and multiplies with the GEMM library
-    (ANY4_LARGE_M overrides; 0 = never).  Measured on MI355X (profiles/r05_large_m.txt), 4-bit kernels vs
-    dequantise (14 us for 4096 x 4096) + GEMM, one layer per graph node: 4096 x 4096 at 64 / 96 / 128 / 256 / 1024 rows 28.6 / 35.9 / 36.9 /
-    41.7 / 166 vs 26.8 / 31.4 / 33.9 / 32.2 / 50 us; 14336 x 4096 at 64 / 96 / 128 / 256: 53.5 / 76 / 85 / 152 vs 68.7 / 68.2 / 70 / 85: beyond the
-    64 rows the row blocks of the 4-bit kernels cover; from 96 rows for layers of 32 M weights or more."""
+    """Activation rows from which a 4-bit GEMM call takes the OPT-IN library route -- dequantise the weights (tg_dequant_w4, in bounded
+    row panels) and multiply with the GEMM library (torch.matmul = hipBLASLt) -- instead of the library's own kernels; 0 / unset = never
+    (the default: every call runs this library's kernels; beyond 64 rows that is the LDS-tiled MFMA GEMM of w4_gemm_tile.cuh, plan
+    'tile').  ANY4_LARGE_M_GEMM=library turns the route on from 65 rows (96 for layers of 32 M weights or more), ANY4_LARGE_M=<rows> from
+    that many.  Measured on MI355X, one 4096 x 4096 layer per graph node at 256 / 512 / 1024 rows: own kernel 40 / 46 / 69 us, dequantise
+    (14 us) + hipBLASLt 32 / 38 / 50 us (profiles/r06_tile_gemm.txt): the vendor GEMM is ~1.3 x faster there and
+    costs a transient 16-bit copy of a weight panel (at most ANY4_DEQUANT_PANEL_MB, default 256 MB)."""
     global _LARGE_M
     if _LARGE_M is None:
         v = os.environ.get("ANY4_LARGE_M")
-        _LARGE_M = -1 if v is None else (int(v) if int(v) > 0 else 1 << 62)
+        if v is not None:
+            _LARGE_M = int(v) if int(v) > 0 else 1 << 62
+        else:
+            _LARGE_M = -1 if os.environ.get("ANY4_LARGE_M_GEMM", "") == "library" else 1 << 62
     if _LARGE_M >= 0:
         return _LARGE_M
     return 96 if weights >= (1 << 25) else 65
 
 
-def dequant_w4(w: torch.Tensor, qinfo: torch.Tensor, lut, q_group: int, qtype: int, k: int, inner: int, wrows: int) -> torch.Tensor:
+def dequant_w4(w: torch.Tensor, qinfo: torch.Tensor, lut, q_group: int, qtype: int, k: int, inner: int, wrows: int, rows=None) -> torch.Tensor:
     """[wrows][k] 16-bit = the dequantised weights of a Bint4-packed tensor (or the native weights-on-the-left tensor: the same words):
-    RNE16(fma(lut[row][code], scale, zero)) per element (tg_dequant_w4)."""
-    out = torch.empty((wrows, k), dtype=qinfo.dtype, device=w.device)
-    _lib.check(_L.tg_dequant_w4(w.data_ptr(), qinfo.data_ptr(), None if lut is None else lut.data_ptr(), wrows, k, q_group, qtype,
-                                TG_BF16 if qinfo.dtype == torch.bfloat16 else TG_F16, inner, out.data_ptr(), _dev(w), _stream(w)), "tg_dequant_w4")
+    RNE16(fma(lut[row][code], scale, zero)) per element (tg_dequant_w4).  rows = (r0, r1): that panel of weight rows only (multiples of 8)."""
+    r0, r1 = (0, wrows) if rows is None else rows
+    out = torch.empty((r1 - r0, k), dtype=qinfo.dtype, device=w.device)
+    ksuper = k // (16 * inner)
+    wp = w.data_ptr() + (r0 // 8) * ksuper * 32 * (inner // 2) * 4
+    # qinfo is [k / g][wrows][2]: a row panel starts r0 entries into every group's row (the kernel indexes group * wrows + row)
+    qp = qinfo.data_ptr() + r0 * 2 * qinfo.element_size()
+    lp = None if lut is None else (lut.data_ptr() + (r0 * 16 * lut.element_size() if lut.dim() == 2 else 0))
+    _lib.check(_L.tg_dequant_w4_panel(wp, qp, lp, r1 - r0, wrows, k, q_group, qtype,
+                                      TG_BF16 if qinfo.dtype == torch.bfloat16 else TG_F16, inner, out.data_ptr(), _dev(w), _stream(w)), "tg_dequant_w4")
     return out
+
+
+def _library_gemm_w4(x, w, qinfo, lut, q_group, qtype, k, inner, wrows):
+    """The opt-in route of large_m_rows: y = x . dequant(W)^T with the weights dequantised in row panels of bounded size."""
+    cap = int(max(0.01, float(os.environ.get("ANY4_DEQUANT_PANEL_MB", "256"))) * (1 << 20))
+    panel = max(8, min(wrows, (cap // (2 * k)) // 8 * 8))
+    if x.data_ptr() % 16:
+        x = x.clone()
+    if panel >= wrows:
+        return torch.matmul(x, dequant_w4(w, qinfo, lut, q_group, qtype, k, inner, wrows).t())
+    y = torch.empty((x.shape[0], wrows), dtype=x.dtype, device=x.device)
+    for r0 in range(0, wrows, panel):
+        r1 = min(wrows, r0 + panel)
+        torch.matmul(x, dequant_w4(w, qinfo, lut, q_group, qtype, k, inner, wrows, rows=(r0, r1)).t(), out=y[:, r0:r1])
+    return y
 
 
 def _w4_rm(A, B, q_group, qinfo, lut, qtype, weight_on_right, opname, frag=False):
@@ -486,13 +513,9 @@ def _w4_rm(A, B, q_group, qinfo, lut, qtype, weight_on_right, opname, frag=False
     if lut is not None and lut.data_ptr() % 16:
         lut = lut.clone()
     if not frag and m >= large_m_rows(wrows * k) and qtype != TG_Q_MX4 and k % 512 == 0 and (weight_on_right or w_format == _lib.TG_WFMT_ROWS):
-        # MANY activation rows: the 4-bit kernels walk the weights once per 16-row tile of m (as the reference's grid does) -- from
-        # about a hundred rows on it is cheaper to dequantise the matrix once (tg_dequant_w4: the reference's per-element formula,
-        # bit for bit) and hand the product to the GEMM library (hipBLASLt behind torch.matmul: 16-bit operands, f32 accumulation)
-        wdq = dequant_w4(w, qinfo, lut, q_group, qtype, k, inner, wrows)
-        if x.data_ptr() % 16:
-            x = x.clone()
-        y = torch.matmul(x, wdq.t())
+        # OPT-IN (ANY4_LARGE_M_GEMM=library / ANY4_LARGE_M): dequantise in bounded row panels and hand the product to the GEMM library
+        # (hipBLASLt behind torch.matmul).  The default keeps every call on this library's own kernels (tg_gemm_w4 -> plan 'tile').
+        y = _library_gemm_w4(x, w, qinfo, lut, q_group, qtype, k, inner, wrows)
         bias = _take_bias(wrows, x)
         return y if bias is None else y + bias
     if frag:

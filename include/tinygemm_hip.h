@@ -246,8 +246,11 @@ TG_API int tg_gemm_w4(const tg_w4_gemm* args, int device, tg_stream_t stream);
  *                                          2 ... 16 activation rows, k = 4096, stacked launches)
  *   TG_PLAN_GEMV    w4_gemv_kernel         the same tables and numerics for ONE layer per launch with 1 ... 4 activation rows (a
  *                                          decode step's GEMMs): one workgroup per CU over a contiguous range of weight rows,
- *                                          v_dot2 contraction, fused norm / residual / SwiGLU stages  */
-enum { TG_PLAN_SPLITK = 1, TG_PLAN_STREAM = 2, TG_PLAN_PAIR = 3, TG_PLAN_PAIR_XR = 4, TG_PLAN_GEMV = 5 };
+ *                                          v_dot2 contraction, fused norm / residual / SwiGLU stages
+ *   TG_PLAN_TILE    w4_gemm_tile_kernel    more than 64 activation rows (Bint4 innerKTiles 4, int4 / any4): an LDS-tiled MFMA GEMM
+ *                                          (128 x 64 / 128 tiles) whose weight tile is dequantised on the way in -- the reference's
+ *                                          weights bit for bit (both numerics settings), no workspace  */
+enum { TG_PLAN_SPLITK = 1, TG_PLAN_STREAM = 2, TG_PLAN_PAIR = 3, TG_PLAN_PAIR_XR = 4, TG_PLAN_GEMV = 5, TG_PLAN_TILE = 6 };
 enum { TG_LAYOUT_RM = 0, TG_LAYOUT_TC_A = 1 };
 TG_API int tg_gemm_w4_plan(const tg_w4_gemm* args, int device);
 
@@ -265,6 +268,10 @@ TG_API int64_t tg_gemm_w4_workspace_bytes(const tg_w4_gemm* args);
  * k % 512 == 0; mx4 is not covered (TG_E_QTYPE). */
 TG_API int tg_dequant_w4(const void* packed, const void* qinfo, const void* lut, int64_t wrows, int64_t k, int group, int qtype, int dtype,
                          int inner_k_tiles, void* out, int device, tg_stream_t stream);
+/* ABI 7: a PANEL of `wrows` weight rows of a matrix whose quantisation info has `wrows_q` rows per group (qinfo [k / group][wrows_q][2]):
+ * packed / qinfo / lut point at the panel's first row (a multiple of 8); out [wrows][k].  tg_dequant_w4 is the panel wrows_q = wrows. */
+TG_API int tg_dequant_w4_panel(const void* packed, const void* qinfo, const void* lut, int64_t wrows, int64_t wrows_q, int64_t k, int group,
+                               int qtype, int dtype, int inner_k_tiles, void* out, int device, tg_stream_t stream);
 
 /*
  * int8 weights.

@@ -16,6 +16,8 @@ Tolerances (stated once, used everywhere):
   * against the reference's own CPU dequant-matmul (fixture H-Q): max-abs <= 1e-2 at max|y| ~ 2.2
     (north_star).
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -739,16 +741,63 @@ def test_dequant_w4_is_the_reference_weights_bit_for_bit(T, oracle, qtype, g, in
     w = ops.dequant_w4(packed, qinfo.to(DEV), None if lut is None else lut.to(DEV), g, {"int4": 0, "any4_global": 1, "any4_rowwise": 2}[qtype], k, inner, wrows)
     want = oracle_weights(oracle, codes, g, qtype, qinfo, lut, dtype)
     assert np.array_equal(bits16(w[:n].cpu()), np.asarray(want).reshape(n, k))
-    assert ops.large_m_rows(n * k) == 65 and ops.large_m_rows(14336 * 4096) == 96
+    # a PANEL of weight rows (what the opt-in library route dequantises at a time): the same bits
+    if wrows >= 48:
+        wp = ops.dequant_w4(packed, qinfo.to(DEV), None if lut is None else lut.to(DEV), g, {"int4": 0, "any4_global": 1, "any4_rowwise": 2}[qtype], k, inner, wrows, rows=(16, 48))
+        assert torch.equal(wp, w[16:48])
+    y = run_rm(T, codes, x, qinfo, lut, g, qtype, True, inner)
+    assert_gemm_close(y[:, :n], x, want, dtype)
+    if inner <= 4:
+        with any4_amd.weight_format("native"):
+            y2 = run_rm(T, codes, x, qinfo, lut, g, qtype, False, inner)
+        assert_gemm_close(y2[:, :n], x, want, dtype)
+    # the OPT-IN library route (dequantise in bounded panels + the GEMM library) gives the same result within the GEMM tolerance
+    saved = ops._LARGE_M
     try:
-        y = run_rm(T, codes, x, qinfo, lut, g, qtype, True, inner)
-        assert_gemm_close(y[:, :n], x, want, dtype)
-        if inner <= 4:
-            with any4_amd.weight_format("native"):
-                y2 = run_rm(T, codes, x, qinfo, lut, g, qtype, False, inner)
-            assert_gemm_close(y2[:, :n], x, want, dtype)
+        ops._LARGE_M = 65
+        os.environ["ANY4_DEQUANT_PANEL_MB"] = "0.1"   # 0.1 MB / (2 k) = 48 weight rows per panel at k = 1024: three panels
+        y3 = run_rm(T, codes, x, qinfo, lut, g, qtype, True, inner)
+        assert_gemm_close(y3[:, :n], x, want, dtype)
+        if k % 512 == 0:
+            yp = ops._library_gemm_w4(x.to(DEV), packed, qinfo.to(DEV), None if lut is None else lut.to(DEV), g, {"int4": 0, "any4_global": 1, "any4_rowwise": 2}[qtype], k, inner, wrows)
+            assert_gemm_close(yp[:, :n].cpu(), x, want, dtype)
     finally:
-        pass
+        ops._LARGE_M = saved
+        os.environ.pop("ANY4_DEQUANT_PANEL_MB", None)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("qtype,g", [("any4_rowwise", 128), ("any4_rowwise", 32), ("int4", 64), ("any4_global", 256)])
+@pytest.mark.parametrize("m,n,k", [(65, 200, 512), (128, 64, 64), (130, 1000, 1024), (512, 520, 2048)])
+def test_tile_gemm_many_rows_against_oracle(T, oracle, dtype, qtype, g, m, n, k):
+    """TinyGemmImpl.cuh:379-392: the reference's one kernel walks any m.  Here more than 64 activation rows run w4_gemm_tile_kernel (plan
+    'tile'): an LDS-tiled MFMA GEMM whose weight tile is dequantised on the way in.  Ragged m (not a multiple of 128), ragged weight rows
+    (not a multiple of 64 / 128), k of one step and of many, every group size, both 16-bit types, both numerics settings, both operand
+    sides, with and without a fused bias -- against the oracle's reference-faithful weights at the GEMM tolerance."""
+    import any4_amd
+    from any4_amd import ops
+
+    if g > k:
+        pytest.skip("group larger than k")
+    QT = {"int4": 0, "any4_global": 1, "any4_rowwise": 2}
+    codes, x, qinfo, lut = rand_problem(n, k, g, m, qtype, dtype=dtype, seed=m + n + g)
+    want = oracle_weights(oracle, codes, g, qtype, qinfo, lut, dtype)
+    assert ops.gemm_w4_plan(m, -(-n // 8) * 8, k, g, QT[qtype], True, 4, dtype=dtype) == "tile"
+    for num in ("fast", "reference"):
+        with any4_amd.numerics(num):
+            y = run_rm(T, codes, x, qinfo, lut, g, qtype, True, 4)
+            assert y.shape[0] == m and torch.isfinite(y.float()).all()
+            assert_gemm_close(y[:, :n], x, want, dtype)
+    with any4_amd.weight_format("native"):
+        y2 = run_rm(T, codes, x, qinfo, lut, g, qtype, False, 4)
+    assert_gemm_close(y2[:, :n], x, want, dtype)
+    assert torch.equal(y2[:, :n], y[:, :n])            # the same words, the same kernel: the same bits on either operand side
+    # a fused bias: bit-identical to the separate rounded add of the reference module (modules.py:221-222)
+    wrows = y.shape[1]
+    bias = torch.randn(wrows, generator=torch.Generator().manual_seed(5)).to(dtype).to(DEV)
+    with ops.fused_bias(bias) as fb:
+        yb = run_rm(T, codes, x, qinfo, lut, g, qtype, True, 4)
+    assert fb.consumed and torch.equal(yb, y + bias)
 
 
 @pytest.mark.parametrize("on_right,inner", [(True, 4), (False, 2)])

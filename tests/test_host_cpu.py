@@ -328,7 +328,18 @@ def test_xr_kernel_routing():
     # the 16-row block's; shapes whose blocks have no group-scaled kernel (innerKTiles 8 at one layer per launch) stay where they were
     assert plan(17, 4096, 4096, 128, "any4_rowwise") == "pair_xr" and plan(64, 4096, 4096, 128, "any4_rowwise") == "pair_xr"
     assert ops.gemm_w4_plan(33, 4096, 4096, 128, q2["any4_rowwise"], True, 4) == "pair"
-    assert ops.gemm_w4_plan(65, 4096, 4096, 128, q2["any4_rowwise"], True, 4, detail=True) in ("stream", "splitk")   # (one launch wins from here on)
+    # beyond the 64 rows of the row blocks: the LDS-tiled MFMA GEMM (w4_gemm_tile.cuh), in BOTH numerics settings (it computes the reference's
+    # weights), on both operand sides of the native words; not for mx4 / innerKTiles != 4 / fragment-order operands
+    for num in ("fast", "reference"):
+        assert ops.gemm_w4_plan(65, 4096, 4096, 128, q2["any4_rowwise"], True, 4, numerics=num, detail=True) == "tile"
+        assert ops.gemm_w4_plan(512, 14336, 4096, 32, q2["int4"], True, 4, numerics=num) == "tile"
+        assert ops.gemm_w4_plan(2048, 4096, 4096, 128, q2["any4_global"], False, 4, numerics=num, weight_format="native") == "tile"
+    assert ops.gemm_w4_plan(64, 4096, 4096, 128, q2["any4_rowwise"], True, 4, detail=True) == "pair_xr"
+    assert ops.gemm_w4_plan(512, 4096, 4096, 32, q2["mx4"], True, 4) in ("stream", "splitk", "pair")
+    assert ops.gemm_w4_plan(512, 4096, 4096, 128, q2["any4_rowwise"], True, 8, detail=True) in ("stream", "splitk")
+    assert ops.gemm_w4_plan(512, 4096, 4096, 128, q2["any4_rowwise"], False, 4, weight_format="reference", detail=True) in ("stream", "splitk")
+    assert ops.gemm_w4_plan(512, 4096, 4096, 128, q2["any4_rowwise"], True, 4, workspace=False) == "tile"          # (no workspace)
+    assert ops.large_m_rows(4096 * 4096) > 1 << 40      # the library-GEMM route is opt-in (ANY4_LARGE_M_GEMM=library / ANY4_LARGE_M)
     assert ops.gemm_w4_plan(33, 4096, 4096, 128, q2["any4_rowwise"], True, 8, detail=True) in ("stream", "splitk")
     assert ops.gemm_w4_plan(33, 4096, 4096, 128, q2["any4_rowwise"], True, 4, numerics="reference", detail=True) in ("stream", "splitk")
 
