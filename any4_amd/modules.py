@@ -126,6 +126,7 @@ class _PackedLinear(torch.nn.Module):
             if self.__dict__["_relayout_pending"] and self.weight.is_cuda:
                 self._auto_relayout()
         self.__dict__.pop("_plan", None)
+        self.__dict__.pop("_no_plan", None)
 
     def _auto_relayout(self):
         self.__dict__["_relayout_pending"] = False
@@ -147,31 +148,31 @@ class _PackedLinear(torch.nn.Module):
 
     _PLAN_PARAMS = ("weight", "scales_and_zeros", "exponents", "lut")
 
-    def _plan_key(self, x2d):
-        p = self._parameters
-        # (pointer AND version of every parameter: an in-place update -- load_state_dict, copy_ -- drops the plan as well)
-        # (inference tensors -- a model built under torch.inference_mode() -- keep no version counter: the pointer alone)
-        tag = tuple((t.data_ptr(), 0 if t.is_inference() else t._version, t.shape) for t in (p.get(n) for n in self._PLAN_PARAMS) if t is not None)
-        return (x2d.shape, x2d.dtype, x2d.device, self.kernel, self.group_size, self.w_inner_k, tag, _ops.get_numerics())
-
     def _forward(self, input: torch.Tensor) -> torch.Tensor:
-        lead = input.shape[:-1]
-        if self.__dict__.get("_relayout_pending") and self.weight.is_cuda:
+        d = self.__dict__
+        plan = d.get("_plan")
+        if plan is not None:
+            # the validated launch of this (module, activation shape) re-issued with new pointers (ops.LaunchPlan.try_run): the eager hot path
+            p = self._parameters
+            y = plan.try_run(input, p["weight"], p.get("scales_and_zeros") if "scales_and_zeros" in p else p.get("exponents"), p.get("lut"),
+                             (self.kernel, self.group_size, self.w_inner_k))
+            if y is not None:
+                return y
+        if d.get("_relayout_pending") and self.weight.is_cuda:
             self._auto_relayout()    # (a checkpoint in the reference's Aint4 words that was loaded on the CPU: repacked once, see above)
-        if input.is_cuda and self.bias is None and self.weight_reshaped:
-            # the validated launch of this (module, activation shape) re-issued with new pointers (ops.LaunchPlan); a packed weight
-            # only: the plan points at the parameters themselves
+        lead = input.shape[:-1]
+        if input.is_cuda and self.bias is None and self.weight_reshaped and d.get("_no_plan") != (input.shape, _ops.get_numerics()):
+            # a packed weight only: the plan points at the parameters themselves
             x2d = input.view(-1, input.shape[-1])
             if x2d.is_contiguous() and x2d.data_ptr() % 16 == 0:
-                key = self._plan_key(x2d)
-                plan = self.__dict__.get("_plan")
-                if plan is None or plan[0] != key:
-                    y, lp = _ops.record_plan(self._gemm, x2d, key, [self._parameters.get(n) for n in self._PLAN_PARAMS])
-                    self.__dict__["_plan"] = (key, lp)   # (lp None: this kernel flavour has no single-launch plan -- remembered too)
-                    return y.view(*lead, y.shape[-1])
-                if plan[1] is not None:
-                    y = plan[1].run(x2d)
-                    return y.view(*lead, y.shape[-1])
+                y, lp = _ops.record_plan(self._gemm, x2d, None, [self._parameters.get(n) for n in self._PLAN_PARAMS])
+                if lp is not None:
+                    lp.attrs = (self.kernel, self.group_size, self.w_inner_k)
+                    d["_plan"] = lp
+                else:
+                    d.pop("_plan", None)
+                    d["_no_plan"] = (input.shape, _ops.get_numerics())   # (this flavour has no single-launch plan: remembered, not retried per call)
+                return y.view(*lead, y.shape[-1])
         if self.bias is None:
             y = self._gemm(input.view(-1, input.shape[-1]))
         else:

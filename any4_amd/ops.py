@@ -571,39 +571,65 @@ class LaunchPlan:
     """One validated row-major 4-bit GEMM launch of a module, re-issued with new activation / output pointers: the eager
     `forward` of Any4Linear / Int4Linear spends ~20 us in Python (35 precondition checks, the op dispatcher, building the argument
     struct) around a 5 us kernel; the checks only depend on the parameters and the activations' shape / dtype / device, which the
-    plan's key pins.  Anything else (another shape, a re-assigned parameter, another numerics / weight-format setting, a
+    plan pins.  Anything else (another shape, a re-assigned parameter, another numerics / weight-format setting, a
     non-contiguous or misaligned input) takes the full path again.
 
     Re-entrant like the reference's host functions (TinyGemm_int4.cu:41-42: no state, the current stream of the calling thread):
     the recorded struct is a template that is never written after construction; every host thread fills in x / y in ITS OWN copy
     (made once per thread), so two threads running the same module on two streams cannot see each other's pointers.  A plan is
-    only recorded for launches without a workspace (nothing but x and y differs between calls)."""
+    only recorded for launches without a workspace (nothing but x and y differs between calls).
 
-    __slots__ = ("args", "key", "m", "n", "dtype", "device", "dev_index", "opname", "keep", "_per_thread")
+    `try_run` is the whole eager hot path of a module (measured on MI355X, dev/host_path.py: 10.7 -> ~8 us per forward at 4096 x 4096,
+    of which the HIP launch is 3-4 and torch.empty 1.5): no tuples built, no views, the parameters checked by POINTER (the struct points
+    at their storage: an in-place update needs no new plan, a re-assigned or re-allocated parameter has a new pointer)."""
+
+    __slots__ = ("args", "key", "m", "n", "k", "dtype", "device", "dev_index", "opname", "keep", "_per_thread", "ptrs", "numerics", "wformat", "attrs")
 
     def __init__(self, args, x, keep, opname, key):
         self.args, self.key, self.opname, self.keep = args, key, opname, keep  # (keep: the tensors the struct points at stay alive)
-        self.m, self.n, self.dtype, self.device, self.dev_index = x.shape[0], args.wrows, x.dtype, x.device, _dev(x)
-        self._per_thread = {}   # thread id -> that thread's private copy of the struct (dict get / set are atomic under the GIL)
+        self.m, self.n, self.k, self.dtype, self.device, self.dev_index = x.shape[0], args.wrows, x.shape[1], x.dtype, x.device, _dev(x)
+        self._per_thread = {}   # thread id -> (that thread's private copy of the struct, its byref) (dict get / set are atomic under the GIL)
+        self.ptrs = (args.w, args.qinfo, args.lut)
+        self.numerics, self.wformat = get_numerics(), get_weight_format()
+        self.attrs = None       # (set by the module: its kernel / group size / innerKTiles at recording time)
 
     def thread_args(self):
-        """The calling thread's private copy of the argument struct (live threads never share an ident)."""
+        """The calling thread's private copy of the argument struct (live threads never share an ident) and its ctypes reference."""
         tid = threading.get_ident()
         a = self._per_thread.get(tid)
         if a is None:
             if len(self._per_thread) >= 64:      # (threads come and go: do not grow without bound)
                 self._per_thread.clear()
-            a = self._per_thread[tid] = W4Gemm.from_buffer_copy(self.args)
+            c = W4Gemm.from_buffer_copy(self.args)
+            a = self._per_thread[tid] = (c, ctypes.byref(c))
         return a
 
-    def run(self, x):
-        y = torch.empty((self.m, self.n), dtype=self.dtype, device=self.device)
-        a = self.thread_args()
-        a.x, a.y = x.data_ptr(), y.data_ptr()
-        rc = _L.tg_gemm_w4(ctypes.byref(a), self.dev_index, _raw_stream(self.dev_index) if _raw_stream is not None else torch.cuda.current_stream(self.device).cuda_stream)
+    def _launch(self, xp, y):
+        a, ref = self.thread_args()
+        a.x, a.y = xp, y.data_ptr()
+        rc = _L.tg_gemm_w4(ref, self.dev_index, _raw_stream(self.dev_index) if _raw_stream is not None else torch.cuda.current_stream(self.device).cuda_stream)
         if rc:
             _lib.check(rc, self.opname)
         return y
+
+    def run(self, x):
+        return self._launch(x.data_ptr(), torch.empty((self.m, self.n), dtype=self.dtype, device=self.device))
+
+    def try_run(self, input, w, q, lut, attrs):
+        """The recorded launch on `input` ([..., k], any leading shape with m rows in all) if everything the plan pins still holds, else
+        None (the caller takes the full path and records again).  w / q / lut: the module's parameter tensors NOW."""
+        if input.dtype is not self.dtype or attrs != self.attrs or not input.is_contiguous():
+            return None
+        shp = input.shape
+        if shp[-1] != self.k or input.numel() != self.m * self.k or input.device != self.device:
+            return None
+        xp = input.data_ptr()
+        pw, pq, pl = self.ptrs
+        if (xp & 15) or w.data_ptr() != pw or q.data_ptr() != pq or (pl is not None and (lut is None or lut.data_ptr() != pl)):
+            return None
+        if get_numerics() != self.numerics or get_weight_format() != self.wformat:
+            return None
+        return self._launch(xp, torch.empty((*shp[:-1], self.n), dtype=self.dtype, device=self.device))
 
 
 def record_plan(fn, x, key, params=()):

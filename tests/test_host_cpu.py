@@ -548,14 +548,41 @@ def test_reference_words_from_a_checkpoint_are_marked_for_one_repack():
     assert nat.__dict__["_relayout_pending"] is False
 
 
-def test_plan_key_under_inference_mode():
-    """Parameters created under torch.inference_mode() keep no version counter: the plan key falls back to the pointer."""
-    import modules
+def test_launch_plan_try_run_checks_what_the_plan_pins():
+    """LaunchPlan.try_run (the eager hot path of a module): the recorded launch is re-issued only while the activations' shape / dtype /
+    contiguity / alignment, the parameters' POINTERS (not versions: the struct points at their storage, and parameters made under
+    torch.inference_mode() keep no version counter), the module's kernel attributes and the numerics / weight-format settings are those
+    of the recording; anything else returns None and the module records again."""
+    import any4_amd
+    from any4_amd import _lib, ops
 
     with torch.inference_mode():
-        lin = modules.Any4Linear(256, 64, bias=False, dtype=torch.bfloat16, group_size=64)
-        key = lin._plan_key(torch.zeros((1, 256), dtype=torch.bfloat16))
-    assert key[0] == (1, 256)
+        w, q, lut = torch.zeros(64, dtype=torch.int32), torch.zeros(64, dtype=torch.bfloat16), torch.zeros(16, dtype=torch.bfloat16)
+    lp = ops.LaunchPlan.__new__(ops.LaunchPlan)
+    lp.args, lp._per_thread = _lib.W4Gemm(wrows=8), {}
+    lp.m, lp.n, lp.k, lp.dtype, lp.device, lp.dev_index = 2, 8, 32, torch.bfloat16, torch.device("cpu"), 0
+    lp.ptrs, lp.numerics, lp.wformat, lp.attrs = (w.data_ptr(), q.data_ptr(), lut.data_ptr()), ops.get_numerics(), ops.get_weight_format(), ("kern", 128, 4)
+    launched = []
+    ops.LaunchPlan._launch, saved = (lambda self, xp, y: launched.append((xp, tuple(y.shape))) or y), ops.LaunchPlan._launch
+    try:
+        x = torch.zeros((2, 32), dtype=torch.bfloat16)
+        ok = lambda inp, ww=w, qq=q, ll=lut, attrs=("kern", 128, 4): lp.try_run(inp, ww, qq, ll, attrs)  # noqa: E731
+        assert ok(x) is not None and launched[-1] == (x.data_ptr(), (2, 8))
+        assert tuple(ok(x.view(1, 2, 32)).shape) == (1, 2, 8)                      # any leading shape with the same rows
+        assert ok(torch.zeros((3, 32), dtype=torch.bfloat16)) is None               # another number of rows
+        assert ok(x.to(torch.float16)) is None and ok(torch.zeros((2, 64), dtype=torch.bfloat16)[:, :32]) is None   # dtype, contiguity
+        assert ok(torch.zeros(2 * 32 + 1, dtype=torch.bfloat16)[1:].view(2, 32)) is None                              # 16-byte alignment
+        assert ok(x, ww=torch.zeros(64, dtype=torch.int32)) is None and ok(x, ll=None) is None                        # a re-assigned parameter
+        assert ok(x, attrs=("other", 128, 4)) is None
+        with torch.inference_mode():
+            w.copy_(torch.ones_like(w))                                              # an in-place update: the same storage, the same plan
+        assert ok(x) is not None
+        with any4_amd.numerics("reference"):
+            assert ok(x) is None
+        with any4_amd.weight_format("reference"):
+            assert ok(x) is None
+    finally:
+        ops.LaunchPlan._launch = saved
 
 
 def test_launch_plan_is_per_thread_and_plan_sink_thread_local():
@@ -573,10 +600,10 @@ def test_launch_plan_is_per_thread_and_plan_sink_thread_local():
 
     def copy_for_thread(i):
         both.wait()                 # both threads alive at once (a finished thread's ident may be reused, harmlessly)
-        a = lp.thread_args()
+        a, ref = lp.thread_args()
         a.x = 100 + i
         seen[i] = a
-        assert lp.thread_args() is a
+        assert lp.thread_args()[0] is a
         both.wait()
 
     th = [threading.Thread(target=copy_for_thread, args=(i,)) for i in range(2)]

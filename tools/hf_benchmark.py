@@ -42,6 +42,9 @@ def main():
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--quantize", default="anyq", choices=["anyq", "intq"])
     ap.add_argument("--group-size", type=int, default=128)
+    ap.add_argument("--graph", action="store_true",
+                    help="also time both models with the forward captured in ONE hipGraph (torch.cuda.CUDAGraph) and replayed: what the GPU "
+                         "needs per forward, without HuggingFace's ~0.3 ms of Python per decoder layer (the eager numbers are host-bound at seqlen 1)")
     a = ap.parse_args()
     if not torch.cuda.is_available():
         raise SystemExit("needs a GPU (no CPU fallback)")
@@ -63,6 +66,34 @@ def main():
     mask = torch.ones_like(ids)
     f = lambda m: m(input_ids=ids, attention_mask=mask, use_cache=False)
 
+    def graphed_ms(m):
+        """(ms per replay on the device, ms per replay wall, logits of the captured forward) or an error string."""
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    f(m)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr):
+                logits = f(m).logits
+            for _ in range(max(3, a.warmup // 4)):
+                gr.replay()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            w0 = time.perf_counter()
+            e0.record()
+            for _ in range(a.iters):
+                gr.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / a.iters, (time.perf_counter() - w0) * 1e3 / a.iters, logits.float().clone()
+        except Exception as e:  # noqa: BLE001  (a model whose forward cannot be captured: report, keep the eager numbers)
+            torch.cuda.synchronize()
+            return f"{type(e).__name__}: {e}"
+
     from any4_amd.accuracy import HookProfiler
 
     def split(m):  # attention / MLP time per forward (benchmark.py:37-111): host wall-clock and device events
@@ -78,6 +109,7 @@ def main():
     size0, peak0 = model_size_bytes(model), memory_allocated_mb()
     split0 = split(model)
     ref = f(model).logits.float()
+    g0 = graphed_ms(model) if a.graph else None
 
     t0 = time.perf_counter()
     layer_to = Q.anyq_layer if a.quantize == "anyq" else Q.intq_layer
@@ -87,6 +119,7 @@ def main():
     torch.cuda.reset_peak_memory_stats()
     qt, qtc = benchmark_in_ms(f, a.warmup, a.iters, model), benchmark_cuda_only_in_ms(f, a.warmup, a.iters, model)
     out = f(model).logits.float()
+    g1 = graphed_ms(model) if a.graph else None
     split1 = split(model)
     n_q = sum(type(m).__name__ in ("Any4Linear", "Int4Linear") for m in model.modules())
 
@@ -98,6 +131,13 @@ def main():
     print(f"\tModel Size:\t{model_size_bytes(model) / 2**30:.2f} GB\tPeak: {memory_allocated_mb():.0f} MB")
     print(f"\tModel:\tTotal {qt:.3f} ms\tCUDA {qtc:.3f} ms")
     print(f"Speedup:\tTotal {t / qt:.2f}x\tCUDA {tc / qtc:.2f}x")
+    if a.graph:
+        if isinstance(g0, str) or isinstance(g1, str):
+            print(f"hipGraph:\tcapture failed: baseline {g0 if isinstance(g0, str) else 'ok'}; quantized {g1 if isinstance(g1, str) else 'ok'}")
+        else:
+            print(f"hipGraph (one captured forward, {a.iters} replays):\tbaseline {g0[0]:.3f} ms device / {g0[1]:.3f} ms wall\tquantized {g1[0]:.3f} / {g1[1]:.3f} ms"
+                  f"\tSpeedup {g0[0] / g1[0]:.2f}x device / {g0[1] / g1[1]:.2f}x wall")
+            print(f"\tcaptured logits vs eager: baseline max |d| = {(g0[2] - ref).abs().max():.3g}, quantized max |d| = {(g1[2] - out).abs().max():.3g}")
     for kind in ("attention", "mlp"):
         b_c, b_g = split0["cpu"][f"{kind}_time"], split0["cuda"][f"{kind}_time"]
         q_c, q_g = split1["cpu"][f"{kind}_time"], split1["cuda"][f"{kind}_time"]
