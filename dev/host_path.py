@@ -39,7 +39,7 @@ def main():
             best = min(best, (time.perf_counter() - t0) / 1000 * 1e6)
         # host-only: the same calls while the GPU is kept far behind is the same thing here (launches are asynchronous)
         plan = m.__dict__.get("_plan")
-        info = "" if name == "nn.Linear" else f"  plan={'yes' if plan and plan[1] is not None else 'NO'}  params aligned16: " + \
+        info = "" if name == "nn.Linear" else f"  plan={'yes' if plan is not None else 'NO'}  params aligned16: " + \
             str({n: (p.data_ptr() % 16 == 0) for n, p in m.named_parameters()})
         print(f"{name:22s} {best:7.2f} us per forward (wall, 1000 calls){info}")
         if a.profile and name != "nn.Linear":
