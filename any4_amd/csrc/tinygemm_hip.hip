@@ -872,7 +872,7 @@ static int gemm_w4_impl(const tg_w4_gemm* caller, int device, tg_stream_t stream
   }
   // MANY activation rows (a prefill through the modules): the LDS-tiled MFMA GEMM that dequantises the weights once per 128-row tile of m
   // instead of once per 16 rows (w4_gemm_tile.cuh; the reference's weights bit for bit, so it serves both numerics settings).  4096^2 at
-  // m = 128 / 256 / 1024: 37 / 40 / 69 us against 37.8 / 44.5 / 166 on the stream kernel and 55 / 102 / 427 in 16-row blocks.
+  // m = 128 / 256 / 1024: 32.6 / 33.7 / 58.6 us against 37.8 / 44.5 / 166 on the stream kernel and 55 / 102 / 427 in 16-row blocks.
   if (on_right && a->m >= TG_TILE_MIN_M) {
     const int trc = tgx::tile(a->dtype, I, a->qtype == TG_Q_MX4, p, batch, st);
     if (trc != TG_PAIR_NA) {

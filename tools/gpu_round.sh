@@ -1,7 +1,7 @@
 # One GPU-box visit: smoke, gpu tests, bench line, rocprofv3 kernel stats of the bench run and of every leg, PMC counters
 # (MfmaUtil, VALU / LDS / L2, HBM bytes) of the bench kernel and of the m = 8 / config 3 / m = 16 legs.  Writes gpurun_out/.
 set -u
-RN=${ROUND:-r05}
+RN=${ROUND:-r06}
 mkdir -p gpurun_out
 R=$GRAFT_REPO_ROOT
 cd $R

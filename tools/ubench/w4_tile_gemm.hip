@@ -35,11 +35,11 @@ static uint16_t f2bf(float f) {
 #endif
 template <int BN>
 static int launch(const TileParams& p, hipStream_t st) {
-  constexpr auto kern = w4_gemm_tile_kernel<BF16, BM_, BN, NPW_, DX_, EW_>;
+  constexpr auto kern = w4_gemm_tile_kernel<BF16, BM_, BN, DX_>;
   static bool prepared = false;
   if (!prepared) { CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); prepared = true; }
-  constexpr unsigned lds_bytes = TileLds<BM_, BN, DX_, EW_>::BYTES;
-  hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(256 + 64 * NPW_), lds_bytes, st, p);
+  constexpr unsigned lds_bytes = TileLds<BM_, BN, DX_>::BYTES;
+  hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(BN == 64 ? 1024 : 768), lds_bytes, st, p);
   return 0;
 }
 
