@@ -10,7 +10,7 @@ int go(const TileParams& tp, hipStream_t st) {
   const int prc = prepare_lds_kernel<kern>();
   if (prc != 0) return prc == TG_E_INTERNAL ? prc : TG_PAIR_NA;  // (a part with less LDS: the older kernels take over)
   constexpr unsigned lds = TileLds<128, BN, 3>::BYTES;
-  hipLaunchKernelGGL(kern, dim3((unsigned)(tp.tiles_m * tp.tiles_n)), dim3(BN == 64 ? 1024 : 768), lds, st, tp);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(tp.tiles_m * tp.tiles_n)), dim3(1024), lds, st, tp);
   return launch_status();
 }
 }  // namespace

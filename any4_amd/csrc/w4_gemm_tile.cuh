@@ -11,7 +11,7 @@
 //                                per-(row, group) tables (their scale / zero words come by plain loads four steps ahead: these waves have
 //                                no other memory traffic, so hipcc's own vmcnt bookkeeping is exact)
 //                waves 4 ... 7   request the x tiles (LDS-DMA), nothing else
-//                waves 8 ...     dequantise (8 waves at BN = 64, 4 at BN = 128): packed words by plain non-temporal loads into a register ring four steps ahead, table
+//                waves 8 ... 15  dequantise: packed words by plain non-temporal loads into a register ring four steps ahead, table
 //                                lookups, the w tile
 //              Every role is a chain of dependent LDS / memory round trips per step; a wave that carries two of them pays their SUM
 //              (all roles on every wave: 2300 cycles per step, 261 TFLOP/s at m = 512; words and scale / zero through LDS-DMA on the
@@ -70,9 +70,10 @@ __device__ __forceinline__ void tile_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-// NDW = dequantising waves: 8 (BN = 64: one word per thread) or 4 (BN = 128: four words per thread; 12 waves leave the consumers' 64
-// accumulator registers + fragments room -- at 16 waves, 128 registers per lane, they spilled 1 KiB per lane)
-template <typename DT, int BM, int BN, int DX = 3, int NDW = (BN == 64 ? 8 : 4)>
+// NDW = dequantising waves: 8 (one / two words per thread at BN = 64 / 128; 16 waves = 128 registers per lane: the consumers' 64 accumulator
+// registers at BN = 128 fit because a step's fragments are read one k32 block at a time and their LDS offsets are two registers + constants;
+// with all fragments up front they spilled 1 KiB per lane) or 4 (12 waves; measured 10 % slower at BN = 128)
+template <typename DT, int BM, int BN, int DX = 3, int NDW = 8>
 __global__ void __launch_bounds__(512 + 64 * NDW) w4_gemm_tile_kernel(const TileParams p) {
   constexpr int WN = BN / 2;             // weight rows of a consumer wave
   constexpr int NT = WN / 16;            // its 16-row tiles
@@ -255,19 +256,14 @@ __global__ void __launch_bounds__(512 + 64 * NDW) w4_gemm_tile_kernel(const Tile
   };
   const int wm = wave >> 1, wn = wave & 1;
   const int fi = lane & 15, kq = lane >> 4;
-  uint32_t a_off[2][MT], b_off[2][NT];   // [k32 block][tile]: byte offset of this lane's fragment in a stage
+  // byte offset of this lane's fragment of 16-row tile 0 in a stage, per k32 block; tile t is 16 rows = 2048 bytes further (the swizzle
+  // term (row >> 1) & 7 does not change with 16 t): a constant in the ds_read's offset field
+  uint32_t a_base[2], b_base[2];
 #pragma unroll
   for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-    for (int t = 0; t < MT; ++t) {
-      const int row = wm * (BM / 2) + t * 16 + fi;
-      a_off[kb][t] = (uint32_t)(row * 128) + (((uint32_t)(4 * kb + kq) ^ (uint32_t)((row >> 1) & 7)) << 4);
-    }
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const int row = wn * WN + t * 16 + fi;
-      b_off[kb][t] = (uint32_t)(row * 128) + (((uint32_t)(4 * kb + kq) ^ (uint32_t)((row >> 1) & 7)) << 4);
-    }
+    const int ra = wm * (BM / 2) + fi, rb = wn * WN + fi;
+    a_base[kb] = (uint32_t)(ra * 128) + (((uint32_t)(4 * kb + kq) ^ (uint32_t)((ra >> 1) & 7)) << 4);
+    b_base[kb] = (uint32_t)(rb * 128) + (((uint32_t)(4 * kb + kq) ^ (uint32_t)((rb >> 1) & 7)) << 4);
   }
   f32x4 acc[NT][MT];
 #pragma unroll
@@ -282,9 +278,9 @@ __global__ void __launch_bounds__(512 + 64 * NDW) w4_gemm_tile_kernel(const Tile
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-        for (int t = 0; t < NT; ++t) wf[kb][t] = *reinterpret_cast<const u32x4*>(bst + b_off[kb][t]);
+        for (int t = 0; t < NT; ++t) wf[kb][t] = *reinterpret_cast<const u32x4*>(bst + b_base[kb] + t * 2048);
 #pragma unroll
-        for (int t = 0; t < MT; ++t) xf[kb][t] = *reinterpret_cast<const u32x4*>(ast + a_off[kb][t]);
+        for (int t = 0; t < MT; ++t) xf[kb][t] = *reinterpret_cast<const u32x4*>(ast + a_base[kb] + t * 2048);
       }
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
@@ -297,9 +293,9 @@ __global__ void __launch_bounds__(512 + 64 * NDW) w4_gemm_tile_kernel(const Tile
       for (int kb = 0; kb < 2; ++kb) {
         u32x4 wf[NT], xf[MT];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) wf[t] = *reinterpret_cast<const u32x4*>(bst + b_off[kb][t]);
+        for (int t = 0; t < NT; ++t) wf[t] = *reinterpret_cast<const u32x4*>(bst + b_base[kb] + t * 2048);
 #pragma unroll
-        for (int t = 0; t < MT; ++t) xf[t] = *reinterpret_cast<const u32x4*>(ast + a_off[kb][t]);
+        for (int t = 0; t < MT; ++t) xf[t] = *reinterpret_cast<const u32x4*>(ast + a_base[kb] + t * 2048);
 #pragma unroll
         for (int a = 0; a < NT; ++a)
 #pragma unroll

@@ -191,6 +191,18 @@ __global__ void __launch_bounds__(512, 2) w4_gemv_kernel(const GemvParams p) {
     }
   };
 
+#ifndef TG_GEMV_PRE_BARRIER
+#define TG_GEMV_PRE_BARRIER 1  // 1: the first weight requests behind the staging requests AND a workgroup barrier (below); developer A/B: 0 = no barrier
+                               // (every wave requests its weights right behind its own staging requests), 2 = the weights FIRST
+#endif
+#if TG_GEMV_PRE_BARRIER == 2
+#pragma unroll
+  for (int j = 0; j < D; ++j) {
+    __builtin_amdgcn_sched_barrier(0);
+    issue(ring[j]);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#endif
   // ---- requests: this thread's share of the activations, norm weights, LUT rows, bias values -- then, behind a workgroup barrier,
   // the first D steps of the weight stream (the CU's vector-memory path takes requests in arrival order: 64 KiB of weight
   // requests of the waves that got there first would sit in front of the last wave's 16 bytes of activations) ----
@@ -291,17 +303,21 @@ __global__ void __launch_bounds__(512, 2) w4_gemv_kernel(const GemvParams p) {
 #ifndef TG_GEMV_ASM_BARRIER
 #define TG_GEMV_ASM_BARRIER 1
 #endif
+#if TG_GEMV_PRE_BARRIER == 1
 #if TG_GEMV_ASM_BARRIER
   asm volatile("s_barrier" ::: "memory");  // (spelled out: in front of the builtin hipcc waits vmcnt(0) -- the staging loads would have to RETURN before the first weight request)
 #else
   __builtin_amdgcn_s_barrier();
 #endif
+#endif
+#if TG_GEMV_PRE_BARRIER != 2
 #pragma unroll
   for (int j = 0; j < D; ++j) {
     __builtin_amdgcn_sched_barrier(0);
     issue(ring[j]);
   }
   __builtin_amdgcn_sched_barrier(0);
+#endif
 #if GEMV_TRACE
   tr[1] = __builtin_amdgcn_s_memrealtime();
 #endif
