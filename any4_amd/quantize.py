@@ -46,6 +46,17 @@ def extract_scales_and_zeros(scales_and_zeros: torch.Tensor, w_shape, q_group_si
     return expand_q_groups(s[:, :, 0], w_shape, q_group_size), expand_q_groups(s[:, :, 1], w_shape, q_group_size)
 
 
+_DIVISORS: dict = {}
+
+
+def _divisor(value: float, device) -> torch.Tensor:
+    key = (value, str(device))
+    t = _DIVISORS.get(key)
+    if t is None:
+        t = _DIVISORS[key] = torch.tensor(value, device=device)
+    return t
+
+
 def group_q(w_orig: torch.Tensor, n_bit: int, q_group_size: int = 128, assymetric: bool = True, unsigned: bool = True,
             zero_point: bool = True):
     """Scale every q-group onto the integer grid WITHOUT rounding: returns (w in grid units, the image of 0,
@@ -60,13 +71,16 @@ def group_q(w_orig: torch.Tensor, n_bit: int, q_group_size: int = 128, assymetri
         mx, mn = tq.amax(dim=1, keepdim=True), tq.amin(dim=1, keepdim=True)
         lo, hi = (0, 2 ** n_bit - 1) if unsigned else (-(2 ** (n_bit - 1)), 2 ** (n_bit - 1) - 1)
         # (divisor as a tensor on w's device: torch turns `tensor / python_scalar` on the GPU into a multiplication by the rounded
-        # reciprocal, one ulp off the IEEE quotient the reference's CPU path computes -- enough to flip a bf16 scale)
-        scales = (mx - mn).clamp(min=1e-6) / torch.tensor(float(hi - lo), device=w.device)
+        # reciprocal, one ulp off the IEEE quotient the reference's CPU path computes -- enough to flip a bf16 scale.  PARITY TARGET: the
+        # reference run on the CPU, which is what tests/golden/group_quant.npz captured and tests/test_quantize_cpu.py /
+        # test_gpu_decode.py check bit for bit on both devices; a checkpoint quantised by the reference ON A GPU can differ from this
+        # by one ulp of a scale.  The divisor tensor is made once per (device, value): no host-to-device copy per call.)
+        scales = (mx - mn).clamp(min=1e-6) / _divisor(float(hi - lo), w.device)
         zeros = mn + scales * (2 ** (n_bit - 1)) if zero_point else mn
         w_new = tq.sub(mn).div(scales).reshape(w.shape)
         w_zero = torch.zeros_like(tq).sub(mn).div(scales).reshape(w.shape)
     else:
-        scales = tq.abs().amax(dim=1, keepdim=True).clamp(min=1e-6) / torch.tensor(float(2 ** (n_bit - 1) - 1), device=w.device)
+        scales = tq.abs().amax(dim=1, keepdim=True).clamp(min=1e-6) / _divisor(float(2 ** (n_bit - 1) - 1), w.device)
         zeros = torch.zeros_like(scales)
         w_new = tq.div(scales).reshape(w.shape)
         w_zero = torch.zeros_like(w_new)

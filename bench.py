@@ -788,6 +788,51 @@ def main():
             },
         }
 
+        def many_rows_leg(mm, nn, kk, gg, layers=8):
+            """More than 64 activation rows (a prefill through the modules): one nn x kk layer per launch on the library's own LDS-tiled
+            MFMA GEMM (w4_gemm_tile_kernel, plan 'tile').  Matrix-core bound: achieved TFLOP/s against the dense bf16 MFMA peak; checked
+            against the oracle's reference-faithful weights on a sample of rows."""
+            ww, xx, qq, ll, yy = make_batch(layers, mm, nn, kk, gg, inner, device, 55, "any4_rowwise", True)
+            xx.mul_(2.0 ** -5)   # (k = 4096 products of unit-variance activations: keep max|y| near 1 like the other legs)
+            singles = [make_args(_lib, ww[i:i + 1], xx[i:i + 1], qq[i:i + 1], ll[i:i + 1], yy[i:i + 1], mm, nn, kk, gg, "any4_rowwise", True, inner, 1)
+                       for i in range(layers)]
+            for sa in singles:
+                launch(sa)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            for _ in range(5):
+                for sa in singles:
+                    launch(sa)
+            e1.record(stream)
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / (5 * layers)
+            # a sample of 8 activation rows x 256 weight rows of the last layer against the oracle (f64 sums of the reference's weights)
+            import numpy as np
+
+            from oracle import oracle as orc
+
+            bits = lambda t: t.detach().cpu().contiguous().view(torch.int16).numpy().view(np.uint16)  # noqa: E731
+            rows = 256
+            codes = orc.unpack_Bint4(ww[-1].cpu().numpy(), nn, kk)[:rows]
+            wq = orc.bf16_to_f32(orc.dequant(codes, gg, orc.Q_ANY4_ROWWISE, bits(qq[-1][:, :rows].contiguous()), bits(ll[-1][:rows]))).astype(np.float64)
+            xs = xx[-1][:: max(1, mm // 8)][:8].double().cpu().numpy()
+            want = xs @ wq.T
+            got = yy[-1][:: max(1, mm // 8)][:8, :rows].double().cpu().numpy()
+            tol = np.abs(want) * 2.0 ** -8 + (np.abs(xs) @ np.abs(wq).T) * 4e-6 + 1e-30
+            err = float((np.abs(got - want) / tol).max())
+            if not err <= 1.0:
+                raise SystemExit(f"bench.py: many-rows GEMM (m = {mm}) does not match the oracle: err / tol = {err:.3f}")
+            flop = 2.0 * mm * nn * kk
+            return {"m": mm, "n": nn, "k": kk, "us_per_layer": round(us, 2), "TFLOPs": round(flop / us * 1e-6, 1),
+                    "frac_of_mfma_peak": round(flop / us * 1e-6 / 2500.0, 4), "peak_TFLOPs": 2500.0, "bound": "mfma",
+                    "kernel_plan": ops.gemm_w4_plan(mm, nn, kk, gg, QT["any4_rowwise"], True, inner, torch.bfloat16, 1, "fast"),
+                    "check_err_over_tol": round(err, 3),
+                    "note": "one layer per launch, distinct weights per launch; the reference walks m in 16-row blocks (TinyGemmImpl.cuh:379-392), "
+                            "this kernel dequantises once per 128-row tile; a 16-bit GEMM of the vendor library on the dequantised weights is an opt-in route (ANY4_LARGE_M_GEMM=library)"}
+
+        many_rows = {} if world > 1 else {"m512": many_rows_leg(512, n, k, g), "m2048": many_rows_leg(2048, n, k, g, layers=4)}
+
         # (c) single-layer launches: what one module forward issues (the reference's microbenchmark shape) -- Any4Linear's
         # default kernel (per-row LUT any4, weights on the B side) and Int4Linear's (modules.py:21: uniform int4, A side)
         def single_layer(qtype, on_right, tensors=None, m=m, n=n, k=k, layers=None):
@@ -934,6 +979,7 @@ def main():
                         "floor on this stack: ~4.3 us); in_hipgraph = the same launches replayed from one captured graph; launch_floor = a 16 x 512 "
                         "problem through the same entry point, back to back: the host/runtime cost per launch that back_to_back cannot go below",
             },
+            "many_rows_gemm": many_rows,
             "decode_llama3_8b": decode,
         }
         if m1_ab is not None:
