@@ -144,6 +144,7 @@ class _PackedLinear(torch.nn.Module):
         # (the recorded launch plan holds raw device pointers in a ctypes struct: never copied or pickled with the module)
         state = self.__dict__.copy()
         state.pop("_plan", None)
+        state.pop("_no_plan", None)
         return state
 
     _PLAN_PARAMS = ("weight", "scales_and_zeros", "exponents", "lut")
@@ -151,9 +152,9 @@ class _PackedLinear(torch.nn.Module):
     def _forward(self, input: torch.Tensor) -> torch.Tensor:
         d = self.__dict__
         plan = d.get("_plan")
-        if plan is not None:
+        p = self._parameters
+        if plan is not None and p.get("bias") is None:   # (a bias assigned after the recording: the full path, which offers it to the kernel)
             # the validated launch of this (module, activation shape) re-issued with new pointers (ops.LaunchPlan.try_run): the eager hot path
-            p = self._parameters
             y = plan.try_run(input, p["weight"], p.get("scales_and_zeros") if "scales_and_zeros" in p else p.get("exponents"), p.get("lut"),
                              (self.kernel, self.group_size, self.w_inner_k))
             if y is not None:
