@@ -26,15 +26,16 @@
 //   w tile     every thread takes whole packed words (8 codes of ONE weight row: k = 2 i + {0, 1} + 8 h, h = 0 ... 3, of a 32-k run,
 //              TinyGemmConvertB.cu:252-308) -- each word is loaded exactly once per tile -- looks its codes up in the per-(row, group)
 //              table of FINAL 16-bit values (16 entries, built once per group with the reference's fma: one 2-byte LDS read per weight
-//              instead of a select tree and an fma) and writes four 4-byte pieces into the swizzled tile.  Lane = (row & 3, word, row >> 2):
-//              a 32-lane LDS access group touches 4 tables = 4 x 8 of the 32 banks a 4-byte access sees.
+//              instead of a select tree and an fma) and writes four 4-byte pieces into the swizzled tile.  Lane = 8 row + word (the word's
+//              place in the packed layout: contiguous wave-loads): a 32-lane LDS access group touches 4 tables = 4 x 8 of the 32 banks a
+//              4-byte access sees.
 //   pipeline   step s: x of step s + DX requested; the words of step s + 1 dequantised into the other w buffer; the tables of the group
 //              that starts at step s + 2 built; the MFMAs of step s; ONE barrier per step.
 //   grid       one workgroup per tile; tile index -> (n tile, m tile) with the m tiles of one n tile on ONE XCD (block b runs on XCD
 //              b % 8: observed, used for speed only), so that the packed weights of an n tile leave HBM once.
 #pragma once
 #ifndef TILE_ABL
-#define TILE_ABL 0  // developer ablations (timing only, wrong results), bit mask: 1 no dequantisation, 2 no MFMA stage, 4 no LDS-DMA, 8 no table builds
+#define TILE_ABL 0  // developer ablations (timing only, wrong results), bit mask: 1 no dequantisation, 2 no MFMA stage, 4 no LDS-DMA, 8 no table builds, 16 no lookups, 32 no w-tile writes, 64 no word loads
 #endif
 
 struct TileParams {
@@ -48,12 +49,15 @@ struct TileParams {
   int32_t tiles_m, tiles_n;
 };
 
-template <int BM, int BN, int DX>
+template <int BM, int BN, int DX, int KS>
 struct TileLds {
   static constexpr int NST = DX + 1;                 // x of step u is requested DX steps ahead: live DX + 1 steps
-  static constexpr int A_STAGE = BM * 128;           // BM rows x 64 k x 2 bytes
-  static constexpr int B_STAGE = BN * 128;
-  static constexpr int T_BUF = 2 * BN * 32;          // [sub-group of the step: 2][row][16 entries] 16-bit
+  static constexpr int A_PLANE = BM * 128;           // BM rows x 64 k x 2 bytes: one super-tile of a step
+  static constexpr int B_PLANE = BN * 128;
+  static constexpr int A_STAGE = KS * A_PLANE;       // a step = KS super-tiles (KS x 64 k between two barriers)
+  static constexpr int B_STAGE = KS * B_PLANE;
+  static constexpr int NSUB = 2 * KS;                // quantisation groups per step at most (g = 32)
+  static constexpr int T_BUF = NSUB * BN * 32;       // [sub-group of the step][row][16 entries] 16-bit
   static constexpr int A_OFF = 0;
   static constexpr int B_OFF = NST * A_STAGE;
   static constexpr int T_OFF = B_OFF + 2 * B_STAGE;
@@ -73,7 +77,10 @@ __device__ __forceinline__ void tile_barrier() {
 // NDW = dequantising waves: 8 (one / two words per thread at BN = 64 / 128; 16 waves = 128 registers per lane: the consumers' 64 accumulator
 // registers at BN = 128 fit because a step's fragments are read one k32 block at a time and their LDS offsets are two registers + constants;
 // with all fragments up front they spilled 1 KiB per lane) or 4 (12 waves; measured 10 % slower at BN = 128)
-template <typename DT, int BM, int BN, int DX = 3, int NDW = 8>
+// KS  = 64-k super-tiles per step (= per barrier): 1, or 2 where the LDS allows (128 x 64 tiles): every role's chain of dependent LDS /
+//       memory round trips is paid once per step whatever the step holds -- waves wait 54 % of their cycles at KS = 1 (SQ_WAIT_ANY), the
+//       LDS array is 41 % busy -- so two super-tiles per step nearly halve the time per k
+template <typename DT, int BM, int BN, int DX = 3, int NDW = 8, int KS = 1>
 __global__ void __launch_bounds__(512 + 64 * NDW) w4_gemm_tile_kernel(const TileParams p) {
   constexpr int WN = BN / 2;             // weight rows of a consumer wave
   constexpr int NT = WN / 16;            // its 16-row tiles
@@ -81,8 +88,15 @@ __global__ void __launch_bounds__(512 + 64 * NDW) w4_gemm_tile_kernel(const Tile
   constexpr int XPW = BM / 32;           // x DMA instructions (1 KiB = 8 rows) per step of each of the four x waves
   constexpr int WPT = BN / 8 / NDW;      // 8-row tiles per dequantising wave = packed words per thread and step
   constexpr int RPT = BN / 64;           // table rows per consumer thread (BN rows x 4 entry quads / 256 threads)
-  constexpr int PW = 4;                  // the register rings of the packed words and of scale / zero: steps ahead
-  using L = TileLds<BM, BN, DX>;
+  constexpr int PW = 4;                  // the register ring of scale / zero: steps ahead
+#ifndef TILE_PWD
+#define TILE_PWD 4
+#endif
+  constexpr int PWD = TILE_PWD;          // the register ring of the packed words: steps ahead (their requests queue behind DX steps of x DMA
+                                         // requests in the CU's vector-memory path; 4 / 8 / 12 steps ahead measured equal)
+  using L = TileLds<BM, BN, DX, KS>;
+  constexpr int KSH = KS == 1 ? 0 : 1;   // log2(KS)
+  static_assert(KS == 1 || KS == 2, "super-tiles per step");
   static_assert(BM == 64 || BM == 128, "activation rows per tile");
   static_assert(BN == 64 || BN == 128, "weight rows per tile");
   constexpr int NST = L::NST;
@@ -98,13 +112,13 @@ __global__ void __launch_bounds__(512 + 64 * NDW) w4_gemm_tile_kernel(const Tile
   }
   const int tn = tile / p.tiles_m, tm = tile - tn * p.tiles_m;
   const int m0 = tm * BM, n0 = tn * BN;
-  const int ksteps = p.ksuper;                                 // one super-tile of 64 k per step
+  const int ksteps = p.ksuper >> KSH;                          // KS super-tiles of 64 k per step (host: ksuper % KS == 0)
   const int last = ksteps - 1;
   const int gshift = p.gshift;
-  const int spg_shift = gshift > 6 ? gshift - 6 : 0;           // steps per group (g = 128: 2, 256: 4; g <= 64: 1)
-  const int nsub = gshift == 5 ? 2 : 1;                        // groups per step (g = 32: 2)
+  const int spg_shift = gshift > 6 + KSH ? gshift - 6 - KSH : 0;        // log2(steps per group)            (KS = 1: g = 128: 2, 256: 4)
+  const int nsub = gshift < 6 + KSH ? 1 << (6 + KSH - gshift) : 1;      // groups per step                  (KS = 1: g = 32: 2)
   const int ngroups = p.k >> gshift;
-  auto new_group = [&](int step) { return nsub == 2 || step == 0 || ((step >> spg_shift) != ((step - 1) >> spg_shift)); };
+  auto new_group = [&](int step) { return nsub > 1 || step == 0 || ((step >> spg_shift) != ((step - 1) >> spg_shift)); };
   // Schedule (u = a k-step).  Data of step u is consumed by the MFMAs in step u: x(u) lands by the end of step u - 1 (requested DX steps
   // ahead; vmcnt leaves the requests of the last DX - 1 steps in flight); the w tile of step u is written in step u - 1 from tables
   // built in step u - 2.  Every wave passes the same barriers: two in the prologue, one per step.
@@ -113,12 +127,15 @@ __global__ void __launch_bounds__(512 + 64 * NDW) w4_gemm_tile_kernel(const Tile
     // =================================== dequantising waves ===================================
     const int dw = wave_all - 8;                                // 0 ... NDW - 1: owns the 8-row tiles dw * WPT ... of the BN rows
     const int ntiles8 = p.wrows >> 3;
-    // lane = (row & 3, word 2 i + j, row >> 2): a 32-lane LDS access group (4-byte accesses: 32 banks) looks up in FOUR tables of 8 banks
-    // each (with eight rows per group, rows r and r + 4 met in the same banks: every lookup instruction twice as long)
-    const int drow8 = (lane & 3) | ((lane >> 5) << 2), dword = (lane >> 2) & 7, di = dword >> 1, dj = dword & 1;   // row of the tile, word 2 i + j of the row
+    // lane = 8 (row of the tile) + (word 2 i + j of the row) = the word's own position in the tile's 256-byte block of the packed layout: a
+    // wave-load is 64 CONSECUTIVE dwords (with lanes = (row & 3, word, row >> 2) a quad of adjacent lanes touched two 64-byte chunks: 8 x the
+    // requests, and the eight wave-loads per step cost 5 of 32 us), and a 32-lane LDS access group (4-byte accesses: 32 banks) still looks up
+    // in FOUR tables of 8 banks each (with eight rows per group, rows r and r + 4 met in the same banks: every lookup twice as long)
+    const int drow8 = lane >> 3, dword = lane & 7, di = dword >> 1, dj = dword & 1;   // row of the tile, word 2 i + j of the row
+    constexpr int NW = WPT * KS;   // words per thread and step: word u * KS + pl = 8-row tile u of the wave, super-tile pl of the step
     const uint32_t* wsrc[WPT];
-    uint32_t dst0[WPT][4];     // byte offset of the thread's 4-byte piece h in a w stage
-    uint32_t tab_off[WPT];     // byte offset of its row's table in a table buffer (sub-group j at g = 32)
+    uint32_t dst0[WPT][4];     // byte offset of the thread's 4-byte piece h in a plane of a w stage
+    uint32_t tab_off[NW];      // byte offset of its row's table in a table buffer (sub-group of the word's 32-k run)
 #pragma unroll
     for (int u = 0; u < WPT; ++u) {
       const int t8 = dw * WPT + u;
@@ -128,45 +145,60 @@ __global__ void __launch_bounds__(512 + 64 * NDW) w4_gemm_tile_kernel(const Tile
       const int row = t8 * 8 + drow8;
 #pragma unroll
       for (int h = 0; h < 4; ++h) dst0[u][h] = (uint32_t)(row * 128 + 4 * di) + (((uint32_t)(4 * dj + h) ^ (uint32_t)((row >> 1) & 7)) << 4);
-      tab_off[u] = (uint32_t)(row * 32) + (nsub == 2 ? (uint32_t)(dj * (BN * 32)) : 0u);
+#pragma unroll
+      for (int pl = 0; pl < KS; ++pl) {
+        const int sub = nsub > 1 ? (((2 * pl + dj) * 32) >> gshift) : 0;   // the word's 32-k run starts (2 pl + j) 32 k into the step
+        tab_off[u * KS + pl] = (uint32_t)(row * 32 + sub * (BN * 32));
+      }
     }
-    uint32_t ring[PW][WPT];    // words of steps t ... t + PW - 1 (slot = step % PW)
-    auto load_words = [&](int step, uint32_t (&dst)[WPT]) {
+    uint32_t ring[PWD][NW];     // words of steps t ... t + PW - 1 (slot = step % PWD)
+    auto load_words = [&](int step, uint32_t (&dst)[NW]) {
       const int c = step < last ? step : last;                 // (past the end: the last step again, never used)
 #pragma unroll
-      for (int u = 0; u < WPT; ++u) dst[u] = __builtin_nontemporal_load(wsrc[u] + (int64_t)c * 64);
+      for (int u = 0; u < WPT; ++u)
+#pragma unroll
+        for (int pl = 0; pl < KS; ++pl) {
+          if constexpr (TILE_ABL & 64) dst[u * KS + pl] = (uint32_t)(c * 0x9e3779b9u) + (uint32_t)(uintptr_t)wsrc[u];
+          else dst[u * KS + pl] = __builtin_nontemporal_load(wsrc[u] + (int64_t)(c * KS + pl) * 64);
+        }
     };
-    auto dequant = [&](int step, const uint32_t (&wd)[WPT]) {  // the words of k-step `step` -> w stage step & 1
+    auto dequant = [&](int step, const uint32_t (&wd)[NW]) {   // the words of step `step` -> w stage step & 1
       const char* tab0 = lds + L::T_OFF + ((step >> spg_shift) & 1) * L::T_BUF;
       char* bst = lds + L::B_OFF + (step & 1) * L::B_STAGE;
-      uint32_t v[WPT][4];
+      uint32_t v[NW][4];
 #pragma unroll
-      for (int u = 0; u < WPT; ++u) {
+      for (int u = 0; u < NW; ++u) {
         const char* tab = tab0 + tab_off[u];
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
           const uint32_t c0 = (wd[u] >> (4 * h)) & 15u, c1 = (wd[u] >> (16 + 4 * h)) & 15u;
-          v[u][h] = (uint32_t) * reinterpret_cast<const uint16_t*>(tab + 2 * c0) | ((uint32_t) * reinterpret_cast<const uint16_t*>(tab + 2 * c1) << 16);
+          if constexpr (TILE_ABL & 16) v[u][h] = c0 | (c1 << 16) | (uint32_t)(uintptr_t)tab;
+          else v[u][h] = (uint32_t) * reinterpret_cast<const uint16_t*>(tab + 2 * c0) | ((uint32_t) * reinterpret_cast<const uint16_t*>(tab + 2 * c1) << 16);
         }
       }
 #pragma unroll
       for (int u = 0; u < WPT; ++u)
 #pragma unroll
-        for (int h = 0; h < 4; ++h) *reinterpret_cast<uint32_t*>(bst + dst0[u][h]) = v[u][h];
+        for (int pl = 0; pl < KS; ++pl)
+#pragma unroll
+          for (int h = 0; h < 4; ++h) {
+            if constexpr (TILE_ABL & 32) { if (v[u * KS + pl][h] == 0x12345u) *reinterpret_cast<uint32_t*>(bst) = 1u; }
+            else *reinterpret_cast<uint32_t*>(bst + pl * L::B_PLANE + dst0[u][h]) = v[u * KS + pl][h];
+          }
     };
 #pragma unroll
-    for (int j = 0; j < PW; ++j) load_words(j, ring[j]);
+    for (int j = 0; j < PWD; ++j) load_words(j, ring[j]);
     tile_barrier();            // (tables of steps 0 and 1 built)
     dequant(0, ring[0]);
-    load_words(PW, ring[0]);
+    load_words(PWD, ring[0]);
     tile_barrier();
-    for (int s = 0; s < ksteps; s += PW) {
+    for (int s = 0; s < ksteps; s += PWD) {
 #pragma unroll
-      for (int j = 0; j < PW; ++j) {
+      for (int j = 0; j < PWD; ++j) {
         if (s + j >= ksteps) break;
-        // step t = s + j: the words of step t + 1 are in slot (j + 1) % PW; refilled with step t + 1 + PW
-        if (!(TILE_ABL & 1) && s + j + 1 < ksteps) dequant(s + j + 1, ring[(j + 1) % PW]);
-        load_words(s + j + 1 + PW, ring[(j + 1) % PW]);
+        // step t = s + j: the words of step t + 1 are in slot (j + 1) % PWD; refilled with step t + 1 + PWD
+        if (!(TILE_ABL & 1) && s + j + 1 < ksteps) dequant(s + j + 1, ring[(j + 1) % PWD]);
+        load_words(s + j + 1 + PWD, ring[(j + 1) % PWD]);
         tile_barrier();
       }
     }
@@ -189,9 +221,11 @@ __global__ void __launch_bounds__(512 + 64 * NDW) w4_gemm_tile_kernel(const Tile
       const int c = step < last ? step : last;
       char* adst = lds + L::A_OFF + (step % NST) * L::A_STAGE + xw * XPW * 1024;
 #pragma unroll
-      for (int q = 0; q < XPW; ++q)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xsrc[q] + (int64_t)c * 128),
-                                         (__attribute__((address_space(3))) void*)(adst + q * 1024), 16, 0, 0);
+      for (int pl = 0; pl < KS; ++pl)
+#pragma unroll
+        for (int q = 0; q < XPW; ++q)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xsrc[q] + (int64_t)(c * KS + pl) * 128),
+                                           (__attribute__((address_space(3))) void*)(adst + pl * L::A_PLANE + q * 1024), 16, 0, 0);
     };
 #pragma unroll
     for (int t = 0; t < DX; ++t) dma(t);
@@ -201,7 +235,7 @@ __global__ void __launch_bounds__(512 + 64 * NDW) w4_gemm_tile_kernel(const Tile
     for (int s = 0; s < ksteps; ++s) {
       if (!(TILE_ABL & 4)) {
         dma(s + DX);
-        tile_wait_vm<(DX - 1) * XPW>();
+        tile_wait_vm<(DX - 1) * XPW * KS>();
       }
       tile_barrier();
     }
@@ -228,21 +262,22 @@ __global__ void __launch_bounds__(512 + 64 * NDW) w4_gemm_tile_kernel(const Tile
       lv[v][0] = DT::lo_f32(pr[0]); lv[v][1] = DT::hi_f32(pr[0]); lv[v][2] = DT::lo_f32(pr[1]); lv[v][3] = DT::hi_f32(pr[1]);
     }
   }
-  uint32_t szr[PW][2][RPT];    // scale | zero of the groups of steps t ... t + PW - 1 (slot = step % PW; two sub-groups at g = 32)
-  auto load_sz = [&](int step, uint32_t (&dst)[2][RPT]) {
+  constexpr int NSUB = L::NSUB;
+  uint32_t szr[PW][NSUB][RPT]; // scale | zero of the groups of steps t ... t + PW - 1 (slot = step % PW; up to NSUB sub-groups per step)
+  auto load_sz = [&](int step, uint32_t (&dst)[NSUB][RPT]) {
     const int c = step < last ? step : last;
 #pragma unroll
-    for (int sub = 0; sub < 2; ++sub) {
-      int g = ((c * 64) >> gshift) + (sub < nsub ? sub : 0);
+    for (int sub = 0; sub < NSUB; ++sub) {
+      int g = ((c * (64 * KS)) >> gshift) + (sub < nsub ? sub : 0);
       g = g < ngroups ? g : ngroups - 1;
 #pragma unroll
       for (int v = 0; v < RPT; ++v) dst[sub][v] = qsrc[v][(int64_t)g * p.wrows];
     }
   };
-  auto build_tables = [&](int step, const uint32_t (&sz)[2][RPT]) {   // the tables of the group(s) of k-step `step` into buffer (step >> spg_shift) & 1
+  auto build_tables = [&](int step, const uint32_t (&sz)[NSUB][RPT]) {   // the tables of the group(s) of k-step `step` into buffer (step >> spg_shift) & 1
     char* tb = lds + L::T_OFF + ((step >> spg_shift) & 1) * L::T_BUF + (tid >> 2) * 32 + (tid & 3) * 8;
 #pragma unroll
-    for (int sub = 0; sub < 2; ++sub) {
+    for (int sub = 0; sub < NSUB; ++sub) {
       if (sub < nsub) {
 #pragma unroll
         for (int v = 0; v < RPT; ++v) {
@@ -271,42 +306,45 @@ __global__ void __launch_bounds__(512 + 64 * NDW) w4_gemm_tile_kernel(const Tile
 #pragma unroll
     for (int b = 0; b < MT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
   auto mma = [&](int step) {
-    const char* ast = lds + L::A_OFF + (step % NST) * L::A_STAGE;
-    const char* bst = lds + L::B_OFF + (step & 1) * L::B_STAGE;
-    if constexpr (NT * MT <= 8) {
-      u32x4 wf[2][NT], xf[2][MT];    // every fragment of the step requested up front: the second half's reads land under the first half's MFMAs
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
+    for (int pl = 0; pl < KS; ++pl) {
+      const char* ast = lds + L::A_OFF + (step % NST) * L::A_STAGE + pl * L::A_PLANE;
+      const char* bst = lds + L::B_OFF + (step & 1) * L::B_STAGE + pl * L::B_PLANE;
+      if constexpr (NT * MT <= 8) {
+        u32x4 wf[2][NT], xf[2][MT];  // every fragment of the super-tile requested up front: the second half's reads land under the first half's MFMAs
 #pragma unroll
-        for (int t = 0; t < NT; ++t) wf[kb][t] = *reinterpret_cast<const u32x4*>(bst + b_base[kb] + t * 2048);
+        for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-        for (int t = 0; t < MT; ++t) xf[kb][t] = *reinterpret_cast<const u32x4*>(ast + a_base[kb] + t * 2048);
-      }
+          for (int t = 0; t < NT; ++t) wf[kb][t] = *reinterpret_cast<const u32x4*>(bst + b_base[kb] + t * 2048);
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
+          for (int t = 0; t < MT; ++t) xf[kb][t] = *reinterpret_cast<const u32x4*>(ast + a_base[kb] + t * 2048);
+        }
 #pragma unroll
-        for (int a = 0; a < NT; ++a)
+        for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-          for (int b = 0; b < MT; ++b) acc[a][b] = DT::mfma(wf[kb][a], xf[kb][b], acc[a][b]);
-    } else {                         // (64 accumulator registers: one half's fragments at a time, 128 registers per lane at 16 waves)
+          for (int a = 0; a < NT; ++a)
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
-        u32x4 wf[NT], xf[MT];
+            for (int b = 0; b < MT; ++b) acc[a][b] = DT::mfma(wf[kb][a], xf[kb][b], acc[a][b]);
+      } else {                       // (64 accumulator registers: one half's fragments at a time, 128 registers per lane at 16 waves)
 #pragma unroll
-        for (int t = 0; t < NT; ++t) wf[t] = *reinterpret_cast<const u32x4*>(bst + b_base[kb] + t * 2048);
+        for (int kb = 0; kb < 2; ++kb) {
+          u32x4 wf[NT], xf[MT];
 #pragma unroll
-        for (int t = 0; t < MT; ++t) xf[t] = *reinterpret_cast<const u32x4*>(ast + a_base[kb] + t * 2048);
+          for (int t = 0; t < NT; ++t) wf[t] = *reinterpret_cast<const u32x4*>(bst + b_base[kb] + t * 2048);
 #pragma unroll
-        for (int a = 0; a < NT; ++a)
+          for (int t = 0; t < MT; ++t) xf[t] = *reinterpret_cast<const u32x4*>(ast + a_base[kb] + t * 2048);
 #pragma unroll
-          for (int b = 0; b < MT; ++b) acc[a][b] = DT::mfma(wf[a], xf[b], acc[a][b]);
+          for (int a = 0; a < NT; ++a)
+#pragma unroll
+            for (int b = 0; b < MT; ++b) acc[a][b] = DT::mfma(wf[a], xf[b], acc[a][b]);
+        }
       }
     }
   };
 
   // ---- prologue: the tables of steps 0 and 1; scale / zero of steps 2 ... PW + 1 into the ring ----
   {
-    uint32_t s0[2][RPT], s1[2][RPT];
+    uint32_t s0[NSUB][RPT], s1[NSUB][RPT];
     load_sz(0, s0);
     load_sz(1, s1);
 #pragma unroll

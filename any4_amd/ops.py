@@ -408,9 +408,9 @@ def large_m_rows(weights: int = 0) -> int:
     row panels) and multiply with the GEMM library (torch.matmul = hipBLASLt) -- instead of the library's own kernels; 0 / unset = never
     (the default: every call runs this library's kernels; beyond 64 rows that is the LDS-tiled MFMA GEMM of w4_gemm_tile.cuh, plan
     'tile').  ANY4_LARGE_M_GEMM=library turns the route on from 65 rows (96 for layers of 32 M weights or more), ANY4_LARGE_M=<rows> from
-    that many.  Measured on MI355X, one 4096 x 4096 layer per graph node at 128 / 512 / 1024 / 2048 rows: own kernel 32.6 / 36.4 / 52.4 / 102 us,
-    dequantise (14 us) + hipBLASLt 32.9 / 39.8 / 53.1 / 76 us (profiles/r06_tile_gemm.txt): equal up to ~1024 rows, the
-    vendor GEMM 1.3-1.5 x faster beyond, at the cost of a transient 16-bit copy of a weight panel (at most ANY4_DEQUANT_PANEL_MB, default
+    that many.  Measured on MI355X, one 4096 x 4096 layer per graph node at 128 / 512 / 1024 / 2048 rows: own kernel 29.3 / 32.1 / 52.1 / 102 us,
+    dequantise (14 us) + hipBLASLt 32.9 / 39.8 / 53.1 / 76 us (profiles/r06_tile_gemm.txt): the own kernel 1.1-1.25 x faster up to 512 rows, equal
+    at 1024, the vendor GEMM 1.3-1.5 x faster beyond, at the cost of a transient 16-bit copy of a weight panel (at most ANY4_DEQUANT_PANEL_MB, default
     256 MB)."""
     global _LARGE_M
     if _LARGE_M is None:

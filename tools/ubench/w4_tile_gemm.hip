@@ -33,16 +33,21 @@ static uint16_t f2bf(float f) {
 #ifndef BM_
 #define BM_ 128
 #endif
+#ifndef KS_
+#define KS_ 1
+#endif
 #ifndef NDW128_
 #define NDW128_ 8
 #endif
 template <int BN>
 static int launch(const TileParams& p, hipStream_t st) {
   constexpr int ndw = BN == 64 ? 8 : NDW128_;
-  constexpr auto kern = w4_gemm_tile_kernel<BF16, BM_, BN, DX_, ndw>;
+  constexpr int ks = BN == 64 ? KS_ : 1;
+  constexpr int dx = ks == 2 ? 2 : DX_;
+  constexpr auto kern = w4_gemm_tile_kernel<BF16, BM_, BN, dx, ndw, ks>;
   static bool prepared = false;
   if (!prepared) { CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); prepared = true; }
-  constexpr unsigned lds_bytes = TileLds<BM_, BN, DX_>::BYTES;
+  constexpr unsigned lds_bytes = TileLds<BM_, BN, dx, ks>::BYTES;
   hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(512 + 64 * ndw), lds_bytes, st, p);
   return 0;
 }
