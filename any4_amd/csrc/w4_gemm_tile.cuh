@@ -80,14 +80,20 @@ __device__ __forceinline__ void tile_barrier() {
 // KS  = 64-k super-tiles per step (= per barrier): 1, or 2 where the LDS allows (128 x 64 tiles): every role's chain of dependent LDS /
 //       memory round trips is paid once per step whatever the step holds -- waves wait 54 % of their cycles at KS = 1 (SQ_WAIT_ANY), the
 //       LDS array is 41 % busy -- so two super-tiles per step nearly halve the time per k
-template <typename DT, int BM, int BN, int DX = 3, int NDW = 8, int KS = 1>
-__global__ void __launch_bounds__(512 + 64 * NDW) w4_gemm_tile_kernel(const TileParams p) {
+// NCW = consuming waves: 4 (2 x 2, shipped) or 8 (4 (m) x 2 (n): two per SIMD, one's fragment reads under the other's MFMAs; with 16 waves per
+//       workgroup that leaves 4 dequantising waves, which then bound the 128 x 128 tile: 62.7 vs 55 us at m = 1024 -- developer A/B only)
+template <typename DT, int BM, int BN, int DX = 3, int NDW = 8, int KS = 1, int NCW = 4>
+__global__ void __launch_bounds__(64 * (NCW + 4 + NDW)) w4_gemm_tile_kernel(const TileParams p) {
   constexpr int WN = BN / 2;             // weight rows of a consumer wave
   constexpr int NT = WN / 16;            // its 16-row tiles
-  constexpr int MT = BM / 32;            // 16-row tiles of its BM / 2 activation rows
+  constexpr int WMR = BM / (NCW / 2);    // activation rows of a consumer wave
+  constexpr int MT = WMR / 16;           // its 16-row tiles
   constexpr int XPW = BM / 32;           // x DMA instructions (1 KiB = 8 rows) per step of each of the four x waves
   constexpr int WPT = BN / 8 / NDW;      // 8-row tiles per dequantising wave = packed words per thread and step
-  constexpr int RPT = BN / 64;           // table rows per consumer thread (BN rows x 4 entry quads / 256 threads)
+  constexpr int RPT = BN * 4 / (NCW * 64);  // table rows per consumer thread (BN rows x 4 entry quads / the consumers' threads)
+  constexpr int TRS = NCW * 16;          // table rows one pass of the consumers' threads covers
+  static_assert(NCW == 4 || NCW == 8, "consuming waves");
+  static_assert(RPT >= 1, "table rows per consumer thread");
   constexpr int PW = 4;                  // the register ring of scale / zero: steps ahead
 #ifndef TILE_PWD
 #define TILE_PWD 4
@@ -97,7 +103,7 @@ __global__ void __launch_bounds__(512 + 64 * NDW) w4_gemm_tile_kernel(const Tile
   using L = TileLds<BM, BN, DX, KS>;
   constexpr int KSH = KS == 1 ? 0 : 1;   // log2(KS)
   static_assert(KS == 1 || KS == 2, "super-tiles per step");
-  static_assert(BM == 64 || BM == 128, "activation rows per tile");
+  static_assert(BM == 64 || BM == 128 || BM == 256, "activation rows per tile");
   static_assert(BN == 64 || BN == 128, "weight rows per tile");
   constexpr int NST = L::NST;
   extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -123,9 +129,9 @@ __global__ void __launch_bounds__(512 + 64 * NDW) w4_gemm_tile_kernel(const Tile
   // ahead; vmcnt leaves the requests of the last DX - 1 steps in flight); the w tile of step u is written in step u - 1 from tables
   // built in step u - 2.  Every wave passes the same barriers: two in the prologue, one per step.
 
-  if (wave_all >= 8) {
+  if (wave_all >= NCW + 4) {
     // =================================== dequantising waves ===================================
-    const int dw = wave_all - 8;                                // 0 ... NDW - 1: owns the 8-row tiles dw * WPT ... of the BN rows
+    const int dw = wave_all - (NCW + 4);                                // 0 ... NDW - 1: owns the 8-row tiles dw * WPT ... of the BN rows
     const int ntiles8 = p.wrows >> 3;
     // lane = 8 (row of the tile) + (word 2 i + j of the row) = the word's own position in the tile's 256-byte block of the packed layout: a
     // wave-load is 64 CONSECUTIVE dwords (with lanes = (row & 3, word, row >> 2) a quad of adjacent lanes touched two 64-byte chunks: 8 x the
@@ -205,9 +211,9 @@ __global__ void __launch_bounds__(512 + 64 * NDW) w4_gemm_tile_kernel(const Tile
     return;
   }
 
-  if (wave_all >= 4) {
+  if (wave_all >= NCW) {
     // =================================== x waves: LDS-DMA only ===================================
-    const int xw = wave_all - 4;
+    const int xw = wave_all - NCW;
     const char* xsrc[XPW];
 #pragma unroll
     for (int q = 0; q < XPW; ++q) {
@@ -245,12 +251,12 @@ __global__ void __launch_bounds__(512 + 64 * NDW) w4_gemm_tile_kernel(const Tile
 
   // =================================== consumer waves: MFMAs and tables ===================================
   const int wave = wave_all, tid = wave * 64 + lane;
-  // tables: row (tid >> 2) + 64 v, entries 4 (tid & 3) ... + 3
+  // tables: row (tid >> 2) + TRS v, entries 4 (tid & 3) ... + 3
   float lv[RPT][4];
   const uint32_t* qsrc[RPT];
 #pragma unroll
   for (int v = 0; v < RPT; ++v) {
-    int gr = n0 + (tid >> 2) + 64 * v;
+    int gr = n0 + (tid >> 2) + TRS * v;
     gr = gr < p.wrows ? gr : p.wrows - 1;
     qsrc[v] = reinterpret_cast<const uint32_t*>(p.qinfo) + gr;
     const int e4 = (tid & 3) * 4;
@@ -284,7 +290,7 @@ __global__ void __launch_bounds__(512 + 64 * NDW) w4_gemm_tile_kernel(const Tile
           const float sc = DT::lo_f32(sz[sub][v]), z = DT::hi_f32(sz[sub][v]);
           u32x2 o = {DT::pack2(__builtin_fmaf(lv[v][0], sc, z), __builtin_fmaf(lv[v][1], sc, z)),
                      DT::pack2(__builtin_fmaf(lv[v][2], sc, z), __builtin_fmaf(lv[v][3], sc, z))};
-          *reinterpret_cast<u32x2*>(tb + sub * (BN * 32) + v * (64 * 32)) = o;
+          *reinterpret_cast<u32x2*>(tb + sub * (BN * 32) + v * (TRS * 32)) = o;
         }
       }
     }
@@ -296,7 +302,7 @@ __global__ void __launch_bounds__(512 + 64 * NDW) w4_gemm_tile_kernel(const Tile
   uint32_t a_base[2], b_base[2];
 #pragma unroll
   for (int kb = 0; kb < 2; ++kb) {
-    const int ra = wm * (BM / 2) + fi, rb = wn * WN + fi;
+    const int ra = wm * WMR + fi, rb = wn * WN + fi;
     a_base[kb] = (uint32_t)(ra * 128) + (((uint32_t)(4 * kb + kq) ^ (uint32_t)((ra >> 1) & 7)) << 4);
     b_base[kb] = (uint32_t)(rb * 128) + (((uint32_t)(4 * kb + kq) ^ (uint32_t)((rb >> 1) & 7)) << 4);
   }
@@ -369,7 +375,7 @@ __global__ void __launch_bounds__(512 + 64 * NDW) w4_gemm_tile_kernel(const Tile
   // ---- store: lane (j = activation row fi of tile b, weight rows 4 kq ... 4 kq + 3 of tile a) ----
 #pragma unroll
   for (int b = 0; b < MT; ++b) {
-    const int mr = m0 + wm * (BM / 2) + b * 16 + fi;
+    const int mr = m0 + wm * WMR + b * 16 + fi;
     if (mr >= p.m) continue;
 #pragma unroll
     for (int a = 0; a < NT; ++a) {

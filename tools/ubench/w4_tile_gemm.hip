@@ -36,6 +36,9 @@ static uint16_t f2bf(float f) {
 #ifndef KS_
 #define KS_ 1
 #endif
+#ifndef NCW128_
+#define NCW128_ 4
+#endif
 #ifndef NDW128_
 #define NDW128_ 8
 #endif
@@ -43,12 +46,13 @@ template <int BN>
 static int launch(const TileParams& p, hipStream_t st) {
   constexpr int ndw = BN == 64 ? 8 : NDW128_;
   constexpr int ks = BN == 64 ? KS_ : 1;
-  constexpr int dx = ks == 2 ? 2 : DX_;
-  constexpr auto kern = w4_gemm_tile_kernel<BF16, BM_, BN, dx, ndw, ks>;
+  constexpr int dx = (ks == 2 || BM_ == 256) ? 2 : DX_;
+  constexpr int ncw = BN == 64 ? 4 : NCW128_;
+  constexpr auto kern = w4_gemm_tile_kernel<BF16, BM_, BN, dx, ndw, ks, ncw>;
   static bool prepared = false;
   if (!prepared) { CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); prepared = true; }
   constexpr unsigned lds_bytes = TileLds<BM_, BN, dx, ks>::BYTES;
-  hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(512 + 64 * ndw), lds_bytes, st, p);
+  hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(64 * (ncw + 4 + ndw)), lds_bytes, st, p);
   return 0;
 }
 
