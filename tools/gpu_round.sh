@@ -38,6 +38,7 @@ tail -2 gpurun_out/${RN}_decode_bench.log | cut -c1-300; cat gpurun_out/${RN}_de
 [ -x variants/grid_barrier ] && timeout 120 variants/grid_barrier > gpurun_out/${RN}_ubench_grid_barrier.txt 2>&1
 [ -x variants/fused_qkv_attn ] && timeout 120 variants/fused_qkv_attn > gpurun_out/${RN}_ubench_fused_qkv_attn.txt 2>&1
 [ -x variants/lds_store ] && timeout 120 variants/lds_store > gpurun_out/${RN}_ubench_lds_store.txt 2>&1
+[ -x variants/persistent_chain ] && timeout 120 variants/persistent_chain 16 > gpurun_out/${RN}_ubench_persistent_chain.txt 2>&1
 [ -x variants/x_broadcast ] && timeout 120 variants/x_broadcast > gpurun_out/${RN}_ubench_x_broadcast.txt 2>&1
 # the reference's module-level protocol (microbenchmark.py)
 (for k in 4096 8192; do for q in "anyq" "intq" "anyq --quantize-args per_row=False"; do echo "##### K=$k --quantize $q"; timeout 600 python tools/microbenchmark.py --input-dim $k --output-dim $k --quantize $q 2>&1 | grep -v "amdgpu.ids\|ROCTracer" | tail -5; done; done) > gpurun_out/${RN}_microbenchmark.txt 2>&1
