@@ -175,7 +175,7 @@ int pair16(int dt, int I, bool qmx, const GemmParams& p, int64_t batch, hipStrea
 int pair16_loop(int dt, int I, bool qmx, const GemmParams& p, int64_t batch, hipStream_t st);  // w4_gemm_pair16_loop.cuh: one layer, more 16-row tiles than CUs
 int splitk(int dt, bool layout_a, int canon, bool qmx, int waves, const GemmParams& p, dim3 grid, hipStream_t st);
 int gemv(int dt, int I, bool qmx, GemmParams& p, int64_t batch, hipStream_t st);
-int tile(int dt, int I, bool qmx, const GemmParams& p, int64_t batch, hipStream_t st);  // w4_gemm_tile.cuh: many activation rows
+int tile(int dt, int I, bool qmx, GemmParams& p, int64_t batch, hipStream_t st);  // w4_gemm_tile.cuh: many activation rows
 inline int pair(int dt, int I, bool qmx, GemmParams& p, int64_t batch, hipStream_t st) {
   return dt == TG_BF16 ? pair_bf16(I, qmx, p, batch, st) : pair_f16(I, qmx, p, batch, st);
 }
@@ -355,6 +355,9 @@ inline int cu_count() {
 #endif
 #ifndef TG_B16_CHUNK
 #define TG_B16_CHUNK 4         // consecutive 32-row work items per workgroup visit of those kernels (1 / 4 / 8 within 1 %)
+#endif
+#ifndef TG_TILE_MIN_M_SPLIT
+#define TG_TILE_MIN_M_SPLIT 17  // ... and with a split-K launch of ONE layer (caller's workspace; tg_tile.hip): 12.6-14.8 us at 17 ... 64 rows against 7.5 us per 16-row pass
 #endif
 #ifndef TG_TILE_MIN_M
 #define TG_TILE_MIN_M 65  // activation rows from which a call takes the LDS-tiled MFMA GEMM (w4_gemm_tile.cuh): beyond the 64 rows the row blocks of the group-scaled kernels cover

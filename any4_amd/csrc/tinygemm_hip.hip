@@ -824,6 +824,18 @@ static int gemm_w4_impl(const tg_w4_gemm* caller, int device, tg_stream_t stream
   // packed words per lane-quad in the layout decide the in-register transpose
   const int canon = on_right ? (I == 2 ? CANON_NONE : I == 4 ? CANON_PAIR : CANON_QUAD)
                              : (I == 1 ? CANON_NONE : I == 2 ? CANON_PAIR : CANON_QUAD);
+  // MANY activation rows (a prefill through the modules, a wide decode batch): the LDS-tiled MFMA GEMM that dequantises the weights once per
+  // 128-row tile of m instead of once per 16 rows (w4_gemm_tile.cuh; the reference's weights bit for bit, so it serves both numerics
+  // settings).  From 65 rows; ONE layer from 17 rows when the caller's workspace allows a split-K launch (tg_tile.hip).  4096^2 at m = 128 / 256 / 1024:
+  // 17.9 / 25.5 / 52 us against 37.8 / 44.5 / 166 on the stream kernel and 55 / 102 / 427 in 16-row blocks.
+  if (on_right && a->m >= TG_TILE_MIN_M_SPLIT) {
+    const int trc = tgx::tile(a->dtype, I, a->qtype == TG_Q_MX4, p, batch, st);
+    if (trc != TG_PAIR_NA) {
+      if (ws_need) *ws_need = p.ws_need;
+      return trc;
+    }
+    p.ws_need = 0;
+  }
   // More than 16 activation rows in the default numerics (row-major operands, weights on the B side): the group-scaled kernels hold at
   // most one 16-row MFMA tile of activations, so the call is issued as ceil(m / 16) launches of up to 16 rows each on the caller's stream
   // (the reference's own grid walks the 16-row tiles of m the same way and re-reads the weights per tile, TinyGemmImpl.cuh:379-392).
@@ -869,16 +881,6 @@ static int gemm_w4_impl(const tg_w4_gemm* caller, int device, tg_stream_t stream
       return dry ? r16 : 0;
     }
     p.ws_need = 0;
-  }
-  // MANY activation rows (a prefill through the modules): the LDS-tiled MFMA GEMM that dequantises the weights once per 128-row tile of m
-  // instead of once per 16 rows (w4_gemm_tile.cuh; the reference's weights bit for bit, so it serves both numerics settings).  4096^2 at
-  // m = 128 / 256 / 1024: 32.6 / 33.7 / 58.6 us against 37.8 / 44.5 / 166 on the stream kernel and 55 / 102 / 427 in 16-row blocks.
-  if (on_right && a->m >= TG_TILE_MIN_M) {
-    const int trc = tgx::tile(a->dtype, I, a->qtype == TG_Q_MX4, p, batch, st);
-    if (trc != TG_PAIR_NA) {
-      if (ws_need) *ws_need = 0;
-      return trc;
-    }
   }
   const int rc = launch_w4(a->dtype, !on_right, canon, a->qtype == TG_Q_MX4, p, coltiles, batch, st);
   if (ws_need) *ws_need = (rc == TG_PLAN_PAIR || rc == TG_PLAN_PAIR_XR) ? p.ws_need : 0;

@@ -47,6 +47,11 @@ struct TileParams {
   const char* bias;    // optional [wrows] 16-bit
   int32_t m, wrows, k, ksuper, gshift, qtype;
   int32_t tiles_m, tiles_n;
+  // split-K (few tiles: m <= 256 against 256 CUs): `splits` workgroups per tile, each over ksuper / splits super-tiles, f32 partial tiles
+  // [split][m][wrows] in `part`; tile_split_sum_kernel adds them in split order.  splits <= 1: the kernel stores y itself
+  int32_t splits;
+  float* part;
+  int64_t x_pitch;     // elements between activation rows (>= k)
 };
 
 template <int BM, int BN, int DX, int KS>
@@ -110,20 +115,26 @@ __global__ void __launch_bounds__(64 * (NCW + 4 + NDW)) w4_gemm_tile_kernel(cons
 
   const int lane = threadIdx.x & 63, wave_all = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   // ---- tile of this workgroup: consecutive tiles on ONE XCD (block b runs on XCD b % 8) ----
-  const int ntot = p.tiles_m * p.tiles_n;
+  const int nsplit = p.splits > 1 ? p.splits : 1;
+  const int ntot = p.tiles_m * p.tiles_n * nsplit;
   int tile;
   {
     const int b = blockIdx.x, q = ntot >> 3, r = ntot & 7, xcd = b & 7, idx = b >> 3;
     tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;   // bijective for every ntot (cdna_hip_programming.md T1)
   }
-  const int tn = tile / p.tiles_m, tm = tile - tn * p.tiles_m;
+  // (n tile, split, m tile): the m tiles of one n tile and k range next to each other
+  const int tns = tile / p.tiles_m, tm = tile - tns * p.tiles_m;
+  const int tn = tns / nsplit, split = tns - tn * nsplit;
   const int m0 = tm * BM, n0 = tn * BN;
-  const int ksteps = p.ksuper >> KSH;                          // KS super-tiles of 64 k per step (host: ksuper % KS == 0)
+  const int ksuper_l = p.ksuper / nsplit;                      // this workgroup's super-tiles: split * ksuper_l ... (host: divides, a multiple of KS
+  const int ks0 = split * ksuper_l;                            // and of the quantisation group)
+  const int ksteps = ksuper_l >> KSH;                          // KS super-tiles of 64 k per step
   const int last = ksteps - 1;
   const int gshift = p.gshift;
   const int spg_shift = gshift > 6 + KSH ? gshift - 6 - KSH : 0;        // log2(steps per group)            (KS = 1: g = 128: 2, 256: 4)
   const int nsub = gshift < 6 + KSH ? 1 << (6 + KSH - gshift) : 1;      // groups per step                  (KS = 1: g = 32: 2)
-  const int ngroups = p.k >> gshift;
+  const int ngroups = (ksuper_l << 6) >> gshift;              // groups of this workgroup's k range, counted from g0
+  const int g0 = (ks0 << 6) >> gshift;
   auto new_group = [&](int step) { return nsub > 1 || step == 0 || ((step >> spg_shift) != ((step - 1) >> spg_shift)); };
   // Schedule (u = a k-step).  Data of step u is consumed by the MFMAs in step u: x(u) lands by the end of step u - 1 (requested DX steps
   // ahead; vmcnt leaves the requests of the last DX - 1 steps in flight); the w tile of step u is written in step u - 1 from tables
@@ -147,7 +158,7 @@ __global__ void __launch_bounds__(64 * (NCW + 4 + NDW)) w4_gemm_tile_kernel(cons
       const int t8 = dw * WPT + u;
       int gt = (n0 >> 3) + t8;
       gt = gt < ntiles8 ? gt : ntiles8 - 1;
-      wsrc[u] = reinterpret_cast<const uint32_t*>(p.w) + ((int64_t)gt * p.ksuper * 32 + 4 * drow8 + di) * 2 + dj;
+      wsrc[u] = reinterpret_cast<const uint32_t*>(p.w) + (((int64_t)gt * p.ksuper + ks0) * 32 + 4 * drow8 + di) * 2 + dj;
       const int row = t8 * 8 + drow8;
 #pragma unroll
       for (int h = 0; h < 4; ++h) dst0[u][h] = (uint32_t)(row * 128 + 4 * di) + (((uint32_t)(4 * dj + h) ^ (uint32_t)((row >> 1) & 7)) << 4);
@@ -221,7 +232,7 @@ __global__ void __launch_bounds__(64 * (NCW + 4 + NDW)) w4_gemm_tile_kernel(cons
       int mr = m0 + row;
       mr = mr < p.m ? mr : p.m - 1;                             // (rows beyond m: a valid row, never stored)
       const int chunk = (lane & 7) ^ ((row >> 1) & 7);          // LDS slot lane & 7 <- global chunk slot ^ f(row)
-      xsrc[q] = p.x + ((int64_t)mr * p.k) * 2 + chunk * 16;
+      xsrc[q] = p.x + ((int64_t)mr * p.x_pitch + ks0 * 64) * 2 + chunk * 16;
     }
     auto dma = [&](int step) {                                  // (past the end: the last step again, into a stage nobody reads)
       const int c = step < last ? step : last;
@@ -258,7 +269,7 @@ __global__ void __launch_bounds__(64 * (NCW + 4 + NDW)) w4_gemm_tile_kernel(cons
   for (int v = 0; v < RPT; ++v) {
     int gr = n0 + (tid >> 2) + TRS * v;
     gr = gr < p.wrows ? gr : p.wrows - 1;
-    qsrc[v] = reinterpret_cast<const uint32_t*>(p.qinfo) + gr;
+    qsrc[v] = reinterpret_cast<const uint32_t*>(p.qinfo) + (int64_t)g0 * p.wrows + gr;
     const int e4 = (tid & 3) * 4;
     if (p.qtype == TG_Q_INT4) {
 #pragma unroll
@@ -381,7 +392,22 @@ __global__ void __launch_bounds__(64 * (NCW + 4 + NDW)) w4_gemm_tile_kernel(cons
     for (int a = 0; a < NT; ++a) {
       const int nr = n0 + wn * WN + a * 16 + 4 * kq;
       if (nr >= p.wrows) continue;   // (wrows is a multiple of 8: a group of four rows is inside or outside)
-      store_rows4<DT>(p.y, p.bias, (int64_t)mr * p.wrows + nr, nr, acc[a][b]);
+      if (nsplit > 1) *reinterpret_cast<f32x4*>(p.part + ((int64_t)split * p.m + mr) * p.wrows + nr) = acc[a][b];
+      else store_rows4<DT>(p.y, p.bias, (int64_t)mr * p.wrows + nr, nr, acc[a][b]);
     }
   }
+}
+
+// y[a][row ... row + 3] = RNE16(sum of the k-splits' f32 partial tiles, in split order) (+ bias, rounded again as everywhere)
+template <typename DT>
+__global__ void __launch_bounds__(256) tile_split_sum_kernel(const float* __restrict__ part, int splits, int64_t part_stride, char* __restrict__ y,
+                                                             const char* __restrict__ bias, int wrows, int64_t quads) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= quads) return;
+  f32x4 acc = *reinterpret_cast<const f32x4*>(part + i * 4);
+  for (int s = 1; s < splits; ++s) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(part + s * part_stride + i * 4);
+    acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
+  }
+  store_rows4<DT>(y, bias, i * 4, (int)((i * 4) % wrows), acc);
 }

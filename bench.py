@@ -796,6 +796,10 @@ def main():
             xx.mul_(2.0 ** -5)   # (k = 4096 products of unit-variance activations: keep max|y| near 1 like the other legs)
             singles = [make_args(_lib, ww[i:i + 1], xx[i:i + 1], qq[i:i + 1], ll[i:i + 1], yy[i:i + 1], mm, nn, kk, gg, "any4_rowwise", True, inner, 1)
                        for i in range(layers)]
+            # the caller's scratch (as the ops bring it): fewer tiles than CUs -> a split-K launch, f32 partial tiles summed in split order
+            ws_keep = attach_workspace(lib, singles[0], device)  # noqa: F841  (kept alive)
+            for sa in singles[1:]:
+                sa.workspace, sa.workspace_bytes = singles[0].workspace, singles[0].workspace_bytes   # (one stream: the launches are ordered)
             for sa in singles:
                 launch(sa)
             torch.cuda.synchronize()
@@ -829,11 +833,12 @@ def main():
             return {"m": mm, "n": nn, "k": kk, "us_per_layer": round(us, 2), "TFLOPs": round(flop / us * 1e-6, 1),
                     "frac_of_mfma_peak": round(flop / us * 1e-6 / 2500.0, 4), "peak_TFLOPs": 2500.0, "bound": "mfma",
                     "kernel_plan": ops.gemm_w4_plan(mm, nn, kk, gg, QT["any4_rowwise"], True, inner, torch.bfloat16, 1, "fast"),
-                    "check_err_over_tol": round(err, 3),
+                    "split_k_workspace_bytes": int(singles[0].workspace_bytes), "check_err_over_tol": round(err, 3),
                     "note": "one layer per launch, distinct weights per launch; the reference walks m in 16-row blocks (TinyGemmImpl.cuh:379-392), "
                             "this kernel dequantises once per 128-row tile; a 16-bit GEMM of the vendor library on the dequantised weights is an opt-in route (ANY4_LARGE_M_GEMM=library)"}
 
-        many_rows = {} if world > 1 else {"m512": many_rows_leg(512, n, k, g), "m2048": many_rows_leg(2048, n, k, g, layers=4)}
+        many_rows = {} if world > 1 else {"m64": many_rows_leg(64, n, k, g), "m128": many_rows_leg(128, n, k, g), "m512": many_rows_leg(512, n, k, g),
+                                          "m2048": many_rows_leg(2048, n, k, g, layers=4)}
 
         # (c) single-layer launches: what one module forward issues (the reference's microbenchmark shape) -- Any4Linear's
         # default kernel (per-row LUT any4, weights on the B side) and Int4Linear's (modules.py:21: uniform int4, A side)
@@ -1012,6 +1017,7 @@ def main():
                                     "any4_m8_per_graph_node": single_m8.get("us_per_launch_in_hipgraph"),
                                     "any4_m16_per_graph_node": single_m16.get("us_per_launch_in_hipgraph"),
                                     "any4_m16_28672x4096_per_graph_node": single_m16_gate_up.get("us_per_launch_in_hipgraph")},
+                "many_rows_us_per_4096x4096_layer": {kk_: vv_["us_per_layer"] for kk_, vv_ in many_rows.items()},
                 "decode_llama3_8b": None if not decode or "error" in decode else
                 {"ms_per_token": decode["ms_per_token"], "frac_of_hbm_roofline": decode["frac_of_hbm_roofline"],
                  "kernels_per_layer": decode["kernels_per_layer"]},

@@ -768,10 +768,11 @@ def test_dequant_w4_is_the_reference_weights_bit_for_bit(T, oracle, qtype, g, in
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("qtype,g", [("any4_rowwise", 128), ("any4_rowwise", 32), ("int4", 64), ("any4_global", 256)])
-@pytest.mark.parametrize("m,n,k", [(65, 200, 512), (128, 64, 64), (130, 1008, 1024), (512, 528, 2048)])
+@pytest.mark.parametrize("m,n,k", [(65, 200, 512), (128, 64, 64), (130, 1008, 1024), (512, 528, 2048), (33, 200, 2048), (64, 528, 2048), (48, 1008, 4096), (130, 1008, 4096), (256, 2056, 2048), (17, 72, 2048), (20, 4096, 2048)])
 def test_tile_gemm_many_rows_against_oracle(T, oracle, dtype, qtype, g, m, n, k):
     """TinyGemmImpl.cuh:379-392: the reference's one kernel walks any m.  Here more than 64 activation rows run w4_gemm_tile_kernel (plan
-    'tile'): an LDS-tiled MFMA GEMM whose weight tile is dequantised on the way in.  Ragged m (not a multiple of 128), ragged weight rows
+    'tile'): an LDS-tiled MFMA GEMM whose weight tile is dequantised on the way in -- from 33 rows on as a split-K launch (2 / 4 / 8 k ranges,
+    f32 partial tiles in the op's workspace, summed in split order) when the tiles do not fill the chip.  Ragged m (not a multiple of 128), ragged weight rows
     (not a multiple of 64 / 128), k of one step and of many, every group size, both 16-bit types, both numerics settings, both operand
     sides, with and without a fused bias -- against the oracle's reference-faithful weights at the GEMM tolerance."""
     import any4_amd
@@ -799,6 +800,30 @@ def test_tile_gemm_many_rows_against_oracle(T, oracle, dtype, qtype, g, m, n, k)
     with ops.fused_bias(bias) as fb:
         yb = run_rm(T, codes, x, qinfo, lut, g, qtype, True, 4)
     assert fb.consumed and torch.equal(yb, y + bias)
+
+
+def test_tile_gemm_without_a_workspace(T, oracle, monkeypatch):
+    """The C ABI's workspace is optional (include/tinygemm_hip.h): without one the tile GEMM runs unsplit from 65 rows (below: 16-row passes).
+    Same weights, another summation order: both within the GEMM tolerance of the oracle; and the split launch is deterministic."""
+    from any4_amd import ops
+
+    m, n, k, g = 128, 1008, 4096, 128
+    codes, x, qinfo, lut = rand_problem(n, k, g, m, "any4_rowwise", seed=77)
+    want = oracle_weights(oracle, codes, g, "any4_rowwise", qinfo, lut, torch.bfloat16)
+    y_split = run_rm(T, codes, x, qinfo, lut, g, "any4_rowwise", True, 4)
+    assert torch.equal(y_split, run_rm(T, codes, x, qinfo, lut, g, "any4_rowwise", True, 4))
+    saved = dict(ops._WS_BYTES)
+    ops._WS_BYTES.clear()
+    monkeypatch.setattr(ops._L, "tg_gemm_w4_workspace_bytes", lambda a: 0, raising=False)
+    try:
+        y_plain = run_rm(T, codes, x, qinfo, lut, g, "any4_rowwise", True, 4)
+        y48 = run_rm(T, codes, x[:48].contiguous(), qinfo, lut, g, "any4_rowwise", True, 4)      # (no workspace, 48 rows: three 16-row passes)
+    finally:
+        ops._WS_BYTES.clear()
+        ops._WS_BYTES.update(saved)
+    assert_gemm_close(y_split[:, :n], x, want, torch.bfloat16)
+    assert_gemm_close(y_plain[:, :n], x, want, torch.bfloat16)
+    assert_gemm_close(y48[:, :n], x[:48], want, torch.bfloat16)
 
 
 @pytest.mark.parametrize("on_right,inner", [(True, 4), (False, 2)])

@@ -327,21 +327,27 @@ def test_xr_kernel_routing():
     # more than 16 rows (default numerics, row-major operands): ceil(m / 16) launches of up to 16 rows on the same kernels -- the plan is
     # the 16-row block's; shapes whose blocks have no group-scaled kernel (innerKTiles 8 at one layer per launch) stay where they were
     assert plan(17, 4096, 4096, 128, "any4_rowwise") == "pair_xr" and plan(64, 4096, 4096, 128, "any4_rowwise") == "pair_xr"
-    assert ops.gemm_w4_plan(33, 4096, 4096, 128, q2["any4_rowwise"], True, 4) == "pair"
+    assert ops.gemm_w4_plan(33, 4096, 4096, 128, q2["any4_rowwise"], True, 4, workspace=False) == "pair"
+    # ONE layer at 33 ... 64 rows with the caller's workspace: the tile GEMM as a split-K launch (f32 partial tiles in the workspace)
+    assert ops.gemm_w4_plan(33, 4096, 4096, 128, q2["any4_rowwise"], True, 4) == "tile" and ops.gemm_w4_plan(17, 4096, 4096, 128, q2["any4_rowwise"], True, 4) == "tile"
+    assert ops.gemm_w4_plan(64, 4096, 4096, 128, q2["any4_rowwise"], True, 4, batch=2) == "pair"
+    assert ops.gemm_w4_plan(16, 4096, 4096, 128, q2["any4_rowwise"], True, 4) == "pair"      # (one 16-row pass stays)
+    assert ops.gemm_w4_plan(17, 4096, 512, 128, q2["any4_rowwise"], True, 4) == "pair"       # (k too short to split)
     # beyond the 64 rows of the row blocks: the LDS-tiled MFMA GEMM (w4_gemm_tile.cuh), in BOTH numerics settings (it computes the reference's
     # weights), on both operand sides of the native words; not for mx4 / innerKTiles != 4 / fragment-order operands
     for num in ("fast", "reference"):
         assert ops.gemm_w4_plan(65, 4096, 4096, 128, q2["any4_rowwise"], True, 4, numerics=num, detail=True) == "tile"
         assert ops.gemm_w4_plan(512, 14336, 4096, 32, q2["int4"], True, 4, numerics=num) == "tile"
         assert ops.gemm_w4_plan(2048, 4096, 4096, 128, q2["any4_global"], False, 4, numerics=num, weight_format="native") == "tile"
-    assert ops.gemm_w4_plan(64, 4096, 4096, 128, q2["any4_rowwise"], True, 4) == "pair"      # (64 rows: still four 16-row blocks)
+    assert ops.gemm_w4_plan(64, 4096, 4096, 128, q2["any4_rowwise"], True, 4, workspace=False) == "pair"      # (64 rows, no workspace: four 16-row blocks)
     assert ops.gemm_w4_plan(512, 4096, 4096, 32, q2["mx4"], True, 4) in ("stream", "splitk", "pair")
     assert ops.gemm_w4_plan(512, 4096, 4096, 128, q2["any4_rowwise"], True, 8, detail=True) in ("stream", "splitk")
     assert ops.gemm_w4_plan(512, 4096, 4096, 128, q2["any4_rowwise"], False, 4, weight_format="reference", detail=True) in ("stream", "splitk")
     assert ops.gemm_w4_plan(512, 4096, 4096, 128, q2["any4_rowwise"], True, 4, workspace=False) == "tile"          # (no workspace)
     assert ops.large_m_rows(4096 * 4096) > 1 << 40      # the library-GEMM route is opt-in (ANY4_LARGE_M_GEMM=library / ANY4_LARGE_M)
     assert ops.gemm_w4_plan(33, 4096, 4096, 128, q2["any4_rowwise"], True, 8, detail=True) in ("stream", "splitk")
-    assert ops.gemm_w4_plan(33, 4096, 4096, 128, q2["any4_rowwise"], True, 4, numerics="reference", detail=True) in ("stream", "splitk")
+    assert ops.gemm_w4_plan(33, 4096, 4096, 128, q2["any4_rowwise"], True, 4, numerics="reference", detail=True, workspace=False) in ("stream", "splitk")
+    assert ops.gemm_w4_plan(33, 4096, 4096, 128, q2["any4_rowwise"], True, 4, numerics="reference", detail=True) == "tile"
 
 
 def test_integration_md_binding_and_struct_bytes():

@@ -52,13 +52,21 @@ static int launch(const TileParams& p, hipStream_t st) {
   static bool prepared = false;
   if (!prepared) { CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); prepared = true; }
   constexpr unsigned lds_bytes = TileLds<BM_, BN, dx, ks>::BYTES;
-  hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(64 * (ncw + 4 + ndw)), lds_bytes, st, p);
+  const int ns = p.splits > 1 ? p.splits : 1;
+  hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n * ns), dim3(64 * (ncw + 4 + ndw)), lds_bytes, st, p);
+  if (ns > 1) {
+    const int64_t quads = (int64_t)p.m * p.wrows / 4;
+    hipLaunchKernelGGL(tile_split_sum_kernel<BF16>, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, st, p.part, ns, (int64_t)p.m * p.wrows, p.y, p.bias, p.wrows, quads);
+  }
   return 0;
 }
 
 int main(int argc, char** argv) {
   int m = argc > 1 ? atoi(argv[1]) : 512, n = argc > 2 ? atoi(argv[2]) : 4096, k = argc > 3 ? atoi(argv[3]) : 4096;
   int g = argc > 4 ? atoi(argv[4]) : 128, qtype = argc > 5 ? atoi(argv[5]) : 2, bn = argc > 6 ? atoi(argv[6]) : 64;
+  const int splits = argc > 7 ? atoi(argv[7]) : 1;
+  const int xpad = argc > 8 ? atoi(argv[8]) : 0;   // extra elements per activation row (pitch experiment)
+  const size_t xp = (size_t)k + xpad;
   const int SETS = 6;
   std::mt19937 rng(123);
   std::uniform_int_distribution<uint32_t> u32;
@@ -67,7 +75,7 @@ int main(int argc, char** argv) {
   const int ksuper = k / 64, ngroups = k / g;
   std::vector<uint32_t> w((size_t)SETS * (n / 8) * ksuper * 64);
   for (auto& v : w) v = u32(rng);
-  std::vector<uint16_t> lut((size_t)n * 16), qinfo((size_t)ngroups * n * 2), x((size_t)m * k), y((size_t)m * n), bias(n);
+  std::vector<uint16_t> lut((size_t)n * 16), qinfo((size_t)ngroups * n * 2), x((size_t)m * xp), y((size_t)m * n), bias(n);
   for (auto& v : lut) v = f2bf(nd(rng));
   for (size_t i = 0; i < (size_t)ngroups * n; ++i) { qinfo[2 * i] = f2bf(ud(rng) * 0.02f + 0.005f); qinfo[2 * i + 1] = f2bf(nd(rng) * 0.01f); }
   for (auto& v : x) v = f2bf(nd(rng));
@@ -84,6 +92,8 @@ int main(int argc, char** argv) {
   p.m = m; p.wrows = n; p.k = k; p.ksuper = ksuper; p.qtype = qtype;
   p.gshift = 0; while ((1 << p.gshift) < g) ++p.gshift;
   p.tiles_m = (m + BM_ - 1) / BM_; p.tiles_n = (n + bn - 1) / bn;
+  p.splits = splits; p.part = nullptr; p.x_pitch = (int64_t)xp;
+  if (splits > 1) CK(hipMalloc(&p.part, (size_t)splits * m * n * 4));
   auto go = [&](const TileParams& pp) { return bn == 64 ? launch<64>(pp, 0) : launch<128>(pp, 0); };
   go(p);
   CK(hipDeviceSynchronize());
@@ -108,14 +118,14 @@ int main(int argc, char** argv) {
   for (int r : rows)
     for (int c = 0; c < n; ++c) {
       double s = 0, sa = 0;
-      for (int kk = 0; kk < k; ++kk) { const double pr = (double)bf2f(x[(size_t)r * k + kk]) * wdq[(size_t)c * k + kk]; s += pr; sa += fabs(pr); }
+      for (int kk = 0; kk < k; ++kk) { const double pr = (double)bf2f(x[(size_t)r * xp + kk]) * wdq[(size_t)c * k + kk]; s += pr; sa += fabs(pr); }
       const double got = bf2f(y[(size_t)r * n + c]);
       const double tol = fabs(s) * 0.0045 + sa * 4e-6 + 1e-30;
       const double e = fabs(got - s);
       if (!(e <= tol)) { if (bad < 5) printf("MISMATCH y[%d][%d] = %g want %g (tol %g)\n", r, c, got, s, tol); ++bad; }
       worst = fmax(worst, e / tol); ++checked;
     }
-  printf("check m=%d n=%d k=%d g=%d qtype=%d bn=%d: %ld / %ld bad, worst err/tol %.3f\n", m, n, k, g, qtype, bn, bad, checked, worst);
+  printf("check m=%d n=%d k=%d g=%d qtype=%d bn=%d splits=%d: %ld / %ld bad, worst err/tol %.3f\n", m, n, k, g, qtype, bn, splits, bad, checked, worst);
   // ---- timing: rotating weight sets ----
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   const int iters = 60;
