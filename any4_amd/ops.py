@@ -561,9 +561,9 @@ def _w4_rm(A, B, q_group, qinfo, lut, qtype, weight_on_right, opname, frag=False
         args.workspace, args.workspace_bytes = ws.data_ptr(), ws_bytes
     _lib.check(_L.tg_gemm_w4(ctypes.byref(args), _dev(x), _stream(x)), opname)
     sink = getattr(_tls, "plan_sink", None)
-    if sink is not None and not frag and ws_bytes == 0:
-        # a caller (modules._PackedLinear) keeps the validated argument struct to re-issue the same launch with new x / y pointers
-        sink.append((W4Gemm.from_buffer_copy(args), x, (w, qinfo, lut, bias), opname))
+    if sink is not None and not frag:
+        # a caller (modules._PackedLinear) keeps the validated argument struct to re-issue the same launch with new x / y (/ scratch) pointers
+        sink.append((W4Gemm.from_buffer_copy(args), x, (w, qinfo, lut, bias), opname, max(ws_bytes, 0)))
     return y
 
 
@@ -577,17 +577,19 @@ class LaunchPlan:
 
     Re-entrant like the reference's host functions (TinyGemm_int4.cu:41-42: no state, the current stream of the calling thread):
     the recorded struct is a template that is never written after construction; every host thread fills in x / y in ITS OWN copy
-    (made once per thread), so two threads running the same module on two streams cannot see each other's pointers.  A plan is
-    only recorded for launches without a workspace (nothing but x and y differs between calls).
+    (made once per thread), so two threads running the same module on two streams cannot see each other's pointers.  A launch
+    that takes a workspace (split-K tile launches at 17 ... ~256 rows, activation pre-passes) gets a fresh one from torch's caching allocator
+    per call like the full path does (stream-ordered, never shared between calls in flight).
 
     `try_run` is the whole eager hot path of a module (measured on MI355X, dev/host_path.py: 10.7 -> ~8 us per forward at 4096 x 4096,
     of which the HIP launch is 3-4 and torch.empty 1.5): no tuples built, no views, the parameters checked by POINTER (the struct points
     at their storage: an in-place update needs no new plan, a re-assigned or re-allocated parameter has a new pointer)."""
 
-    __slots__ = ("args", "key", "m", "n", "k", "dtype", "device", "dev_index", "opname", "keep", "_per_thread", "ptrs", "numerics", "wformat", "attrs")
+    __slots__ = ("args", "key", "m", "n", "k", "dtype", "device", "dev_index", "opname", "keep", "_per_thread", "ptrs", "numerics", "wformat", "attrs", "ws_bytes")
 
-    def __init__(self, args, x, keep, opname, key):
+    def __init__(self, args, x, keep, opname, key, ws_bytes=0):
         self.args, self.key, self.opname, self.keep = args, key, opname, keep  # (keep: the tensors the struct points at stay alive)
+        self.ws_bytes = ws_bytes
         self.m, self.n, self.k, self.dtype, self.device, self.dev_index = x.shape[0], args.wrows, x.shape[1], x.dtype, x.device, _dev(x)
         self._per_thread = {}   # thread id -> (that thread's private copy of the struct, its byref) (dict get / set are atomic under the GIL)
         self.ptrs = (args.w, args.qinfo, args.lut)
@@ -608,6 +610,9 @@ class LaunchPlan:
     def _launch(self, xp, y):
         a, ref = self.thread_args()
         a.x, a.y = xp, y.data_ptr()
+        if self.ws_bytes:
+            ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=self.device)   # (alive until the launch is enqueued: the allocator is stream-ordered)
+            a.workspace = ws.data_ptr()
         rc = _L.tg_gemm_w4(ref, self.dev_index, _raw_stream(self.dev_index) if _raw_stream is not None else torch.cuda.current_stream(self.device).cuda_stream)
         if rc:
             _lib.check(rc, self.opname)
@@ -645,11 +650,11 @@ def record_plan(fn, x, key, params=()):
         _tls.plan_sink = prev
     if len(sink) != 1 or sink[0][1].data_ptr() != x.data_ptr() or tuple(y.shape) != (x.shape[0], sink[0][0].wrows):
         return y, None
-    args, _, keep, opname = sink[0]
+    args, _, keep, opname, ws_bytes = sink[0]
     own = {t.data_ptr() for t in params if t is not None}
     if params and any(p is not None and p not in own for p in (args.w, args.qinfo, args.lut)):
         return y, None
-    return y, LaunchPlan(args, x, keep, opname, key)
+    return y, LaunchPlan(args, x, keep, opname, key, ws_bytes)
 
 
 def w4_linear_fused(x, w, q_group, qinfo, lut=None, *, residual=None, norm_weight=None, norm_eps=1e-5, swiglu=False, out=None):

@@ -286,3 +286,44 @@ def test_same_module_from_two_threads_on_two_streams(T):
     [t.join() for t in th]
     assert not bad
     assert len(lin.__dict__["_plan"]._per_thread) >= 2   # every thread filled in its own copy of the argument struct
+
+
+def test_launch_plan_with_a_workspace_two_threads(T, oracle):
+    """A module at 17 ... ~256 rows runs the tile GEMM as a split-K launch: the recorded launch plan carries the workspace SIZE and every
+    replay takes a fresh scratch from the (stream-ordered) caching allocator.  Two threads on two streams, the same module: every result is
+    its own, equal to the first (the split sum is deterministic), and right against the oracle."""
+    import threading
+
+    import modules
+    from any4_amd import ops
+
+    n, k, g, m = 1024, 4096, 128, 96
+    codes, x, qinfo, lut = rand_problem(n, k, g, m, "any4_rowwise", seed=11)
+    lin = modules.Any4Linear(k, n, bias=False, device=DEV, dtype=torch.bfloat16, group_size=g)
+    lin.weight.data, lin.scales_and_zeros.data, lin.lut.data = codes.to(DEV), qinfo.to(DEV), lut.to(DEV)
+    lin.reshape_weight()
+    assert ops.gemm_w4_plan(m, n, k, g, 2, True, 4) == "tile"
+    xs = [(x * s).to(DEV) for s in (1.0, -0.5)]
+    want = [lin(xi).clone() for xi in xs]
+    plan = lin.__dict__["_plan"]
+    assert plan is not None and plan.ws_bytes >= 2 * m * n * 4
+    assert_gemm_close(want[0].cpu(), x, oracle_weights(oracle, codes, g, "any4_rowwise", qinfo, lut, torch.bfloat16), torch.bfloat16)
+    torch.cuda.synchronize()
+    bad, go = [], threading.Barrier(2)
+
+    def work(i):
+        st = torch.cuda.Stream()
+        go.wait()
+        with torch.cuda.stream(st):
+            for it in range(400):
+                y = lin(xs[i])
+                if it % 50 == 0 and not torch.equal(y, want[i]):
+                    bad.append(i)
+            st.synchronize()
+            if not torch.equal(lin(xs[i]), want[i]):
+                bad.append(i)
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not bad
