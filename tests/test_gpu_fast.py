@@ -391,7 +391,7 @@ def test_more_than_16_rows_in_row_blocks(T, oracle, case):
                            bias_row_stride=(n if bias is not None else 0))
         need = L.tg_gemm_w4_workspace_bytes(ctypes.byref(args))
         assert need >= 0
-        if need:
+        if need and copies > 1:   # (ONE layer with a workspace would take the split-K tile launch: tests/test_gpu_parity.py; without one: row blocks)
             ws = torch.full((need,), 0xff, dtype=torch.uint8, device=DEV)
             args.workspace, args.workspace_bytes = ws.data_ptr(), need
         assert L.tg_gemm_w4_plan(ctypes.byref(args), 0) in (_lib.TG_PLAN_PAIR, _lib.TG_PLAN_PAIR_XR, _lib.TG_PLAN_GEMV)
@@ -1077,7 +1077,8 @@ def test_module_bias_is_fused_and_bit_identical(T, kernel, cls, numerics):
 @pytest.mark.parametrize("kernel,cls", [("linear_y_f16RM_x_f16RM_W_any4TC", "Any4Linear"), ("linear_y_f16RM_W_any4TC_x_f16RM", "Any4Linear"),
                                         ("linear_y_f16RM_W_int4TC_x_f16RM", "Int4Linear")])
 def test_module_more_than_16_rows(T, oracle, kernel, cls):
-    """A module forward with 2 x 21 = 42 activation rows (default numerics): three launches of up to 16 rows inside ONE op call, on both
+    """A module forward with 2 x 21 = 42 activation rows (default numerics): the split-K tile launch with the op's workspace, three launches of
+    up to 16 rows inside ONE op call without, on both
     operand sides (weights on the left = the native row-per-lane words, a B-side call), bias fused into every block's store -- every row
     within the group-scaled tolerance of the oracle, the same bits as the separate add."""
     import any4_amd
@@ -1098,7 +1099,9 @@ def test_module_more_than_16_rows(T, oracle, kernel, cls):
         mod.reshape_weight()
     on_right = "x_f16RM_W" in kernel
     assert mod.weight_format == (None if on_right else "native")
-    assert ops.gemm_w4_plan(2 * m, n, k, g, QT[qtype], on_right, 4, weight_format="native") in ("pair", "pair_xr", "gemv")
+    # (round 6: ONE layer from 17 rows with the op's workspace = the split-K tile launch; without a workspace: 16-row blocks -- both checked here)
+    assert ops.gemm_w4_plan(2 * m, n, k, g, QT[qtype], on_right, 4, weight_format="native") == "tile"
+    assert ops.gemm_w4_plan(2 * m, n, k, g, QT[qtype], on_right, 4, weight_format="native", workspace=False) in ("pair", "pair_xr", "gemv")
     x = x2.view(2, m, k).to(DEV)
     y = mod(x)
     bias = mod.bias
@@ -1107,7 +1110,28 @@ def test_module_more_than_16_rows(T, oracle, kernel, cls):
     mod.bias = bias
     assert y.shape == (2, m, n)
     assert torch.equal(y, y_plain + bias)
-    _check_rows(oracle, y_plain.view(2 * m, n), codes, x2, qinfo, lut, g, qtype, torch.bfloat16)
+    # (the tile GEMM computes the reference's own weights: the GEMM tolerance against the reference-faithful oracle)
+    from tests.test_gpu_parity import assert_gemm_close, oracle_weights
+    assert_gemm_close(y_plain.view(2 * m, n).cpu(), x2, oracle_weights(oracle, codes, g, qtype, qinfo, lut, torch.bfloat16), torch.bfloat16)
+    # the same forward without the workspace: three launches of up to 16 rows inside ONE op call
+    saved = dict(ops._WS_BYTES)
+    ops._WS_BYTES.clear()
+    real = ops._L.tg_gemm_w4_workspace_bytes
+    ops._L.tg_gemm_w4_workspace_bytes = lambda a: 0
+    mod.__dict__.pop("_plan", None)
+    mod.__dict__.pop("_no_plan", None)
+    try:
+        yb = mod(x)
+        mod.bias = None
+        yb_plain = mod(x)
+    finally:
+        mod.bias = bias
+        ops._L.tg_gemm_w4_workspace_bytes = real
+        ops._WS_BYTES.clear()
+        ops._WS_BYTES.update(saved)
+        mod.__dict__.pop("_plan", None)
+    assert torch.equal(yb, yb_plain + bias)
+    _check_rows(oracle, yb_plain.view(2 * m, n), codes, x2, qinfo, lut, g, qtype, torch.bfloat16)
 
 
 def test_pair_kernel_fused_bias(T, oracle):
