@@ -82,9 +82,10 @@ int main(int argc, char** argv) {
   for (auto& v : bias) v = f2bf(nd(rng));
   char *dw, *dl, *dq, *dx, *dy, *db;
   CK(hipMalloc(&dw, w.size() * 4)); CK(hipMalloc(&dl, lut.size() * 2)); CK(hipMalloc(&dq, qinfo.size() * 2));
-  CK(hipMalloc(&dx, x.size() * 2)); CK(hipMalloc(&dy, y.size() * 2)); CK(hipMalloc(&db, bias.size() * 2));
+  const int xrot = getenv("XROT") ? atoi(getenv("XROT")) : 1;   // distinct copies of the activations, rotated per launch (cold x)
+  CK(hipMalloc(&dx, x.size() * 2 * xrot)); CK(hipMalloc(&dy, y.size() * 2)); CK(hipMalloc(&db, bias.size() * 2));
   CK(hipMemcpy(dw, w.data(), w.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dl, lut.data(), lut.size() * 2, hipMemcpyHostToDevice));
-  CK(hipMemcpy(dq, qinfo.data(), qinfo.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(dx, x.data(), x.size() * 2, hipMemcpyHostToDevice));
+  CK(hipMemcpy(dq, qinfo.data(), qinfo.size() * 2, hipMemcpyHostToDevice)); for (int c = 0; c < xrot; ++c) CK(hipMemcpy(dx + (size_t)c * x.size() * 2, x.data(), x.size() * 2, hipMemcpyHostToDevice));
   CK(hipMemcpy(db, bias.data(), bias.size() * 2, hipMemcpyHostToDevice));
   CK(hipMemset(dy, 0xff, y.size() * 2));
   TileParams p{};
@@ -132,7 +133,7 @@ int main(int argc, char** argv) {
   for (int rep = 0; rep < 3; ++rep) {
     for (int i = 0; i < 6; ++i) { TileParams q = p; q.w = dw + (size_t)(i % SETS) * (n / 8) * ksuper * 256; go(q); }
     CK(hipEventRecord(e0));
-    for (int i = 0; i < iters; ++i) { TileParams q = p; q.w = dw + (size_t)(i % SETS) * (n / 8) * ksuper * 256; go(q); }
+    for (int i = 0; i < iters; ++i) { TileParams q = p; q.w = dw + (size_t)(i % SETS) * (n / 8) * ksuper * 256; q.x = dx + (size_t)(i % xrot) * x.size() * 2; go(q); }
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     const double us = ms * 1e3 / iters;
