@@ -6,10 +6,10 @@ namespace {
 
 // KS = 2 (two super-tiles per step, 128 x 64 tiles, k % 128 == 0): 5-7 % faster than KS = 1 there (4096^2 at m = 512: 37.4 -> 34.7 us); the
 // 128 x 128 tile does not fit two super-tiles per stage in 160 KiB
-template <typename DT, int BM, int BN, int KS>
+template <typename DT, int BM, int BN, int KS, bool QMX = false>
 int go(const TileParams& tp, hipStream_t st) {
   constexpr int DX = KS == 2 ? 2 : 3;
-  constexpr auto kern = w4_gemm_tile_kernel<DT, BM, BN, DX, 8, KS>;
+  constexpr auto kern = w4_gemm_tile_kernel<DT, BM, BN, DX, 8, KS, 4, QMX>;
   const int prc = prepare_lds_kernel<kern>();
   if (prc != 0) return prc == TG_E_INTERNAL ? prc : TG_PAIR_NA;  // (a part with less LDS: the older kernels take over)
   constexpr unsigned lds = TileLds<BM, BN, DX, KS>::BYTES;
@@ -22,16 +22,18 @@ int go(const TileParams& tp, hipStream_t st) {
   }
   return launch_status();
 }
-template <typename DT>
+template <typename DT, bool QMX = false>
 int go_dt(const TileParams& tp, bool wide, bool small, bool two, hipStream_t st) {
-  if (wide) return go<DT, 128, 128, 1>(tp, st);
-  if (small) return two ? go<DT, 64, 64, 2>(tp, st) : go<DT, 64, 64, 1>(tp, st);
-  return two ? go<DT, 128, 64, 2>(tp, st) : go<DT, 128, 64, 1>(tp, st);
+  if constexpr (!QMX) {   // (mx4: the 128 x 128 tile's table build spills at 128 registers; 128 x 64 tiles throughout)
+    if (wide) return go<DT, 128, 128, 1>(tp, st);
+  }
+  if (small) return two ? go<DT, 64, 64, 2, QMX>(tp, st) : go<DT, 64, 64, 1, QMX>(tp, st);
+  return two ? go<DT, 128, 64, 2, QMX>(tp, st) : go<DT, 128, 64, 1, QMX>(tp, st);
 }
 }  // namespace
 
 namespace tgx {
-// Bint4 words of innerKTiles 4 (k % 64 == 0), int4 / any4 (global or per-row LUT), row-major operands, no fused norm / SwiGLU; any
+// Bint4 words of innerKTiles 4 (k % 64 == 0), int4 / any4 (global or per-row LUT) / mx4, row-major operands, no fused norm / SwiGLU; any
 // numerics setting: the kernel computes the reference's own weights, RNE16(fma(lut, scale, zero)).  TG_PAIR_NA: not this kernel's call.
 //
 // Split-K: a tile's k-steps are a chain of dependent LDS round trips (0.6-0.9 us per 128 k whatever the tile holds), so a launch with fewer
@@ -41,13 +43,14 @@ namespace tgx {
 // One layer per call from 17 rows on (64 x 64 tiles up to 64 rows) when the split is available (through the modules, graph nodes of one
 // 4096^2 layer at 33 / 48 / 64 / 128 rows: 13.6 / 14.2 / 14.8 / 19.5 us; 16-row passes: 19.6 / 22.2 / 29.2 / -); without a workspace: from 65 rows, unsplit.
 int tile(int dt, int I, bool qmx, GemmParams& p, int64_t batch, hipStream_t st) {
-  if (I != 4 || qmx || p.x_tc || p.y_tc || p.norm_w || p.epilogue || p.bias_row_stride || p.m < TG_TILE_MIN_M_SPLIT) return TG_PAIR_NA;
+  if (I != 4 || p.x_tc || p.y_tc || p.norm_w || p.epilogue || p.bias_row_stride || p.m < TG_TILE_MIN_M_SPLIT) return TG_PAIR_NA;
   if (p.k % 64 != 0 || p.wrows % 8 != 0 || p.wrows < 8) return TG_PAIR_NA;
-  if (!(p.qtype == TG_Q_INT4 || p.qtype == TG_Q_ANY4_GLOBAL || p.qtype == TG_Q_ANY4_ROWWISE)) return TG_PAIR_NA;
+  if (!(p.qtype == TG_Q_INT4 || p.qtype == TG_Q_ANY4_GLOBAL || p.qtype == TG_Q_ANY4_ROWWISE || p.qtype == TG_Q_MX4)) return TG_PAIR_NA;
+  if ((p.qtype == TG_Q_MX4) != qmx || (qmx && (dt != TG_BF16 || p.gshift != 5))) return TG_PAIR_NA;   // (mx4: bf16, groups of 32: TinyGemm_int4.cu:758)
   const bool small = p.m <= 64;
   const int tiles_m = small ? 1 : (p.m + 127) / 128;
   // 128 x 128 tiles once they fill the chip (half the activation traffic per weight row), else 128 x 64 (twice the workgroups)
-  const bool wide = !small && (int64_t)tiles_m * ((p.wrows + 127) / 128) >= cu_count();
+  const bool wide = !small && !qmx && (int64_t)tiles_m * ((p.wrows + 127) / 128) >= cu_count();
   const int tiles_n = (p.wrows + (wide ? 127 : 63)) / (wide ? 128 : 64);
   int splits = 1;
   if (!wide) {
@@ -74,7 +77,7 @@ int tile(int dt, int I, bool qmx, GemmParams& p, int64_t batch, hipStream_t st) 
     tp.splits = splits; tp.part = splits > 1 ? reinterpret_cast<float*>(p.ws) : nullptr;   // (the launches of a batch are ordered on the stream: one scratch)
     tp.x_pitch = p.k;
     const bool two = !wide && (p.ksuper / splits) % 2 == 0;
-    const int rc = dt == TG_BF16 ? go_dt<BF16>(tp, wide, small, two, st) : go_dt<F16>(tp, wide, small, two, st);
+    const int rc = qmx ? go_dt<BF16, true>(tp, wide, small, two, st) : dt == TG_BF16 ? go_dt<BF16>(tp, wide, small, two, st) : go_dt<F16>(tp, wide, small, two, st);
     if (rc != 0) return rc;
   }
   return 0;

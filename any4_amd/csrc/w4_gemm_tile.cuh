@@ -41,7 +41,7 @@
 struct TileParams {
   const char* x;       // [m][k] 16-bit, row-major
   const char* w;       // Bint4 words, innerKTiles 4: [wrows / 8][k / 64][32][2] uint32
-  const char* qinfo;   // [k / g][wrows][2] 16-bit (scale, zero)
+  const char* qinfo;   // [k / g][wrows][2] 16-bit (scale, zero); mx4: [wrows][k / 32] uint8 exponents
   const char* lut;     // [wrows][16] (row-wise) / [16] (global) 16-bit, nullptr for int4
   char* y;             // [m][wrows] 16-bit
   const char* bias;    // optional [wrows] 16-bit
@@ -87,7 +87,8 @@ __device__ __forceinline__ void tile_barrier() {
 //       LDS array is 41 % busy -- so two super-tiles per step nearly halve the time per k
 // NCW = consuming waves: 4 (2 x 2, shipped) or 8 (4 (m) x 2 (n): two per SIMD, one's fragment reads under the other's MFMAs; with 16 waves per
 //       workgroup that leaves 4 dequantising waves, which then bound the 128 x 128 tile: 62.7 vs 55 us at m = 1024 -- developer A/B only)
-template <typename DT, int BM, int BN, int DX = 3, int NDW = 8, int KS = 1, int NCW = 4>
+// QMX = mx4 weights (a template parameter: as a run-time branch its code cost the other formats 10 % at 128 x 64 tiles and spilled the 128 x 128 tile: 106 -> 207 us)
+template <typename DT, int BM, int BN, int DX = 3, int NDW = 8, int KS = 1, int NCW = 4, bool QMX = false>
 __global__ void __launch_bounds__(64 * (NCW + 4 + NDW)) w4_gemm_tile_kernel(const TileParams p) {
   constexpr int WN = BN / 2;             // weight rows of a consumer wave
   constexpr int NT = WN / 16;            // its 16-row tiles
@@ -269,11 +270,19 @@ __global__ void __launch_bounds__(64 * (NCW + 4 + NDW)) w4_gemm_tile_kernel(cons
   for (int v = 0; v < RPT; ++v) {
     int gr = n0 + (tid >> 2) + TRS * v;
     gr = gr < p.wrows ? gr : p.wrows - 1;
-    qsrc[v] = reinterpret_cast<const uint32_t*>(p.qinfo) + (int64_t)g0 * p.wrows + gr;
+    // (mx4, bf16 only: one exponent byte per row and 32-k group, row-major; the table entry is fp4[code] * 2^(e - 127), exact)
+    if constexpr (QMX) qsrc[v] = reinterpret_cast<const uint32_t*>(p.qinfo + (int64_t)gr * (p.k >> 5) + g0);
+    else qsrc[v] = reinterpret_cast<const uint32_t*>(p.qinfo) + (int64_t)g0 * p.wrows + gr;
     const int e4 = (tid & 3) * 4;
     if (p.qtype == TG_Q_INT4) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) lv[v][e] = (float)(e4 + e - 8);
+    } else if (QMX) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int c = e4 + e, mag = c & 7;
+        lv[v][e] = (c & 8 ? -1.f : 1.f) * (mag < 5 ? 0.5f * mag : (mag == 5 ? 3.f : mag == 6 ? 4.f : 6.f));   // fp4-e2m1 (FloatDefs.cuh:18-34)
+      }
     } else {
       const u32x2 pr = *reinterpret_cast<const u32x2*>(p.lut + ((p.qtype == TG_Q_ANY4_ROWWISE ? (int64_t)gr * 16 : 0) + e4) * 2);
       lv[v][0] = DT::lo_f32(pr[0]); lv[v][1] = DT::hi_f32(pr[0]); lv[v][2] = DT::lo_f32(pr[1]); lv[v][3] = DT::hi_f32(pr[1]);
@@ -287,8 +296,17 @@ __global__ void __launch_bounds__(64 * (NCW + 4 + NDW)) w4_gemm_tile_kernel(cons
     for (int sub = 0; sub < NSUB; ++sub) {
       int g = ((c * (64 * KS)) >> gshift) + (sub < nsub ? sub : 0);
       g = g < ngroups ? g : ngroups - 1;
+      if constexpr (QMX) {
 #pragma unroll
-      for (int v = 0; v < RPT; ++v) dst[sub][v] = qsrc[v][(int64_t)g * p.wrows];
+        for (int v = 0; v < RPT; ++v) {
+          // scale = 2^(e - 127) as bf16 bits (Dequantization.cuh:331-346: 255 -> NaN, 0 -> the subnormal 2^-127), zero = -0.0: fma(v, s, -0) = v * s
+          const uint32_t q = reinterpret_cast<const uint8_t*>(qsrc[v])[g];
+          dst[sub][v] = (q == 255u ? 0x7fc0u : (q == 0u ? 0x0040u : (q << 7))) | 0x80000000u;
+        }
+      } else {
+#pragma unroll
+        for (int v = 0; v < RPT; ++v) dst[sub][v] = qsrc[v][(int64_t)g * p.wrows];
+      }
     }
   };
   auto build_tables = [&](int step, const uint32_t (&sz)[NSUB][RPT]) {   // the tables of the group(s) of k-step `step` into buffer (step >> spg_shift) & 1

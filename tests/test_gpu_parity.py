@@ -802,6 +802,33 @@ def test_tile_gemm_many_rows_against_oracle(T, oracle, dtype, qtype, g, m, n, k)
     assert fb.consumed and torch.equal(yb, y + bias)
 
 
+@pytest.mark.parametrize("m,n,k", [(65, 200, 512), (130, 1008, 1024), (512, 528, 2048), (40, 264, 2048), (100, 4096, 4096)])
+def test_tile_gemm_many_rows_mx4(T, oracle, m, n, k):
+    """mx4 (bf16, groups of 32: TinyGemm_int4.cu:758) at many rows on the tile GEMM: the table of a (row, group) holds fp4[code] * 2^(e - 127),
+    exact in bf16 -- the reference's weights bit for bit (Dequantization.cuh:331-346, MatrixLayoutB.cuh:1086-1088); unsplit and split-K
+    launches; an exponent of 255 makes exactly its rows' outputs NaN."""
+    from any4_amd import ops
+
+    codes, x, qinfo, lut = rand_problem(n, k, 32, m, "mx4", seed=m + n)
+    want = oracle_weights(oracle, codes, 32, "mx4", qinfo, None, torch.bfloat16)
+    assert ops.gemm_w4_plan(m, -(-n // 8) * 8, k, 32, 3, True, 4) == "tile"
+    y = run_rm(T, codes, x, qinfo, None, 32, "mx4", True, 4)
+    assert y.shape[0] == m and torch.isfinite(y.float()).all()
+    assert_gemm_close(y[:, :n], x, want, torch.bfloat16)
+    bias = torch.randn(y.shape[1], generator=torch.Generator().manual_seed(5)).bfloat16().to(DEV)
+    with ops.fused_bias(bias) as fb:
+        yb = run_rm(T, codes, x, qinfo, None, 32, "mx4", True, 4)
+    assert fb.consumed and torch.equal(yb, y + bias)
+    q2 = qinfo.clone()
+    q2[3, (k // 32) - 1] = 255          # weight row 3: NaN in its last group
+    q2[n - 1, 0] = 255
+    yn = run_rm(T, codes, x, q2, None, 32, "mx4", True, 4)
+    nan_rows = torch.isnan(yn.float()).all(dim=0).nonzero().flatten().tolist()
+    assert nan_rows == [3, n - 1]
+    keep = [r for r in range(n) if r not in (3, n - 1)]
+    assert torch.equal(yn[:, keep], y[:, keep])
+
+
 def test_tile_gemm_without_a_workspace(T, oracle, monkeypatch):
     """The C ABI's workspace is optional (include/tinygemm_hip.h): without one the tile GEMM runs unsplit from 65 rows (below: 16-row passes).
     Same weights, another summation order: both within the GEMM tolerance of the oracle; and the split launch is deterministic."""

@@ -340,7 +340,8 @@ def test_xr_kernel_routing():
         assert ops.gemm_w4_plan(512, 14336, 4096, 32, q2["int4"], True, 4, numerics=num) == "tile"
         assert ops.gemm_w4_plan(2048, 4096, 4096, 128, q2["any4_global"], False, 4, numerics=num, weight_format="native") == "tile"
     assert ops.gemm_w4_plan(64, 4096, 4096, 128, q2["any4_rowwise"], True, 4, workspace=False) == "pair"      # (64 rows, no workspace: four 16-row blocks)
-    assert ops.gemm_w4_plan(512, 4096, 4096, 32, q2["mx4"], True, 4) in ("stream", "splitk", "pair")
+    assert ops.gemm_w4_plan(512, 4096, 4096, 32, q2["mx4"], True, 4) == "tile"      # (mx4: the same tables, entries fp4 * 2^e)
+    assert ops.gemm_w4_plan(512, 4096, 4096, 32, q2["mx4"], True, 2) in ("stream", "splitk", "pair")
     assert ops.gemm_w4_plan(512, 4096, 4096, 128, q2["any4_rowwise"], True, 8, detail=True) in ("stream", "splitk")
     assert ops.gemm_w4_plan(512, 4096, 4096, 128, q2["any4_rowwise"], False, 4, weight_format="reference", detail=True) in ("stream", "splitk")
     assert ops.gemm_w4_plan(512, 4096, 4096, 128, q2["any4_rowwise"], True, 4, workspace=False) == "tile"          # (no workspace)

@@ -45,3 +45,8 @@ tail -2 gpurun_out/${RN}_decode_bench.log | cut -c1-300; cat gpurun_out/${RN}_de
 # seeded random shapes through the ops against the oracle; batched decode steps
 timeout 300 python tests/stress_random.py --cases 80 --seed 3 2>&1 | grep -E "bad=[1-9]|TOTAL" > gpurun_out/${RN}_stress_random_summary.txt
 (for bs in 4 8 16; do echo -n "bs $bs: "; timeout 300 python tools/llama_decode_bench.py --config llama3_8b --bs $bs --steps 20 --warmup 5 --max-seq 1024 --start-pos 136 --interleave 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['any4']['ms_per_token'] if 'any4' in d else d)"; done) > gpurun_out/${RN}_decode_batched.txt 2>&1
+# many activation rows through the modules (tile GEMM, split-K launches) against nn.Linear; the HF protocol at prefill lengths
+timeout 600 python dev/many_rows_bench.py 2>&1 | grep "^m=" > gpurun_out/${RN}_many_rows_modules.txt
+(for sl in 512 128; do echo "##### seqlen $sl (own kernels, eager)"; timeout 600 python tools/hf_benchmark.py --arch llama3_8b --layers 2 --seqlen $sl 2>&1 | grep -E "Model:|Speedup"; done) > gpurun_out/${RN}_hf_benchmark_prefill.txt 2>&1
+# PMC counters of the tile GEMM (m = 512 and the split-K launch at m = 128)
+python tools/collect_counters.py --out gpurun_out/${RN}_counters_tile_m128_splitk.json --match w4_gemm_tile_kernel --label "tile GEMM, split-K launch: m=128 4096^2 (64 tiles x 4 splits)" -- python dev/many_rows_bench.py --shapes "128,4096,4096" --layers 6 | cut -c1-300
