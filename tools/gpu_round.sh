@@ -41,7 +41,8 @@ tail -2 gpurun_out/${RN}_decode_bench.log | cut -c1-300; cat gpurun_out/${RN}_de
 [ -x variants/persistent_chain ] && timeout 120 variants/persistent_chain 16 > gpurun_out/${RN}_ubench_persistent_chain.txt 2>&1
 [ -x variants/x_broadcast ] && timeout 120 variants/x_broadcast > gpurun_out/${RN}_ubench_x_broadcast.txt 2>&1
 # the reference's module-level protocol (microbenchmark.py)
-(for k in 4096 8192; do for q in "anyq" "intq" "anyq --quantize-args per_row=False"; do echo "##### K=$k --quantize $q"; timeout 600 python tools/microbenchmark.py --input-dim $k --output-dim $k --quantize $q 2>&1 | grep -v "amdgpu.ids\|ROCTracer" | tail -5; done; done) > gpurun_out/${RN}_microbenchmark.txt 2>&1
+timeout 600 python tools/microbenchmark.py --input-dim 4096 --output-dim 4096 --quantize anyq > /dev/null 2>&1   # (the first process on a fresh box reads ~5 us high in its wall-clock column: discarded)
+(for k in 4096 8192; do for q in "anyq" "intq" "anyq --quantize-args per_row=False" "anyq"; do echo "##### K=$k --quantize $q"; timeout 600 python tools/microbenchmark.py --input-dim $k --output-dim $k --quantize $q 2>&1 | grep -v "amdgpu.ids\|ROCTracer" | tail -5; done; done) > gpurun_out/${RN}_microbenchmark.txt 2>&1
 # seeded random shapes through the ops against the oracle; batched decode steps
 timeout 300 python tests/stress_random.py --cases 80 --seed 3 2>&1 | grep -E "bad=[1-9]|TOTAL" > gpurun_out/${RN}_stress_random_summary.txt
 (for bs in 4 8 16; do echo -n "bs $bs: "; timeout 300 python tools/llama_decode_bench.py --config llama3_8b --bs $bs --steps 20 --warmup 5 --max-seq 1024 --start-pos 136 --interleave 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['any4']['ms_per_token'] if 'any4' in d else d)"; done) > gpurun_out/${RN}_decode_batched.txt 2>&1
