@@ -345,6 +345,18 @@ def test_xr_kernel_routing():
     assert ops.gemm_w4_plan(512, 4096, 4096, 128, q2["any4_rowwise"], True, 8, detail=True) in ("stream", "splitk")
     assert ops.gemm_w4_plan(512, 4096, 4096, 128, q2["any4_rowwise"], False, 4, weight_format="reference", detail=True) in ("stream", "splitk")
     assert ops.gemm_w4_plan(512, 4096, 4096, 128, q2["any4_rowwise"], True, 4, workspace=False) == "tile"          # (no workspace)
+    # the split-K tile launch asks for splits x m x rows x 4 bytes of f32 partial tiles (as many splits as keep tiles x splits <= CUs)
+    def ws_need(m, n, k, g=128, q=2):
+        from any4_amd import _lib
+
+        buf = ctypes.create_string_buffer(256)
+        pz = (ctypes.addressof(buf) + 63) & ~63
+        a = _lib.W4Gemm(x=pz, w=pz, qinfo=pz, lut=pz, y=pz, m=m, wrows=n, k=k, group=g, qtype=q, dtype=_lib.TG_BF16, w_on_right=1, inner_k_tiles=4, batch=1,
+                        stride_x=16, stride_w=16, stride_qinfo=16, stride_lut=16, stride_y=16)
+        return _lib.load().tg_gemm_w4_workspace_bytes(ctypes.byref(a))
+    assert ws_need(128, 4096, 4096) == 4 * 128 * 4096 * 4 and ws_need(64, 4096, 4096) == 4 * 64 * 4096 * 4      # 64 tiles x 4 splits
+    assert ws_need(256, 4096, 4096) == 2 * 256 * 4096 * 4 and ws_need(512, 4096, 4096) == 0                     # 128 tiles x 2; 256 tiles: unsplit
+    assert ws_need(512, 1024, 4096) == 4 * 512 * 1024 * 4 and ws_need(128, 4096, 14336) == 4 * 128 * 4096 * 4
     assert ops.large_m_rows(4096 * 4096) > 1 << 40      # the library-GEMM route is opt-in (ANY4_LARGE_M_GEMM=library / ANY4_LARGE_M)
     assert ops.gemm_w4_plan(33, 4096, 4096, 128, q2["any4_rowwise"], True, 8, detail=True) in ("stream", "splitk")
     assert ops.gemm_w4_plan(33, 4096, 4096, 128, q2["any4_rowwise"], True, 4, numerics="reference", detail=True, workspace=False) in ("stream", "splitk")
