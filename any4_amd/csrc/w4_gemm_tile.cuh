@@ -31,8 +31,15 @@
 //              4-byte access sees.
 //   pipeline   step s: x of step s + DX requested; the words of step s + 1 dequantised into the other w buffer; the tables of the group
 //              that starts at step s + 2 built; the MFMAs of step s; ONE barrier per step.
-//   grid       one workgroup per tile; tile index -> (n tile, m tile) with the m tiles of one n tile on ONE XCD (block b runs on XCD
-//              b % 8: observed, used for speed only), so that the packed weights of an n tile leave HBM once.
+//   grid       one workgroup per (tile, k-split); index -> (n tile, split, m tile) with the m tiles of one n tile and k range on ONE XCD
+//              (block b runs on XCD b % 8: observed, used for speed only), so that the packed weights of an n tile leave HBM once.
+//   split-K    TileParams::splits > 1: the workgroup covers ksuper / splits super-tiles from split * (ksuper / splits) on (a whole number of
+//              steps and of quantisation groups: the host's job) and stores its f32 accumulators to part[split][m][rows];
+//              tile_split_sum_kernel (below) adds the splits in order, applies the bias and rounds once.  Why: a tile's k-steps are a chain
+//              of dependent LDS round trips, 0.6-0.9 us per 128 k whatever the tile holds -- a launch with 64 tiles takes as long as one with
+//              256 (tg_tile.hip chooses the splits; profiles/r06_tile_splitk.txt).
+//   mx4        template flag QMX: the table entries are fp4[code] * 2^(e - 127) (exact in bf16; e = 255: NaN), the exponents one byte per row
+//              and 32-k group.  A flavour of its own because as a run-time branch it cost the other formats registers (128 x 128 tile: spill).
 #pragma once
 #ifndef TILE_ABL
 #define TILE_ABL 0  // developer ablations (timing only, wrong results), bit mask: 1 no dequantisation, 2 no MFMA stage, 4 no LDS-DMA, 8 no table builds, 16 no lookups, 32 no w-tile writes, 64 no word loads
