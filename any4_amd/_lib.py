@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libtinygemm_hip.so")
 TG_BF16, TG_F16 = 0, 1
 TG_Q_INT4, TG_Q_ANY4_GLOBAL, TG_Q_ANY4_ROWWISE, TG_Q_MX4, TG_Q_INT8 = 0, 1, 2, 3, 4
 TG_NUM_FAST, TG_NUM_REFERENCE, TG_NUM_FAST_MFMA, TG_NUM_FAST_DOT2 = 0, 1, 2, 3
-TG_ABI_VERSION = 7
+TG_ABI_VERSION = 8
 TG_PLAN_SPLITK, TG_PLAN_STREAM, TG_PLAN_PAIR, TG_PLAN_PAIR_XR, TG_PLAN_GEMV, TG_PLAN_TILE = 1, 2, 3, 4, 5, 6
 TG_LAYOUT_RM, TG_LAYOUT_TC_A = 0, 1
 TG_E_LAYOUT = -12
@@ -86,6 +86,7 @@ SYMBOLS = {
     "tg_convert_to_Bint8": [_vp, _i64, _i64, ctypes.c_int, _vp, ctypes.c_int, _vp],
     "tg_convert_to_Aint8": [_vp, _i64, _i64, ctypes.c_int, _vp, ctypes.c_int, _vp],
     "tg_gemm_w8": [ctypes.POINTER(W4Gemm), ctypes.c_int, _vp],
+    "tg_gemm_w8_workspace_bytes": [ctypes.POINTER(W4Gemm)],
     # include/peer_gather_hip.h (one-shot peer-write gather of row-sharded outputs)
     "tg_peer_alloc": [ctypes.c_int, _i64, ctypes.POINTER(_vp)],
     "tg_peer_free": [ctypes.c_int, _vp],
@@ -131,7 +132,7 @@ def load() -> ctypes.CDLL:
             raise ImportError(f"{LIB_PATH} does not export {name}; rebuild with `python -m any4_amd.build`") from e
         fn.argtypes = argtypes
         fn.restype = (ctypes.c_char_p if name == "tg_error_string" else
-                      ctypes.c_int64 if name in ("dg_rope_attn_split_scratch_bytes", "tg_gemm_w4_workspace_bytes") else ctypes.c_int)
+                      ctypes.c_int64 if name in ("dg_rope_attn_split_scratch_bytes", "tg_gemm_w4_workspace_bytes", "tg_gemm_w8_workspace_bytes") else ctypes.c_int)
     if lib.tg_abi_version() != TG_ABI_VERSION:
         raise ImportError(f"{LIB_PATH}: ABI version {lib.tg_abi_version()} != {TG_ABI_VERSION}; rebuild")
     _lib = lib

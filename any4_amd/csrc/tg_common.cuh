@@ -176,6 +176,7 @@ int pair16_loop(int dt, int I, bool qmx, const GemmParams& p, int64_t batch, hip
 int splitk(int dt, bool layout_a, int canon, bool qmx, int waves, const GemmParams& p, dim3 grid, hipStream_t st);
 int gemv(int dt, int I, bool qmx, GemmParams& p, int64_t batch, hipStream_t st);
 int tile(int dt, int I, bool qmx, GemmParams& p, int64_t batch, hipStream_t st);  // w4_gemm_tile.cuh: many activation rows
+int tile_w8(int dt, bool on_right, int I, GemmParams& p, int64_t batch, hipStream_t st);  // ... int8 weights (tg_gemm_w8)
 inline int pair(int dt, int I, bool qmx, GemmParams& p, int64_t batch, hipStream_t st) {
   return dt == TG_BF16 ? pair_bf16(I, qmx, p, batch, st) : pair_f16(I, qmx, p, batch, st);
 }
@@ -355,6 +356,9 @@ inline int cu_count() {
 #endif
 #ifndef TG_B16_CHUNK
 #define TG_B16_CHUNK 4         // consecutive 32-row work items per workgroup visit of those kernels (1 / 4 / 8 within 1 %)
+#endif
+#ifndef TG_TILE_W8_MIN_M
+#define TG_TILE_W8_MIN_M 9   // int8 weights: activation rows from which tg_gemm_w8 takes the tile GEMM (tg_tile.hip)
 #endif
 #ifndef TG_TILE_MIN_M_SPLIT
 #define TG_TILE_MIN_M_SPLIT 17  // ... and with a split-K launch of ONE layer (caller's workspace; tg_tile.hip): 12.6-14.8 us at 17 ... 64 rows against 7.5 us per 16-row pass

@@ -30,9 +30,59 @@ int go_dt(const TileParams& tp, bool wide, bool small, bool two, hipStream_t st)
   if (small) return two ? go<DT, 64, 64, 2, QMX>(tp, st) : go<DT, 64, 64, 1, QMX>(tp, st);
   return two ? go<DT, 128, 64, 2, QMX>(tp, st) : go<DT, 128, 64, 1, QMX>(tp, st);
 }
+template <typename DT, int KS, int W8>
+int go_w8(const TileParams& tp, hipStream_t st) {
+  constexpr int DX = KS == 2 ? 2 : 3;
+  constexpr auto kern = w4_gemm_tile_kernel<DT, 128, 64, DX, 8, KS, 4, false, W8>;
+  const int prc = prepare_lds_kernel<kern>();
+  if (prc != 0) return prc == TG_E_INTERNAL ? prc : TG_PAIR_NA;
+  constexpr unsigned lds = TileLds<128, 64, DX, KS>::BYTES;
+  const int ns = tp.splits > 1 ? tp.splits : 1;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(tp.tiles_m * tp.tiles_n * ns)), dim3(1024), lds, st, tp);
+  if (ns > 1) {
+    const int64_t quads = (int64_t)tp.m * tp.wrows / 4;
+    hipLaunchKernelGGL(tile_split_sum_kernel<DT>, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, st, tp.part, ns, (int64_t)tp.m * tp.wrows, tp.y,
+                       tp.bias, tp.wrows, quads);
+  }
+  return launch_status();
+}
 }  // namespace
 
 namespace tgx {
+// int8 weights (tg_gemm_w8) at more than TG_TILE_W8_MIN_M - 1 activation rows on the same tile GEMM: Bint8 / Aint8 words of innerKTiles 2 (what
+// Int8Linear packs by default, modules.py:85-152), groups of 64 or more, k % 64 == 0; 128 x 64 tiles, split-K like the 4-bit launches.  The
+// 16-row kernel this replaces walks m in 16-row tiles that each re-read (and re-convert) the weights: 4096^2 at 128 / 512 / 2048 rows 130 / 509 /
+// 2023 us.  TG_PAIR_NA: not this kernel's call.
+int tile_w8(int dt, bool on_right, int I, GemmParams& p, int64_t batch, hipStream_t st) {
+  if (I != 2 || p.gshift < 6 || p.k % 64 != 0 || p.bias_row_stride || p.m < TG_TILE_W8_MIN_M || p.wrows % (on_right ? 8 : 16) != 0) return TG_PAIR_NA;
+  const int ksuper = p.k / 64;
+  const int tiles_m = (p.m + 127) / 128, tiles_n = (p.wrows + 63) / 64;
+  const int g64 = (1 << p.gshift) / 64;        // 64-k super-tiles per quantisation group (>= 1)
+  int splits = 1;
+  while (splits < 8 && (int64_t)tiles_m * tiles_n * splits * 2 <= cu_count() && ksuper % (splits * 2) == 0 && (ksuper / (splits * 2)) % g64 == 0 &&
+         ksuper / (splits * 2) >= 8)
+    splits *= 2;
+  const int64_t need = splits > 1 ? (int64_t)splits * p.m * p.wrows * 4 : 0;
+  if (splits > 1 && !p.ws_query && (p.ws == nullptr || p.ws_bytes < need)) splits = 1;
+  p.ws_need = splits > 1 ? need : 0;
+  if (p.dry) return TG_PLAN_TILE;
+  const bool two = p.gshift >= 7 && (ksuper / splits) % 2 == 0;   // (two super-tiles per step: one group per step needs g >= 128)
+  for (int64_t b = 0; b < batch; ++b) {
+    TileParams tp;
+    tp.x = p.x + b * p.stride_x; tp.w = p.w + b * p.stride_w; tp.qinfo = p.qinfo + b * p.stride_qinfo; tp.lut = nullptr;
+    tp.y = p.y + b * p.stride_y; tp.bias = p.bias ? p.bias + b * p.stride_bias : nullptr;
+    tp.m = p.m; tp.wrows = p.wrows; tp.k = p.k; tp.ksuper = ksuper; tp.gshift = p.gshift; tp.qtype = p.qtype;
+    tp.tiles_m = tiles_m; tp.tiles_n = tiles_n;
+    tp.splits = splits; tp.part = splits > 1 ? reinterpret_cast<float*>(p.ws) : nullptr;
+    tp.x_pitch = p.k;
+    int rc;
+    if (dt == TG_BF16) rc = on_right ? (two ? go_w8<BF16, 2, 1>(tp, st) : go_w8<BF16, 1, 1>(tp, st)) : (two ? go_w8<BF16, 2, 2>(tp, st) : go_w8<BF16, 1, 2>(tp, st));
+    else rc = on_right ? (two ? go_w8<F16, 2, 1>(tp, st) : go_w8<F16, 1, 1>(tp, st)) : (two ? go_w8<F16, 2, 2>(tp, st) : go_w8<F16, 1, 2>(tp, st));
+    if (rc != 0) return rc;
+  }
+  return 0;
+}
+
 // Bint4 words of innerKTiles 4 (k % 64 == 0), int4 / any4 (global or per-row LUT) / mx4, row-major operands, no fused norm / SwiGLU; any
 // numerics setting: the kernel computes the reference's own weights, RNE16(fma(lut, scale, zero)).  TG_PAIR_NA: not this kernel's call.
 //

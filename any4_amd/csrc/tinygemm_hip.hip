@@ -927,7 +927,8 @@ int tg_convert_to_Aint8(const int32_t* in, int64_t m, int64_t k, int I, int32_t*
   return launch_status();
 }
 
-int tg_gemm_w8(const tg_w4_gemm* caller, int device, tg_stream_t stream) {
+// dry: 0 launch, 2 report the workspace the fastest kernel wants (tg_gemm_w8_workspace_bytes)
+static int gemm_w8_impl(const tg_w4_gemm* caller, int device, tg_stream_t stream, int dry, int64_t* ws_need) {
   tg_w4_gemm full;
   const int src = take_args(caller, &full);
   if (src != 0) return src;
@@ -965,11 +966,14 @@ int tg_gemm_w8(const tg_w4_gemm* caller, int device, tg_stream_t stream) {
   p.ksuper = (int32_t)(a->k / (16 * I));
   p.gshift = g == 32 ? 5 : g == 64 ? 6 : g == 128 ? 7 : 8;
   p.ngroups = (int32_t)(a->k / g);
-  p.qtype = a->qtype; p.dbg = 0; p.dry = 0;
+  p.qtype = a->qtype; p.dbg = 0; p.dry = dry != 0;
   p.stride_x = batch > 1 ? a->stride_x : 0; p.stride_w = batch > 1 ? a->stride_w : 0;
   p.stride_qinfo = batch > 1 ? a->stride_qinfo : 0; p.stride_lut = 0; p.stride_y = batch > 1 ? a->stride_y : 0;
-  DeviceScope ds(device);
-  if (!ds.ok) return TG_E_DEVICE;
+  if (a->workspace && (!aligned16(a->workspace) || a->workspace_bytes < 0)) return TG_E_ALIGN;
+  p.ws = (char*)a->workspace; p.ws_bytes = a->workspace ? a->workspace_bytes : 0; p.ws_need = 0; p.ws_query = dry == 2;
+  p.x_tc = p.y_tc = 0;
+  DeviceScope ds(dry ? -1 : device);
+  if (!dry && !ds.ok) return TG_E_DEVICE;
   hipStream_t st = (hipStream_t)stream;
   p.rowtiles = (int32_t)cdiv(a->wrows, 16);
   const int64_t coltiles = cdiv(a->m, 16);
@@ -977,6 +981,13 @@ int tg_gemm_w8(const tg_w4_gemm* caller, int device, tg_stream_t stream) {
   (void)coltiles; (void)st;
   return TG_E_SHAPE;
 #else
+  // many activation rows: the LDS-tiled MFMA GEMM's int8 flavour (w4_gemm_tile.cuh; the same weights bit for bit), split-K with the caller's workspace
+  {
+    const int trc = tgx::tile_w8(a->dtype, on_right, I, p, batch, st);
+    if (ws_need) *ws_need = trc == TG_PAIR_NA ? 0 : p.ws_need;
+    if (trc != TG_PAIR_NA) return trc == TG_PLAN_TILE ? 0 : trc;
+    if (dry) return 0;
+  }
 #define TG_W8(DTT)                                                                                    \
   do {                                                                                                \
     if (on_right) {                                                                                   \
@@ -991,6 +1002,14 @@ int tg_gemm_w8(const tg_w4_gemm* caller, int device, tg_stream_t stream) {
   TG_W8(F16);
 #undef TG_W8
 #endif
+}
+
+int tg_gemm_w8(const tg_w4_gemm* a, int device, tg_stream_t stream) { return gemm_w8_impl(a, device, stream, 0, nullptr); }
+
+int64_t tg_gemm_w8_workspace_bytes(const tg_w4_gemm* a) {
+  int64_t need = 0;
+  const int rc = gemm_w8_impl(a, -1, nullptr, 2, &need);
+  return rc < 0 ? rc : need;
 }
 
 int tg_gemm_f16(const void* x, const void* w, void* y, int64_t m, int64_t wrows, int64_t k, int dtype,

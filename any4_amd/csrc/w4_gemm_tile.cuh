@@ -95,7 +95,13 @@ __device__ __forceinline__ void tile_barrier() {
 // NCW = consuming waves: 4 (2 x 2, shipped) or 8 (4 (m) x 2 (n): two per SIMD, one's fragment reads under the other's MFMAs; with 16 waves per
 //       workgroup that leaves 4 dequantising waves, which then bound the 128 x 128 tile: 62.7 vs 55 us at m = 1024 -- developer A/B only)
 // QMX = mx4 weights (a template parameter: as a run-time branch its code cost the other formats 10 % at 128 x 64 tiles and spilled the 128 x 128 tile: 106 -> 207 us)
-template <typename DT, int BM, int BN, int DX = 3, int NDW = 8, int KS = 1, int NCW = 4, bool QMX = false>
+// W8  = int8 weights (tinygemm_y_f16RM_x_f16RM_w_int8TC at many rows; TinyGemm_int8.cu:216-399): 0 = 4-bit, 1 = Bint8 words of innerKTiles 2
+//       ([n / 8][k / 32][32][2]: lane t, k-tile kt -> one word, bytes = k 2q, 2q + 8, 2q + 1, 2q + 9 of row t / 4, q = t % 4;
+//       MatrixLayoutB.cuh:1104-1327), 2 = Aint8 words of innerKTiles 2 ([n / 16][k / 32][32][4]: lane t, k-tile kt -> two words, bytes =
+//       (m0, k0) (m1, k0) (m0, k0 + 1) (m1, k0 + 1), the second word at k0 + 8; m0 = t / 4, m1 = m0 + 8, k0 = 2q).  No tables: the
+//       dequantising waves compute w = RNE16(fma(byte - 128, scale, zero)) (Dequantization.cuh:262-330) in the vector ALU -- 2.75 operations
+//       per weight against one LDS lookup -- from scale / zero words they prefetch themselves; one quantisation group per step (g >= 64 KS).
+template <typename DT, int BM, int BN, int DX = 3, int NDW = 8, int KS = 1, int NCW = 4, bool QMX = false, int W8 = 0>
 __global__ void __launch_bounds__(64 * (NCW + 4 + NDW)) w4_gemm_tile_kernel(const TileParams p) {
   constexpr int WN = BN / 2;             // weight rows of a consumer wave
   constexpr int NT = WN / 16;            // its 16-row tiles
@@ -151,6 +157,110 @@ __global__ void __launch_bounds__(64 * (NCW + 4 + NDW)) w4_gemm_tile_kernel(cons
   if (wave_all >= NCW + 4) {
     // =================================== dequantising waves ===================================
     const int dw = wave_all - (NCW + 4);                                // 0 ... NDW - 1: owns the 8-row tiles dw * WPT ... of the BN rows
+    if constexpr (W8 != 0) {
+      // ---- int8: a wave-load is 512 consecutive bytes = one (8-row tile, 64 k) block of Bint8 / one (16-row tile, 32 k) block of Aint8 ----
+      constexpr int UW = (W8 == 1 ? BN / 8 : BN / 16 * 2) / NDW;       // blocks per wave and super-tile
+      constexpr int NW8 = UW * KS;
+      constexpr int RW = W8 == 1 ? 1 : 2;                              // weight rows a lane's bytes belong to
+      const int64_t k32 = (int64_t)p.ksuper * 2;                        // 32-k super-tiles of the packed layout (innerKTiles 2)
+      const u32x2* wsrc[UW];
+      uint32_t dst[UW][RW][2];    // byte offset in a plane of a w stage of (row rr, the piece of word / k-tile j); the second piece of it: ^ 16 in the chunk
+      const uint32_t* qrow[UW][RW];
+      int kt_or_sup;              // B: the lane's 32-k half of the block; A: its k-tile within the block's 32 k
+#pragma unroll
+      for (int u = 0; u < UW; ++u) {
+        const int blk = dw * UW + u;
+        if constexpr (W8 == 1) {
+          const int sup = lane >> 5, t = lane & 31, q = t & 3;
+          kt_or_sup = sup;
+          int gt = (n0 >> 3) + blk;
+          gt = gt < (p.wrows >> 3) ? gt : (p.wrows >> 3) - 1;
+          wsrc[u] = reinterpret_cast<const u32x2*>(p.w) + ((int64_t)gt * k32 + 2 * ks0 + sup) * 32 + t;
+          const int row = blk * 8 + (t >> 2);
+          int gr = n0 + row;
+          gr = gr < p.wrows ? gr : p.wrows - 1;
+          qrow[u][0] = reinterpret_cast<const uint32_t*>(p.qinfo) + (int64_t)g0 * p.wrows + gr;
+#pragma unroll
+          for (int kt = 0; kt < 2; ++kt)   // word kt: k = 32 sup + 16 kt + 2q (+ 1) and + 8: chunks 4 sup + 2 kt and + 1, byte 4 q
+            dst[u][0][kt] = (uint32_t)(row * 128 + 4 * q) + (((uint32_t)(4 * sup + 2 * kt) ^ (uint32_t)((row >> 1) & 7)) << 4);
+        } else {
+          const int t16 = blk >> 1, ko = blk & 1, t = lane >> 1, kt = lane & 1, q = t & 3;
+          kt_or_sup = kt;
+          int gt = (n0 >> 4) + t16;
+          gt = gt < (p.wrows >> 4) ? gt : (p.wrows >> 4) - 1;
+          wsrc[u] = reinterpret_cast<const u32x2*>(p.w) + (((int64_t)gt * k32 + 2 * ks0 + ko) * 32 + t) * 2 + kt;
+#pragma unroll
+          for (int rr = 0; rr < 2; ++rr) {
+            const int row = t16 * 16 + (t >> 2) + 8 * rr;
+            int gr = n0 + row;
+            gr = gr < p.wrows ? gr : p.wrows - 1;
+            qrow[u][rr] = reinterpret_cast<const uint32_t*>(p.qinfo) + (int64_t)g0 * p.wrows + gr;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)    // word j: k = 32 ko + 16 kt + 2q + 8 j (+ 1): chunk 4 ko + 2 kt + j, byte 4 q
+              dst[u][rr][j] = (uint32_t)(row * 128 + 4 * q) + (((uint32_t)(4 * ko + 2 * kt + j) ^ (uint32_t)((row >> 1) & 7)) << 4);
+          }
+        }
+      }
+      (void)kt_or_sup;
+      u32x2 ring[PWD][NW8];
+      uint32_t szq[PWD][UW][RW];
+      auto load_step = [&](int step, u32x2 (&wd)[NW8], uint32_t (&sz)[UW][RW]) {
+        const int c = step < last ? step : last;
+        int g = (c * (64 * KS)) >> gshift;
+        g = g < ngroups ? g : ngroups - 1;
+#pragma unroll
+        for (int u = 0; u < UW; ++u) {
+#pragma unroll
+          for (int pl = 0; pl < KS; ++pl) wd[u * KS + pl] = __builtin_nontemporal_load(wsrc[u] + (int64_t)(c * KS + pl) * (W8 == 1 ? 64 : 128));
+#pragma unroll
+          for (int rr = 0; rr < RW; ++rr) sz[u][rr] = qrow[u][rr][(int64_t)g * p.wrows];
+        }
+      };
+      auto deq = [&](uint32_t b, float sc, float z) { return __builtin_fmaf((float)b - 128.f, sc, z); };
+      auto dequant8 = [&](int step, const u32x2 (&wd)[NW8], const uint32_t (&sz)[UW][RW]) {
+        char* bst = lds + L::B_OFF + (step & 1) * L::B_STAGE;
+#pragma unroll
+        for (int u = 0; u < UW; ++u)
+#pragma unroll
+          for (int pl = 0; pl < KS; ++pl) {
+            const u32x2 v = wd[u * KS + pl];
+            char* pb = bst + pl * L::B_PLANE;
+            if constexpr (W8 == 1) {
+              const float sc = DT::lo_f32(sz[u][0]), z = DT::hi_f32(sz[u][0]);
+#pragma unroll
+              for (int kt = 0; kt < 2; ++kt) {   // bytes: k 2q, 2q + 8, 2q + 1, 2q + 9
+                const uint32_t w = v[kt];
+                *reinterpret_cast<uint32_t*>(pb + dst[u][0][kt]) = DT::pack2(deq(w & 0xffu, sc, z), deq((w >> 16) & 0xffu, sc, z));
+                *reinterpret_cast<uint32_t*>(pb + (dst[u][0][kt] ^ 16u)) = DT::pack2(deq((w >> 8) & 0xffu, sc, z), deq(w >> 24, sc, z));
+              }
+            } else {
+              const float s0 = DT::lo_f32(sz[u][0]), z0 = DT::hi_f32(sz[u][0]), s1 = DT::lo_f32(sz[u][1]), z1 = DT::hi_f32(sz[u][1]);
+#pragma unroll
+              for (int j = 0; j < 2; ++j) {      // bytes: (m0, k0) (m1, k0) (m0, k0 + 1) (m1, k0 + 1)
+                const uint32_t w = v[j];
+                *reinterpret_cast<uint32_t*>(pb + dst[u][0][j]) = DT::pack2(deq(w & 0xffu, s0, z0), deq((w >> 16) & 0xffu, s0, z0));
+                *reinterpret_cast<uint32_t*>(pb + dst[u][1][j]) = DT::pack2(deq((w >> 8) & 0xffu, s1, z1), deq(w >> 24, s1, z1));
+              }
+            }
+          }
+      };
+#pragma unroll
+      for (int j = 0; j < PWD; ++j) load_step(j, ring[j], szq[j]);
+      tile_barrier();
+      dequant8(0, ring[0], szq[0]);
+      load_step(PWD, ring[0], szq[0]);
+      tile_barrier();
+      for (int s = 0; s < ksteps; s += PWD) {
+#pragma unroll
+        for (int j = 0; j < PWD; ++j) {
+          if (s + j >= ksteps) break;
+          if (s + j + 1 < ksteps) dequant8(s + j + 1, ring[(j + 1) % PWD], szq[(j + 1) % PWD]);
+          load_step(s + j + 1 + PWD, ring[(j + 1) % PWD], szq[(j + 1) % PWD]);
+          tile_barrier();
+        }
+      }
+      return;
+    } else {
     const int ntiles8 = p.wrows >> 3;
     // lane = 8 (row of the tile) + (word 2 i + j of the row) = the word's own position in the tile's 256-byte block of the packed layout: a
     // wave-load is 64 CONSECUTIVE dwords (with lanes = (row & 3, word, row >> 2) a quad of adjacent lanes touched two 64-byte chunks: 8 x the
@@ -228,6 +338,7 @@ __global__ void __launch_bounds__(64 * (NCW + 4 + NDW)) w4_gemm_tile_kernel(cons
       }
     }
     return;
+    }  // W8 == 0
   }
 
   if (wave_all >= NCW) {
@@ -281,7 +392,10 @@ __global__ void __launch_bounds__(64 * (NCW + 4 + NDW)) w4_gemm_tile_kernel(cons
     if constexpr (QMX) qsrc[v] = reinterpret_cast<const uint32_t*>(p.qinfo + (int64_t)gr * (p.k >> 5) + g0);
     else qsrc[v] = reinterpret_cast<const uint32_t*>(p.qinfo) + (int64_t)g0 * p.wrows + gr;
     const int e4 = (tid & 3) * 4;
-    if (p.qtype == TG_Q_INT4) {
+    if constexpr (W8 != 0) {      // (int8: no tables)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) lv[v][e] = 0.f;
+    } else if (p.qtype == TG_Q_INT4) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) lv[v][e] = (float)(e4 + e - 8);
     } else if (QMX) {
@@ -384,8 +498,8 @@ __global__ void __launch_bounds__(64 * (NCW + 4 + NDW)) w4_gemm_tile_kernel(cons
     }
   };
 
-  // ---- prologue: the tables of steps 0 and 1; scale / zero of steps 2 ... PW + 1 into the ring ----
-  {
+  // ---- prologue: the tables of steps 0 and 1; scale / zero of steps 2 ... PW + 1 into the ring (int8: no tables) ----
+  if constexpr (W8 == 0) {
     uint32_t s0[NSUB][RPT], s1[NSUB][RPT];
     load_sz(0, s0);
     load_sz(1, s1);
@@ -402,8 +516,10 @@ __global__ void __launch_bounds__(64 * (NCW + 4 + NDW)) w4_gemm_tile_kernel(cons
       if (s + j >= ksteps) break;
       // step t = s + j: the MFMAs of step t; the tables of step t + 2 (slot (j + 2) % PW), refilled with step t + 2 + PW
       if (!(TILE_ABL & 2)) mma(s + j);
-      if (!(TILE_ABL & 8) && s + j + 2 < ksteps && new_group(s + j + 2)) build_tables(s + j + 2, szr[(j + 2) % PW]);
-      load_sz(s + j + 2 + PW, szr[(j + 2) % PW]);
+      if constexpr (W8 == 0) {
+        if (!(TILE_ABL & 8) && s + j + 2 < ksteps && new_group(s + j + 2)) build_tables(s + j + 2, szr[(j + 2) % PW]);
+        load_sz(s + j + 2 + PW, szr[(j + 2) % PW]);
+      }
       tile_barrier();
     }
   }

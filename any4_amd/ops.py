@@ -902,6 +902,16 @@ def tinygemm_y_f16RM_x_f16RM_w_int8TC(A, B, qGroupSize, qScaleAndZeros, weightOn
     args = W4Gemm(x=x.data_ptr(), w=w.data_ptr(), qinfo=qinfo.data_ptr(), lut=None, y=y.data_ptr(), m=m, wrows=wrows, k=k,
                   group=qGroupSize, qtype=_lib.TG_Q_INT8, dtype=_dt(x), w_on_right=1 if weightOnRight else 0,
                   inner_k_tiles=inner, batch=1, bias=(bias.data_ptr() if bias is not None else None))
+    # many activation rows of innerKTiles-2 words: the tile GEMM's int8 flavour, split-K with a scratch from the caching allocator
+    key = ("w8", m, wrows, k, qGroupSize, args.dtype, args.w_on_right, inner, bias is not None, _dev(x))
+    ws_bytes = _WS_BYTES.get(key)
+    if ws_bytes is None:
+        ws_bytes = _L.tg_gemm_w8_workspace_bytes(ctypes.byref(args))
+        if len(_WS_BYTES) < 4096 and ws_bytes >= 0:
+            _WS_BYTES[key] = ws_bytes
+    if ws_bytes > 0:
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
+        args.workspace, args.workspace_bytes = ws.data_ptr(), ws_bytes
     _lib.check(_L.tg_gemm_w8(ctypes.byref(args), _dev(x), _stream(x)), opname)
     return y
 

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define TG_ABI_VERSION 7
+#define TG_ABI_VERSION 8
 
 #if defined(__GNUC__)
 #define TG_API __attribute__((visibility("default")))
@@ -289,6 +289,10 @@ TG_API int tg_convert_to_Bint8(const int32_t* in, int64_t n, int64_t k, int inne
 TG_API int tg_convert_to_Aint8(const int32_t* in, int64_t m, int64_t k, int inner_k_tiles, int32_t* out, int device,
                                tg_stream_t stream);
 TG_API int tg_gemm_w8(const tg_w4_gemm* args, int device, tg_stream_t stream);
+/* ABI version 8: bytes of `workspace` with which tg_gemm_w8 takes its fastest kernel (needs no GPU; 0: none; negative: the TG_E_* code
+ * tg_gemm_w8 would return): many activation rows of innerKTiles-2 words run the tile GEMM as a split-K launch (f32 partial tiles).  Without
+ * a workspace the call still succeeds (unsplit, or on the 16-row kernel). */
+TG_API int64_t tg_gemm_w8_workspace_bytes(const tg_w4_gemm* args);
 
 /*
  * replaces tinygemm_y_f16RM_x_f16RM_w_f16TC (TinyGemm_bf16.cu:163-327): un-quantised 16-bit

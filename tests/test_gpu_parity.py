@@ -690,6 +690,41 @@ def test_gemm_int8_vs_oracle(T, oracle, on_right, inner, g, m, n, k, dtype):
     assert (y[:, n:] == 0).all()  # padded rows: zero codes... with scale = zero = 0 they dequantise to 0
 
 
+@pytest.mark.parametrize("on_right", [True, False])
+@pytest.mark.parametrize("g", [64, 128, 256])
+@pytest.mark.parametrize("m,n,k,dtype", [(9, 200, 512, torch.bfloat16), (33, 264, 2048, torch.bfloat16), (64, 4096, 2048, torch.float16), (130, 1008, 4096, torch.bfloat16),
+                                         (512, 528, 1024, torch.float16), (100, 48, 192, torch.bfloat16)])
+def test_gemm_int8_many_rows_on_the_tile_gemm(T, oracle, on_right, g, m, n, k, dtype):
+    """tinygemm_y_f16RM_x_f16RM_w_int8TC (TinyGemm_int8.cu:216-399) from 9 activation rows on the tile GEMM's int8 flavour (innerKTiles 2, the
+    packing Int8Linear defaults to; groups of 64 or more): w = RNE16(fma(byte - 128, scale, zero)) computed by the dequantising waves, unsplit
+    and split-K launches, both operand sides, ragged rows, a k of one step and a half (192), fused bias."""
+    from any4_amd import ops
+
+    if k % g:
+        pytest.skip("group does not divide k")
+    codes, x, sz = _rand_int8_problem(n, k, g, m, dtype, seed=n + k + m)
+    d = lambda t: t.to(DEV)
+    if on_right:
+        w2 = T.convert_matrix_to_m16n8k16_Bint8_layout(d(codes), 2)
+        n_pad = w2.size(0) * 8
+    else:
+        w2 = T.convert_matrix_to_m16n8k16_Aint8_layout(d(codes), 2)
+        n_pad = w2.size(0) * 16
+    szp = torch.zeros(k // g, n_pad, 2, dtype=dtype)
+    szp[:, :n] = sz
+    run = lambda: T.tinygemm_y_f16RM_x_f16RM_w_int8TC(d(x), w2, g, d(szp), True) if on_right else T.tinygemm_y_f16RM_x_f16RM_w_int8TC(w2, d(x), g, d(szp), False)
+    y = run()
+    assert y.shape == (m, n_pad)
+    w = oracle.dequant(codes.numpy(), g, oracle.Q_INT8, bits16(sz), None, oracle.BF16 if dtype == torch.bfloat16 else oracle.F16)
+    assert_gemm_close(y[:, :n], x, w, dtype)
+    assert (y[:, n:] == 0).all()
+    assert torch.equal(y, run())
+    bias = torch.randn(n_pad, generator=torch.Generator().manual_seed(5)).to(dtype).to(DEV)
+    with ops.fused_bias(bias) as fb:
+        yb = run()
+    assert fb.consumed and torch.equal(yb, y + bias)
+
+
 @pytest.mark.parametrize("api", ["RM_right", "RM_left", "TC_right", "TC_left"])
 @pytest.mark.parametrize("k,g,inner", [(256, 32, 1), (1024, 64, 2), (2048, 256, 2), (1024, 128, 4)])
 def test_int8_identity_bit_exact(T, api, k, g, inner):

@@ -30,7 +30,7 @@ def test_c_abi_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in include/*.h but not exported"
     assert set(syms) == set(_lib.SYMBOLS), "ctypes binding and header disagree"
-    assert _lib.load().tg_abi_version() == _lib.TG_ABI_VERSION == 7
+    assert _lib.load().tg_abi_version() == _lib.TG_ABI_VERSION == 8
 
 
 def test_peer_gather_preconditions_fail_before_any_launch():
