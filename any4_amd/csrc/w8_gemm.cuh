@@ -16,6 +16,9 @@
 // scale = zero = 0 and contribute exact zeros).  A correct, HBM-streaming kernel; not tuned like the 4-bit path.
 #pragma once
 
+#ifndef W8_RING
+#define W8_RING 4
+#endif
 template <typename DT, bool LAYOUT_A, int I, int WAVES>
 __global__ void __launch_bounds__(WAVES * 64, 2) w8_gemm_kernel(const GemmParams p) {
   __shared__ f32x4 s_red[WAVES * 64];
@@ -119,13 +122,21 @@ __global__ void __launch_bounds__(WAVES * 64, 2) w8_gemm_kernel(const GemmParams
     }
   };
   if (rt_ok && slice < nsteps_total) {
-    Step cur, nxt;
-    load_step(slice, cur);
-    for (int s = slice; s < nsteps_total; s += p.splitk) {
-      const bool more = s + p.splitk < nsteps_total;
-      if (more) load_step(s + p.splitk, nxt);
-      compute_step(cur);
-      if (more) cur = nxt;
+    // a ring of W8_RING steps in flight per wave (round 6; 4096^2 at one activation row: 11.8 -> 11.45 us per graph node -- the latency of one
+    // step ahead was not what bounds this kernel; with unconditional (clamped) refills 12.5.  Not tuned like the 4-bit path: SURVEY 8f N3)
+    Step ring[W8_RING];
+#pragma unroll
+    for (int j = 0; j < W8_RING; ++j)
+      if (slice + j * p.splitk < nsteps_total) load_step(slice + j * p.splitk, ring[j]);
+    for (int s = slice; s < nsteps_total; s += W8_RING * p.splitk) {
+#pragma unroll
+      for (int j = 0; j < W8_RING; ++j) {
+        const int ss = s + j * p.splitk;
+        if (ss < nsteps_total) {
+          compute_step(ring[j]);
+          if (ss + W8_RING * p.splitk < nsteps_total) load_step(ss + W8_RING * p.splitk, ring[j]);
+        }
+      }
     }
   }
 
