@@ -358,7 +358,7 @@ inline int cu_count() {
 #define TG_B16_CHUNK 4         // consecutive 32-row work items per workgroup visit of those kernels (1 / 4 / 8 within 1 %)
 #endif
 #ifndef TG_TILE_W8_MIN_M
-#define TG_TILE_W8_MIN_M 9   // int8 weights: activation rows from which tg_gemm_w8 takes the tile GEMM (tg_tile.hip)
+#define TG_TILE_W8_MIN_M 7   // int8 weights: activation rows from which tg_gemm_w8 takes the tile GEMM (tg_tile.hip): 14.3 us per 4096^2 layer; the 16-row kernel: 8.4 / 12.1 / 15.4 at 1 / 4 / 8 rows
 #endif
 #ifndef TG_TILE_MIN_M_SPLIT
 #define TG_TILE_MIN_M_SPLIT 17  // ... and with a split-K launch of ONE layer (caller's workspace; tg_tile.hip): 12.6-14.8 us at 17 ... 64 rows against 7.5 us per 16-row pass

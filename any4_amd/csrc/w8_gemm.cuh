@@ -17,10 +17,10 @@
 #pragma once
 
 #ifndef W8_RING
-#define W8_RING 4
+#define W8_RING 2   // steps in flight per wave (1 / 2 / 4 / 8 measured: 7.7 / 7.4 / 7.4 / 7.7 us at one row: VALU-bound at ~ 190 instructions per step, not latency-bound)
 #endif
 template <typename DT, bool LAYOUT_A, int I, int WAVES>
-__global__ void __launch_bounds__(WAVES * 64, 2) w8_gemm_kernel(const GemmParams p) {
+__global__ void __launch_bounds__(WAVES * 64, WAVES <= 8 ? 2 : 1) w8_gemm_kernel(const GemmParams p) {
   __shared__ f32x4 s_red[WAVES * 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, Q = lane >> 4;
@@ -87,20 +87,21 @@ __global__ void __launch_bounds__(WAVES * 64, 2) w8_gemm_kernel(const GemmParams
     for (int h = 0; h < 2; ++h) {
       const int kt0 = 4 * s + 2 * h;
       const int kt0_c = min(kt0, ktiles - 2);
-      const uint32_t q = qb[(uint32_t)(((kt0_c << 4) >> p.gshift) * p.wrows + row_c)];
-      st.q[h] = (row_ok && kt0 < ktiles) ? q : 0u;  // scale = zero = 0: this lane contributes exact zeros
-      st.x[h] = u32x4{0u, 0u, 0u, 0u};
-      if (xcol) {
-        const char* xp = xlane + (int64_t)kt0_c * 32;
+      // (every load of a step is unconditional per lane, with clamped addresses, and nothing of it is touched before compute_step: a load
+      //  under a branch or a select right behind it made hipcc wait vmcnt(0) inside load_step -- every step then exposed the whole memory
+      //  latency whatever the ring depth: 0.86 us per step and wave, a one-row 4096^2 layer at the 16-bit layer's time)
+      st.q[h] = qb[(uint32_t)(((kt0_c << 4) >> p.gshift) * p.wrows + row_c)];
+      const char* xp = xlane + (int64_t)kt0_c * 32;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) st.x[h][e] = *reinterpret_cast<const uint32_t*>(xp + 16 * e);
-      }
+      for (int e = 0; e < 4; ++e) st.x[h][e] = *reinterpret_cast<const uint32_t*>(xp + 16 * e);
     }
   };
-  auto compute_step = [&](const Step& st) {
+  auto compute_step = [&](int s, const Step& st) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {  // two K-slots of two k-tiles each
-      const float sc = DT::lo_f32(st.q[h]), zp = DT::hi_f32(st.q[h]);
+      // out-of-range rows / k-tiles: scale = zero = 0, the lane contributes exact zeros; activation rows beyond m: zeros
+      const uint32_t qh = (row_ok && 4 * s + 2 * h < ktiles) ? st.q[h] : 0u;
+      const float sc = DT::lo_f32(qh), zp = DT::hi_f32(qh);
       u32x4 a;
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
@@ -118,13 +119,16 @@ __global__ void __launch_bounds__(WAVES * 64, 2) w8_gemm_kernel(const GemmParams
         a[2 * j] = DT::pack2(f0, f1);
         a[2 * j + 1] = DT::pack2(f2, f3);
       }
-      acc = DT::mfma(a, st.x[h], acc);
+      const u32x4 xv = {xcol ? st.x[h][0] : 0u, xcol ? st.x[h][1] : 0u, xcol ? st.x[h][2] : 0u, xcol ? st.x[h][3] : 0u};
+      acc = DT::mfma(a, xv, acc);
     }
   };
   if (rt_ok && slice < nsteps_total) {
-    // a ring of W8_RING steps in flight per wave (round 6; 4096^2 at one activation row: 11.8 -> 11.45 us per graph node -- the latency of one
-    // step ahead was not what bounds this kernel; with unconditional (clamped) refills 12.5.  Not tuned like the 4-bit path: SURVEY 8f N3)
+    // a ring of W8_RING steps in flight per wave (round 6)
     Step ring[W8_RING];
+    // (refills under a wave-uniform branch: hipcc's vmcnt bookkeeping then drains the queue per slot, but unconditional clamped refills --
+    //  exact counts -- measured slower: one row 7.4 -> 7.8 us, eight rows 14.9 -> 18.9: the activation requests of the steps past the end
+    //  are real work for the CU's vector-memory path, which this kernel's 4-byte activation loads already load 4 x as much as the weights)
 #pragma unroll
     for (int j = 0; j < W8_RING; ++j)
       if (slice + j * p.splitk < nsteps_total) load_step(slice + j * p.splitk, ring[j]);
@@ -133,7 +137,7 @@ __global__ void __launch_bounds__(WAVES * 64, 2) w8_gemm_kernel(const GemmParams
       for (int j = 0; j < W8_RING; ++j) {
         const int ss = s + j * p.splitk;
         if (ss < nsteps_total) {
-          compute_step(ring[j]);
+          compute_step(ss, ring[j]);
           if (ss + W8_RING * p.splitk < nsteps_total) load_step(ss + W8_RING * p.splitk, ring[j]);
         }
       }
