@@ -34,6 +34,9 @@
 // and a lookup address is just (nibble << 8 | lane << 2); otherwise address bits 12..15 (the table
 // select) are OR-ed into the nibble bytes before the v_perm_b32.
 #pragma once
+#ifndef TG_STREAM_UNCOND
+#define TG_STREAM_UNCOND 0
+#endif
 
 
 struct StreamParams {
@@ -389,9 +392,18 @@ __global__ void __launch_bounds__(WAVES * 64, MINW) w4_gemm_stream_kernel(const 
     // All control flow below is workgroup-uniform (NU, splitk, group size), barriers included.
     auto do_unit = [&](int u, const u32x4 (&Lc)[4], uint32_t qc, u32x4 (&Ln)[4], uint32_t& qn) {
       const int U = u_first + u;
+#if TG_STREAM_UNCOND
+      // (the next unit's words and scale are requested unconditionally -- load_unit / load_q clamp their addresses, the unit past the end is
+      //  never consumed: with the requests under the branch hipcc cannot count them and waits vmcnt(0) in front of build_table below,
+      //  i.e. for the requests it has just issued)
+      load_unit(U + 1, Ln);
+      qn = load_q(U + 1);
+#endif
       if (u + 1 < NU) {
+#if !TG_STREAM_UNCOND
         load_unit(U + 1, Ln);
         qn = load_q(U + 1);
+#endif
         if constexpr (!XRES) {
           stage_store((u + 1) & 1, XR);           // slab u+1 (requested one unit ago) -> LDS
           if (u + 2 < NU) stage_load(u + 2, XR);  // request slab u+2
