@@ -45,7 +45,7 @@ struct F16GemmParams {
   int32_t inner;          // I
 };
 
-template <typename DT, bool LAYOUT_A, int WAVES>
+template <typename DT, bool LAYOUT_A, int WAVES, int I>
 __global__ void __launch_bounds__(WAVES * 64) f16_gemm_kernel(const F16GemmParams p) {
   __shared__ f32x4 s_red[WAVES * 64];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -65,33 +65,75 @@ __global__ void __launch_bounds__(WAVES * 64) f16_gemm_kernel(const F16GemmParam
   const int nsteps_total = ktiles >> 1;
   const int t = 4 * r + Q;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  for (int s = wave; s < nsteps_total; s += WAVES) {
-    u32x4 a = {0, 0, 0, 0}, xv = {0, 0, 0, 0};
-    if (row_ok) {
-      if constexpr (LAYOUT_A) {
-        // [mT][kT][32][8 halfs] = 4 dwords per lane slot: (m0;k0,k1) (m1;k0,k1) (m0;k8,k9) (m1;k8,k9)
-        const u32x4 v0 = *reinterpret_cast<const u32x4*>(wd + (((int64_t)rt * p.ktiles_padded + 2 * s) * 32 + t) * 4);
-        const u32x4 v1 = *reinterpret_cast<const u32x4*>(wd + (((int64_t)rt * p.ktiles_padded + 2 * s + 1) * 32 + t) * 4);
-        const int h = i >> 3;
-        a = u32x4{h ? v0[1] : v0[0], h ? v0[3] : v0[2], h ? v1[1] : v1[0], h ? v1[3] : v1[2]};
+  // A ring of F16_RING steps in flight per wave.  Every load is unconditional per lane with clamped addresses and nothing of a step is touched
+  // before it is consumed (round 6: a load under a lane mask makes hipcc wait vmcnt(0) right behind it -- every step then exposed the whole
+  // memory latency); rows / columns beyond the problem are masked at the consumer.
+  constexpr int F16_RING = 4;
+  struct Step { u32x4 w0, w1, x; };
+  const int rt_c = rt;  // (row tiles are never out of range: the grid is exact; rows beyond wrows within the last tile are masked below)
+  auto load_step = [&](int s, Step& st) {
+    const int sc = min(s, nsteps_total - 1);
+    if constexpr (LAYOUT_A) {
+      // [mT][kT][32][8 halfs] = 4 dwords per lane slot: (m0;k0,k1) (m1;k0,k1) (m0;k8,k9) (m1;k8,k9)
+      st.w0 = *reinterpret_cast<const u32x4*>(wd + (((int64_t)rt_c * p.ktiles_padded + 2 * sc) * 32 + t) * 4);
+      st.w1 = *reinterpret_cast<const u32x4*>(wd + (((int64_t)rt_c * p.ktiles_padded + 2 * sc + 1) * 32 + t) * 4);
+    } else {
+      // [nT][kT/I][32][4 I halfs]: per k-tile the dwords (k0,k1) (k8,k9)
+      const int tile = min(2 * rt + (i >> 3), (p.wrows + 7) / 8 - 1);
+      if constexpr (I == 2) {
+        st.w0 = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wd + (((int64_t)tile * (p.ktiles_padded / 2) + sc) * 32 + t) * 4));
+        st.w1 = st.w0;
       } else {
-        // [nT][kT/I][32][4 I halfs]: per k-tile the dwords (k0,k1) (k8,k9)
-        const int tile = 2 * rt + (i >> 3);
-        if (p.inner == 2) {
-          a = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wd + (((int64_t)tile * (p.ktiles_padded / 2) + s) * 32 + t) * 4));
-        } else {
-          const u32x2 v0 = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(wd + (((int64_t)tile * p.ktiles_padded + 2 * s) * 32 + t) * 2));
-          const u32x2 v1 = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(wd + (((int64_t)tile * p.ktiles_padded + 2 * s + 1) * 32 + t) * 2));
-          a = u32x4{v0[0], v0[1], v1[0], v1[1]};
+        const u32x2 v0 = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(wd + (((int64_t)tile * p.ktiles_padded + 2 * sc) * 32 + t) * 2));
+        const u32x2 v1 = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(wd + (((int64_t)tile * p.ktiles_padded + 2 * sc + 1) * 32 + t) * 2));
+        st.w0 = u32x4{v0[0], v0[1], v1[0], v1[1]};
+        st.w1 = st.w0;
+      }
+    }
+    const char* xp = p.x + ((int64_t)xrow * p.k + 32 * sc) * 2 + 4 * Q;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) st.x[e] = *reinterpret_cast<const uint32_t*>(xp + 16 * e);
+  };
+  auto compute_step = [&](const Step& st) {
+    u32x4 a;
+    if constexpr (LAYOUT_A) {
+      const int h = i >> 3;
+      a = u32x4{h ? st.w0[1] : st.w0[0], h ? st.w0[3] : st.w0[2], h ? st.w1[1] : st.w1[0], h ? st.w1[3] : st.w1[2]};
+    } else {
+      a = st.w0;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) a[e] = row_ok ? a[e] : 0u;
+    const u32x4 xv = {xcol ? st.x[0] : 0u, xcol ? st.x[1] : 0u, xcol ? st.x[2] : 0u, xcol ? st.x[3] : 0u};
+    acc = DT::mfma(a, xv, acc);
+  };
+  {
+    // this wave's steps: wave, wave + WAVES, ...: nw of them.  Rounds of F16_RING steps whose refills are all in range run without a branch
+    // around a load (exact vmcnt); the last round(s) only consume (a refill past the end would be real work for the vector-memory path).
+    const int nw = (nsteps_total - wave + WAVES - 1) / WAVES;
+    Step ring[F16_RING];
+#pragma unroll
+    for (int j = 0; j < F16_RING; ++j) load_step(wave + j * WAVES, ring[j]);   // (clamped: a wave with fewer steps loads its last one again)
+    int base = 0;
+    for (; base + 2 * F16_RING <= nw; base += F16_RING) {
+#pragma unroll
+      for (int j = 0; j < F16_RING; ++j) {
+        compute_step(ring[j]);
+        load_step(wave + (base + F16_RING + j) * WAVES, ring[j]);
+      }
+    }
+    // the remainder: fewer than two rounds; refills only where a step exists
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+#pragma unroll
+      for (int j = 0; j < F16_RING; ++j) {
+        const int jj = base + r * F16_RING + j;
+        if (jj < nw) {
+          compute_step(ring[j]);
+          if (jj + F16_RING < nw) load_step(wave + (jj + F16_RING) * WAVES, ring[j]);
         }
       }
     }
-    if (xcol) {
-      const char* xp = p.x + ((int64_t)xrow * p.k + 32 * s) * 2 + 4 * Q;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) xv[e] = *reinterpret_cast<const uint32_t*>(xp + 16 * e);
-    }
-    acc = DT::mfma(a, xv, acc);
   }
   s_red[wave * 64 + lane] = acc;
   __syncthreads();
@@ -1036,11 +1078,13 @@ int tg_gemm_f16(const void* x, const void* w, void* y, int64_t m, int64_t wrows,
   dim3 grid((unsigned)cdiv(wrows, 16), (unsigned)cdiv(m, 16));
   constexpr int WAVES = 8;
   if (dtype == TG_BF16) {
-    if (w_on_right) hipLaunchKernelGGL((f16_gemm_kernel<BF16, false, WAVES>), grid, dim3(WAVES * 64), 0, st, p);
-    else hipLaunchKernelGGL((f16_gemm_kernel<BF16, true, WAVES>), grid, dim3(WAVES * 64), 0, st, p);
+    if (w_on_right && I == 2) hipLaunchKernelGGL((f16_gemm_kernel<BF16, false, WAVES, 2>), grid, dim3(WAVES * 64), 0, st, p);
+    else if (w_on_right) hipLaunchKernelGGL((f16_gemm_kernel<BF16, false, WAVES, 1>), grid, dim3(WAVES * 64), 0, st, p);
+    else hipLaunchKernelGGL((f16_gemm_kernel<BF16, true, WAVES, 1>), grid, dim3(WAVES * 64), 0, st, p);
   } else {
-    if (w_on_right) hipLaunchKernelGGL((f16_gemm_kernel<F16, false, WAVES>), grid, dim3(WAVES * 64), 0, st, p);
-    else hipLaunchKernelGGL((f16_gemm_kernel<F16, true, WAVES>), grid, dim3(WAVES * 64), 0, st, p);
+    if (w_on_right && I == 2) hipLaunchKernelGGL((f16_gemm_kernel<F16, false, WAVES, 2>), grid, dim3(WAVES * 64), 0, st, p);
+    else if (w_on_right) hipLaunchKernelGGL((f16_gemm_kernel<F16, false, WAVES, 1>), grid, dim3(WAVES * 64), 0, st, p);
+    else hipLaunchKernelGGL((f16_gemm_kernel<F16, true, WAVES, 1>), grid, dim3(WAVES * 64), 0, st, p);
   }
   return launch_status();
 }

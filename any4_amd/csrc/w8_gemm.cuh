@@ -126,19 +126,28 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES <= 8 ? 2 : 1) w8_gemm_kernel
   if (rt_ok && slice < nsteps_total) {
     // a ring of W8_RING steps in flight per wave (round 6)
     Step ring[W8_RING];
-    // (refills under a wave-uniform branch: hipcc's vmcnt bookkeeping then drains the queue per slot, but unconditional clamped refills --
-    //  exact counts -- measured slower: one row 7.4 -> 7.8 us, eight rows 14.9 -> 18.9: the activation requests of the steps past the end
-    //  are real work for the CU's vector-memory path, which this kernel's 4-byte activation loads already load 4 x as much as the weights)
+    // this wave's steps: slice, slice + splitk, ...: nw of them.  Rounds of W8_RING steps whose refills are all in range run without a branch
+    // around a load (exact vmcnt); the last round(s) only consume -- a refill past the end is real work for the CU's vector-memory path, which
+    // this kernel's 4-byte activation loads load 4 x as much as the weights do (unconditional clamped refills throughout: 8 rows 14.9 -> 18.9 us)
+    const int nw = (nsteps_total - slice + p.splitk - 1) >> p.sk_shift;
 #pragma unroll
-    for (int j = 0; j < W8_RING; ++j)
-      if (slice + j * p.splitk < nsteps_total) load_step(slice + j * p.splitk, ring[j]);
-    for (int s = slice; s < nsteps_total; s += W8_RING * p.splitk) {
+    for (int j = 0; j < W8_RING; ++j) load_step(slice + j * p.splitk, ring[j]);
+    int base = 0;
+    for (; base + 2 * W8_RING <= nw; base += W8_RING) {
 #pragma unroll
       for (int j = 0; j < W8_RING; ++j) {
-        const int ss = s + j * p.splitk;
-        if (ss < nsteps_total) {
-          compute_step(ss, ring[j]);
-          if (ss + W8_RING * p.splitk < nsteps_total) load_step(ss + W8_RING * p.splitk, ring[j]);
+        compute_step(slice + (base + j) * p.splitk, ring[j]);
+        load_step(slice + (base + W8_RING + j) * p.splitk, ring[j]);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+#pragma unroll
+      for (int j = 0; j < W8_RING; ++j) {
+        const int jj = base + r * W8_RING + j;
+        if (jj < nw) {
+          compute_step(slice + jj * p.splitk, ring[j]);
+          if (jj + W8_RING < nw) load_step(slice + (jj + W8_RING) * p.splitk, ring[j]);
         }
       }
     }
