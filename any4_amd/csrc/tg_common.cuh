@@ -263,6 +263,18 @@ __device__ __forceinline__ void store_rows4(char* yb, const char* bias, int64_t 
 }
 
 
+// 4 x 4 transpose across the four 16-lane rows of a wave: out[e] in row Q = in[Q] of row e (lane = i + 16 row).  Two v_permlane16_swap
+// (odd rows of the first operand <-> even rows of the second) and two v_permlane32_swap (upper half of the first <-> lower half of the second).
+// Use: the MFMA 16x16x32 fragment of lane (i, Q) is the dwords Q, Q + 4, Q + 8, Q + 12 of a 64-byte block of row i -- one 16-byte load per
+// lane of dwords 4Q ... 4Q + 3 and this transpose instead of four 4-byte loads (a quarter of the requests in the vector-memory path).
+__device__ __forceinline__ u32x4 transpose_rows4(u32x4 v) {
+  const auto s01 = __builtin_amdgcn_permlane16_swap(v[0], v[1], false, false);
+  const auto s23 = __builtin_amdgcn_permlane16_swap(v[2], v[3], false, false);
+  const auto t02 = __builtin_amdgcn_permlane32_swap(s01[0], s23[0], false, false);
+  const auto t13 = __builtin_amdgcn_permlane32_swap(s01[1], s23[1], false, false);
+  return u32x4{t02[0], t13[0], t02[1], t13[1]};
+}
+
 struct DeviceScope {
   int prev = -1;
   bool ok = true;
@@ -358,7 +370,7 @@ inline int cu_count() {
 #define TG_B16_CHUNK 4         // consecutive 32-row work items per workgroup visit of those kernels (1 / 4 / 8 within 1 %)
 #endif
 #ifndef TG_TILE_W8_MIN_M
-#define TG_TILE_W8_MIN_M 7   // int8 weights: activation rows from which tg_gemm_w8 takes the tile GEMM (tg_tile.hip): 14.3 us per 4096^2 layer; the 16-row kernel: 8.4 / 12.1 / 15.4 at 1 / 4 / 8 rows
+#define TG_TILE_W8_MIN_M 17  // int8 weights: activation rows from which tg_gemm_w8 takes the tile GEMM (tg_tile.hip): 14.3 us per 4096^2 layer; the 16-row kernel: 8.6 us up to 6 rows
 #endif
 #ifndef TG_TILE_MIN_M_SPLIT
 #define TG_TILE_MIN_M_SPLIT 17  // ... and with a split-K launch of ONE layer (caller's workspace; tg_tile.hip): 12.6-14.8 us at 17 ... 64 rows against 7.5 us per 16-row pass

@@ -90,9 +90,7 @@ __global__ void __launch_bounds__(WAVES * 64) f16_gemm_kernel(const F16GemmParam
         st.w1 = st.w0;
       }
     }
-    const char* xp = p.x + ((int64_t)xrow * p.k + 32 * sc) * 2 + 4 * Q;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) st.x[e] = *reinterpret_cast<const uint32_t*>(xp + 16 * e);
+    st.x = *reinterpret_cast<const u32x4*>(p.x + ((int64_t)xrow * p.k + 32 * sc) * 2 + 16 * Q);   // dwords 4Q ... 4Q + 3: transposed at the consumer
   };
   auto compute_step = [&](const Step& st) {
     u32x4 a;
@@ -104,7 +102,8 @@ __global__ void __launch_bounds__(WAVES * 64) f16_gemm_kernel(const F16GemmParam
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) a[e] = row_ok ? a[e] : 0u;
-    const u32x4 xv = {xcol ? st.x[0] : 0u, xcol ? st.x[1] : 0u, xcol ? st.x[2] : 0u, xcol ? st.x[3] : 0u};
+    const u32x4 xt = transpose_rows4(st.x);
+    const u32x4 xv = {xcol ? xt[0] : 0u, xcol ? xt[1] : 0u, xcol ? xt[2] : 0u, xcol ? xt[3] : 0u};
     acc = DT::mfma(a, xv, acc);
   };
   {
@@ -987,7 +986,8 @@ static int gemm_w8_impl(const tg_w4_gemm* caller, int device, tg_stream_t stream
   if (!(g == 32 || g == 64 || g == 128 || g == 256) || a->k % g != 0) return TG_E_GROUP;     // TinyGemm_int8.cu:293-301
   const int rows_per_tile = on_right ? 8 : 16;
   if (a->wrows % rows_per_tile != 0) return TG_E_SHAPE;
-  if ((reinterpret_cast<uintptr_t>(a->x) & 3u) || (reinterpret_cast<uintptr_t>(a->w) & 3u) ||
+  // (x: 16-byte loads of the activation fragments / LDS-DMA of the tile flavour; rows are k * 2 bytes with k % 32 == 0)
+  if ((reinterpret_cast<uintptr_t>(a->x) & 15u) || (a->batch > 1 && (a->stride_x & 15)) || (reinterpret_cast<uintptr_t>(a->w) & 3u) ||
       (reinterpret_cast<uintptr_t>(a->qinfo) & 3u) || (reinterpret_cast<uintptr_t>(a->y) & 7u))
     return TG_E_ALIGN;
   if (a->bias && (reinterpret_cast<uintptr_t>(a->bias) & 7u)) return TG_E_ALIGN;

@@ -48,7 +48,7 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES <= 8 ? 2 : 1) w8_gemm_kernel
 
   const int xrow = min(ct * 16 + i, p.m - 1);
   const bool xcol = ct * 16 + i < p.m;
-  const char* xlane = xb + ((int64_t)xrow * p.k) * 2 + 4 * Q;
+  const char* xlane = xb + ((int64_t)xrow * p.k) * 2 + 16 * Q;   // (dwords 4Q ... 4Q + 3 of a K-slot's 64 bytes: transposed across the Q rows at the consumer)
 
   const int nsteps_total = (ktiles + 3) >> 2;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -91,9 +91,7 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES <= 8 ? 2 : 1) w8_gemm_kernel
       //  under a branch or a select right behind it made hipcc wait vmcnt(0) inside load_step -- every step then exposed the whole memory
       //  latency whatever the ring depth: 0.86 us per step and wave, a one-row 4096^2 layer at the 16-bit layer's time)
       st.q[h] = qb[(uint32_t)(((kt0_c << 4) >> p.gshift) * p.wrows + row_c)];
-      const char* xp = xlane + (int64_t)kt0_c * 32;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) st.x[h][e] = *reinterpret_cast<const uint32_t*>(xp + 16 * e);
+      st.x[h] = *reinterpret_cast<const u32x4*>(xlane + (int64_t)kt0_c * 32);   // (16-byte aligned: the host checks x)
     }
   };
   auto compute_step = [&](int s, const Step& st) {
@@ -119,7 +117,8 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES <= 8 ? 2 : 1) w8_gemm_kernel
         a[2 * j] = DT::pack2(f0, f1);
         a[2 * j + 1] = DT::pack2(f2, f3);
       }
-      const u32x4 xv = {xcol ? st.x[h][0] : 0u, xcol ? st.x[h][1] : 0u, xcol ? st.x[h][2] : 0u, xcol ? st.x[h][3] : 0u};
+      const u32x4 xt = transpose_rows4(st.x[h]);
+      const u32x4 xv = {xcol ? xt[0] : 0u, xcol ? xt[1] : 0u, xcol ? xt[2] : 0u, xcol ? xt[3] : 0u};
       acc = DT::mfma(a, xv, acc);
     }
   };

@@ -898,6 +898,8 @@ def tinygemm_y_f16RM_x_f16RM_w_int8TC(A, B, qGroupSize, qScaleAndZeros, weightOn
     y = torch.empty((m, wrows), dtype=x.dtype, device=x.device)
     if m == 0:
         return y
+    if x.data_ptr() % 16:   # (a view at an odd element offset: the kernels load the activations in 16-byte pieces)
+        x = x.clone()
     bias = _take_bias(wrows, x)
     args = W4Gemm(x=x.data_ptr(), w=w.data_ptr(), qinfo=qinfo.data_ptr(), lut=None, y=y.data_ptr(), m=m, wrows=wrows, k=k,
                   group=qGroupSize, qtype=_lib.TG_Q_INT8, dtype=_dt(x), w_on_right=1 if weightOnRight else 0,

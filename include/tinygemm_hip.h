@@ -283,6 +283,7 @@ TG_API int tg_dequant_w4_panel(const void* packed, const void* qinfo, const void
  * tg_gemm_w8 replaces tinygemm_y_f16RM_x_f16RM_w_int8TC (TinyGemm_int8.cu:216-399, 430-458): same argument struct as
  *   tg_gemm_w4 with qtype = TG_Q_INT8, inner_k_tiles = I of the packed layout (B: 1,2,4; A: 1,2 = size(3)/2), lut unused;
  *   w = RNE16(fma(byte - 128, scale, zero)) (Dequantization.cuh:262-330, MatrixLayoutB.cuh:1296-1316).
+ *   x (and stride_x of a batch) must be 16-byte aligned (TG_E_ALIGN otherwise): the kernels load activation fragments in 16-byte pieces.
  */
 TG_API int tg_convert_to_Bint8(const int32_t* in, int64_t n, int64_t k, int inner_k_tiles, int32_t* out, int device,
                                tg_stream_t stream);

@@ -692,10 +692,10 @@ def test_gemm_int8_vs_oracle(T, oracle, on_right, inner, g, m, n, k, dtype):
 
 @pytest.mark.parametrize("on_right", [True, False])
 @pytest.mark.parametrize("g", [64, 128, 256])
-@pytest.mark.parametrize("m,n,k,dtype", [(7, 200, 512, torch.bfloat16), (33, 264, 2048, torch.bfloat16), (64, 4096, 2048, torch.float16), (130, 1008, 4096, torch.bfloat16),
+@pytest.mark.parametrize("m,n,k,dtype", [(17, 200, 512, torch.bfloat16), (7, 200, 512, torch.bfloat16), (33, 264, 2048, torch.bfloat16), (64, 4096, 2048, torch.float16), (130, 1008, 4096, torch.bfloat16),
                                          (512, 528, 1024, torch.float16), (100, 48, 192, torch.bfloat16)])
 def test_gemm_int8_many_rows_on_the_tile_gemm(T, oracle, on_right, g, m, n, k, dtype):
-    """tinygemm_y_f16RM_x_f16RM_w_int8TC (TinyGemm_int8.cu:216-399) from 7 activation rows on the tile GEMM's int8 flavour (innerKTiles 2, the
+    """tinygemm_y_f16RM_x_f16RM_w_int8TC (TinyGemm_int8.cu:216-399) from 17 activation rows on the tile GEMM's int8 flavour (innerKTiles 2, the
     packing Int8Linear defaults to; groups of 64 or more): w = RNE16(fma(byte - 128, scale, zero)) computed by the dequantising waves, unsplit
     and split-K launches, both operand sides, ragged rows, a k of one step and a half (192), fused bias."""
     from any4_amd import ops
