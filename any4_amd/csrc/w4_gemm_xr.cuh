@@ -291,6 +291,9 @@ __global__ void __launch_bounds__(WV * 64, WV == 16 ? 1 : 2) w4_gemm_xr_kernel(c
 #ifndef TG_XR_XLDS
 #define TG_XR_XLDS 1
 #endif
+#ifndef TG_XR_XT
+#define TG_XR_XT 1   // the later problems' activations by 16-byte loads + a lane transpose (0: four 4-byte loads per chunk; developer A/B)
+#endif
   constexpr bool XLDS = TG_XR_XLDS && !PK && !QMX && WV == 8 && NCH == 16;  // (mx4: its eight-deep ring plus the 64 staging registers spill)
   u32x4 xg[XLDS ? 16 : 1];
   auto x_prepare = [&](int b, auto STAGED) {
@@ -331,15 +334,23 @@ __global__ void __launch_bounds__(WV * 64, WV == 16 ? 1 : 2) w4_gemm_xr_kernel(c
       const int ci = PK ? 2 * cx + par : cx;         // (PK: run-time in the lane, the register index stays a constant)
       const int k0 = (wave * NCH + ci) * 32 + 2 * kq;
       uint32_t d[4];
+      if constexpr (staged) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        if constexpr (staged) {
-          d[e] = on ? xr[cx][e] : 0u;
-        } else {
+        for (int e = 0; e < 4; ++e) d[e] = on ? xr[cx][e] : 0u;
+      } else if (!TG_XR_XT || p.x_tc) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
           const int64_t idx = p.x_tc ? tc_a_index(xi, k0 + 8 * e, p.k >> 4) : (int64_t)xi * p.k + k0 + 8 * e;
           const uint32_t v = *reinterpret_cast<const uint32_t*>(xb + idx * 2);
           d[e] = on ? v : 0u;
         }
+      } else {
+        // row-major x: the lane's dwords kq, kq + 4, kq + 8, kq + 12 of the chunk's 64 bytes as ONE 16-byte load of dwords 4 kq ... 4 kq + 3 and
+        // a 4 x 4 transpose across the four 16-lane rows (tg_common.cuh: transpose_rows4) -- a quarter of the gather's requests (round 6)
+        const u32x4 v = *reinterpret_cast<const u32x4*>(xb + ((int64_t)xi * p.k + (wave * NCH + ci) * 32) * 2 + 16 * kq);
+        const u32x4 vt = transpose_rows4(v);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) d[e] = on ? vt[e] : 0u;
       }
       xr[cx] = u32x4{__builtin_amdgcn_perm(d[1], d[0], 0x05040100u), __builtin_amdgcn_perm(d[3], d[2], 0x05040100u),
                      __builtin_amdgcn_perm(d[1], d[0], 0x07060302u), __builtin_amdgcn_perm(d[3], d[2], 0x07060302u)};
