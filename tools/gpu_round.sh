@@ -52,4 +52,4 @@ timeout 600 python dev/many_rows_bench.py 2>&1 | grep "^m=" > gpurun_out/${RN}_m
 # PMC counters of the tile GEMM (m = 512 and the split-K launch at m = 128)
 python tools/collect_counters.py --out gpurun_out/${RN}_counters_tile_m128_splitk.json --match w4_gemm_tile_kernel --label "tile GEMM, split-K launch: m=128 4096^2 (64 tiles x 4 splits)" -- python dev/many_rows_bench.py --shapes "128,4096,4096" --layers 6 | cut -c1-300
 # the side formats: Int8Linear and the 16-bit-weight tinygemm op against nn.Linear, one 4096^2 layer per graph node
-(bash dev/jobs/int8.sh; bash dev/jobs/f16.sh) 2>&1 | grep -E "^int8|^f16" > gpurun_out/${RN}_int8_f16_modules.txt
+timeout 600 python tools/side_formats_bench.py 2>&1 | grep -E "^int8|^f16" > gpurun_out/${RN}_int8_f16_modules.txt
