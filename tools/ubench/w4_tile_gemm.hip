@@ -5,6 +5,7 @@
 #include "../../any4_amd/csrc/tg_common.cuh"
 namespace {
 #include "../../any4_amd/csrc/w4_gemm_tile.cuh"
+#include "w4_gemm_tile2.cuh"
 }
 #include <cmath>
 #include <cstdio>
@@ -48,12 +49,18 @@ static int launch(const TileParams& p, hipStream_t st) {
   constexpr int ks = BN == 64 ? KS_ : 1;
   constexpr int dx = (ks == 2 || BM_ == 256) ? 2 : DX_;
   constexpr int ncw = BN == 64 ? 4 : NCW128_;
+#ifdef TILE2
+  constexpr auto kern = w4_gemm_tile2_kernel<BF16, BM_, BN, dx, ks>;
+  constexpr int nthreads = 768;
+#else
   constexpr auto kern = w4_gemm_tile_kernel<BF16, BM_, BN, dx, ndw, ks, ncw>;
+  constexpr int nthreads = 64 * (ncw + 4 + ndw);
+#endif
   static bool prepared = false;
   if (!prepared) { CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); prepared = true; }
   constexpr unsigned lds_bytes = TileLds<BM_, BN, dx, ks>::BYTES;
   const int ns = p.splits > 1 ? p.splits : 1;
-  hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n * ns), dim3(64 * (ncw + 4 + ndw)), lds_bytes, st, p);
+  hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n * ns), dim3(nthreads), lds_bytes, st, p);
   if (ns > 1) {
     const int64_t quads = (int64_t)p.m * p.wrows / 4;
     hipLaunchKernelGGL(tile_split_sum_kernel<BF16>, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, st, p.part, ns, (int64_t)p.m * p.wrows, p.y, p.bias, p.wrows, quads);
