@@ -27,11 +27,11 @@ def main():
     lins = [torch.nn.Linear(k, n, dtype=torch.bfloat16, device="cuda", bias=False) for _ in range(6)]
     q = Q.intq_layer(torch.nn.Linear(k, n, dtype=torch.bfloat16, device="cuda", bias=False), n_bit=8)
     mods = [copy.deepcopy(q) for _ in range(6)]
-    for m in (int(v) for v in a.rows.split(",")):
+    for m in (int(v) for v in a.rows.split(",") if v):
         x = torch.randn(m, k, dtype=torch.bfloat16, device="cuda") * 0.05
         print(f"int8 m={m}: nn.Linear {graph_time(lins, x):.2f} us  Int8Linear {graph_time(mods, x):.2f} us", flush=True)
     w = torch.randn(n, k, dtype=torch.bfloat16, device="cuda")
-    for m in (int(v) for v in a.f16_rows.split(",")):
+    for m in (int(v) for v in a.f16_rows.split(",") if v):
         x = torch.randn(m, k, dtype=torch.bfloat16, device="cuda") * 0.05
         for side, inner in ((True, 2), (True, 1), (False, 1)):
             wp = T.convert_matrix_to_m16n8k16_B_layout(w, inner) if side else T.convert_matrix_to_m16n8k16_A_layout(w, 1)
